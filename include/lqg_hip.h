@@ -1,0 +1,158 @@
+/*
+ * lqg_hip.h — C ABI of liblqg_hip.so: MI355X (gfx950) batched LQG solve path.
+ *
+ * The reference (RothkopfLab/lqg) is pure Python on JAX and has NO FFI/plugin layer; its boundary for
+ * this path is the Python call surface listed below.  Each entry point names the reference function it
+ * replaces (paths relative to the reference checkout).  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - Plain C: pointers, sizes, POD structs.  No torch / HIP types in signatures (`stream` is a
+ *     hipStream_t passed as void*; NULL = the default stream).
+ *   - The caller owns ALL device memory (inputs, outputs, workspace).  The library never allocates,
+ *     frees or retains a pointer past the call, and holds no mutable global state: re-entrant.
+ *   - Calls are stream-ordered and asynchronous; the library never synchronises.
+ *   - Return 0 on success; <0 invalid argument / unsupported shape (nothing launched; see
+ *     lqg_last_error()); >0 a hipError_t from the launch.
+ *   - NaN/inf in results are data, not errors (the reference propagates them silently).
+ *   - All strides are in ELEMENTS of the problem dtype.  A batch stride of 0 shares the array between
+ *     systems (parameter candidates); a time stride of 0 marks it time-invariant (what
+ *     lqg/utils.py:10-35 `time_stack_spec` builds by replicating T copies).
+ *   - "system" = one parameter candidate (one actor spec + one dynamics spec); "trial" = one observed
+ *     trajectory.  B systems x N trials per call.
+ *   - Q, Qf, R, Sigma0 are cost / covariance matrices: the library uses their symmetric part
+ *     (identical to the reference for symmetric input, which is the only meaningful input).
+ */
+#ifndef LQG_HIP_H
+#define LQG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LQG_ABI_VERSION 1
+
+typedef enum lqg_dtype { LQG_F32 = 0, LQG_F64 = 1 } lqg_dtype;
+
+/* error codes (negative return values) */
+#define LQG_ERR_NULL        (-1)  /* required pointer missing            */
+#define LQG_ERR_DIMS        (-2)  /* dims not instantiated in this build */
+#define LQG_ERR_ARG         (-3)  /* bad size / dtype / flag             */
+#define LQG_ERR_WORKSPACE   (-4)  /* workspace too small                 */
+
+/* strided view of a [system][time][row][col] array (vectors: sc unused, scalars: sr, sc unused) */
+typedef struct lqg_view {
+  void*   ptr;
+  int64_t sb;   /* stride between systems; 0 = shared by all systems */
+  int64_t st;   /* stride between time steps; 0 = time-invariant     */
+  int64_t sr;   /* row stride                                        */
+  int64_t sc;   /* column stride                                     */
+} lqg_view;
+
+/* strided view of a [system][trial][time][component] array (x, mu, simulated trajectories) */
+typedef struct lqg_traj {
+  void*   ptr;
+  int64_t sb;   /* stride between systems; 0 = all systems see the same trials */
+  int64_t sn;   /* stride between trials                                        */
+  int64_t st;   /* stride between time steps                                    */
+  int64_t sd;   /* stride between components                                    */
+} lqg_traj;
+
+/* lqg/spec.py:5-19 LQGSpec, field for field.  Shapes per (system, time):
+ * Q[b,b] q[b] Qf[b,b] qf[b] P[u,b] R[u,u] r[u] A[b,b] B[b,u] V[b,nv] F[y,b] W[y,nw]
+ * (Qf, qf have no time axis: st ignored).  q, qf, P, r may have ptr == NULL meaning "all zero"
+ * (what time_stack_spec builds, lqg/utils.py:29-33). */
+typedef struct lqg_spec {
+  lqg_view Q, q, Qf, qf, P, R, r, A, B, V, F, W;
+} lqg_spec;
+
+typedef struct lqg_dims {
+  int32_t x;    /* true state dim       (System.xdim, lqg/system.py:27-33)  */
+  int32_t b;    /* belief / actor dim   (System.bdim, :45-51)               */
+  int32_t u;    /* action dim           (System.udim, :54-60)               */
+  int32_t y;    /* observation dim      (System.ydim, :36-42)               */
+  int32_t d;    /* observed dims of the data x[..., :d], d <= x (system.py:152) */
+  int32_t nva, nwa;  /* columns of actor V, W    */
+  int32_t nvd, nwd;  /* columns of dynamics V, W */
+} lqg_dims;
+
+typedef struct lqg_problem {
+  int32_t  dtype;      /* lqg_dtype: arithmetic and storage type of every array */
+  int32_t  T;          /* number of steps (System.T, lqg/system.py:17-24); data has T+1 rows */
+  int64_t  n_sys;      /* B */
+  int64_t  n_trials;   /* N trials per system */
+  lqg_dims dims;
+  lqg_spec actor;      /* all fields used                                        */
+  lqg_spec dynamics;   /* only A, B, F, V, W are read (lqg/system.py:331-344)    */
+  lqg_view Sigma0;     /* [b,b] initial belief covariance for the Kalman sweep; ptr NULL =
+                          actor.V[0] actor.V[0]^T (lqg/system.py:79,160)          */
+  double   eps;        /* eigenvalue floor of lqr.backward (lqg/control/lqr.py:16, default 1e-8) */
+} lqg_problem;
+
+int lqg_abi_version(void);
+/* thread-local, valid until the next failing call on this thread */
+const char* lqg_last_error(void);
+/* 1 if (dtype, dims) has a compiled instantiation in this build, else 0 */
+int lqg_dims_supported(int32_t dtype, const lqg_dims* dims);
+/* number of GPUs visible / name of the code object target ("gfx950") */
+const char* lqg_target_arch(void);
+
+/* Replaces lqg.control.lqr.backward(spec, eps) -> Gains(L, l, H)   [lqg/control/lqr.py:16-42]
+ * Reads p->actor.  L[B,T,u,b], l[B,T,u], H[B,T,u,u] (H = regularised Ht) in forward time order.
+ * Any of l, H may have ptr NULL (not written). */
+int lqg_riccati_backward(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view H, void* stream);
+
+/* Replaces lqg.belief.kf.forward(spec, Sigma0) -> K               [lqg/belief/kf.py:6-21]
+ * Reads p->actor (A, F, V, W) and p->Sigma0.  K[B,T,b,y]. */
+int lqg_kalman_forward(const lqg_problem* p, lqg_view K, void* stream);
+
+/* Bytes of caller-provided device workspace the call `op` needs for problem p
+ * (LQG_OP_LOG_LIKELIHOOD with n_trials == 1 runs fused and needs only the gain scratch). */
+#define LQG_OP_LOG_LIKELIHOOD      0
+#define LQG_OP_CONDITIONAL_MOMENTS 1
+size_t lqg_workspace_bytes(const lqg_problem* p, int32_t op);
+
+/* Replaces System.conditional_moments vmapped over trials         [lqg/system.py:142-235, :241]
+ * x[B,N,T+1,d] -> mu[B,N,T,m] (m = x+b), Sigma[B,T,m,m].  Sigma does not depend on the data
+ * (only mu does), so it is emitted once per system; the reference returns N identical copies.
+ * mu or Sigma may have ptr NULL (not written). */
+int lqg_conditional_moments(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_view Sigma,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* Replaces System.log_likelihood(x) [lqg/system.py:246-248] (= conditional_distribution(x)
+ * .log_prob(x[:,1:]), :237-244, numpyro MultivariateNormal): the fused hot path
+ * Riccati -> Kalman -> joint system -> moment recursion -> Gaussian log-density summed over time.
+ * x[B,N,T+1,d] -> ll[b*ll_sb + n*ll_sn], one value per (system, trial), dtype of the problem. */
+int lqg_log_likelihood(const lqg_problem* p, lqg_traj x, void* ll, int64_t ll_sb, int64_t ll_sn,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* Objective of lqg_model / the candidate sweep [lqg/infer/models.py:34, notebooks/Tutorial.ipynb
+ * cell 38 `.log_likelihood(x).sum()`]: out[b] = sum_n ll[b,n], accumulated and stored in fp64
+ * regardless of the problem dtype (so the cross-GPU all-reduce is order-insensitive to ~1e-15). */
+int lqg_sum_trials(int32_t dtype, const void* ll, int64_t n_sys, int64_t n_trials, int64_t ll_sb,
+                   int64_t ll_sn, double* out, void* stream);
+
+/* Replaces the per-trial scan of System.simulate [lqg/system.py:106-128] with the standard-normal
+ * draws supplied by the caller (the reference draws them from jax.random, :102-105).
+ * gains L[B,T,u,b], l[B,T,u] (l.ptr NULL = 0), K[B,T,b,y] as produced by the two calls above;
+ * eps[B,N,T,xdim], eta[B,N,T,ydim]; x0[B,xdim], xhat0[B,bdim] views (ptr NULL = zeros; only sb, sr used).
+ * Outputs xs[B,N,T+1,x] (row 0 = x0), and optionally xhat[B,N,T+1,b], ys[B,N,T,y], us[B,N,T,u]. */
+int lqg_simulate(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view K, lqg_traj eps, lqg_traj eta,
+                 lqg_view x0, lqg_view xhat0, lqg_traj xs, lqg_traj xhat, lqg_traj ys, lqg_traj us,
+                 void* stream);
+
+/* Replaces numpyro MultivariateNormal(mu, Sigma).to_event(1).log_prob(value) as used by
+ * System.conditional_distribution [lqg/system.py:244,248]: value[B,N,T,k], mu[B,N,T,k] (k = dims.d
+ * components read from each), Sigma[B,T,m,m] of which the leading k x k block is used;
+ * out[b*sb + n*sn] = sum_t log N(value_t; mu_t, Sigma_t). */
+int lqg_gaussian_logprob(int32_t dtype, int32_t k, int32_t T, int64_t n_sys, int64_t n_trials,
+                         lqg_traj value, lqg_traj mu, lqg_view Sigma, void* out, int64_t out_sb,
+                         int64_t out_sn, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LQG_HIP_H */

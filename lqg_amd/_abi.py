@@ -1,0 +1,136 @@
+"""ctypes mirror of include/lqg_hip.h and the loader for liblqg_hip.so.
+
+The HIP library is the ONLY compute backend of this package: if it cannot be loaded the import of any
+compute entry point raises (no CPU fallback, by design — see DESIGN.md "Boundary").
+"""
+import ctypes as C
+import os
+
+ABI_VERSION = 1
+F32, F64 = 0, 1
+OP_LOG_LIKELIHOOD, OP_CONDITIONAL_MOMENTS = 0, 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblqg_hip.so")
+
+
+class View(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("sb", C.c_int64), ("st", C.c_int64), ("sr", C.c_int64), ("sc", C.c_int64)]
+
+
+class Traj(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("sb", C.c_int64), ("sn", C.c_int64), ("st", C.c_int64), ("sd", C.c_int64)]
+
+
+SPEC_FIELDS = ("Q", "q", "Qf", "qf", "P", "R", "r", "A", "B", "V", "F", "W")
+
+
+class Spec(C.Structure):
+    _fields_ = [(f, View) for f in SPEC_FIELDS]
+
+
+class Dims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("x", "b", "u", "y", "d", "nva", "nwa", "nvd", "nwd")]
+
+
+class Problem(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("T", C.c_int32), ("n_sys", C.c_int64), ("n_trials", C.c_int64),
+                ("dims", Dims), ("actor", Spec), ("dynamics", Spec), ("Sigma0", View), ("eps", C.c_double)]
+
+
+NULL_VIEW = View(None, 0, 0, 0, 0)
+NULL_TRAJ = Traj(None, 0, 0, 0, 0)
+
+
+class LqgHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def declare(lib, prefix="lqg_", with_stream=True):
+    """Attach argtypes/restype for the entry points of include/lqg_hip.h (also used for the oracle's
+    host twins `lqg_oracle_*`, which drop the workspace/stream arguments)."""
+    P = C.POINTER(Problem)
+    tail = [C.c_void_p] if with_stream else []
+    ws = [C.c_void_p, C.c_size_t] if with_stream else []
+    sig = {
+        "riccati_backward": [P, View, View, View] + tail,
+        "kalman_forward": [P, View] + tail,
+        "conditional_moments": [P, Traj, Traj, View] + ws + tail,
+        "log_likelihood": [P, Traj, C.c_void_p, C.c_int64, C.c_int64] + ws + tail,
+        "simulate": [P, View, View, View, Traj, Traj, View, View, Traj, Traj, Traj, Traj] + tail,
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, prefix + name)
+        fn.argtypes, fn.restype = args, C.c_int
+    return lib
+
+
+def load():
+    """Load liblqg_hip.so (built in-tree by __graft_entry__.build() / lqg_amd/csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LqgHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C lqg_amd/csrc`. lqg_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.lqg_abi_version.restype = C.c_int
+    if lib.lqg_abi_version() != ABI_VERSION:
+        raise LqgHipError(f"ABI mismatch: library {lib.lqg_abi_version()} vs binding {ABI_VERSION}")
+    lib.lqg_last_error.restype = C.c_char_p
+    lib.lqg_target_arch.restype = C.c_char_p
+    lib.lqg_dims_supported.argtypes, lib.lqg_dims_supported.restype = [C.c_int32, C.POINTER(Dims)], C.c_int
+    lib.lqg_workspace_bytes.argtypes, lib.lqg_workspace_bytes.restype = [C.POINTER(Problem), C.c_int32], C.c_size_t
+    lib.lqg_sum_trials.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                   C.c_void_p, C.c_void_p]
+    lib.lqg_sum_trials.restype = C.c_int
+    lib.lqg_gaussian_logprob.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, Traj, Traj, View,
+                                         C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+    lib.lqg_gaussian_logprob.restype = C.c_int
+    declare(lib)
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    lib = load()
+    msg = lib.lqg_last_error()
+    msg = msg.decode() if msg else ""
+    kind = "invalid argument" if rc < 0 else "hipError_t"
+    raise LqgHipError(f"{what} failed: {kind} {rc}: {msg}")
+
+
+# ---- view construction from (ptr, shape, element strides) ----------------------------------------------------
+
+def mat_view(ptr, shape, strides, batched, has_time=True, vector=False):
+    """Strided view of a spec field.
+
+    shape/strides exclude nothing: [B?][T?][rows][cols?].  `batched` says whether a leading system axis
+    is present; `has_time` whether a time axis is present (Qf, qf, Sigma0 have none)."""
+    shape, strides = list(shape), list(strides)
+    sb = st = 0
+    if batched:
+        sb = strides.pop(0) if shape[0] > 1 else (strides.pop(0) and 0)
+        shape.pop(0)
+    if has_time:
+        st = strides.pop(0) if shape[0] > 1 else (strides.pop(0) and 0)
+        shape.pop(0)
+    if vector:
+        return View(ptr, sb, st, strides[0], 0)
+    return View(ptr, sb, st, strides[0], strides[1])
+
+
+def traj_view(ptr, shape, strides, batched):
+    """Strided view of a trajectory array [B?][N][T][d]."""
+    strides = list(strides)
+    sb = 0
+    if batched:
+        sb = strides[0] if shape[0] > 1 else 0
+        strides = strides[1:]
+    return Traj(ptr, sb, strides[0], strides[1], strides[2])

@@ -1,0 +1,245 @@
+"""Launch glue: torch tensors -> include/lqg_hip.h argument structs -> liblqg_hip.so.
+
+PyTorch is plumbing here (device memory, the current HIP stream); every number is produced by the HIP
+kernels behind the C ABI.  There is NO CPU path: tensors must live on a `cuda` (ROCm) device, otherwise
+LqgHipError is raised.
+"""
+import ctypes as C
+
+import torch
+
+from lqg_amd import _abi
+from lqg_amd._abi import LqgHipError
+from lqg_amd.spec import LQGSpec
+
+_VEC = {"q", "qf", "r"}
+_NOTIME = {"Qf", "qf"}
+_DT = {torch.float32: _abi.F32, torch.float64: _abi.F64}
+
+
+def _es(t):
+    return list(t.stride())
+
+
+def _is_zero(t):
+    return t is None or getattr(t, "_lqg_zero", False)
+
+
+def spec_is_batched(spec: LQGSpec):
+    return spec.A.dim() == 4
+
+
+def _field_view(t, name, batched):
+    """View of one spec field; a field without the system axis is shared (sb = 0)."""
+    base = (1 if name in _VEC else 2) + (0 if name in _NOTIME else 1)
+    has_b = t.dim() == base + 1
+    if t.dim() not in (base, base + 1) or (has_b and not batched):
+        raise LqgHipError(f"spec field {name}: unexpected shape {tuple(t.shape)}")
+    return _abi.mat_view(t.data_ptr(), t.shape, _es(t), has_b, name not in _NOTIME, name in _VEC)
+
+
+class Launch:
+    """One problem description plus the tensors it points into (kept alive for the call)."""
+
+    def __init__(self, actor: LQGSpec, dynamics: LQGSpec = None, d=None, n_trials=1, Sigma0=None, eps=1e-8):
+        dynamics = actor if dynamics is None else dynamics
+        A = actor.A
+        if A.dtype not in _DT:
+            raise LqgHipError(f"unsupported dtype {A.dtype}: float32 or float64")
+        self.dtype, self.device = A.dtype, A.device
+        self.batched = spec_is_batched(actor) or spec_is_batched(dynamics)
+        self.B = 1
+        for sp in (actor, dynamics):
+            if spec_is_batched(sp):
+                self.B = max(self.B, sp.A.shape[0])
+        self.T = A.shape[-3]
+        b, u, y, x = A.shape[-1], actor.B.shape[-1], actor.F.shape[-2], dynamics.A.shape[-1]
+        self.dims = dict(x=x, b=b, u=u, y=y, d=(x if d is None else int(d)), nva=actor.V.shape[-1],
+                         nwa=actor.W.shape[-1], nvd=dynamics.V.shape[-1], nwd=dynamics.W.shape[-1])
+        self.m = x + b
+        p = _abi.Problem()
+        p.dtype, p.T, p.n_sys, p.n_trials, p.eps = _DT[A.dtype], self.T, self.B, n_trials, float(eps)
+        p.dims = _abi.Dims(**self.dims)
+        self._keep = []
+        for spec, dst, fields in ((actor, p.actor, _abi.SPEC_FIELDS), (dynamics, p.dynamics, ("A", "B", "F", "V", "W"))):
+            for f in _abi.SPEC_FIELDS:
+                t = getattr(spec, f) if f in fields else None
+                if t is None or (f in ("q", "qf", "P", "r") and _is_zero(t)):
+                    setattr(dst, f, _abi.NULL_VIEW)
+                    continue
+                if t.dtype != self.dtype or t.device != self.device:
+                    raise LqgHipError(f"spec field {f}: dtype/device {t.dtype}/{t.device} differs from A's")
+                self._keep.append(t)
+                setattr(dst, f, _field_view(t, f, self.batched))
+        if Sigma0 is not None:
+            S0 = Sigma0.to(dtype=self.dtype, device=self.device)
+            self._keep.append(S0)
+            p.Sigma0 = _abi.mat_view(S0.data_ptr(), S0.shape, _es(S0), S0.dim() == 3, False, False)
+        else:
+            p.Sigma0 = _abi.NULL_VIEW
+        self.p = p
+
+    # ---- helpers
+    def require_gpu(self):
+        if self.device.type != "cuda":
+            raise LqgHipError(
+                f"lqg_amd computes on MI355X only: tensors are on '{self.device}'. Move the spec to a cuda "
+                "(ROCm) device; there is no CPU fallback.")
+        return _abi.load()
+
+    def lead(self):
+        return (self.B,) if self.batched else ()
+
+    def empty(self, *shape):
+        return torch.empty(self.lead() + tuple(shape), dtype=self.dtype, device=self.device)
+
+    def view(self, t, vector=False):
+        return _abi.mat_view(t.data_ptr(), t.shape, _es(t), self.batched, True, vector)
+
+    def traj(self, t, batched=None):
+        batched = self.batched if batched is None else batched
+        return _abi.traj_view(t.data_ptr(), t.shape, _es(t), batched)
+
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def workspace(self, lib, op):
+        nbytes = lib.lqg_workspace_bytes(C.byref(self.p), op)
+        return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device), nbytes
+
+
+def riccati_backward(spec: LQGSpec, eps=1e-8):
+    ln = Launch(spec, eps=eps)
+    lib = ln.require_gpu()
+    dm = ln.dims
+    L, l, H = ln.empty(ln.T, dm["u"], dm["b"]), ln.empty(ln.T, dm["u"]), ln.empty(ln.T, dm["u"], dm["u"])
+    with torch.cuda.device(ln.device):
+        _abi.check(lib.lqg_riccati_backward(C.byref(ln.p), ln.view(L), ln.view(l, vector=True), ln.view(H),
+                                            ln.stream()), "lqg_riccati_backward")
+    return L, l, H
+
+
+def kalman_forward(spec: LQGSpec, Sigma0=None):
+    ln = Launch(spec, Sigma0=Sigma0)
+    lib = ln.require_gpu()
+    K = ln.empty(ln.T, ln.dims["b"], ln.dims["y"])
+    with torch.cuda.device(ln.device):
+        _abi.check(lib.lqg_kalman_forward(C.byref(ln.p), ln.view(K), ln.stream()), "lqg_kalman_forward")
+    return K
+
+
+def _prep_x(ln, x):
+    """x[n,T+1,d] (shared by all systems) or [B,n,T+1,d]."""
+    if x.dim() not in (3, 4):
+        raise LqgHipError(f"x must be [n,T+1,d] or [B,n,T+1,d], got {tuple(x.shape)}")
+    if x.shape[-2] != ln.T + 1:
+        raise LqgHipError(f"x has {x.shape[-2]} rows; a system with T={ln.T} steps needs T+1={ln.T + 1}")
+    if x.dtype != ln.dtype or x.device != ln.device:
+        x = x.to(dtype=ln.dtype, device=ln.device)
+    xb = x.dim() == 4
+    if xb and x.shape[0] not in (1, ln.B):
+        raise LqgHipError(f"x has {x.shape[0]} systems, spec has {ln.B}")
+    return x, xb
+
+
+def conditional_moments(actor, dynamics, x, Sigma0=None, eps=1e-8, want_mu=True, want_sigma=True):
+    """x[n,T+1,d] | [B,n,T+1,d] -> mu[(B,)n,T,m], Sigma[(B,)T,m,m]."""
+    d, n = x.shape[-1], x.shape[-3]
+    ln = Launch(actor, dynamics, d=d, n_trials=n, Sigma0=Sigma0, eps=eps)
+    lib = ln.require_gpu()
+    x, xb = _prep_x(ln, x)
+    mu = ln.empty(n, ln.T, ln.m) if want_mu else None
+    Sig = ln.empty(ln.T, ln.m, ln.m) if want_sigma else None
+    with torch.cuda.device(ln.device):
+        ws, nbytes = ln.workspace(lib, _abi.OP_CONDITIONAL_MOMENTS)
+        _abi.check(lib.lqg_conditional_moments(
+            C.byref(ln.p), ln.traj(x, xb), ln.traj(mu) if want_mu else _abi.NULL_TRAJ,
+            ln.view(Sig) if want_sigma else _abi.NULL_VIEW, C.c_void_p(ws.data_ptr()), nbytes, ln.stream()),
+            "lqg_conditional_moments")
+    return mu, Sig
+
+
+def log_likelihood(actor, dynamics, x, Sigma0=None, eps=1e-8):
+    """x[n,T+1,d] | [B,n,T+1,d] -> ll[(B,)n]."""
+    d, n = x.shape[-1], x.shape[-3]
+    ln = Launch(actor, dynamics, d=d, n_trials=n, Sigma0=Sigma0, eps=eps)
+    lib = ln.require_gpu()
+    x, xb = _prep_x(ln, x)
+    ll = ln.empty(n)
+    with torch.cuda.device(ln.device):
+        ws, nbytes = ln.workspace(lib, _abi.OP_LOG_LIKELIHOOD)
+        _abi.check(lib.lqg_log_likelihood(C.byref(ln.p), ln.traj(x, xb), C.c_void_p(ll.data_ptr()),
+                                          n if ln.batched else 0, 1, C.c_void_p(ws.data_ptr()), nbytes,
+                                          ln.stream()), "lqg_log_likelihood")
+    return ll
+
+
+def sum_trials(ll):
+    """ll[(B,)n] -> fp64 sums [(B,)] with a fixed reduction tree (lqg_sum_trials)."""
+    lib = _abi.load()
+    if ll.device.type != "cuda":
+        raise LqgHipError("sum_trials needs a cuda tensor")
+    batched = ll.dim() == 2
+    B = ll.shape[0] if batched else 1
+    n = ll.shape[-1]
+    out = torch.empty((B,), dtype=torch.float64, device=ll.device)
+    with torch.cuda.device(ll.device):
+        _abi.check(lib.lqg_sum_trials(_DT[ll.dtype], C.c_void_p(ll.data_ptr()), B, n,
+                                      ll.stride(0) if batched else 0, ll.stride(-1), C.c_void_p(out.data_ptr()),
+                                      C.c_void_p(torch.cuda.current_stream(ll.device).cuda_stream)), "lqg_sum_trials")
+    return out if batched else out[0]
+
+
+def gaussian_logprob(value, mu, Sigma, k):
+    """value, mu [(B,)n,T,>=k]; Sigma [(B,)T,m,m] -> [(B,)n] (lqg_gaussian_logprob)."""
+    lib = _abi.load()
+    if value.device.type != "cuda":
+        raise LqgHipError("gaussian_logprob needs cuda tensors")
+    batched = mu.dim() == 4
+    B = mu.shape[0] if batched else 1
+    n, T = mu.shape[-3], mu.shape[-2]
+    value = value.to(dtype=mu.dtype, device=mu.device)
+    vb = value.dim() == 4
+    out = torch.empty(((B,) if batched else ()) + (n,), dtype=mu.dtype, device=mu.device)
+    sview = _abi.mat_view(Sigma.data_ptr(), Sigma.shape, _es(Sigma), Sigma.dim() == 4, True, False)
+    with torch.cuda.device(mu.device):
+        _abi.check(lib.lqg_gaussian_logprob(
+            _DT[mu.dtype], k, T, B, n, _abi.traj_view(value.data_ptr(), value.shape, _es(value), vb),
+            _abi.traj_view(mu.data_ptr(), mu.shape, _es(mu), batched), sview, C.c_void_p(out.data_ptr()),
+            n if batched else 0, 1, C.c_void_p(torch.cuda.current_stream(mu.device).cuda_stream)),
+            "lqg_gaussian_logprob")
+    return out
+
+
+def simulate(actor, dynamics, L, l, K, eps_noise, eta_noise, x0=None, xhat0=None, return_all=True):
+    """eps_noise[(B,)n,T,x], eta_noise[(B,)n,T,y] -> x[(B,)n,T+1,x] (and xhat, y, u)."""
+    n = eps_noise.shape[-3]
+    ln = Launch(actor, dynamics, n_trials=n)
+    lib = ln.require_gpu()
+    dm = ln.dims
+    xs = ln.empty(n, ln.T + 1, dm["x"])
+    xh = ln.empty(n, ln.T + 1, dm["b"]) if return_all else None
+    ys = ln.empty(n, ln.T, dm["y"]) if return_all else None
+    us = ln.empty(n, ln.T, dm["u"]) if return_all else None
+
+    def init(v):
+        if v is None:
+            return _abi.NULL_VIEW, None
+        v = torch.as_tensor(v, dtype=ln.dtype, device=ln.device).contiguous()
+        if v.dim() == 1:
+            return _abi.View(v.data_ptr(), 0, 0, 1, 0), v
+        return _abi.View(v.data_ptr(), v.stride(0), 0, v.stride(1), 0), v
+
+    v0, k0 = init(x0)
+    vh, kh = init(xhat0)
+    nt = _abi.NULL_TRAJ
+    lview = _abi.NULL_VIEW if (l is None or _is_zero(l)) else _abi.mat_view(l.data_ptr(), l.shape, _es(l),
+                                                                           l.dim() == 3, True, True)
+    gview = lambda t: _abi.mat_view(t.data_ptr(), t.shape, _es(t), t.dim() == 4, True, False)
+    eb = eps_noise.dim() == 4
+    with torch.cuda.device(ln.device):
+        _abi.check(lib.lqg_simulate(
+            C.byref(ln.p), gview(L), lview, gview(K), ln.traj(eps_noise, eb), ln.traj(eta_noise, eb), v0, vh,
+            ln.traj(xs), ln.traj(xh) if return_all else nt, ln.traj(ys) if return_all else nt,
+            ln.traj(us) if return_all else nt, ln.stream()), "lqg_simulate")
+    return xs, xh, ys, us

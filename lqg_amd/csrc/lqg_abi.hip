@@ -1,0 +1,342 @@
+// lqg_abi.hip — the C ABI of liblqg_hip.so (include/lqg_hip.h): argument checking, dispatch on
+// (dtype, dims) to the compiled kernel instantiations, stream-ordered launches.  No allocation, no
+// synchronisation, no global mutable state (the error string is thread-local).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/lqg_hip.h"
+#include "lqg_launch.hpp"
+#include "lqg_dims.def"
+
+// ---------------------------------------------------------------- extern instantiations (defined by lqg_inst.hip)
+#define X(B_, U_)                                                                                              \
+  extern template hipError_t lqg::host::launch_riccati<float, B_, U_>(const lqg_problem*, lqg_view, lqg_view, \
+                                                                       lqg_view, void*, long, hipStream_t);    \
+  extern template hipError_t lqg::host::launch_riccati<double, B_, U_>(const lqg_problem*, lqg_view, lqg_view, \
+                                                                        lqg_view, void*, long, hipStream_t);
+LQG_RICCATI_DIMS(X)
+#undef X
+#define X(B_, Y_)                                                                                          \
+  extern template hipError_t lqg::host::launch_kalman<float, B_, Y_>(const lqg_problem*, lqg_view, hipStream_t); \
+  extern template hipError_t lqg::host::launch_kalman<double, B_, Y_>(const lqg_problem*, lqg_view, hipStream_t);
+LQG_KALMAN_DIMS(X)
+#undef X
+#define X(X_, B_, U_, Y_, D_)                                                                                   \
+  extern template hipError_t lqg::host::launch_forward<float, X_, B_, U_, Y_, D_>(                              \
+      const lqg_problem*, const void*, long, bool, lqg_traj, void*, long, void*, lqg_view, hipStream_t);        \
+  extern template hipError_t lqg::host::launch_forward<double, X_, B_, U_, Y_, D_>(                             \
+      const lqg_problem*, const void*, long, bool, lqg_traj, void*, long, void*, lqg_view, hipStream_t);
+LQG_FORWARD_DIMS(X)
+#undef X
+#define X(M_, D_)                                                                                              \
+  extern template hipError_t lqg::host::launch_trial<float, M_, D_>(const lqg_problem*, const void*, lqg_traj, \
+                                                                     lqg_traj, void*, long, long, hipStream_t); \
+  extern template hipError_t lqg::host::launch_trial<double, M_, D_>(const lqg_problem*, const void*, lqg_traj, \
+                                                                      lqg_traj, void*, long, long, hipStream_t);
+LQG_TRIAL_DIMS(X)
+#undef X
+#define X(X_, B_, U_, Y_)                                                                                       \
+  extern template hipError_t lqg::host::launch_simulate<float, X_, B_, U_, Y_>(                                 \
+      const lqg_problem*, lqg_view, lqg_view, lqg_view, lqg_traj, lqg_traj, lqg_view, lqg_view, lqg_traj,       \
+      lqg_traj, lqg_traj, lqg_traj, hipStream_t);                                                               \
+  extern template hipError_t lqg::host::launch_simulate<double, X_, B_, U_, Y_>(                                \
+      const lqg_problem*, lqg_view, lqg_view, lqg_view, lqg_traj, lqg_traj, lqg_view, lqg_view, lqg_traj,       \
+      lqg_traj, lqg_traj, lqg_traj, hipStream_t);
+LQG_SIM_DIMS(X)
+#undef X
+
+using namespace lqg::host;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+template <typename R>
+hipError_t dispatch_riccati(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view H, void* Ls, long ldb,
+                            hipStream_t st, bool* found) {
+  *found = true;
+#define X(B_, U_) \
+  if (p->dims.b == B_ && p->dims.u == U_) return launch_riccati<R, B_, U_>(p, L, l, H, Ls, ldb, st);
+  LQG_RICCATI_DIMS(X)
+#undef X
+  *found = false;
+  return hipSuccess;
+}
+template <typename R>
+hipError_t dispatch_kalman(const lqg_problem* p, lqg_view K, hipStream_t st, bool* found) {
+  *found = true;
+#define X(B_, Y_) \
+  if (p->dims.b == B_ && p->dims.y == Y_) return launch_kalman<R, B_, Y_>(p, K, st);
+  LQG_KALMAN_DIMS(X)
+#undef X
+  *found = false;
+  return hipSuccess;
+}
+template <typename R>
+hipError_t dispatch_forward(const lqg_problem* p, const void* Ls, long ldb, bool fused, lqg_traj x, void* ll,
+                            long ll_sb, void* ops, lqg_view Sig, hipStream_t st, bool* found) {
+  *found = true;
+  const lqg_dims& d = p->dims;
+#define X(X_, B_, U_, Y_, D_)                                                  \
+  if (d.x == X_ && d.b == B_ && d.u == U_ && d.y == Y_ && d.d == D_)          \
+    return launch_forward<R, X_, B_, U_, Y_, D_>(p, Ls, ldb, fused, x, ll, ll_sb, ops, Sig, st);
+  LQG_FORWARD_DIMS(X)
+#undef X
+  *found = false;
+  return hipSuccess;
+}
+template <typename R>
+hipError_t dispatch_trial(const lqg_problem* p, const void* ops, lqg_traj x, lqg_traj mu, void* ll, long ll_sb,
+                          long ll_sn, hipStream_t st, bool* found) {
+  *found = true;
+  const int m = p->dims.x + p->dims.b;
+#define X(M_, D_) \
+  if (m == M_ && p->dims.d == D_) return launch_trial<R, M_, D_>(p, ops, x, mu, ll, ll_sb, ll_sn, st);
+  LQG_TRIAL_DIMS(X)
+#undef X
+  *found = false;
+  return hipSuccess;
+}
+template <typename R>
+hipError_t dispatch_simulate(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view K, lqg_traj eps, lqg_traj eta,
+                             lqg_view x0, lqg_view xhat0, lqg_traj xs, lqg_traj xhat, lqg_traj ys, lqg_traj us,
+                             hipStream_t st, bool* found) {
+  *found = true;
+  const lqg_dims& d = p->dims;
+#define X(X_, B_, U_, Y_)                                     \
+  if (d.x == X_ && d.b == B_ && d.u == U_ && d.y == Y_)      \
+    return launch_simulate<R, X_, B_, U_, Y_>(p, L, l, K, eps, eta, x0, xhat0, xs, xhat, ys, us, st);
+  LQG_SIM_DIMS(X)
+#undef X
+  *found = false;
+  return hipSuccess;
+}
+
+bool has_forward(const lqg_dims& d) {
+#define X(X_, B_, U_, Y_, D_) \
+  if (d.x == X_ && d.b == B_ && d.u == U_ && d.y == Y_ && d.d == D_) return true;
+  LQG_FORWARD_DIMS(X)
+#undef X
+  return false;
+}
+
+int check_problem(const lqg_problem* p, const char* who) {
+  if (!p) return fail(LQG_ERR_NULL, "%s: problem is NULL", who);
+  if (p->dtype != LQG_F32 && p->dtype != LQG_F64) return fail(LQG_ERR_ARG, "%s: bad dtype %d", who, p->dtype);
+  if (p->T < 1) return fail(LQG_ERR_ARG, "%s: T=%d < 1", who, p->T);
+  if (p->n_sys < 0 || p->n_trials < 0) return fail(LQG_ERR_ARG, "%s: negative batch", who);
+  const lqg_dims& d = p->dims;
+  if (d.x < 1 || d.b < 1 || d.u < 1 || d.y < 1) return fail(LQG_ERR_DIMS, "%s: non-positive dims", who);
+  return 0;
+}
+int need(const lqg_view& v, const char* who, const char* name) {
+  return v.ptr ? 0 : fail(LQG_ERR_NULL, "%s: %s.ptr is NULL", who, name);
+}
+int unsupported(const lqg_problem* p, const char* who) {
+  const lqg_dims& d = p->dims;
+  return fail(LQG_ERR_DIMS,
+              "%s: no kernel instantiation for dims (x=%d,b=%d,u=%d,y=%d,d=%d); add it to the LQG_*_DIMS lists in "
+              "lqg_amd/csrc/lqg_abi.hip and rebuild",
+              who, d.x, d.b, d.u, d.y, d.d);
+}
+int done(hipError_t e, const char* who) {
+  if (e == hipSuccess) return 0;
+  fail((int)e, "%s: %s", who, hipGetErrorString(e));
+  return (int)e;
+}
+
+int check_full(const lqg_problem* p, const char* who) {
+  if (int rc = check_problem(p, who)) return rc;
+  const lqg_spec& a = p->actor;
+  const lqg_spec& d = p->dynamics;
+  if (need(a.Q, who, "actor.Q") || need(a.Qf, who, "actor.Qf") || need(a.R, who, "actor.R") ||
+      need(a.A, who, "actor.A") || need(a.B, who, "actor.B") || need(a.F, who, "actor.F") ||
+      need(a.V, who, "actor.V") || need(a.W, who, "actor.W") || need(d.A, who, "dynamics.A") ||
+      need(d.B, who, "dynamics.B") || need(d.F, who, "dynamics.F") || need(d.V, who, "dynamics.V") ||
+      need(d.W, who, "dynamics.W"))
+    return LQG_ERR_NULL;
+  if (p->dims.d < 1 || p->dims.d > p->dims.x)
+    return fail(LQG_ERR_DIMS, "%s: observed dims d=%d must be in [1, x=%d]", who, p->dims.d, p->dims.x);
+  if (!has_forward(p->dims)) return unsupported(p, who);
+  return 0;
+}
+
+template <typename R>
+int run_moments(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_view Sigma, void* ll, long ll_sb,
+                       long ll_sn, bool allow_fused, void* workspace, size_t workspace_bytes, hipStream_t st,
+                       const char* who) {
+  const bool fused = allow_fused && p->n_trials == 1;
+  const Workspace w = carve(p, !fused);
+  if (!workspace || workspace_bytes < w.total)
+    return fail(LQG_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B", who, workspace_bytes, w.total);
+  char* base = static_cast<char*>(workspace);
+  void* Ls = base + w.ls_off;
+  void* ops = fused ? nullptr : base + w.ops_off;
+  bool found;
+  const lqg_view none{nullptr, 0, 0, 0, 0};
+  hipError_t e = dispatch_riccati<R>(p, none, none, none, Ls, w.ldb, st, &found);
+  if (!found) return unsupported(p, who);
+  if (e != hipSuccess) return done(e, who);
+  e = dispatch_forward<R>(p, Ls, w.ldb, fused, x, ll, ll_sb, ops, Sigma, st, &found);
+  if (!found) return unsupported(p, who);
+  if (e != hipSuccess) return done(e, who);
+  if (!fused && p->n_trials > 0 && (ll || mu.ptr)) {
+    e = dispatch_trial<R>(p, ops, x, mu, ll, ll_sb, ll_sn, st, &found);
+    if (!found) return unsupported(p, who);
+  }
+  return done(e, who);
+}
+
+}  // namespace
+
+extern "C" {
+
+int lqg_abi_version(void) { return LQG_ABI_VERSION; }
+const char* lqg_last_error(void) { return g_err; }
+const char* lqg_target_arch(void) { return "gfx950"; }
+
+int lqg_dims_supported(int32_t dtype, const lqg_dims* dims) {
+  if (!dims || (dtype != LQG_F32 && dtype != LQG_F64)) return 0;
+  return has_forward(*dims) ? 1 : 0;
+}
+
+int lqg_riccati_backward(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view H, void* stream) {
+  static const char* who = "lqg_riccati_backward";
+  if (int rc = check_problem(p, who)) return rc;
+  const lqg_spec& a = p->actor;
+  if (need(a.Q, who, "actor.Q") || need(a.Qf, who, "actor.Qf") || need(a.R, who, "actor.R") ||
+      need(a.A, who, "actor.A") || need(a.B, who, "actor.B") || need(L, who, "L"))
+    return LQG_ERR_NULL;
+  if (p->n_sys == 0) return 0;
+  bool found;
+  hipError_t e = p->dtype == LQG_F64
+                     ? dispatch_riccati<double>(p, L, l, H, nullptr, 0, (hipStream_t)stream, &found)
+                     : dispatch_riccati<float>(p, L, l, H, nullptr, 0, (hipStream_t)stream, &found);
+  if (!found) return unsupported(p, who);
+  return done(e, who);
+}
+
+int lqg_kalman_forward(const lqg_problem* p, lqg_view K, void* stream) {
+  static const char* who = "lqg_kalman_forward";
+  if (int rc = check_problem(p, who)) return rc;
+  const lqg_spec& a = p->actor;
+  if (need(a.A, who, "actor.A") || need(a.F, who, "actor.F") || need(a.V, who, "actor.V") ||
+      need(a.W, who, "actor.W") || need(K, who, "K"))
+    return LQG_ERR_NULL;
+  if (p->n_sys == 0) return 0;
+  bool found;
+  hipError_t e = p->dtype == LQG_F64 ? dispatch_kalman<double>(p, K, (hipStream_t)stream, &found)
+                                     : dispatch_kalman<float>(p, K, (hipStream_t)stream, &found);
+  if (!found) return unsupported(p, who);
+  return done(e, who);
+}
+
+size_t lqg_workspace_bytes(const lqg_problem* p, int32_t op) {
+  if (!p) return 0;
+  const bool fused = op == LQG_OP_LOG_LIKELIHOOD && p->n_trials == 1;
+  return carve(p, !fused).total;
+}
+
+int lqg_conditional_moments(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_view Sigma, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  static const char* who = "lqg_conditional_moments";
+  if (int rc = check_full(p, who)) return rc;
+  if (!x.ptr && mu.ptr) return fail(LQG_ERR_NULL, "%s: x.ptr is NULL", who);
+  if (p->n_sys == 0) return 0;
+  return p->dtype == LQG_F64
+             ? run_moments<double>(p, x, mu, Sigma, nullptr, 0, 0, false, workspace, workspace_bytes,
+                                   (hipStream_t)stream, who)
+             : run_moments<float>(p, x, mu, Sigma, nullptr, 0, 0, false, workspace, workspace_bytes,
+                                  (hipStream_t)stream, who);
+}
+
+int lqg_log_likelihood(const lqg_problem* p, lqg_traj x, void* ll, int64_t ll_sb, int64_t ll_sn, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+  static const char* who = "lqg_log_likelihood";
+  if (int rc = check_full(p, who)) return rc;
+  if (!x.ptr) return fail(LQG_ERR_NULL, "%s: x.ptr is NULL", who);
+  if (!ll) return fail(LQG_ERR_NULL, "%s: ll is NULL", who);
+  if (p->n_sys == 0 || p->n_trials == 0) return 0;
+  const lqg_traj no_mu{nullptr, 0, 0, 0, 0};
+  const lqg_view no_sig{nullptr, 0, 0, 0, 0};
+  return p->dtype == LQG_F64
+             ? run_moments<double>(p, x, no_mu, no_sig, ll, ll_sb, ll_sn, true, workspace, workspace_bytes,
+                                   (hipStream_t)stream, who)
+             : run_moments<float>(p, x, no_mu, no_sig, ll, ll_sb, ll_sn, true, workspace, workspace_bytes,
+                                  (hipStream_t)stream, who);
+}
+
+int lqg_sum_trials(int32_t dtype, const void* ll, int64_t n_sys, int64_t n_trials, int64_t ll_sb, int64_t ll_sn,
+                   double* out, void* stream) {
+  static const char* who = "lqg_sum_trials";
+  if (!ll || !out) return fail(LQG_ERR_NULL, "%s: NULL pointer", who);
+  if (dtype != LQG_F32 && dtype != LQG_F64) return fail(LQG_ERR_ARG, "%s: bad dtype %d", who, dtype);
+  if (n_sys <= 0) return 0;
+  const dim3 grid((unsigned)n_sys), block(256);
+  if (dtype == LQG_F64)
+    hipLaunchKernelGGL((lqg::k_sum_trials<double>), grid, block, 0, (hipStream_t)stream, static_cast<const double*>(ll),
+                       (long)n_trials, (long)ll_sb, (long)ll_sn, out);
+  else
+    hipLaunchKernelGGL((lqg::k_sum_trials<float>), grid, block, 0, (hipStream_t)stream, static_cast<const float*>(ll),
+                       (long)n_trials, (long)ll_sb, (long)ll_sn, out);
+  return done(hipGetLastError(), who);
+}
+
+int lqg_simulate(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view K, lqg_traj eps, lqg_traj eta, lqg_view x0,
+                 lqg_view xhat0, lqg_traj xs, lqg_traj xhat, lqg_traj ys, lqg_traj us, void* stream) {
+  static const char* who = "lqg_simulate";
+  if (int rc = check_problem(p, who)) return rc;
+  const lqg_spec& a = p->actor;
+  const lqg_spec& d = p->dynamics;
+  if (need(a.A, who, "actor.A") || need(a.B, who, "actor.B") || need(a.F, who, "actor.F") ||
+      need(d.A, who, "dynamics.A") || need(d.B, who, "dynamics.B") || need(d.F, who, "dynamics.F") ||
+      need(d.V, who, "dynamics.V") || need(d.W, who, "dynamics.W") || need(L, who, "L") || need(K, who, "K"))
+    return LQG_ERR_NULL;
+  if (!eps.ptr || !eta.ptr || !xs.ptr) return fail(LQG_ERR_NULL, "%s: eps/eta/xs must be non-NULL", who);
+  if (p->n_sys == 0 || p->n_trials == 0) return 0;
+  bool found;
+  hipError_t e = p->dtype == LQG_F64
+                     ? dispatch_simulate<double>(p, L, l, K, eps, eta, x0, xhat0, xs, xhat, ys, us,
+                                                 (hipStream_t)stream, &found)
+                     : dispatch_simulate<float>(p, L, l, K, eps, eta, x0, xhat0, xs, xhat, ys, us,
+                                                (hipStream_t)stream, &found);
+  if (!found) return unsupported(p, who);
+  return done(e, who);
+}
+
+int lqg_gaussian_logprob(int32_t dtype, int32_t k, int32_t T, int64_t n_sys, int64_t n_trials, lqg_traj value,
+                         lqg_traj mu, lqg_view Sigma, void* out, int64_t out_sb, int64_t out_sn, void* stream) {
+  static const char* who = "lqg_gaussian_logprob";
+  if (!value.ptr || !mu.ptr || !Sigma.ptr || !out) return fail(LQG_ERR_NULL, "%s: NULL pointer", who);
+  if (dtype != LQG_F32 && dtype != LQG_F64) return fail(LQG_ERR_ARG, "%s: bad dtype %d", who, dtype);
+  if (k < 1 || k > 6) return fail(LQG_ERR_DIMS, "%s: event dim %d not in [1,6]", who, k);
+  if (n_sys <= 0 || n_trials <= 0) return 0;
+  const dim3 grid(blocks_for(n_trials), (unsigned)n_sys), block(LQG_BLOCK);
+  hipStream_t st = (hipStream_t)stream;
+#define LP(R, KD)                                                                                           \
+  {                                                                                                         \
+    lqg::LogprobArgs<R> a{dt<R>(value), dt<R>(mu), dv<R>(Sigma), static_cast<R*>(out), (long)out_sb,        \
+                          (long)out_sn, (long)n_sys, (long)n_trials, T};                                    \
+    hipLaunchKernelGGL((lqg::k_gaussian_logprob<R, KD>), grid, block, 0, st, a);                            \
+  }
+#define LPK(KD)                 \
+  case KD:                      \
+    if (dtype == LQG_F64) LP(double, KD) else LP(float, KD) break;
+  switch (k) { LPK(1) LPK(2) LPK(3) LPK(4) LPK(5) LPK(6) }
+#undef LPK
+#undef LP
+  return done(hipGetLastError(), who);
+}
+
+}  // extern "C"

@@ -1,0 +1,150 @@
+// lqg_launch.hpp — host-side launchers: lqg_problem -> kernel argument structs -> hipLaunchKernelGGL.
+// One function template per kernel family; lqg_inst.hip instantiates them per (dtype, dims) in separate
+// translation units (parallel build), lqg_abi.hip dispatches to them.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/lqg_hip.h"
+#include "lqg_kernels.hpp"
+
+namespace lqg {
+namespace host {
+
+template <typename R>
+lqg::DView<R> dv(const lqg_view& v) {
+  return lqg::DView<R>{static_cast<const R*>(v.ptr), (long)v.sb, (long)v.st, (long)v.sr, (long)v.sc};
+}
+template <typename R>
+lqg::DTraj<R> dt(const lqg_traj& v) {
+  return lqg::DTraj<R>{static_cast<const R*>(v.ptr), (long)v.sb, (long)v.sn, (long)v.st, (long)v.sd};
+}
+
+inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
+inline unsigned blocks_for(long n) { return (unsigned)((n + LQG_BLOCK - 1) / LQG_BLOCK); }
+
+inline bool time_invariant(const lqg_view& v, int T) { return v.ptr == nullptr || v.st == 0 || T <= 1; }
+
+inline bool actor_ti_riccati(const lqg_problem* p) {
+  const lqg_spec& a = p->actor;
+  return time_invariant(a.Q, p->T) && time_invariant(a.q, p->T) && time_invariant(a.P, p->T) &&
+         time_invariant(a.R, p->T) && time_invariant(a.r, p->T) && time_invariant(a.A, p->T) &&
+         time_invariant(a.B, p->T);
+}
+inline bool actor_ti_kalman(const lqg_problem* p) {
+  const lqg_spec& a = p->actor;
+  return time_invariant(a.A, p->T) && time_invariant(a.F, p->T) && time_invariant(a.V, p->T) &&
+         time_invariant(a.W, p->T);
+}
+inline bool forward_ti(const lqg_problem* p) {
+  const lqg_spec& a = p->actor;
+  const lqg_spec& d = p->dynamics;
+  return actor_ti_kalman(p) && time_invariant(a.B, p->T) && time_invariant(d.A, p->T) &&
+         time_invariant(d.B, p->T) && time_invariant(d.F, p->T) && time_invariant(d.V, p->T) &&
+         time_invariant(d.W, p->T);
+}
+inline bool affine(const lqg_problem* p) {
+  const lqg_spec& a = p->actor;
+  return a.q.ptr || a.qf.ptr || a.P.ptr || a.r.ptr;
+}
+
+// ---------------------------------------------------------------- workspace carving
+struct Workspace {
+  size_t ls_off, ls_bytes, ops_off, ops_bytes, total;
+  long ldb;
+};
+inline size_t ops_reals(const lqg_dims& d) {
+  const size_t m = d.x + d.b, o = d.d, rr = m - o;
+  const size_t raw = m * m + rr * o + o * (o + 1) / 2 + 1;
+  return (raw + 3) / 4 * 4;
+}
+inline Workspace carve(const lqg_problem* p, bool need_ops) {
+  Workspace w{};
+  const size_t esz = p->dtype == LQG_F64 ? 8 : 4;
+  w.ldb = round_up(p->n_sys, 64);
+  w.ls_off = 0;
+  w.ls_bytes = (size_t)p->T * p->dims.u * p->dims.b * (size_t)w.ldb * esz;
+  w.ops_off = (w.ls_bytes + 255) / 256 * 256;
+  w.ops_bytes = need_ops ? (size_t)p->n_sys * (size_t)(p->T + 1) * ops_reals(p->dims) * esz : 0;
+  w.total = w.ops_off + (w.ops_bytes + 255) / 256 * 256;
+  return w;
+}
+
+// ---------------------------------------------------------------- launchers (one per kernel family)
+template <typename R, int NB, int NU>
+hipError_t launch_riccati(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view H, void* Ls, long ldb,
+                          hipStream_t st) {
+  const lqg_spec& a = p->actor;
+  lqg::RiccatiArgs<R> k{dv<R>(a.Q), dv<R>(a.q), dv<R>(a.Qf), dv<R>(a.qf), dv<R>(a.P), dv<R>(a.R), dv<R>(a.r),
+                        dv<R>(a.A), dv<R>(a.B), dv<R>(L), dv<R>(l), dv<R>(H), static_cast<R*>(Ls), ldb,
+                        (long)p->n_sys, p->T, (R)p->eps};
+  const dim3 grid(blocks_for(p->n_sys)), block(LQG_BLOCK);
+  const bool ti = actor_ti_riccati(p), af = affine(p);
+  if (ti && !af) hipLaunchKernelGGL((lqg::k_riccati<R, NB, NU, true, false>), grid, block, 0, st, k);
+  else if (ti && af) hipLaunchKernelGGL((lqg::k_riccati<R, NB, NU, true, true>), grid, block, 0, st, k);
+  else if (!ti && !af) hipLaunchKernelGGL((lqg::k_riccati<R, NB, NU, false, false>), grid, block, 0, st, k);
+  else hipLaunchKernelGGL((lqg::k_riccati<R, NB, NU, false, true>), grid, block, 0, st, k);
+  return hipGetLastError();
+}
+
+template <typename R, int NB, int NY>
+hipError_t launch_kalman(const lqg_problem* p, lqg_view K, hipStream_t st) {
+  const lqg_spec& a = p->actor;
+  lqg::KalmanArgs<R> k{dv<R>(a.A), dv<R>(a.F), dv<R>(a.V), dv<R>(a.W), dv<R>(p->Sigma0), dv<R>(K),
+                       (long)p->n_sys, p->T, p->dims.nva, p->dims.nwa};
+  const dim3 grid(blocks_for(p->n_sys)), block(LQG_BLOCK);
+  if (actor_ti_kalman(p)) hipLaunchKernelGGL((lqg::k_kalman<R, NB, NY, true>), grid, block, 0, st, k);
+  else hipLaunchKernelGGL((lqg::k_kalman<R, NB, NY, false>), grid, block, 0, st, k);
+  return hipGetLastError();
+}
+
+template <typename R, int NX, int NB, int NU, int NY, int ND>
+hipError_t launch_forward(const lqg_problem* p, const void* Ls, long ldb, bool fused, lqg_traj x, void* ll,
+                          long ll_sb, void* ops, lqg_view Sig, hipStream_t st) {
+  const lqg_spec& a = p->actor;
+  const lqg_spec& d = p->dynamics;
+  lqg::ForwardArgs<R> k{dv<R>(a.A), dv<R>(a.B), dv<R>(a.F), dv<R>(a.V), dv<R>(a.W),
+                        dv<R>(d.A), dv<R>(d.B), dv<R>(d.F), dv<R>(d.V), dv<R>(d.W),
+                        dv<R>(p->Sigma0), static_cast<const R*>(Ls), ldb, dt<R>(x), static_cast<R*>(ll), ll_sb,
+                        static_cast<R*>(ops), dv<R>(Sig), (long)p->n_sys, p->T,
+                        p->dims.nva, p->dims.nwa, p->dims.nvd, p->dims.nwd};
+  const dim3 grid(blocks_for(p->n_sys)), block(LQG_BLOCK);
+  const bool ti = forward_ti(p);
+  if (ti && fused) hipLaunchKernelGGL((lqg::k_forward<R, NX, NB, NU, NY, ND, true, true>), grid, block, 0, st, k);
+  else if (ti && !fused) hipLaunchKernelGGL((lqg::k_forward<R, NX, NB, NU, NY, ND, true, false>), grid, block, 0, st, k);
+  else if (!ti && fused) hipLaunchKernelGGL((lqg::k_forward<R, NX, NB, NU, NY, ND, false, true>), grid, block, 0, st, k);
+  else hipLaunchKernelGGL((lqg::k_forward<R, NX, NB, NU, NY, ND, false, false>), grid, block, 0, st, k);
+  return hipGetLastError();
+}
+
+#ifndef LQG_TRIALS_PER_LANE
+#define LQG_TRIALS_PER_LANE 2
+#endif
+template <typename R, int M, int ND>
+hipError_t launch_trial(const lqg_problem* p, const void* ops, lqg_traj x, lqg_traj mu, void* ll, long ll_sb,
+                        long ll_sn, hipStream_t st) {
+  lqg::TrialArgs<R> k{static_cast<const R*>(ops), dt<R>(x), dt<R>(mu), static_cast<R*>(ll), ll_sb, ll_sn,
+                      (long)p->n_trials, p->T};
+  constexpr int TPL = LQG_TRIALS_PER_LANE;
+  const long per_block = (long)LQG_BLOCK * TPL;
+  const dim3 grid((unsigned)((p->n_trials + per_block - 1) / per_block), (unsigned)p->n_sys), block(LQG_BLOCK);
+  hipLaunchKernelGGL((lqg::k_trial<R, M, ND, TPL>), grid, block, 0, st, k);
+  return hipGetLastError();
+}
+
+template <typename R, int NX, int NB, int NU, int NY>
+hipError_t launch_simulate(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view K, lqg_traj eps, lqg_traj eta,
+                           lqg_view x0, lqg_view xhat0, lqg_traj xs, lqg_traj xhat, lqg_traj ys, lqg_traj us,
+                           hipStream_t st) {
+  const lqg_spec& a = p->actor;
+  const lqg_spec& d = p->dynamics;
+  lqg::SimArgs<R> k{dv<R>(a.A), dv<R>(a.B), dv<R>(a.F), dv<R>(d.A), dv<R>(d.B), dv<R>(d.F), dv<R>(d.V), dv<R>(d.W),
+                    dv<R>(L), dv<R>(l), dv<R>(K), dt<R>(eps), dt<R>(eta), dv<R>(x0), dv<R>(xhat0),
+                    dt<R>(xs), dt<R>(xhat), dt<R>(ys), dt<R>(us), (long)p->n_sys, (long)p->n_trials, p->T,
+                    p->dims.nvd, p->dims.nwd};
+  const dim3 grid(blocks_for(p->n_sys * p->n_trials)), block(LQG_BLOCK);
+  hipLaunchKernelGGL((lqg::k_simulate<R, NX, NB, NU, NY>), grid, block, 0, st, k);
+  return hipGetLastError();
+}
+
+}  // namespace host
+}  // namespace lqg

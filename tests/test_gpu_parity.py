@@ -1,0 +1,101 @@
+"""-m gpu: the HIP path (through the C ABI) against the golden vectors produced by the reference's own
+source (tests/golden/, generator oracle/gen_golden.py).
+
+Tolerances: the kernels restructure the arithmetic (symmetric updates, Cholesky instead of
+LU, Schur-complement moment recursion), so agreement is to rounding, not bitwise.
+  fp64: log-likelihood 1e-10 rel; gains / moments 1e-9 rel (max-norm)
+  fp32: log-likelihood 1e-6 rel (north-star tolerance); gains / moments 2e-5 rel
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names, load_golden, relerr
+from gpu_common import np_, system_from_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float64: dict(ll=1e-10, mat=1e-9), torch.float32: dict(ll=1e-6, mat=2e-5)}
+# pointmass_d4: the observed 4x4 block has condition number ~1e12 (1e-3 process noise on velocity/activation),
+# the reference's own fp64 result is only reproducible to ~1e-10 and fp32 cannot represent it (the literal
+# fp32 oracle returns NaN).  fp64 is checked at a looser tolerance, fp32 only for finiteness of the gains.
+ILL = {"pointmass_d4_T50"}
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("name", golden_names())
+def test_golden(name, dtype):
+    from lqg_amd.belief import kf
+    from lqg_amd.control import lqr
+
+    g, actor, dyn = load_golden(name)
+    sys_ = system_from_golden(actor, dyn, dtype)
+    tol = dict(TOL[dtype])
+    if name in ILL:
+        tol = dict(ll=1e-7, mat=1e-6) if dtype == torch.float64 else None
+    S0 = torch.as_tensor(g["Sigma0"], dtype=dtype, device="cuda") if "Sigma0" in g else None
+
+    gains = lqr.backward(sys_.actor)
+    K = kf.forward(sys_.actor, S0)
+    assert gains.L.shape == g["L"].shape and gains.l.shape == g["l"].shape and gains.H.shape == g["H"].shape
+    assert K.shape == g["K"].shape
+    gt = TOL[dtype]["mat"]
+    assert relerr(np_(gains.L), g["L"]) < gt
+    assert relerr(np_(gains.H), g["H"]) < gt
+    assert relerr(np_(K), g["K"]) < gt
+    if np.abs(g["l"]).max() > 0:
+        assert relerr(np_(gains.l), g["l"]) < gt
+    else:
+        assert np.abs(np_(gains.l)).max() == 0.0
+    if tol is None:
+        return
+
+    x = torch.as_tensor(g["x"], dtype=dtype, device="cuda")
+    n, T1, d = x.shape
+    # single-trajectory conditional_moments (lqg/system.py:142-235)
+    mu0, Sig0 = sys_.conditional_moments(x[0], Sigma0=S0)
+    assert mu0.shape == g["mu"][0].shape and Sig0.shape == g["Sigma"][0].shape
+    assert relerr(np_(mu0), g["mu"][0]) < tol["mat"]
+    assert relerr(np_(Sig0), g["Sigma"][0]) < tol["mat"]
+    # log_likelihood: multi-trial (split) path and single-trial (fused) path
+    ll = sys_.log_likelihood(x, Sigma0=S0)
+    assert ll.shape == (n,)
+    assert np.abs(np_(ll) / g["ll"] - 1).max() < tol["ll"]
+    ll1 = sys_.log_likelihood(x[:1], Sigma0=S0)
+    assert np.abs(np_(ll1) / g["ll"][:1] - 1).max() < tol["ll"]
+    # conditional_distribution(x).log_prob(x[:, 1:]) is the same number (lqg/system.py:237-248)
+    dist = sys_.conditional_distribution(x, Sigma0=S0)
+    assert dist.shape() == (n, T1 - 1, d)
+    lp = dist.log_prob(x[:, 1:])
+    assert np.abs(np_(lp) / g["ll"] - 1).max() < max(tol["ll"], 5e-6 if dtype == torch.float32 else 0)
+    assert relerr(np_(dist.loc), g["mu"][:, :, :d]) < tol["mat"]
+    # belief_tracking_distribution (lqg/system.py:250-257)
+    bt = sys_.belief_tracking_distribution(x, Sigma0=S0)
+    xd = sys_.xdim
+    assert bt.shape() == (n, T1 - 1, sys_.bdim)
+    assert relerr(np_(bt.loc), g["mu"][:, :, xd:]) < tol["mat"]
+    assert relerr(np_(bt.covariance_matrix[0]), g["Sigma"][0][:, xd:, xd:]) < tol["mat"]
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("name", ["tutorial_lqg_T100", "subjective2d_T60", "timevarying_T30", "hand2d_T40"])
+def test_simulate_golden(name, dtype):
+    """lqg_simulate with the recorded normal draws reproduces System.simulate (lqg/system.py:62-140)."""
+    from lqg_amd import _hip
+    from lqg_amd.belief import kf
+    from lqg_amd.control import lqr
+
+    g, actor, dyn = load_golden(name)
+    sys_ = system_from_golden(actor, dyn, dtype)
+    S0 = torch.as_tensor(g["Sigma0"], dtype=dtype, device="cuda") if "Sigma0" in g else None
+    x0 = torch.as_tensor(g["x0"], dtype=dtype, device="cuda") if "x0" in g else None
+    gains = lqr.backward(sys_.actor)
+    K = kf.forward(sys_.actor, S0)
+    eps = torch.as_tensor(g["sim_eps"], dtype=dtype, device="cuda")
+    eta = torch.as_tensor(g["sim_eta"], dtype=dtype, device="cuda")
+    xs, xh, ys, us = _hip.simulate(sys_.actor, sys_.dynamics, gains.L, gains.l, K, eps, eta, x0=x0)
+    tol = 1e-9 if dtype == torch.float64 else 5e-4
+    assert relerr(np_(xs), g["sim_x"]) < tol
+    assert relerr(np_(xh), g["sim_xhat"]) < tol
+    assert relerr(np_(ys), g["sim_y"]) < tol
+    assert relerr(np_(us), g["sim_u"]) < tol
