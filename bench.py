@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""bench.py — LQG solves/sec (Riccati + Kalman + log-likelihood), n=6, T=500, on N MI355X.
+
+One "step" = one pass of the hot path (lqg_log_likelihood through the C ABI: k_riccati -> k_forward fused
+with the per-trial density) over one batch of B independent (candidate, trajectory) pairs per GPU; inputs are
+resident in HBM before the timed region.  Workload = BASELINE.json headline / config 5 shape:
+SubjectiveActor(dim=2) (x=4, b=6, u=2, y=4, d=4), T=500, synthetic candidates, trajectories
+simulated from the model.  Weak scaling: every rank owns B solves; the only collective is the all-reduce of
+the summed log-likelihood (the objective of lqg.infer / lqg.optim), issued once per step.
+
+    python bench.py [--gpus N --steps K --warmup W --log2-batch 18 --dtype f32|f64]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector == FP32 matrix (MFMA f32) peak
+PEAK_FP64_TFLOPS = 78.6    # datasheet FP64 vector == FP64 matrix peak
+PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_flops_per_step(x, b, u, y, d):
+    """flops of ONE time step of the reference's formulation (2mnk per matmul, no symmetry
+    exploitation, no hoisting) — the 'algorithmic' figure the roofline uses."""
+    m, o = x + b, d
+    ric = (4 * u * b * b + 2 * u * u * b + 2 * u * b + 10.67 * u ** 3 + 2 * u * u * (b + 1) + 4 * b ** 3
+           + 2 * u * u * b + 4 * u * b * b + 2 * b * b + 6 * u * b + 2 * u * u)
+    kal = 6 * b ** 3 + 2 * b ** 3 + 2 * y * b * b + 2 * y * y * b + 2 * y ** 3 + 2 * y ** 3 + 2 * b * y * y + 2 * b * b * y
+    joint = (2 * x * u * b + 2 * b * y * x + 2 * b * x * x + 2 * b * b * u + 2 * b * b * y + 2 * b ** 3 + 2 * y * x * u
+             + 2 * y * b * u + 2 * b * y * u + 2 * b * b * u + 2 * b * x * x + 2 * b * y * y)
+    sig = 4 * m ** 3 + 2 * m * m * (x + y) + o ** 3 / 3 + 2 * o * o * m + 2 * m * m * o
+    mean = 2 * m * m + 2 * m * o + o
+    lp = d ** 3 / 3 + d * d + 3 * d
+    return dict(riccati=ric, kalman=kal, joint=joint, sigma=sig, mean=mean, logprob=lp,
+                total=ric + kal + joint + sig + mean + lp)
+
+
+def algorithmic_bytes_per_solve(x, b, u, y, d, T, w):
+    """SURVEY.md §8(d) mode M1 (time-invariant specs in, one scalar out)."""
+    return w * ((T + 1) * d + (3 * b * b + b * u + y * b + y * y + u * u) + (2 * x * x + x * u + y * x + y * y) + 1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log2-batch", type=int, default=18, help="solves per GPU per step = 2**this")
+    ap.add_argument("--T", type=int, default=500)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--layout", default="packed", choices=["packed", "reference"],
+                    help="trajectory layout in HBM: packed = [T+1][d][B] (batch fastest), reference = [B][T+1][d]")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="solves in the CPU baseline sample (0 = auto)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import lqg_amd
+    from lqg_amd import _abi, _hip, _hipev, workload
+
+    dtype = torch.float32 if args.dtype == "f32" else torch.float64
+    w = 4 if args.dtype == "f32" else 8
+    B, T = 1 << args.log2_batch, args.T
+    lib = _abi.load()
+
+    # ---- synthetic workload, resident in HBM
+    system, params = workload.headline_system(B, T, seed=1234 + rank, device=dev, dtype=dtype)
+    dm = dict(x=system.xdim, b=system.bdim, u=system.udim, y=system.ydim, d=system.xdim)
+    x_ref = workload.simulate_one_trial_each(system, seed=99 + 7919 * rank)            # [B,1,T+1,d]
+    x = workload.pack_trials(x_ref) if args.layout == "packed" else x_ref
+    torch.cuda.synchronize()
+
+    ln = _hip.Launch(system.actor, system.dynamics, d=dm["d"], n_trials=1)
+    xb, _ = _hip._prep_x(ln, x)
+    ll = torch.empty((B, 1), dtype=dtype, device=dev)
+    nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+    ev = [_hipev.Event() for _ in range(4)]
+    for i in range(4):
+        ln.p.phase_events[i] = ev[i].h
+    xtraj = ln.traj(xb, True)
+    stream = ln.stream()
+    total = torch.zeros((), dtype=torch.float64, device=dev)
+
+    def step():
+        _abi.check(lib.lqg_log_likelihood(C.byref(ln.p), xtraj, C.c_void_p(ll.data_ptr()), 1, 1,
+                                          C.c_void_p(ws.data_ptr()), nbytes, stream), "lqg_log_likelihood")
+        s = _hip.sum_trials(ll.view(1, B))                 # objective = sum of log-likelihoods (fp64)
+        if dist is not None:
+            dist.all_reduce(s)                             # the one collective of the path (RCCL over xGMI)
+        return s
+
+    for _ in range(args.warmup):
+        total = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ric_ms, fwd_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        total = step()
+        ev[2].synchronize()                                # events are re-recorded every step: read them now
+        ric_ms.append(ev[0].elapsed_ms(ev[1]))
+        fwd_ms.append(ev[1].elapsed_ms(ev[2]))
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    ll_host = ll[:, 0].double().cpu().numpy()
+    finite = bool(np.isfinite(ll_host).all())
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    solves = float(B) * world * args.steps
+    value = solves / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+    fl = algorithmic_flops_per_step(**dm)
+    flops_solve = fl["total"] * T
+    bytes_solve = algorithmic_bytes_per_solve(T=T, w=w, **dm)
+    fwd_avg_ms = float(np.mean(fwd_ms))
+    ric_avg_ms = float(np.mean(ric_ms))
+    peak = PEAK_FP32_TFLOPS if args.dtype == "f32" else PEAK_FP64_TFLOPS
+    # dominant kernel = k_forward: Kalman + joint + Sigma recursion + mean + log-density for B solves per launch
+    fwd_flops_launch = (fl["total"] - fl["riccati"]) * T * B
+    achieved_tflops = fwd_flops_launch / (fwd_avg_ms * 1e-3) / 1e12
+    hbm_gbs = bytes_solve * B / ((fwd_avg_ms + ric_avg_ms) * 1e-3) / 1e9
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            pj = json.load(open(pmc_path))
+            key = f"k_forward_{args.dtype}_log2B{args.log2_batch}"
+            traffic = pj.get(key, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    # ---- parity spot check against the CPU oracle (not timed)
+    parity = None
+    cpu = None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as OC
+        OC.build()
+        ns = 64
+        idx = np.linspace(0, B - 1, ns).astype(np.int64)
+        sub = workload.slice_system  # noqa
+        actor_np = {f: getattr(system.actor, f) for f in lqg_amd.LQGSpec._fields}
+        dyn_np = {f: getattr(system.dynamics, f) for f in lqg_amd.LQGSpec._fields}
+
+        def host(spec_t, sel):
+            out = {}
+            for f, t in spec_t.items():
+                nd = workload._batched_ndim(f)
+                tt = t[torch.as_tensor(sel, device=t.device)] if t.dim() == nd else t.expand(len(sel), *t.shape)
+                out[f] = tt.double().cpu().numpy()
+            return out
+
+        a64, d64 = host(actor_np, idx), host(dyn_np, idx)
+        x64 = x_ref[torch.as_tensor(idx, device=dev)].double().cpu().numpy()
+        ref = OC.log_likelihood(a64, d64, x64, dtype=np.float64)[:, 0]
+        got = ll_host[idx]
+        parity = dict(samples=int(ns), max_rel_err_vs_fp64_oracle=float(np.abs(got / ref - 1).max()))
+        if not args.no_cpu_baseline and world == 1:
+            ncpu = os.cpu_count() or 1
+            OC.lib().lqg_oracle_set_threads(ncpu)
+            np_dt = np.float32 if args.dtype == "f32" else np.float64
+            nsamp = args.cpu_sample or 1024
+            sel = np.arange(nsamp) % B
+            a_s, d_s = host(actor_np, sel), host(dyn_np, sel)
+            a_s = {k: v.astype(np_dt) for k, v in a_s.items()}
+            d_s = {k: v.astype(np_dt) for k, v in d_s.items()}
+            x_s = x_ref[torch.as_tensor(sel, device=dev)].cpu().numpy().astype(np_dt)
+            OC.log_likelihood({k: v[:8] for k, v in a_s.items()}, {k: v[:8] for k, v in d_s.items()}, x_s[:8], dtype=np_dt)
+            tc = time.perf_counter()
+            OC.log_likelihood(a_s, d_s, x_s, dtype=np_dt)
+            tc1 = time.perf_counter() - tc
+            # scale the sample so that the CPU leg does ~10-20 s of work
+            if tc1 < 8.0 and not args.cpu_sample:
+                rep = int(min(32, max(1, 12.0 / max(tc1, 1e-3))))
+                tc = time.perf_counter()
+                for _ in range(rep):
+                    OC.log_likelihood(a_s, d_s, x_s, dtype=np_dt)
+                tc1 = (time.perf_counter() - tc) / rep
+                nrep = rep
+            else:
+                nrep = 1
+            model = ""
+            try:
+                for line in open("/proc/cpuinfo"):
+                    if line.startswith("model name"):
+                        model = line.split(":", 1)[1].strip()
+                        break
+            except OSError:
+                pass
+            cpu = dict(value=nsamp / tc1, unit="solves/s", cores=OC.lib().lqg_oracle_max_threads(), kind="port",
+                       sample=f"{nsamp} solves of the same workload ({args.dtype}, T={T}) x {nrep} repetitions, "
+                              f"oracle/lqg_oracle.c with OpenMP over systems", cpu_model=model,
+                       host_cpu_count=ncpu)
+    except Exception as e:  # the oracle is a checker: its absence must not break the measurement
+        parity = dict(error=repr(e))
+
+    out = {
+        "metric": "LQG solves/sec (Riccati+Kalman+loglik), n=6 T=500",
+        "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"SubjectiveActor(dim=2) x=4 b=6 u=2 y=4 d=4, T={T}, {B} independent "
+                               f"(candidate, trajectory) solves per GPU per step (BASELINE config 5 / headline shape)",
+                   "solves_per_gpu": B, "T": T, "trajectory_layout": args.layout,
+                   "parallelism": f"candidate-sharded x{world}, all-reduce of the summed log-likelihood"},
+        "roofline": {"bound": "valu", "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s",
+                     "frac": achieved_tflops / peak, "traffic": traffic,
+                     "kernel": "k_forward (Kalman + joint system + Sigma recursion + mean + log-density)",
+                     "kernel_ms": fwd_avg_ms, "riccati_kernel_ms": ric_avg_ms,
+                     "algorithmic_flops_per_solve": flops_solve, "algorithmic_bytes_per_solve": bytes_solve,
+                     "note": "VALU-bound (fp32 vector peak == f32 MFMA peak on gfx950); algorithmic flops = "
+                             "SURVEY.md §8(d) op count of the reference formulation; MFMA deliberately unused",
+                     "hbm": {"achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_gbs / PEAK_HBM_GBS}},
+        "cpu_baseline": cpu, "parity": parity, "all_finite": finite,
+        "objective_sum": float(total.item()),
+    }
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -90,6 +90,10 @@ typedef struct lqg_problem {
   lqg_view Sigma0;     /* [b,b] initial belief covariance for the Kalman sweep; ptr NULL =
                           actor.V[0] actor.V[0]^T (lqg/system.py:79,160)          */
   double   eps;        /* eigenvalue floor of lqr.backward (lqg/control/lqr.py:16, default 1e-8) */
+  void*    phase_events[4]; /* optional profiling: caller-created hipEvent_t handles (or NULL) that
+                          lqg_log_likelihood / lqg_conditional_moments record on `stream`
+                          [0] before the Riccati sweep, [1] after it, [2] after the forward sweep,
+                          [3] after the per-trial sweep.  The library only records; the caller reads them. */
 } lqg_problem;
 
 int lqg_abi_version(void);

@@ -35,7 +35,8 @@ class Dims(C.Structure):
 
 class Problem(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("T", C.c_int32), ("n_sys", C.c_int64), ("n_trials", C.c_int64),
-                ("dims", Dims), ("actor", Spec), ("dynamics", Spec), ("Sigma0", View), ("eps", C.c_double)]
+                ("dims", Dims), ("actor", Spec), ("dynamics", Spec), ("Sigma0", View), ("eps", C.c_double),
+                ("phase_events", C.c_void_p * 4)]
 
 
 NULL_VIEW = View(None, 0, 0, 0, 0)

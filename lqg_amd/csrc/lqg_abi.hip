@@ -185,16 +185,23 @@ int run_moments(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_view Sigma, v
   void* ops = fused ? nullptr : base + w.ops_off;
   bool found;
   const lqg_view none{nullptr, 0, 0, 0, 0};
+  auto mark = [&](int i) {
+    if (p->phase_events[i]) (void)hipEventRecord(static_cast<hipEvent_t>(p->phase_events[i]), st);
+  };
+  mark(0);
   hipError_t e = dispatch_riccati<R>(p, none, none, none, Ls, w.ldb, st, &found);
   if (!found) return unsupported(p, who);
   if (e != hipSuccess) return done(e, who);
+  mark(1);
   e = dispatch_forward<R>(p, Ls, w.ldb, fused, x, ll, ll_sb, ops, Sigma, st, &found);
   if (!found) return unsupported(p, who);
   if (e != hipSuccess) return done(e, who);
+  mark(2);
   if (!fused && p->n_trials > 0 && (ll || mu.ptr)) {
     e = dispatch_trial<R>(p, ops, x, mu, ll, ll_sb, ll_sn, st, &found);
     if (!found) return unsupported(p, who);
   }
+  mark(3);
   return done(e, who);
 }
 
