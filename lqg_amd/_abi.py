@@ -51,8 +51,8 @@ _lib = None
 
 
 def declare(lib, prefix="lqg_", with_stream=True):
-    """Attach argtypes/restype for the entry points of include/lqg_hip.h (also used for the oracle's
-    host twins `lqg_oracle_*`, which drop the workspace/stream arguments)."""
+    """Attach argtypes/restype for the entry points of include/lqg_hip.h.  `prefix` / `with_stream` let a
+    test harness bind host-side twins of the same signatures (without workspace / stream arguments)."""
     P = C.POINTER(Problem)
     tail = [C.c_void_p] if with_stream else []
     ws = [C.c_void_p, C.c_size_t] if with_stream else []

@@ -1,0 +1,132 @@
+"""CPU: the C-ABI library loads without a GPU, exports every symbol include/lqg_hip.h declares, its structs
+have the layout the ctypes mirror assumes, and the host side fails loudly instead of falling back."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+from lqg_amd import _abi
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from lqg_amd import build
+    build.build(verbose=False)
+    return _abi.load()
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "lqg_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lqg_[a-z_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(lib):
+    names = declared_functions()
+    assert {"lqg_log_likelihood", "lqg_riccati_backward", "lqg_kalman_forward", "lqg_conditional_moments",
+            "lqg_simulate", "lqg_sum_trials", "lqg_gaussian_logprob", "lqg_workspace_bytes"} <= set(names)
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_abi_version_and_target(lib):
+    assert lib.lqg_abi_version() == _abi.ABI_VERSION
+    assert lib.lqg_target_arch() == b"gfx950"
+
+
+def test_struct_layout_matches_header():
+    """Compile a probe against the real header and compare sizeof/offsetof with the ctypes mirror."""
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "lqg_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu ", sizeof(lqg_view), sizeof(lqg_traj), sizeof(lqg_spec), sizeof(lqg_dims), sizeof(lqg_problem));
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", offsetof(lqg_problem, n_sys), offsetof(lqg_problem, dims),
+         offsetof(lqg_problem, actor), offsetof(lqg_problem, dynamics), offsetof(lqg_problem, Sigma0),
+         offsetof(lqg_problem, eps), offsetof(lqg_problem, phase_events));
+  return 0;
+}'''
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "probe.c")
+        open(c, "w").write(src)
+        exe = os.path.join(td, "probe")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        got = [int(v) for v in subprocess.check_output([exe]).split()]
+    P = _abi.Problem
+    want = [C.sizeof(_abi.View), C.sizeof(_abi.Traj), C.sizeof(_abi.Spec), C.sizeof(_abi.Dims), C.sizeof(P),
+            P.n_sys.offset, P.dims.offset, P.actor.offset, P.dynamics.offset, P.Sigma0.offset, P.eps.offset,
+            P.phase_events.offset]
+    assert got == want
+
+
+def test_argument_errors_do_not_launch(lib):
+    nv = _abi.NULL_VIEW
+    assert lib.lqg_riccati_backward(None, nv, nv, nv, None) == -1
+    assert b"NULL" in lib.lqg_last_error()
+    p = _abi.Problem()
+    p.dtype, p.T, p.n_sys, p.n_trials = 7, 10, 1, 1
+    assert lib.lqg_kalman_forward(C.byref(p), nv, None) == -3          # bad dtype
+    p.dtype, p.T = _abi.F32, 0
+    assert lib.lqg_kalman_forward(C.byref(p), nv, None) == -3          # T < 1
+    p.T = 10
+    p.dims = _abi.Dims(2, 2, 1, 2, 2, 2, 2, 2, 2)
+    assert lib.lqg_kalman_forward(C.byref(p), nv, None) == -1          # missing spec pointers
+    assert b"actor.A" in lib.lqg_last_error()
+
+
+def test_dims_supported_lists_the_baseline_configs(lib):
+    ok = [(2, 2, 1, 2, 2), (2, 2, 1, 1, 2), (2, 3, 1, 2, 2), (4, 6, 2, 4, 4), (4, 4, 1, 3, 2), (4, 4, 1, 3, 4),
+          (4, 4, 2, 4, 4), (10, 10, 2, 4, 4)]
+    for x, b, u, y, d in ok:
+        dm = _abi.Dims(x, b, u, y, d, b, y, x, y)
+        assert lib.lqg_dims_supported(_abi.F32, C.byref(dm)) == 1
+        assert lib.lqg_dims_supported(_abi.F64, C.byref(dm)) == 1
+    dm = _abi.Dims(3, 7, 2, 4, 3, 7, 4, 3, 4)
+    assert lib.lqg_dims_supported(_abi.F32, C.byref(dm)) == 0
+
+
+def test_workspace_size_formula(lib):
+    from lqg_amd import _hip
+    import lqg_amd
+    m = lqg_amd.SubjectiveActor(dim=2, T=500, sigma_target=torch.linspace(1, 2, 100), device="cpu")
+    ln = _hip.Launch(m.actor, m.dynamics, d=4, n_trials=1)
+    fused = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
+    assert fused == 500 * 2 * 6 * 128 * 4                               # gain scratch [T][u*b][B padded to 64]
+    ln2 = _hip.Launch(m.actor, m.dynamics, d=4, n_trials=16)
+    split = lib.lqg_workspace_bytes(C.byref(ln2.p), _abi.OP_LOG_LIKELIHOOD)
+    ops = (100 + 24 + 10 + 1 + 3) // 4 * 4
+    assert ops == 136 and split == fused + (100 * 501 * ops * 4 + 255) // 256 * 256
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly when it cannot run on the GPU."""
+    import lqg_amd
+    from lqg_amd.control import lqr
+    m = lqg_amd.BoundedActor(T=20, device="cpu")
+    x = torch.zeros(3, 21, 2)
+    with pytest.raises(_abi.LqgHipError, match="no CPU fallback"):
+        m.log_likelihood(x)
+    with pytest.raises(_abi.LqgHipError, match="no CPU fallback"):
+        lqr.backward(m.actor)
+
+
+def test_product_does_not_import_the_oracle():
+    """oracle/ is test infrastructure: nothing under lqg_amd/ may reference it."""
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(ROOT, "lqg_amd")):
+        if "build" in dp.split(os.sep)[-1:]:
+            continue
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".def")):
+                t = open(os.path.join(dp, f)).read()
+                if re.search(r"(import\s+oracle|from\s+oracle|lqg_np|lqg_oracle|jax_standin)", t):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad

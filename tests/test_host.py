@@ -1,0 +1,93 @@
+"""CPU: host-side mirror of the reference's interface — shapes, views, strides, model constructors."""
+import numpy as np
+import pytest
+import torch
+
+import lqg_amd
+from lqg_amd import _abi, _hip, workload
+from lqg_amd.utils import time_stack_spec
+from conftest import load_golden
+
+
+def test_time_stack_spec_matches_reference_shapes_without_copies():
+    """lqg/utils.py:10-35: same shapes/values, but the T copies are a stride-0 view."""
+    A, B = torch.eye(3), torch.ones(3, 1)
+    F, V, W = torch.ones(2, 3), torch.eye(3), torch.eye(2)
+    Q, R = torch.eye(3), torch.eye(1)
+    s = time_stack_spec(A, B, F, V, W, Q, R, T=7)
+    assert s.A.shape == (7, 3, 3) and s.B.shape == (7, 3, 1) and s.F.shape == (7, 2, 3)
+    assert s.q.shape == (7, 3) and s.P.shape == (7, 1, 3) and s.r.shape == (7, 1)
+    assert s.Qf.shape == (3, 3) and s.qf.shape == (3,)
+    assert s.A.stride(0) == 0 and float(s.q.abs().sum()) == 0.0
+    assert tuple(lqg_amd.LQGSpec._fields) == ("Q", "q", "Qf", "qf", "P", "R", "r", "A", "B", "V", "F", "W")
+
+
+@pytest.mark.parametrize("name,ctor,kw,d", [
+    ("bounded_T100", lqg_amd.BoundedActor, dict(T=100, sigma_target=6.0, sigma_cursor=1.0, action_cost=0.05,
+                                                action_variability=0.5), 2),
+    ("optimal_T30", lqg_amd.OptimalActor, dict(T=30), 2),
+    ("relobs_T40", lqg_amd.RelativeObservationBoundedActor, dict(T=40), 2),
+    ("subjective1d_T50", lqg_amd.SubjectiveActor, dict(dim=1, T=50), 2),
+    ("subjective2d_T60", lqg_amd.SubjectiveActor, dict(dim=2, T=60, action_cost=0.5, sigma_cursor=3.0,
+                                                       subj_noise=1.3, subj_vel_noise=0.7), 4),
+    ("bounded2d_T40", lqg_amd.BoundedActor, dict(dim=2, T=40, action_cost=0.2), 4),
+    ("pointmass_d2_T50", lqg_amd.PointMassBoundedActor, dict(T=50, action_variability=0.5), 2),
+])
+def test_model_zoo_builds_the_reference_matrices(name, ctor, kw, d):
+    """Constructors reproduce the matrices the reference built (stored in the golden files)."""
+    g, actor, dyn = load_golden(name)
+    m = ctor(device="cpu", dtype=torch.float64, **kw)
+    for f in lqg_amd.LQGSpec._fields:
+        a, dd = getattr(m.actor, f).numpy(), getattr(m.dynamics, f).numpy()
+        assert a.shape == actor[f].shape, f
+        assert np.allclose(a, actor[f], atol=1e-9, rtol=1e-9), f
+        assert np.allclose(dd, dyn[f], atol=1e-9, rtol=1e-9), f
+    assert (m.xdim, m.bdim, m.udim, m.ydim, m.T) == (dyn["A"].shape[1], actor["A"].shape[1], dyn["B"].shape[2],
+                                                     dyn["F"].shape[1], actor["A"].shape[0])
+
+
+def test_candidate_axis_builds_batched_specs():
+    sig = torch.linspace(5.0, 50.0, 7)
+    m = lqg_amd.BoundedActor(sigma_target=sig, T=30, device="cpu")
+    assert m.n_systems == 7 and m.actor.W.shape == (7, 30, 2, 2) and m.actor.W.stride(1) == 0
+    assert torch.allclose(m.actor.W[:, 0, 0, 0], sig)
+    one = lqg_amd.BoundedActor(sigma_target=float(sig[3]), T=30, device="cpu")
+    assert torch.allclose(m.actor.W[3], one.actor.W)
+
+
+def test_launch_views_and_dims():
+    m = lqg_amd.SubjectiveActor(dim=2, T=50, sigma_target=torch.tensor([3.0, 4.0, 5.0]), device="cpu")
+    ln = _hip.Launch(m.actor, m.dynamics, d=4, n_trials=9)
+    p = ln.p
+    assert (p.n_sys, p.n_trials, p.T, p.dtype) == (3, 9, 50, _abi.F32)
+    dm = p.dims
+    assert (dm.x, dm.b, dm.u, dm.y, dm.d, dm.nva, dm.nwa, dm.nvd, dm.nwd) == (4, 6, 2, 4, 4, 6, 4, 4, 4)
+    assert p.actor.A.st == 0 and p.actor.A.sb == 36 and p.actor.A.sr == 6 and p.actor.A.sc == 1
+    assert p.actor.q.ptr is None and p.actor.P.ptr is None          # known-zero affine terms -> NULL
+    assert p.dynamics.Q.ptr is None                                  # dynamics cost is never read
+    assert p.Sigma0.ptr is None
+    x = torch.zeros(9, 51, 4)
+    xx, xb = _hip._prep_x(ln, x)
+    tv = ln.traj(xx, xb)
+    assert (tv.sb, tv.sn, tv.st, tv.sd) == (0, 51 * 4, 4, 1)        # shared trials: system stride 0
+    xp = workload.pack_trials(x)
+    assert xp.shape == x.shape and torch.equal(xp, x)
+    tv = ln.traj(xp, False)
+    assert (tv.sn, tv.st, tv.sd) == (1, 4 * 9, 9)                   # trial index fastest in memory
+
+
+def test_wrong_trajectory_length_is_rejected():
+    m = lqg_amd.BoundedActor(T=20, device="cpu")
+    ln = _hip.Launch(m.actor, m.dynamics, d=2, n_trials=3)
+    with pytest.raises(_abi.LqgHipError, match="T\\+1"):
+        _hip._prep_x(ln, torch.zeros(3, 20, 2))
+
+
+def test_workload_generators_are_seeded():
+    a, pa = workload.headline_system(16, 10, seed=3, device="cpu", dtype=torch.float64)
+    b, pb = workload.headline_system(16, 10, seed=3, device="cpu", dtype=torch.float64)
+    c, pc = workload.headline_system(16, 10, seed=4, device="cpu", dtype=torch.float64)
+    assert all(torch.equal(pa[k], pb[k]) for k in pa) and not torch.equal(pa["sigma_target"], pc["sigma_target"])
+    for k, (lo, hi) in workload.RANGES.items():
+        assert float(pa[k].min()) >= lo and float(pa[k].max()) <= hi
+    assert (a.xdim, a.bdim, a.udim, a.ydim, a.n_systems) == (4, 6, 2, 4, 16)
