@@ -11,7 +11,8 @@ F32, F64 = 0, 1
 OP_LOG_LIKELIHOOD, OP_CONDITIONAL_MOMENTS = 0, 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblqg_hip.so")
+# LQG_HIP_LIB selects a variant build of the same library (developer A/B kernel experiments); never a fallback
+LIB_PATH = os.environ.get("LQG_HIP_LIB") or os.path.join(_HERE, "csrc", "liblqg_hip.so")
 
 
 class View(C.Structure):

@@ -18,7 +18,10 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "liblqg_hip.so")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
+# -fno-slp-vectorize: hipcc otherwise packs pairs of scalar f32 FMAs into v_pk_fma_f32, which on gfx950 issues at
+# half the instruction rate (no flop gain) and costs ~450 v_mov per step of operand shuffling plus ~300 extra
+# live registers in k_forward (measured: 42.5 ms -> 12.3 ms per 2^18 solves, profiles/README.md).
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-slp-vectorize"]
 HEADERS = ["lqg_small.hpp", "lqg_kernels.hpp", "lqg_launch.hpp", "lqg_dims.def", "../../include/lqg_hip.h"]
 
 
@@ -69,6 +72,36 @@ def _compile(job):
     return name, r.returncode, r.stderr
 
 
+def build_variant(out, extra_flags=(), only=None, objdir=None, workers=None, verbose=True):
+    """Developer tool: build a VARIANT library `out` with extra compile flags, recompiling only the
+    translation units whose object name contains one of `only` (others are reused from the main build).
+    Used for A/B kernel experiments on the GPU box (select with LQG_HIP_LIB=<out>)."""
+    objdir = objdir or (out + ".obj")
+    os.makedirs(objdir, exist_ok=True)
+    sel = [j for j in jobs() if only is None or any(o in j[0] for o in only)]
+
+    def comp(job):
+        name, src, defs = job
+        o = os.path.join(objdir, name)
+        r = subprocess.run([HIPCC] + FLAGS + list(extra_flags) + defs + ["-c", os.path.join(CSRC, src), "-o", o],
+                           capture_output=True, text=True)
+        return name, r.returncode, r.stderr
+
+    with cf.ThreadPoolExecutor(workers or min(8, os.cpu_count() or 1)) as ex:
+        for name, rc, err in ex.map(comp, sel):
+            if rc != 0:
+                raise RuntimeError(f"hipcc failed on {name}:\n{err}")
+            if verbose:
+                print(f"[lqg_amd.build]   variant {name}", flush=True)
+    chosen = {j[0] for j in sel}
+    objs = [os.path.join(objdir if j[0] in chosen else OBJ, j[0]) for j in jobs()]
+    r = subprocess.run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs, capture_output=True,
+                       text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stderr)
+    return out
+
+
 def build(force=False, workers=None, verbose=True):
     if not force and up_to_date():
         if verbose:
@@ -108,5 +141,11 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("-j", type=int, default=None)
     ap.add_argument("--force", action="store_true")
+    ap.add_argument("--variant", default=None, help="output path of a variant library (developer A/B builds)")
+    ap.add_argument("--only", default=None, help="comma-separated object-name substrings to recompile")
+    ap.add_argument("--flags", default="", help="extra hipcc flags for the variant")
     a = ap.parse_args()
-    build(force=a.force, workers=a.j)
+    if a.variant:
+        build_variant(a.variant, a.flags.split(), a.only.split(",") if a.only else None, workers=a.j)
+    else:
+        build(force=a.force, workers=a.j)

@@ -29,6 +29,13 @@
 #ifndef LQG_BLOCK
 #define LQG_BLOCK 64
 #endif
+// minimum waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument)
+#ifndef LQG_FWD_WAVES
+#define LQG_FWD_WAVES 1
+#endif
+#ifndef LQG_RIC_WAVES
+#define LQG_RIC_WAVES 1
+#endif
 
 namespace lqg {
 
@@ -57,7 +64,7 @@ struct RiccatiArgs {
 };
 
 template <typename R, int NB, int NU, bool TI, bool AFFINE>
-__global__ void __launch_bounds__(LQG_BLOCK) k_riccati(const RiccatiArgs<R> a) {
+__global__ void __launch_bounds__(LQG_BLOCK, LQG_RIC_WAVES) k_riccati(const RiccatiArgs<R> a) {
   const long s = blockIdx.x * (long)LQG_BLOCK + threadIdx.x;
   if (s >= a.n_sys) return;
 
@@ -261,7 +268,7 @@ struct ForwardArgs {
 };
 
 template <typename R, int NX, int NB, int NU, int NY, int ND, bool TI, bool FUSED>
-__global__ void __launch_bounds__(LQG_BLOCK) k_forward(const ForwardArgs<R> a) {
+__global__ void __launch_bounds__(LQG_BLOCK, LQG_FWD_WAVES) k_forward(const ForwardArgs<R> a) {
   constexpr int M = NX + NB, O = ND, RR = M - ND;
   using Ops = TrialOps<M, ND>;
   const long s = blockIdx.x * (long)LQG_BLOCK + threadIdx.x;

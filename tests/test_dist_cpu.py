@@ -1,0 +1,81 @@
+"""CPU, world_size 2, gloo: the multi-GPU sharding logic (trial-sharded objective with one all-reduce;
+candidate-sharded evaluation with one all-gather).  The per-rank evaluation is injected with the CPU oracle —
+on the GPU box the same functions run the HIP path per rank (bench.py --gpus N)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_golden
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle as OC
+    from lqg_amd import dist as ld
+
+    g, actor, dyn = load_golden("subjective1d_T50")
+    x = np.concatenate([g["x"], g["x"][::-1] * 0.9, g["x"] * 1.1])           # 9 trials
+    # three candidates: scale the observation noise
+    scales = np.array([1.0, 1.5, 2.0])
+    ab = {k: np.broadcast_to(v, (3,) + v.shape) for k, v in actor.items()}
+    db = {k: np.broadcast_to(v, (3,) + v.shape) for k, v in dyn.items()}
+    ab["W"] = np.ascontiguousarray(ab["W"]) * scales[:, None, None, None]
+    db["W"] = np.ascontiguousarray(db["W"]) * scales[:, None, None, None]
+
+    def local_sum(system, x_local, Sigma0):
+        if x_local.shape[0] == 0:
+            return torch.zeros(3, dtype=torch.float64)
+        xl = np.broadcast_to(x_local.numpy(), (3,) + tuple(x_local.shape))
+        return torch.from_numpy(OC.log_likelihood(ab, db, xl).sum(-1))
+
+    xt = torch.from_numpy(x)
+    mine = ld.shard_trials(xt)
+    total = ld.log_likelihood_sum(None, mine, local_sum=local_sum)
+    full = OC.log_likelihood(ab, db, np.broadcast_to(x, (3,) + x.shape)).sum(-1)
+    assert np.allclose(total.numpy(), full, rtol=1e-12), (total, full)
+
+    # candidate sharding: each rank scores its block of candidates on all trials, then all-gather
+    lo, hi = ld.shard_bounds(3, rank, world)
+    a_loc = {k: v[lo:hi] for k, v in ab.items()}
+    d_loc = {k: v[lo:hi] for k, v in db.items()}
+    loc = OC.log_likelihood(a_loc, d_loc, np.broadcast_to(x, (hi - lo,) + x.shape)).sum(-1) if hi > lo else np.zeros(0)
+    allv = ld.gather_candidates(torch.from_numpy(np.ascontiguousarray(loc)), 3)
+    assert np.allclose(allv.numpy(), full, rtol=1e-12)
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), total.numpy())
+    dist.destroy_process_group()
+
+
+def test_shard_bounds_cover_everything():
+    from lqg_amd.dist import shard_bounds
+    for n in (0, 1, 7, 8, 1024, 1067):
+        for w in (1, 2, 3, 8):
+            blocks = [shard_bounds(n, r, w) for r in range(w)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_trial_and_candidate_sharding_world2(tmp_path, oracle_lib):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "r0.npy"), np.load(tmp_path / "r1.npy")
+    assert np.array_equal(r0, r1)            # identical on every rank after the all-reduce
