@@ -494,7 +494,6 @@ __global__ void __launch_bounds__(LQG_BLOCK, LQG_FWD_WAVES) k_forward(const Forw
 // ===================================================================== per-trial sweep ===============
 template <typename R>
 struct TrialArgs {
-  const R* ops;       // [n_sys][T+1][TrialOps::N]
   DTraj<R> x;         // observed data
   DTraj<R> mu;        // optional output mu[B,N,T,m]
   R* ll;              // optional output
@@ -503,15 +502,17 @@ struct TrialArgs {
   int T;
 };
 
-// grid.x covers trials (LQG_BLOCK * TPL per block), grid.y = system.  The operator stream of the
-// block's system is addressed uniformly (scalar loads); x is read with one trial per lane.
+// grid.x covers trials (LQG_BLOCK * TPL per block), grid.y = system.  The operator stream of the block's system is
+// wave-uniform: `ops_all` is a direct `const __restrict__` kernel argument so that the compiler can prove the loads
+// read-only and issue them as SCALAR loads (s_load_dwordx*, operands consumed straight from SGPRs); x is read with
+// one trial per lane.
 template <typename R, int M, int ND, int TPL>
-__global__ void __launch_bounds__(LQG_BLOCK) k_trial(const TrialArgs<R> a) {
+__global__ void __launch_bounds__(LQG_BLOCK) k_trial(const R* __restrict__ ops_all, const TrialArgs<R> a) {
   constexpr int O = ND, RR = M - ND;
   using Ops = TrialOps<M, ND>;
   const long sys = blockIdx.y;
   const long n0 = (long)blockIdx.x * (LQG_BLOCK * TPL) + threadIdx.x;
-  const R* __restrict__ ops = a.ops + sys * (long)(a.T + 1) * Ops::N;
+  const R* __restrict__ ops = ops_all + sys * (long)(a.T + 1) * Ops::N;
   const R* xp[TPL];
   bool live[TPL];
   R muO[TPL][O], muR[TPL][RR];

@@ -117,17 +117,16 @@ hipError_t launch_forward(const lqg_problem* p, const void* Ls, long ldb, bool f
 }
 
 #ifndef LQG_TRIALS_PER_LANE
-#define LQG_TRIALS_PER_LANE 2
+#define LQG_TRIALS_PER_LANE 4
 #endif
 template <typename R, int M, int ND>
 hipError_t launch_trial(const lqg_problem* p, const void* ops, lqg_traj x, lqg_traj mu, void* ll, long ll_sb,
                         long ll_sn, hipStream_t st) {
-  lqg::TrialArgs<R> k{static_cast<const R*>(ops), dt<R>(x), dt<R>(mu), static_cast<R*>(ll), ll_sb, ll_sn,
-                      (long)p->n_trials, p->T};
+  lqg::TrialArgs<R> k{dt<R>(x), dt<R>(mu), static_cast<R*>(ll), ll_sb, ll_sn, (long)p->n_trials, p->T};
   constexpr int TPL = LQG_TRIALS_PER_LANE;
   const long per_block = (long)LQG_BLOCK * TPL;
   const dim3 grid((unsigned)((p->n_trials + per_block - 1) / per_block), (unsigned)p->n_sys), block(LQG_BLOCK);
-  hipLaunchKernelGGL((lqg::k_trial<R, M, ND, TPL>), grid, block, 0, st, k);
+  hipLaunchKernelGGL((lqg::k_trial<R, M, ND, TPL>), grid, block, 0, st, static_cast<const R*>(ops), k);
   return hipGetLastError();
 }
 
