@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""bench_m2.py — measurement mode M2 of SURVEY.md §8(d): the reference's LITERAL data model.
+
+Genuinely time-varying (T, ...)-stacked specs in, every intermediate the reference materialises out
+(L, H from lqr.backward; K from kf.forward; mu, Sigma from conditional_moments).  This is the HBM-bound regime
+(≈8.5 FLOP/B at n=6): algorithmic bytes per solve = inputs once + outputs once (SURVEY.md §8d formula, 824 kB at
+n=6, T=500, fp32).  Arrays are laid out [T][element][system] (system index fastest) and handed to the C ABI as
+strided views, so that a wave's 64 lanes touch 64 consecutive elements.
+
+    python bench_m2.py [--log2-batch 14] [--T 500] [--reps 5]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import numpy as np
+import torch
+
+import lqg_amd
+from lqg_amd import _abi, _hip, workload
+
+PEAK_HBM_GBS = 8000.0
+
+
+def soa(base, T, B, gen, jitter, sym=False, positive_diag=False):
+    """base[B, r, c] -> time-varying field with physical layout [T, r, c, B], logical shape [B, T, r, c]."""
+    r, c = base.shape[-2:]
+    xi = torch.randn((T, r, c, B), dtype=base.dtype, device=base.device, generator=gen)
+    if sym:
+        xi = 0.5 * (xi + xi.transpose(1, 2))
+    phys = base.permute(1, 2, 0).unsqueeze(0) * (1.0 + jitter * xi)
+    return phys.permute(3, 0, 1, 2)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log2-batch", type=int, default=14)
+    ap.add_argument("--T", type=int, default=500)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    dtype = torch.float32 if args.dtype == "f32" else torch.float64
+    w = 4 if args.dtype == "f32" else 8
+    B, T = 1 << args.log2_batch, args.T
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4321)
+
+    base, _ = workload.headline_system(B, T, seed=77, device=dev, dtype=dtype)
+    a0, d0 = base.actor, base.dynamics
+    first = lambda t: t[:, 0] if t.dim() == 4 else t[0].expand(B, *t.shape[1:])
+    jit = 1e-3
+    act = dict(A=soa(first(a0.A), T, B, gen, jit), B=soa(first(a0.B), T, B, gen, jit), F=soa(first(a0.F), T, B, gen, jit),
+               V=soa(first(a0.V), T, B, gen, jit), W=soa(first(a0.W), T, B, gen, jit),
+               Q=soa(first(a0.Q), T, B, gen, jit, sym=True), R=soa(first(a0.R), T, B, gen, jit, sym=True))
+    actor = lqg_amd.LQGSpec(Q=act["Q"], q=a0.q, Qf=a0.Qf if a0.Qf.dim() == 3 else a0.Qf, qf=a0.qf, P=a0.P, R=act["R"],
+                            r=a0.r, A=act["A"], B=act["B"], V=act["V"], F=act["F"], W=act["W"])
+    dyn = lqg_amd.LQGSpec(Q=d0.Q, q=d0.q, Qf=d0.Qf, qf=d0.qf, P=d0.P, R=d0.R, r=d0.r,
+                          A=soa(first(d0.A), T, B, gen, jit), B=soa(first(d0.B), T, B, gen, jit),
+                          F=soa(first(d0.F), T, B, gen, jit), V=soa(first(d0.V), T, B, gen, jit),
+                          W=soa(first(d0.W), T, B, gen, jit))
+    system = lqg_amd.System(actor=actor, dynamics=dyn)
+    x = workload.pack_trials(workload.simulate_one_trial_each(base, seed=5))          # [B,1,T+1,4]
+    dm = dict(x=4, b=6, u=2, y=4, m=10, d=4)
+
+    def out(*shape):   # physical [T, ..., B], logical [B, T, ...]
+        t = torch.empty((T,) + shape + (B,), dtype=dtype, device=dev)
+        return t.permute(len(shape) + 1, 0, *range(1, len(shape) + 1))
+
+    L, H, K = out(dm["u"], dm["b"]), out(dm["u"], dm["u"]), out(dm["b"], dm["y"])
+    mu = torch.empty((T, dm["m"], B, 1), dtype=dtype, device=dev).permute(2, 3, 0, 1)   # [B,1,T,m]
+    Sig = out(dm["m"], dm["m"])
+
+    lib = _abi.load()
+    lnm = _hip.Launch(system.actor, system.dynamics, d=4, n_trials=1)
+    xx, xb = _hip._prep_x(lnm, x)
+    nbytes = lib.lqg_workspace_bytes(C.byref(lnm.p), _abi.OP_CONDITIONAL_MOMENTS)
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+    ll = torch.empty((B, 1), dtype=dtype, device=dev)
+
+    def one_pass():
+        # one ABI call, two kernels: k_riccati (L, H out + gain scratch) -> k_forward (K, mu, Sigma, ll out)
+        _abi.check(lib.lqg_solve_materialised(
+            C.byref(lnm.p), lnm.traj(xx, xb), lnm.view(L), _abi.NULL_VIEW, lnm.view(H), lnm.view(K), lnm.traj(mu),
+            lnm.view(Sig), C.c_void_p(ll.data_ptr()), 1, 1, C.c_void_p(ws.data_ptr()), nbytes, lnm.stream()),
+            "lqg_solve_materialised")
+
+    one_pass()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ms = []
+    for _ in range(args.reps):
+        e0.record()
+        one_pass()
+        e1.record()
+        e1.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    ms = float(np.median(ms))
+
+    b, u, y, xx_, m, d = dm["b"], dm["u"], dm["y"], dm["x"], dm["m"], dm["d"]
+    in_per_step = (3 * b * b + b * u + y * b + y * y + u * u) + (b + u * b + u) + (2 * xx_ * xx_ + xx_ * u + y * xx_ + y * y)
+    out_per_step = u * b + u + u * u + b * y + m + m * m
+    bytes_solve = w * (T * in_per_step + (T + 1) * d) + w * T * out_per_step          # SURVEY.md §8(d) M2 formula
+    gbs = bytes_solve * B / (ms * 1e-3) / 1e9
+    # parity spot check of the time-varying path against the fp64 oracle
+    import oracle as OC
+    sel = [0, B // 2, B - 1]
+    idx = torch.as_tensor(sel, device=dev)
+    host = lambda spec: {f: (getattr(spec, f)[idx] if getattr(spec, f).dim() == workload._batched_ndim(f)
+                             else getattr(spec, f).expand(len(sel), *getattr(spec, f).shape)).double().cpu().numpy()
+                         for f in lqg_amd.LQGSpec._fields}
+    a64, d64 = host(system.actor), host(system.dynamics)
+    Lr, _, Hr = OC.riccati_backward(a64)
+    Kr = OC.kalman_forward(a64)
+    mur, Sr = OC.conditional_moments(a64, d64, x[idx].double().cpu().numpy())
+    rel = lambda got, ref: float(np.abs(got.double().cpu().numpy() - ref).max() / np.abs(ref).max())
+    parity = dict(L=rel(L[idx], Lr), H=rel(H[idx], Hr), K=rel(K[idx], Kr), mu=rel(mu[idx], mur), Sigma=rel(Sig[idx], Sr))
+    print(json.dumps({
+        "mode": "M2 (time-varying [T,...] specs in; L,H,K,mu,Sigma materialised out)", "dtype": args.dtype,
+        "systems": B, "T": T, "ms_per_pass": ms, "solves_per_s": B / (ms * 1e-3),
+        "algorithmic_bytes_per_solve": bytes_solve,
+        "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS},
+        "calls": "lqg_solve_materialised (1 ABI call, 2 kernels: k_riccati -> k_forward)",
+        "workspace_GB": nbytes / 1e9, "parity_rel_maxnorm_vs_fp64_oracle": parity}))
+
+
+if __name__ == "__main__":
+    main()

@@ -113,8 +113,8 @@ int lqg_riccati_backward(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view 
  * Reads p->actor (A, F, V, W) and p->Sigma0.  K[B,T,b,y]. */
 int lqg_kalman_forward(const lqg_problem* p, lqg_view K, void* stream);
 
-/* Bytes of caller-provided device workspace the call `op` needs for problem p
- * (LQG_OP_LOG_LIKELIHOOD with n_trials == 1 runs fused and needs only the gain scratch). */
+/* Bytes of caller-provided device workspace the call `op` needs for problem p (with n_trials == 1 every op runs
+ * fused and needs only the gain scratch; otherwise also the per-system operator stream). */
 #define LQG_OP_LOG_LIKELIHOOD      0
 #define LQG_OP_CONDITIONAL_MOMENTS 1
 size_t lqg_workspace_bytes(const lqg_problem* p, int32_t op);
@@ -132,6 +132,15 @@ int lqg_conditional_moments(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_v
  * x[B,N,T+1,d] -> ll[b*ll_sb + n*ll_sn], one value per (system, trial), dtype of the problem. */
 int lqg_log_likelihood(const lqg_problem* p, lqg_traj x, void* ll, int64_t ll_sb, int64_t ll_sn,
                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* Everything the reference's path materialises, in ONE pass (two or three kernels instead of the seven that separate
+ * lqr.backward + kf.forward + conditional_moments + log_likelihood calls launch — each of which recomputes the gains
+ * inside, as the reference's own functions do, lqg/system.py:157-161):  L, l, H (lqr.py:42), K (kf.py:21), mu, Sigma
+ * (system.py:235) and ll (system.py:248).  Every output view is optional (ptr NULL = not written).
+ * With genuinely time-varying specs in and all outputs on this is SURVEY.md §8(d) mode M2, the HBM-bound regime. */
+int lqg_solve_materialised(const lqg_problem* p, lqg_traj x, lqg_view L, lqg_view l, lqg_view H, lqg_view K,
+                           lqg_traj mu, lqg_view Sigma, void* ll, int64_t ll_sb, int64_t ll_sn, void* workspace,
+                           size_t workspace_bytes, void* stream);
 
 /* Objective of lqg_model / the candidate sweep [lqg/infer/models.py:34, notebooks/Tutorial.ipynb
  * cell 38 `.log_likelihood(x).sum()`]: out[b] = sum_n ll[b,n], accumulated and stored in fp64

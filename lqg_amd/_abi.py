@@ -62,9 +62,12 @@ def declare(lib, prefix="lqg_", with_stream=True):
         "kalman_forward": [P, View] + tail,
         "conditional_moments": [P, Traj, Traj, View] + ws + tail,
         "log_likelihood": [P, Traj, C.c_void_p, C.c_int64, C.c_int64] + ws + tail,
+        "solve_materialised": [P, Traj, View, View, View, View, Traj, View, C.c_void_p, C.c_int64, C.c_int64] + ws + tail,
         "simulate": [P, View, View, View, Traj, Traj, View, View, Traj, Traj, Traj, Traj] + tail,
     }
     for name, args in sig.items():
+        if not hasattr(lib, prefix + name):
+            continue
         fn = getattr(lib, prefix + name)
         fn.argtypes, fn.restype = args, C.c_int
     return lib

@@ -159,6 +159,33 @@ def conditional_moments(actor, dynamics, x, Sigma0=None, eps=1e-8, want_mu=True,
     return mu, Sig
 
 
+def solve_materialised(actor, dynamics, x, Sigma0=None, eps=1e-8, out=None):
+    """One pass producing everything the reference materialises: dict(L, l, H, K, mu, Sigma, ll).
+
+    `out` may pre-supply any of those tensors (any strides, e.g. [T][element][system] storage)."""
+    d, n = x.shape[-1], x.shape[-3]
+    ln = Launch(actor, dynamics, d=d, n_trials=n, Sigma0=Sigma0, eps=eps)
+    lib = ln.require_gpu()
+    x, xb = _prep_x(ln, x)
+    dm, T, m = ln.dims, ln.T, ln.m
+    o = dict(out or {})
+    o.setdefault("L", ln.empty(T, dm["u"], dm["b"]))
+    o.setdefault("l", ln.empty(T, dm["u"]))
+    o.setdefault("H", ln.empty(T, dm["u"], dm["u"]))
+    o.setdefault("K", ln.empty(T, dm["b"], dm["y"]))
+    o.setdefault("mu", ln.empty(n, T, m))
+    o.setdefault("Sigma", ln.empty(T, m, m))
+    o.setdefault("ll", ln.empty(n))
+    with torch.cuda.device(ln.device):
+        ws, nbytes = ln.workspace(lib, _abi.OP_CONDITIONAL_MOMENTS)
+        _abi.check(lib.lqg_solve_materialised(
+            C.byref(ln.p), ln.traj(x, xb), ln.view(o["L"]), ln.view(o["l"], vector=True), ln.view(o["H"]),
+            ln.view(o["K"]), ln.traj(o["mu"]), ln.view(o["Sigma"]), C.c_void_p(o["ll"].data_ptr()),
+            o["ll"].stride(0) if ln.batched else 0, o["ll"].stride(-1), C.c_void_p(ws.data_ptr()), nbytes, ln.stream()),
+            "lqg_solve_materialised")
+    return o
+
+
 def log_likelihood(actor, dynamics, x, Sigma0=None, eps=1e-8):
     """x[n,T+1,d] | [B,n,T+1,d] -> ll[(B,)n]."""
     d, n = x.shape[-1], x.shape[-3]

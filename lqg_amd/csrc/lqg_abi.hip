@@ -26,9 +26,11 @@ LQG_KALMAN_DIMS(X)
 #undef X
 #define X(X_, B_, U_, Y_, D_)                                                                                   \
   extern template hipError_t lqg::host::launch_forward<float, X_, B_, U_, Y_, D_>(                              \
-      const lqg_problem*, const void*, long, bool, lqg_traj, void*, long, void*, lqg_view, hipStream_t);        \
+      const lqg_problem*, const void*, long, bool, lqg_traj, void*, long, void*, lqg_view, lqg_traj, lqg_view, \
+      hipStream_t);                                                                                             \
   extern template hipError_t lqg::host::launch_forward<double, X_, B_, U_, Y_, D_>(                             \
-      const lqg_problem*, const void*, long, bool, lqg_traj, void*, long, void*, lqg_view, hipStream_t);
+      const lqg_problem*, const void*, long, bool, lqg_traj, void*, long, void*, lqg_view, lqg_traj, lqg_view, \
+      hipStream_t);
 LQG_FORWARD_DIMS(X)
 #undef X
 #define X(M_, D_)                                                                                              \
@@ -85,12 +87,13 @@ hipError_t dispatch_kalman(const lqg_problem* p, lqg_view K, hipStream_t st, boo
 }
 template <typename R>
 hipError_t dispatch_forward(const lqg_problem* p, const void* Ls, long ldb, bool fused, lqg_traj x, void* ll,
-                            long ll_sb, void* ops, lqg_view Sig, hipStream_t st, bool* found) {
+                            long ll_sb, void* ops, lqg_view Sig, lqg_traj mu, lqg_view Kout, hipStream_t st,
+                            bool* found) {
   *found = true;
   const lqg_dims& d = p->dims;
 #define X(X_, B_, U_, Y_, D_)                                                  \
   if (d.x == X_ && d.b == B_ && d.u == U_ && d.y == Y_ && d.d == D_)          \
-    return launch_forward<R, X_, B_, U_, Y_, D_>(p, Ls, ldb, fused, x, ll, ll_sb, ops, Sig, st);
+    return launch_forward<R, X_, B_, U_, Y_, D_>(p, Ls, ldb, fused, x, ll, ll_sb, ops, Sig, mu, Kout, st);
   LQG_FORWARD_DIMS(X)
 #undef X
   *found = false;
@@ -172,11 +175,17 @@ int check_full(const lqg_problem* p, const char* who) {
   return 0;
 }
 
+struct GainOutputs {
+  lqg_view L, l, H, K;
+};
+
+// Shared driver of lqg_log_likelihood / lqg_conditional_moments / lqg_solve_materialised.
+// One trial per system runs FUSED (the trial is swept in-lane by k_forward, no operator stream, no k_trial);
+// more trials go through the per-system operator stream and k_trial.
 template <typename R>
-int run_moments(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_view Sigma, void* ll, long ll_sb,
-                       long ll_sn, bool allow_fused, void* workspace, size_t workspace_bytes, hipStream_t st,
-                       const char* who) {
-  const bool fused = allow_fused && p->n_trials == 1;
+int run_moments(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_view Sigma, void* ll, long ll_sb, long ll_sn,
+                const GainOutputs& g, void* workspace, size_t workspace_bytes, hipStream_t st, const char* who) {
+  const bool fused = p->n_trials == 1;
   const Workspace w = carve(p, !fused);
   if (!workspace || workspace_bytes < w.total)
     return fail(LQG_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B", who, workspace_bytes, w.total);
@@ -184,16 +193,16 @@ int run_moments(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_view Sigma, v
   void* Ls = base + w.ls_off;
   void* ops = fused ? nullptr : base + w.ops_off;
   bool found;
-  const lqg_view none{nullptr, 0, 0, 0, 0};
   auto mark = [&](int i) {
     if (p->phase_events[i]) (void)hipEventRecord(static_cast<hipEvent_t>(p->phase_events[i]), st);
   };
   mark(0);
-  hipError_t e = dispatch_riccati<R>(p, none, none, none, Ls, w.ldb, st, &found);
+  hipError_t e = dispatch_riccati<R>(p, g.L, g.l, g.H, Ls, w.ldb, st, &found);
   if (!found) return unsupported(p, who);
   if (e != hipSuccess) return done(e, who);
   mark(1);
-  e = dispatch_forward<R>(p, Ls, w.ldb, fused, x, ll, ll_sb, ops, Sigma, st, &found);
+  const lqg_traj no_mu{nullptr, 0, 0, 0, 0};
+  e = dispatch_forward<R>(p, Ls, w.ldb, fused, x, ll, ll_sb, ops, Sigma, fused ? mu : no_mu, g.K, st, &found);
   if (!found) return unsupported(p, who);
   if (e != hipSuccess) return done(e, who);
   mark(2);
@@ -251,20 +260,36 @@ int lqg_kalman_forward(const lqg_problem* p, lqg_view K, void* stream) {
 
 size_t lqg_workspace_bytes(const lqg_problem* p, int32_t op) {
   if (!p) return 0;
-  const bool fused = op == LQG_OP_LOG_LIKELIHOOD && p->n_trials == 1;
-  return carve(p, !fused).total;
+  (void)op;   // every op runs fused (no operator stream) when there is one trial per system
+  return carve(p, p->n_trials != 1).total;
 }
 
 int lqg_conditional_moments(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_view Sigma, void* workspace,
                             size_t workspace_bytes, void* stream) {
   static const char* who = "lqg_conditional_moments";
   if (int rc = check_full(p, who)) return rc;
-  if (!x.ptr && mu.ptr) return fail(LQG_ERR_NULL, "%s: x.ptr is NULL", who);
+  if (!x.ptr) return fail(LQG_ERR_NULL, "%s: x.ptr is NULL", who);
   if (p->n_sys == 0) return 0;
+  const GainOutputs none{};
   return p->dtype == LQG_F64
-             ? run_moments<double>(p, x, mu, Sigma, nullptr, 0, 0, false, workspace, workspace_bytes,
+             ? run_moments<double>(p, x, mu, Sigma, nullptr, 0, 0, none, workspace, workspace_bytes,
                                    (hipStream_t)stream, who)
-             : run_moments<float>(p, x, mu, Sigma, nullptr, 0, 0, false, workspace, workspace_bytes,
+             : run_moments<float>(p, x, mu, Sigma, nullptr, 0, 0, none, workspace, workspace_bytes,
+                                  (hipStream_t)stream, who);
+}
+
+int lqg_solve_materialised(const lqg_problem* p, lqg_traj x, lqg_view L, lqg_view l, lqg_view H, lqg_view K,
+                           lqg_traj mu, lqg_view Sigma, void* ll, int64_t ll_sb, int64_t ll_sn, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  static const char* who = "lqg_solve_materialised";
+  if (int rc = check_full(p, who)) return rc;
+  if (!x.ptr) return fail(LQG_ERR_NULL, "%s: x.ptr is NULL", who);
+  if (p->n_sys == 0) return 0;
+  const GainOutputs g{L, l, H, K};
+  return p->dtype == LQG_F64
+             ? run_moments<double>(p, x, mu, Sigma, ll, ll_sb, ll_sn, g, workspace, workspace_bytes,
+                                   (hipStream_t)stream, who)
+             : run_moments<float>(p, x, mu, Sigma, ll, ll_sb, ll_sn, g, workspace, workspace_bytes,
                                   (hipStream_t)stream, who);
 }
 
@@ -277,10 +302,11 @@ int lqg_log_likelihood(const lqg_problem* p, lqg_traj x, void* ll, int64_t ll_sb
   if (p->n_sys == 0 || p->n_trials == 0) return 0;
   const lqg_traj no_mu{nullptr, 0, 0, 0, 0};
   const lqg_view no_sig{nullptr, 0, 0, 0, 0};
+  const GainOutputs none{};
   return p->dtype == LQG_F64
-             ? run_moments<double>(p, x, no_mu, no_sig, ll, ll_sb, ll_sn, true, workspace, workspace_bytes,
+             ? run_moments<double>(p, x, no_mu, no_sig, ll, ll_sb, ll_sn, none, workspace, workspace_bytes,
                                    (hipStream_t)stream, who)
-             : run_moments<float>(p, x, no_mu, no_sig, ll, ll_sb, ll_sn, true, workspace, workspace_bytes,
+             : run_moments<float>(p, x, no_mu, no_sig, ll, ll_sb, ll_sn, none, workspace, workspace_bytes,
                                   (hipStream_t)stream, who);
 }
 

@@ -18,9 +18,11 @@ template hipError_t launch_kalman<double, LQG_INST_KALMAN>(const lqg_problem*, l
 #endif
 #ifdef LQG_INST_FORWARD
 template hipError_t launch_forward<float, LQG_INST_FORWARD>(const lqg_problem*, const void*, long, bool, lqg_traj,
-                                                            void*, long, void*, lqg_view, hipStream_t);
+                                                            void*, long, void*, lqg_view, lqg_traj, lqg_view,
+                                                            hipStream_t);
 template hipError_t launch_forward<double, LQG_INST_FORWARD>(const lqg_problem*, const void*, long, bool, lqg_traj,
-                                                             void*, long, void*, lqg_view, hipStream_t);
+                                                             void*, long, void*, lqg_view, lqg_traj, lqg_view,
+                                                             hipStream_t);
 #endif
 #ifdef LQG_INST_TRIAL
 template hipError_t launch_trial<float, LQG_INST_TRIAL>(const lqg_problem*, const void*, lqg_traj, lqg_traj, void*,

@@ -263,11 +263,15 @@ struct ForwardArgs {
   long ll_sb;
   R* ops;                        // !FUSED: trial-operator stream [n_sys][T+1][TrialOps::N], may be null
   DView<R> Sig;                  // optional Sigma output [B,T,m,m]
+  DTraj<R> mu;                   // optional mu output [B,1,T,m] (FUSED only: the trial swept in-lane)
+  DView<R> Kout;                 // optional Kalman gain output [B,T,b,y]
   long n_sys;
   int T, nva, nwa, nvd, nwd;
 };
 
-template <typename R, int NX, int NB, int NU, int NY, int ND, bool TI, bool FUSED>
+// MAT = materialise (Sigma / mu / K outputs requested): kept out of the pure log-likelihood instantiation so that the
+// hot kernel carries no store code, no output address arithmetic and no extra live pointers.
+template <typename R, int NX, int NB, int NU, int NY, int ND, bool TI, bool FUSED, bool MAT>
 __global__ void __launch_bounds__(LQG_BLOCK, LQG_FWD_WAVES) k_forward(const ForwardArgs<R> a) {
   constexpr int M = NX + NB, O = ND, RR = M - ND;
   using Ops = TrialOps<M, ND>;
@@ -356,6 +360,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, LQG_FWD_WAVES) k_forward(const Forw
     // ---- Kalman gain K_t                                               kf.py:10-14
     R K[NB * NY];
     kalman_step<R, NB, NY>(Aa, Fa, VVa, WWa, P, K);
+    if (MAT && a.Kout.p) store_mat<R, NB, NY>(const_cast<R*>(a.Kout.p) + s * a.Kout.sb + t * a.Kout.st, a.Kout.sr, a.Kout.sc, K);
     // ---- control gain L_t from the backward sweep
     R L[NU * NB];
     {
@@ -437,6 +442,10 @@ __global__ void __launch_bounds__(LQG_BLOCK, LQG_FWD_WAVES) k_forward(const Forw
       }
       LQG_UNROLL for (int i = 0; i < O; ++i) muO[i] = mn[i];
       LQG_UNROLL for (int p = 0; p < RR; ++p) muR[p] = mn[O + p];
+      if (MAT && a.mu.p) {
+        R* dst = const_cast<R*>(a.mu.p) + s * a.mu.sb + (long)t * a.mu.st;
+        LQG_UNROLL for (int i = 0; i < M; ++i) dst[i * a.mu.sd] = mn[i];
+      }
     } else if (a.ops) {
       R* op = a.ops + ((long)s * (a.T + 1) + t) * Ops::N;
       LQG_UNROLL for (int i = 0; i < M * M; ++i) op[Ops::F_OFF + i] = Fj[i];
@@ -473,13 +482,13 @@ __global__ void __launch_bounds__(LQG_BLOCK, LQG_FWD_WAVES) k_forward(const Forw
           Sg[j * M + i] = v;
         }
     }
-    if (a.Sig.p) store_mat<R, M, M>(const_cast<R*>(a.Sig.p) + s * a.Sig.sb + t * a.Sig.st, a.Sig.sr, a.Sig.sc, Sg);
+    if (MAT && a.Sig.p) store_mat<R, M, M>(const_cast<R*>(a.Sig.p) + s * a.Sig.sb + t * a.Sig.st, a.Sig.sr, a.Sig.sc, Sg);
   }
   // ---- last row: only the density of x_T under the final predictive moments
   condition();
   if (FUSED) {
     innovate(a.T, true);
-    a.ll[s * a.ll_sb] = (R)acc;
+    if (a.ll) a.ll[s * a.ll_sb] = (R)acc;
   } else if (a.ops) {
     R* op = a.ops + ((long)s * (a.T + 1) + a.T) * Ops::N;
     {

@@ -99,20 +99,27 @@ hipError_t launch_kalman(const lqg_problem* p, lqg_view K, hipStream_t st) {
 
 template <typename R, int NX, int NB, int NU, int NY, int ND>
 hipError_t launch_forward(const lqg_problem* p, const void* Ls, long ldb, bool fused, lqg_traj x, void* ll,
-                          long ll_sb, void* ops, lqg_view Sig, hipStream_t st) {
+                          long ll_sb, void* ops, lqg_view Sig, lqg_traj mu, lqg_view Kout, hipStream_t st) {
   const lqg_spec& a = p->actor;
   const lqg_spec& d = p->dynamics;
   lqg::ForwardArgs<R> k{dv<R>(a.A), dv<R>(a.B), dv<R>(a.F), dv<R>(a.V), dv<R>(a.W),
                         dv<R>(d.A), dv<R>(d.B), dv<R>(d.F), dv<R>(d.V), dv<R>(d.W),
                         dv<R>(p->Sigma0), static_cast<const R*>(Ls), ldb, dt<R>(x), static_cast<R*>(ll), ll_sb,
-                        static_cast<R*>(ops), dv<R>(Sig), (long)p->n_sys, p->T,
+                        static_cast<R*>(ops), dv<R>(Sig), dt<R>(mu), dv<R>(Kout), (long)p->n_sys, p->T,
                         p->dims.nva, p->dims.nwa, p->dims.nvd, p->dims.nwd};
   const dim3 grid(blocks_for(p->n_sys)), block(LQG_BLOCK);
   const bool ti = forward_ti(p);
-  if (ti && fused) hipLaunchKernelGGL((lqg::k_forward<R, NX, NB, NU, NY, ND, true, true>), grid, block, 0, st, k);
-  else if (ti && !fused) hipLaunchKernelGGL((lqg::k_forward<R, NX, NB, NU, NY, ND, true, false>), grid, block, 0, st, k);
-  else if (!ti && fused) hipLaunchKernelGGL((lqg::k_forward<R, NX, NB, NU, NY, ND, false, true>), grid, block, 0, st, k);
-  else hipLaunchKernelGGL((lqg::k_forward<R, NX, NB, NU, NY, ND, false, false>), grid, block, 0, st, k);
+  const bool mat = Sig.ptr || mu.ptr || Kout.ptr;
+#define LQG_FWD(TI_, FU_, MA_) \
+  hipLaunchKernelGGL((lqg::k_forward<R, NX, NB, NU, NY, ND, TI_, FU_, MA_>), grid, block, 0, st, k)
+  if (ti) {
+    if (fused) { if (mat) LQG_FWD(true, true, true); else LQG_FWD(true, true, false); }
+    else { if (mat) LQG_FWD(true, false, true); else LQG_FWD(true, false, false); }
+  } else {
+    if (fused) { if (mat) LQG_FWD(false, true, true); else LQG_FWD(false, true, false); }
+    else { if (mat) LQG_FWD(false, false, true); else LQG_FWD(false, false, false); }
+  }
+#undef LQG_FWD
   return hipGetLastError();
 }
 

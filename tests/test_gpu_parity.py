@@ -99,3 +99,25 @@ def test_simulate_golden(name, dtype):
     assert relerr(np_(xh), g["sim_xhat"]) < tol
     assert relerr(np_(ys), g["sim_y"]) < tol
     assert relerr(np_(us), g["sim_u"]) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("name", ["subjective2d_T60", "timevarying_T30", "pointmass_d2_T50"])
+def test_solve_materialised_one_pass(name, dtype):
+    """lqg_solve_materialised: every output of the path from one call, identical to the separate calls."""
+    from lqg_amd import _hip
+
+    g, actor, dyn = load_golden(name)
+    sys_ = system_from_golden(actor, dyn, dtype)
+    S0 = torch.as_tensor(g["Sigma0"], dtype=dtype, device="cuda") if "Sigma0" in g else None
+    x = torch.as_tensor(g["x"], dtype=dtype, device="cuda")
+    tol = TOL[dtype]
+    for xs in (x[:1], x):                       # one trial: fused in-lane sweep; several: operator stream + k_trial
+        o = _hip.solve_materialised(sys_.actor, sys_.dynamics, xs, Sigma0=S0)
+        n = xs.shape[0]
+        assert relerr(np_(o["L"]), g["L"]) < tol["mat"] and relerr(np_(o["H"]), g["H"]) < tol["mat"]
+        assert relerr(np_(o["K"]), g["K"]) < tol["mat"]
+        assert relerr(np_(o["mu"]), g["mu"][:n]) < tol["mat"] and relerr(np_(o["Sigma"]), g["Sigma"][0]) < tol["mat"]
+        assert np.abs(np_(o["ll"]) / g["ll"][:n] - 1).max() < tol["ll"]
+        if np.abs(g["l"]).max() > 0:
+            assert relerr(np_(o["l"]), g["l"]) < tol["mat"]
