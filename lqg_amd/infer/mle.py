@@ -1,0 +1,48 @@
+"""Maximum likelihood — the role of lqg/infer/mle.py:14-25 (NumPyro SVI with an empty guide = Adam on the
+log-likelihood of positive-constrained parameters).
+
+The reference differentiates the likelihood with JAX reverse mode.  This round has no adjoint sweep (SURVEY.md §8f
+rank 1), so the gradient is taken by CENTRAL FINITE DIFFERENCES in the unconstrained (log) space and evaluated as ONE
+batched candidate sweep of 2P+1 systems through the fused HIP path — derivative-free use of the same kernels.
+fp64 is used throughout (a finite difference of an fp32 likelihood is noise).  `candidate_search` is the
+derivative-free population evaluation of BASELINE config 3 (thousands of candidates x shared trials).
+"""
+import torch
+
+from lqg_amd.infer.models import get_model_params, log_likelihood_objective
+from lqg_amd.tracking import BoundedActor
+
+
+def candidate_search(x, model=BoundedActor, candidates=None, process_noise=1.0, dt=1.0 / 60, group=None, **fixed):
+    """Objective (summed log-likelihood, fp64) of every candidate: `candidates` maps parameter -> [C] tensor.
+    Returns (objective[C], index of the best candidate)."""
+    obj = log_likelihood_objective(x, model, candidates, process_noise=process_noise, dt=dt, group=group, **fixed)
+    return obj, int(torch.argmax(obj))
+
+
+def max_likelihood(x, model=BoundedActor, process_noise=1.0, dt=1.0 / 60, steps=2_000, step_size=0.01, fd_step=1e-4,
+                   group=None, **fixed):
+    """Adam on the negative log-likelihood of the positive parameters of `model` (defaults as in the reference:
+    2000 steps, step size 0.01, initial values = constructor defaults).  Returns (params, losses) like
+    `svi.run` in lqg/infer/mle.py:23-25: params = dict name -> fitted value, losses[steps] = -log p(x | params)."""
+    x = x.to(torch.float64)
+    names = [k for k in get_model_params(model) if k not in fixed]
+    P = len(names)
+    z = torch.log(torch.tensor([float(get_model_params(model)[k]) for k in names], dtype=torch.float64, device=x.device))
+    m1, m2 = torch.zeros_like(z), torch.zeros_like(z)
+    b1, b2, eps = 0.9, 0.999, 1e-8
+    eye = torch.eye(P, dtype=torch.float64, device=x.device)
+    losses = torch.empty(steps, dtype=torch.float64)
+    for it in range(steps):
+        # one sweep over 2P+1 candidates: z, z + h e_i, z - h e_i
+        Z = torch.cat([z[None], z[None] + fd_step * eye, z[None] - fd_step * eye])
+        cand = {k: torch.exp(Z[:, i]) for i, k in enumerate(names)}
+        obj = log_likelihood_objective(x, model, cand, process_noise=process_noise, dt=dt, group=group, **fixed)
+        loss = -obj[0]
+        grad = -(obj[1:P + 1] - obj[P + 1:]) / (2 * fd_step)
+        losses[it] = loss
+        m1 = b1 * m1 + (1 - b1) * grad
+        m2 = b2 * m2 + (1 - b2) * grad * grad
+        z = z - step_size * (m1 / (1 - b1 ** (it + 1))) / (torch.sqrt(m2 / (1 - b2 ** (it + 1))) + eps)
+    params = {k: float(torch.exp(z[i])) for i, k in enumerate(names)}
+    return params, losses
