@@ -106,9 +106,15 @@ def main():
     stream = ln.stream()
     total = torch.zeros((), dtype=torch.float64, device=dev)
 
+    # structure-specialised library of this model family if one is available (lqg_amd/specialize.py), else the
+    # generic dense kernels; LQG_NO_SPECIALIZE=1 forces the latter
+    sp_entry = _hip.specialised_entry(ln, system, dm["d"])
+    entry = sp_entry or lib.lqg_log_likelihood
+    fwd_name = "k_forward_sp (structure-specialised)" if sp_entry else "k_forward (generic dense)"
+
     def step():
-        _abi.check(lib.lqg_log_likelihood(C.byref(ln.p), xtraj, C.c_void_p(ll.data_ptr()), 1, 1,
-                                          C.c_void_p(ws.data_ptr()), nbytes, stream), "lqg_log_likelihood")
+        _abi.check(entry(C.byref(ln.p), xtraj, C.c_void_p(ll.data_ptr()), 1, 1,
+                         C.c_void_p(ws.data_ptr()), nbytes, stream), "lqg_log_likelihood")
         s = _hip.sum_trials(ll.view(1, B))                 # objective = sum of log-likelihoods (fp64)
         if dist is not None:
             dist.all_reduce(s)                             # the one collective of the path (RCCL over xGMI)
@@ -163,7 +169,7 @@ def main():
     if os.path.exists(pmc_path):
         try:
             pj = json.load(open(pmc_path))
-            key = f"k_forward_{args.dtype}_log2B{args.log2_batch}"
+            key = f"{'k_forward_sp' if sp_entry else 'k_forward'}_{args.dtype}_log2B{args.log2_batch}"
             traffic = pj.get(key, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -244,7 +250,7 @@ def main():
                    "parallelism": f"candidate-sharded x{world}, all-reduce of the summed log-likelihood"},
         "roofline": {"bound": "valu", "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved_tflops / peak, "traffic": traffic,
-                     "kernel": "k_forward (Kalman + joint system + Sigma recursion + mean + log-density)",
+                     "kernel": fwd_name + ": Kalman + joint system + Sigma recursion + mean + log-density",
                      "kernel_ms": fwd_avg_ms, "riccati_kernel_ms": ric_avg_ms,
                      "algorithmic_flops_per_solve": flops_solve, "algorithmic_bytes_per_solve": bytes_solve,
                      "note": "VALU-bound (fp32 vector peak == f32 MFMA peak on gfx950); algorithmic flops = "

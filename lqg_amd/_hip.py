@@ -186,8 +186,29 @@ def solve_materialised(actor, dynamics, x, Sigma0=None, eps=1e-8, out=None):
     return o
 
 
-def log_likelihood(actor, dynamics, x, Sigma0=None, eps=1e-8):
-    """x[n,T+1,d] | [B,n,T+1,d] -> ll[(B,)n]."""
+def specialised_entry(ln, system, d):
+    """The structure-specialised `lqg_log_likelihood_sp` for this launch, or None (lqg_amd/specialize.py).
+
+    Eligible: one trial per system, every spec field time-invariant, no affine cost terms.  LQG_NO_SPECIALIZE=1
+    forces the generic dense library (A/B measurements, tests)."""
+    import os
+    if system is None or os.environ.get("LQG_NO_SPECIALIZE") == "1" or ln.p.n_trials != 1:
+        return None
+    p = ln.p
+    for spec, fields in ((p.actor, ("Q", "R", "A", "B", "V", "F", "W")), (p.dynamics, ("A", "B", "V", "F", "W"))):
+        for f in fields:
+            if getattr(spec, f).st != 0 and ln.T > 1:
+                return None
+    if any(getattr(p.actor, f).ptr for f in ("q", "qf", "P", "r")):
+        return None
+    from lqg_amd import specialize
+    dims, masks, key = specialize.system_pattern(system, d)
+    lib = specialize.load_pattern(key, dims, masks)
+    return None if lib is None else lib.lqg_log_likelihood_sp
+
+
+def log_likelihood(actor, dynamics, x, Sigma0=None, eps=1e-8, system=None):
+    """x[n,T+1,d] | [B,n,T+1,d] -> ll[(B,)n].  `system` (the owning System) enables the structure-specialised path."""
     d, n = x.shape[-1], x.shape[-3]
     ln = Launch(actor, dynamics, d=d, n_trials=n, Sigma0=Sigma0, eps=eps)
     lib = ln.require_gpu()
@@ -195,9 +216,11 @@ def log_likelihood(actor, dynamics, x, Sigma0=None, eps=1e-8):
     ll = ln.empty(n)
     with torch.cuda.device(ln.device):
         ws, nbytes = ln.workspace(lib, _abi.OP_LOG_LIKELIHOOD)
-        _abi.check(lib.lqg_log_likelihood(C.byref(ln.p), ln.traj(x, xb), C.c_void_p(ll.data_ptr()),
-                                          n if ln.batched else 0, 1, C.c_void_p(ws.data_ptr()), nbytes,
-                                          ln.stream()), "lqg_log_likelihood")
+        args = (C.byref(ln.p), ln.traj(x, xb), C.c_void_p(ll.data_ptr()), n if ln.batched else 0, 1,
+                C.c_void_p(ws.data_ptr()), nbytes, ln.stream())
+        sp = specialised_entry(ln, system, d)
+        if sp is None or sp(*args) != 0:
+            _abi.check(lib.lqg_log_likelihood(*args), "lqg_log_likelihood")
     return ll
 
 

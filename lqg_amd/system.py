@@ -184,7 +184,7 @@ class System:
 
     def log_likelihood(self, x, Sigma0=None):
         """log p(x_{1:T} | x_0) per trial: x[n, T+1, d] -> [n] (lqg/system.py:246-248).  Fused HIP path."""
-        return _hip.log_likelihood(self.actor, self.dynamics, x, Sigma0=Sigma0)
+        return _hip.log_likelihood(self.actor, self.dynamics, x, Sigma0=Sigma0, system=self)
 
     def belief_tracking_distribution(self, x, Sigma0=None):
         """Distribution of the actor's belief given the observed trajectory (lqg/system.py:250-257):

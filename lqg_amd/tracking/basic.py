@@ -28,6 +28,7 @@ class TrackingTask(System):
         R = bd.diag([ac] * dim)
         spec = Actor(A=A, B=B, F=F, V=V, W=W, Q=Q, R=R, T=T)
         super().__init__(actor=spec, dynamics=spec)
+        self._zoo_structure = dict(dim=dim)      # what (besides the class) fixes the sparsity pattern
 
 
 class BoundedActor(TrackingTask):
@@ -64,3 +65,4 @@ class RelativeObservationBoundedActor(System):
         R = bd.diag([ac] * dim)
         spec = Actor(A=A, B=B, F=F, V=V, W=W, Q=Q, R=R, T=T)
         super().__init__(actor=spec, dynamics=spec)
+        self._zoo_structure = dict(dim=dim)

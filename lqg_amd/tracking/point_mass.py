@@ -72,3 +72,4 @@ class PointMassBoundedActor(System):
         A, B, V, F, W, Q, R = (t.to(dtype) for t in (A, B, V, F, W, Q, R))
         spec = Actor(A=A, B=B, F=F, V=V, W=W, Q=Q, R=R, T=T)
         super().__init__(actor=spec, dynamics=spec)
+        self._zoo_structure = {}

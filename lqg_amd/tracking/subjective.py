@@ -46,3 +46,4 @@ class SubjectiveActor(System):
         Q = Q[..., dims, :][..., :, dims]
         act = Actor(A=A, B=B, F=F, V=V, W=W, Q=Q, R=R, T=T)
         super().__init__(actor=act, dynamics=dyn)
+        self._zoo_structure = dict(dim=dim)

@@ -121,3 +121,44 @@ def test_solve_materialised_one_pass(name, dtype):
         assert np.abs(np_(o["ll"]) / g["ll"][:n] - 1).max() < tol["ll"]
         if np.abs(g["l"]).max() > 0:
             assert relerr(np_(o["l"]), g["l"]) < tol["mat"]
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("ctor,kw,d,gold", [
+    ("BoundedActor", dict(T=100, sigma_target=6.0, sigma_cursor=1.0, action_cost=0.05, action_variability=0.5), 2, "bounded_T100"),
+    ("OptimalActor", dict(T=30), 2, "optimal_T30"),
+    ("RelativeObservationBoundedActor", dict(T=40), 2, "relobs_T40"),
+    ("SubjectiveActor", dict(dim=1, T=50), 2, "subjective1d_T50"),
+    ("SubjectiveActor", dict(dim=2, T=60, action_cost=0.5, sigma_cursor=3.0, subj_noise=1.3, subj_vel_noise=0.7), 4, "subjective2d_T60"),
+    ("BoundedActor", dict(dim=2, T=40, action_cost=0.2), 4, "bounded2d_T40"),
+    ("PointMassBoundedActor", dict(T=50, action_variability=0.5), 2, "pointmass_d2_T50"),
+])
+def test_structure_specialised_path_matches_golden(ctor, kw, d, gold, dtype, monkeypatch):
+    """The generated structure-specialised kernels (lqg_amd/specialize.py, csrc/lqg_kernels_sp.hpp) against the same
+    golden vectors, and against the generic dense kernels on the same input."""
+    import lqg_amd
+    from lqg_amd import _hip
+
+    g, _, _ = load_golden(gold)
+    m = getattr(lqg_amd, ctor)(device="cuda", dtype=dtype, **kw)
+    x = torch.as_tensor(g["x"][:1], dtype=dtype, device="cuda")
+    ln = _hip.Launch(m.actor, m.dynamics, d=d, n_trials=1)
+    assert _hip.specialised_entry(ln, m, d) is not None            # a specialised library exists for the model zoo
+    ll_sp = m.log_likelihood(x)
+    monkeypatch.setenv("LQG_NO_SPECIALIZE", "1")
+    ll_gen = m.log_likelihood(x)
+    tol = TOL[dtype]["ll"]
+    assert abs(float(ll_sp[0]) / g["ll"][0] - 1) < tol
+    assert abs(float(ll_gen[0]) / g["ll"][0] - 1) < tol
+    assert abs(float(ll_sp[0]) / float(ll_gen[0]) - 1) < tol
+
+
+def test_specialised_path_on_hand_built_system_and_nan_semantics():
+    """A hand-built System gets its pattern from the data; a singular observed block still yields NaN."""
+    import lqg_amd
+    g, actor, dyn = load_golden("tutorial_lqg_T100")
+    s64 = system_from_golden(actor, dyn, torch.float64)
+    x = torch.as_tensor(g["x"][:1], dtype=torch.float64, device="cuda")
+    assert abs(float(s64.log_likelihood(x)[0]) / g["ll"][0] - 1) < 1e-10
+    bad = lqg_amd.BoundedActor(T=10, action_variability=0.0, device="cuda", dtype=torch.float64)
+    assert not torch.isfinite(bad.log_likelihood(torch.zeros(1, 11, 2, dtype=torch.float64, device="cuda"))).all()
