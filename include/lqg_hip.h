@@ -146,7 +146,10 @@ int lqg_solve_materialised(const lqg_problem* p, lqg_traj x, lqg_view L, lqg_vie
  * cell 38 `.log_likelihood(x).sum()`]: out[b] = sum_n ll[b,n], accumulated and stored in fp64
  * regardless of the problem dtype (so the cross-GPU all-reduce is order-insensitive to ~1e-15). */
 int lqg_sum_trials(int32_t dtype, const void* ll, int64_t n_sys, int64_t n_trials, int64_t ll_sb,
-                   int64_t ll_sn, double* out, void* stream);
+                   int64_t ll_sn, double* out, void* workspace, size_t workspace_bytes, void* stream);
+/* workspace for lqg_sum_trials (0 when n_trials fits one reduction chunk): partial sums of a fixed two-stage tree,
+ * so that the result is bitwise reproducible run to run (no atomics) */
+size_t lqg_sum_trials_workspace_bytes(int64_t n_sys, int64_t n_trials);
 
 /* Replaces the per-trial scan of System.simulate [lqg/system.py:106-128] with the standard-normal
  * draws supplied by the caller (the reference draws them from jax.random, :102-105).

@@ -91,8 +91,10 @@ def load():
     lib.lqg_dims_supported.argtypes, lib.lqg_dims_supported.restype = [C.c_int32, C.POINTER(Dims)], C.c_int
     lib.lqg_workspace_bytes.argtypes, lib.lqg_workspace_bytes.restype = [C.POINTER(Problem), C.c_int32], C.c_size_t
     lib.lqg_sum_trials.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
-                                   C.c_void_p, C.c_void_p]
+                                   C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.lqg_sum_trials.restype = C.c_int
+    lib.lqg_sum_trials_workspace_bytes.argtypes = [C.c_int64, C.c_int64]
+    lib.lqg_sum_trials_workspace_bytes.restype = C.c_size_t
     lib.lqg_gaussian_logprob.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, Traj, Traj, View,
                                          C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     lib.lqg_gaussian_logprob.restype = C.c_int

@@ -234,8 +234,11 @@ def sum_trials(ll):
     n = ll.shape[-1]
     out = torch.empty((B,), dtype=torch.float64, device=ll.device)
     with torch.cuda.device(ll.device):
+        nb = lib.lqg_sum_trials_workspace_bytes(B, n)
+        ws = torch.empty(max(int(nb), 8), dtype=torch.uint8, device=ll.device)
         _abi.check(lib.lqg_sum_trials(_DT[ll.dtype], C.c_void_p(ll.data_ptr()), B, n,
                                       ll.stride(0) if batched else 0, ll.stride(-1), C.c_void_p(out.data_ptr()),
+                                      C.c_void_p(ws.data_ptr()), nb,
                                       C.c_void_p(torch.cuda.current_stream(ll.device).cuda_stream)), "lqg_sum_trials")
     return out if batched else out[0]
 

@@ -310,19 +310,32 @@ int lqg_log_likelihood(const lqg_problem* p, lqg_traj x, void* ll, int64_t ll_sb
                                   (hipStream_t)stream, who);
 }
 
+size_t lqg_sum_trials_workspace_bytes(int64_t n_sys, int64_t n_trials) {
+  const size_t chunks = (size_t)((n_trials + lqg::kSumChunk - 1) / lqg::kSumChunk);
+  return chunks > 1 ? (size_t)n_sys * chunks * sizeof(double) : 0;
+}
+
 int lqg_sum_trials(int32_t dtype, const void* ll, int64_t n_sys, int64_t n_trials, int64_t ll_sb, int64_t ll_sn,
-                   double* out, void* stream) {
+                   double* out, void* workspace, size_t workspace_bytes, void* stream) {
   static const char* who = "lqg_sum_trials";
   if (!ll || !out) return fail(LQG_ERR_NULL, "%s: NULL pointer", who);
   if (dtype != LQG_F32 && dtype != LQG_F64) return fail(LQG_ERR_ARG, "%s: bad dtype %d", who, dtype);
   if (n_sys <= 0) return 0;
-  const dim3 grid((unsigned)n_sys), block(256);
+  const long chunks = (long)((n_trials + lqg::kSumChunk - 1) / lqg::kSumChunk);
+  const bool two_stage = chunks > 1;
+  if (two_stage && (!workspace || workspace_bytes < lqg_sum_trials_workspace_bytes(n_sys, n_trials)))
+    return fail(LQG_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B", who, workspace_bytes,
+                lqg_sum_trials_workspace_bytes(n_sys, n_trials));
+  double* part = two_stage ? static_cast<double*>(workspace) : out;
+  const dim3 grid((unsigned)(chunks > 0 ? chunks : 1), (unsigned)n_sys), block(256);
+  hipStream_t st = (hipStream_t)stream;
   if (dtype == LQG_F64)
-    hipLaunchKernelGGL((lqg::k_sum_trials<double>), grid, block, 0, (hipStream_t)stream, static_cast<const double*>(ll),
-                       (long)n_trials, (long)ll_sb, (long)ll_sn, out);
+    hipLaunchKernelGGL((lqg::k_sum_trials<double>), grid, block, 0, st, static_cast<const double*>(ll), (long)n_trials,
+                       (long)ll_sb, (long)ll_sn, part, chunks > 0 ? chunks : 1);
   else
-    hipLaunchKernelGGL((lqg::k_sum_trials<float>), grid, block, 0, (hipStream_t)stream, static_cast<const float*>(ll),
-                       (long)n_trials, (long)ll_sb, (long)ll_sn, out);
+    hipLaunchKernelGGL((lqg::k_sum_trials<float>), grid, block, 0, st, static_cast<const float*>(ll), (long)n_trials,
+                       (long)ll_sb, (long)ll_sn, part, chunks > 0 ? chunks : 1);
+  if (two_stage) hipLaunchKernelGGL((lqg::k_sum_partials<0>), dim3((unsigned)n_sys), block, 0, st, part, chunks, out);
   return done(hipGetLastError(), who);
 }
 

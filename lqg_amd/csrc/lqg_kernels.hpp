@@ -725,17 +725,39 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_gaussian_logprob(const LogprobArg
 }
 
 // ===================================================================== sum over trials ===============
-// out[b] = sum_n ll[b, n] in fp64, fixed reduction tree (bitwise reproducible run to run).
+// out[b] = sum_n ll[b, n] in fp64 with a FIXED reduction tree (bitwise reproducible run to run, no atomics):
+// stage 1: grid (chunks, B), each block reduces one chunk of kSumChunk trials into part[b][chunk];
+// stage 2: grid (B), one block reduces the chunk partials of its system.
+constexpr int kSumChunk = 4096;
+
+template <typename T>
+LQG_DEV double block_sum_256(double acc, double* smem) {
+  LQG_UNROLL for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  return (smem[0] + smem[1]) + (smem[2] + smem[3]);
+}
+
 template <typename R>
-__global__ void __launch_bounds__(256) k_sum_trials(const R* ll, long n_trials, long sb, long sn, double* out) {
-  __shared__ double part[4];
+__global__ void __launch_bounds__(256) k_sum_trials(const R* ll, long n_trials, long sb, long sn, double* part,
+                                                    long n_chunks) {
+  __shared__ double smem[4];
+  const long b = blockIdx.y, c = blockIdx.x;
+  const long lo = c * kSumChunk, hi = (lo + kSumChunk < n_trials) ? lo + kSumChunk : n_trials;
+  double acc = 0.0;
+  for (long n = lo + threadIdx.x; n < hi; n += 256) acc += (double)ll[b * sb + n * sn];
+  const double tot = block_sum_256<R>(acc, smem);
+  if (threadIdx.x == 0) part[b * n_chunks + c] = tot;
+}
+
+template <int UNUSED = 0>   // template only so that the definition may live in this header (one instance per TU)
+__global__ void __launch_bounds__(256) k_sum_partials(const double* part, long n_chunks, double* out) {
+  __shared__ double smem[4];
   const long b = blockIdx.x;
   double acc = 0.0;
-  for (long n = threadIdx.x; n < n_trials; n += 256) acc += (double)ll[b * sb + n * sn];
-  LQG_UNROLL for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) out[b] = (part[0] + part[1]) + (part[2] + part[3]);
+  for (long c = threadIdx.x; c < n_chunks; c += 256) acc += part[b * n_chunks + c];
+  const double tot = block_sum_256<double>(acc, smem);
+  if (threadIdx.x == 0) out[b] = tot;
 }
 
 }  // namespace lqg
