@@ -94,27 +94,21 @@ def main():
     x = workload.pack_trials(x_ref) if args.layout == "packed" else x_ref
     torch.cuda.synchronize()
 
-    ln = _hip.Launch(system.actor, system.dynamics, d=dm["d"], n_trials=1)
-    xb, _ = _hip._prep_x(ln, x)
-    ll = torch.empty((B, 1), dtype=dtype, device=dev)
-    nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
-    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
-    ev = [_hipev.Event() for _ in range(4)]
-    for i in range(4):
-        ln.p.phase_events[i] = ev[i].h
-    xtraj = ln.traj(xb, True)
-    stream = ln.stream()
+    # The hot path exactly as lqg_amd.System.log_likelihood runs it (lqg_amd/plan.py), decided once:
+    # (1) if the model's interaction graph splits into independent components (every dim=2 zoo model is two 1-D
+    #     models) each component is solved on its own and the log-likelihoods add (lqg_amd/decouple.py;
+    #     LQG_NO_DECOUPLE=1 disables); (2) each solve uses the structure-specialised library of its sparsity pattern
+    #     when one exists (lqg_amd/specialize.py; LQG_NO_SPECIALIZE=1 forces the generic dense kernels).
+    # Both are exact and both are derived from the spec DATA, not from the model's name.
+    from lqg_amd.plan import LogLikelihoodPlan
+    plan = LogLikelihoodPlan(system, x, events=True)
+    ll = plan.ll
+    fwd_name = plan.description
+    sp_all = all(wk["specialised"] for wk in plan.work)
     total = torch.zeros((), dtype=torch.float64, device=dev)
 
-    # structure-specialised library of this model family if one is available (lqg_amd/specialize.py), else the
-    # generic dense kernels; LQG_NO_SPECIALIZE=1 forces the latter
-    sp_entry = _hip.specialised_entry(ln, system, dm["d"])
-    entry = sp_entry or lib.lqg_log_likelihood
-    fwd_name = "k_forward_sp (structure-specialised)" if sp_entry else "k_forward (generic dense)"
-
     def step():
-        _abi.check(entry(C.byref(ln.p), xtraj, C.c_void_p(ll.data_ptr()), 1, 1,
-                         C.c_void_p(ws.data_ptr()), nbytes, stream), "lqg_log_likelihood")
+        plan.run()
         s = _hip.sum_trials(ll.view(1, B))                 # objective = sum of log-likelihoods (fp64)
         if dist is not None:
             dist.all_reduce(s)                             # the one collective of the path (RCCL over xGMI)
@@ -130,9 +124,9 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         total = step()
-        ev[2].synchronize()                                # events are re-recorded every step: read them now
-        ric_ms.append(ev[0].elapsed_ms(ev[1]))
-        fwd_ms.append(ev[1].elapsed_ms(ev[2]))
+        r_ms, f_ms, _ = plan.phase_ms()                    # events are re-recorded every step: read them now
+        ric_ms.append(r_ms)
+        fwd_ms.append(f_ms)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -169,7 +163,7 @@ def main():
     if os.path.exists(pmc_path):
         try:
             pj = json.load(open(pmc_path))
-            key = f"{'k_forward_sp' if sp_entry else 'k_forward'}_{args.dtype}_log2B{args.log2_batch}"
+            key = f"{'k_forward_sp' if sp_all else 'k_forward'}_x{len(plan.work)}_{args.dtype}_log2B{args.log2_batch}"
             traffic = pj.get(key, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -247,10 +241,11 @@ def main():
         "config": {"workload": f"SubjectiveActor(dim=2) x=4 b=6 u=2 y=4 d=4, T={T}, {B} independent "
                                f"(candidate, trajectory) solves per GPU per step (BASELINE config 5 / headline shape)",
                    "solves_per_gpu": B, "T": T, "trajectory_layout": args.layout,
+                   "path": fwd_name,
                    "parallelism": f"candidate-sharded x{world}, all-reduce of the summed log-likelihood"},
         "roofline": {"bound": "valu", "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved_tflops / peak, "traffic": traffic,
-                     "kernel": fwd_name + ": Kalman + joint system + Sigma recursion + mean + log-density",
+                     "kernel": "forward sweep (Kalman + joint system + Sigma recursion + mean + log-density) of: " + fwd_name,
                      "kernel_ms": fwd_avg_ms, "riccati_kernel_ms": ric_avg_ms,
                      "algorithmic_flops_per_solve": flops_solve, "algorithmic_bytes_per_solve": bytes_solve,
                      "note": "VALU-bound (fp32 vector peak == f32 MFMA peak on gfx950); algorithmic flops = "

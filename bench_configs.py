@@ -51,28 +51,18 @@ def hand2d_system(T, device, dtype, cursor_noise=0.1):
 
 
 def timed_loglik(system, x, reps):
-    """Run lqg_log_likelihood `reps` times; return ll and median per-phase milliseconds."""
-    lib = _abi.load()
-    d, n = x.shape[-1], x.shape[-3]
-    ln = _hip.Launch(system.actor, system.dynamics, d=d, n_trials=n)
-    xx, xb = _hip._prep_x(ln, x)
-    ll = ln.empty(n)
-    ev = [_hipev.Event() for _ in range(4)]
-    for i in range(4):
-        ln.p.phase_events[i] = ev[i].h
-    nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
-    ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=x.device)
+    """Run the log-likelihood plan `reps` times; return ll, median per-phase milliseconds and the path taken."""
+    from lqg_amd.plan import LogLikelihoodPlan
+    plan = LogLikelihoodPlan(system, x, events=True)
     ph = []
     for r in range(reps + 1):
-        _abi.check(lib.lqg_log_likelihood(C.byref(ln.p), ln.traj(xx, xb), C.c_void_p(ll.data_ptr()),
-                                          n if ln.batched else 0, 1, C.c_void_p(ws.data_ptr()), nbytes, ln.stream()),
-                   "lqg_log_likelihood")
-        ev[3].synchronize()
+        ll = plan.run()
+        p3 = plan.phase_ms()
         if r:
-            ph.append([ev[0].elapsed_ms(ev[1]), ev[1].elapsed_ms(ev[2]), ev[2].elapsed_ms(ev[3]), ev[0].elapsed_ms(ev[3])])
+            ph.append(list(p3) + [sum(p3)])
     ph = np.median(np.array(ph), axis=0)
-    return ll, dict(riccati_ms=float(ph[0]), forward_ms=float(ph[1]), trial_ms=float(ph[2]), total_ms=float(ph[3]),
-                    workspace_MB=nbytes / 1e6)
+    return ll.clone(), dict(riccati_ms=float(ph[0]), forward_ms=float(ph[1]), trial_ms=float(ph[2]), total_ms=float(ph[3]),
+                            workspace_MB=sum(wk["nbytes"] for wk in plan.work) / 1e6, path=plan.description)
 
 
 def host_spec(spec, sel=None):

@@ -1,0 +1,149 @@
+"""Block decoupling of a System: if the joint (state, belief, control, observation) interaction graph of a model
+splits into independent components, the trajectory log-likelihood factorises exactly,
+    log p(x) = sum_c log p_c(x[..., cols_c]),
+and every recursion of the path (Riccati, Kalman, moment recursion) decouples with it.  Each component is a smaller
+LQG problem — cubic work shrinks by (m / m_c)^3 per component.  Every `dim=2` model of the reference's zoo is two
+independent 1-D models built with block_diag and then permuted (lqg/tracking/basic.py:21-35,
+lqg/tracking/subjective.py:18-44), so this halves... in fact quarters their arithmetic.
+
+The components are found from DATA (which entries of A, B, F, V V^T, W W^T, Q, R, Sigma0 are non-zero for any
+candidate), with the class-level probe of lqg_amd/specialize.py for the model zoo.  One documented deviation: the
+eigenvalue floor of lqr.backward (lqg/control/lqr.py:27-28) is applied per component instead of to the joint H;
+the two differ only when the floor is ACTIVE (lambda_min(H) < 1e-8), which no proper cost matrix triggers.
+"""
+import numpy as np
+import torch
+
+from lqg_amd.spec import LQGSpec
+from lqg_amd.system import System
+
+
+def _find(parent, i):
+    while parent[i] != i:
+        parent[i] = parent[parent[i]]
+        i = parent[i]
+    return i
+
+
+def _union(parent, i, j):
+    ri, rj = _find(parent, i), _find(parent, j)
+    if ri != rj:
+        parent[rj] = ri
+
+
+def components_from_masks(dims, m, extra_bb=None):
+    """Connected components of the interaction graph.  Nodes: x_i, b_j, u_k, y_l.  Returns a list of dicts
+    (xs, bs, us, ys as sorted index lists), or None when the graph is connected / a component is degenerate."""
+    nx, nb, nu, ny = dims["x"], dims["b"], dims["u"], dims["y"]
+    X, B, U, Y = 0, nx, nx + nb, nx + nb + nu
+    parent = list(range(nx + nb + nu + ny))
+
+    def link(mask, ro, co):
+        for i, j in zip(*np.nonzero(mask)):
+            _union(parent, ro + int(i), co + int(j))
+
+    link(m["Ad"], X, X); link(m["Bd"], X, U); link(m["Fd"], Y, X); link(m["N1"], X, X); link(m["WWd"], Y, Y)
+    link(m["Aa"], B, B); link(m["Ba"], B, U); link(m["Fa"], Y, B); link(m["VVa"], B, B); link(m["WWa"], Y, Y)
+    link(m["Q"], B, B); link(m["Rr"], U, U)
+    if extra_bb is not None:
+        link(extra_bb, B, B)
+    groups = {}
+    for n in range(len(parent)):
+        groups.setdefault(_find(parent, n), []).append(n)
+    comps = []
+    for nodes in groups.values():
+        c = dict(xs=[n - X for n in nodes if n < B], bs=[n - B for n in nodes if B <= n < U],
+                 us=[n - U for n in nodes if U <= n < Y], ys=[n - Y for n in nodes if n >= Y])
+        comps.append(c)
+    if len(comps) < 2:
+        return None
+    d = dims["d"]
+    keep = []
+    for c in comps:
+        obs = [i for i in c["xs"] if i < d]
+        if not obs:
+            continue                       # a component without observed dims does not enter the likelihood
+        if not (c["bs"] and c["us"] and c["ys"]):
+            return None                    # degenerate component: keep the joint problem
+        c["xs"] = obs + [i for i in c["xs"] if i >= d]      # observed dims lead (the kernels read x[..., :d_c])
+        c["cols"] = obs
+        keep.append(c)
+    if len(keep) < 1:
+        return None
+    keep.sort(key=lambda c: c["cols"][0])
+    return keep
+
+
+def _take(t, rows, cols=None, time_axis=True):
+    """Select rows (and columns) of the last dims of a spec field.  A stride-0 time axis (time-invariant field,
+    lqg_amd.utils.time_stack) is preserved: the selection is made on one time slice and re-expanded, so that the
+    sub-spec is still recognised as time-invariant by the launch glue."""
+    nd = 1 if cols is None else 2
+    tax = -(nd + 1)
+    if time_axis and t.dim() > nd and t.stride(tax) == 0 and t.shape[tax] > 1:
+        T = t.shape[tax]
+        base = _take(t.select(tax, 0), rows, cols, time_axis=False)
+        return base.unsqueeze(tax).expand(*base.shape[:tax + 1 + base.dim()][:base.dim() - nd], T, *base.shape[-nd:])
+    if cols is None:
+        return t[..., rows]
+    return t[..., rows, :][..., :, cols]
+
+
+def _noise_cols(mask_rows):
+    """Columns of a noise factor V that touch the selected rows."""
+    return [int(j) for j in np.nonzero(mask_rows.any(axis=0))[0]]
+
+
+def split_system(system, comps, vmask_a, wmask_a, vmask_d, wmask_d):
+    """Sub-Systems of the components (plain System objects on views / small gathers of the original specs)."""
+    from lqg_amd.utils import mark_zero
+    a, dy = system.actor, system.dynamics
+    out = []
+    for c in comps:
+        xs, bs, us, ys = c["xs"], c["bs"], c["us"], c["ys"]
+        va = _noise_cols(vmask_a[bs]) or [0]
+        wa = _noise_cols(wmask_a[ys]) or [0]
+        vd = _noise_cols(vmask_d[xs]) or [0]
+        wd = _noise_cols(wmask_d[ys]) or [0]
+
+        def zero_like(t, *shape):
+            z = torch.zeros((), dtype=t.dtype, device=t.device).expand(*shape)
+            return mark_zero(z)
+
+        T = a.A.shape[-3]
+        keepz = lambda t, sel: (mark_zero(sel) if getattr(t, "_lqg_zero", False) else sel)
+        act = LQGSpec(Q=_take(a.Q, bs, bs), q=keepz(a.q, _take(a.q, bs)), Qf=_take(a.Qf, bs, bs, time_axis=False),
+                      qf=keepz(a.qf, _take(a.qf, bs, time_axis=False)), P=keepz(a.P, _take(a.P, us, bs)), R=_take(a.R, us, us),
+                      r=keepz(a.r, _take(a.r, us)), A=_take(a.A, bs, bs), B=_take(a.B, bs, us), V=_take(a.V, bs, va),
+                      F=_take(a.F, ys, bs), W=_take(a.W, ys, wa))
+        dyn = LQGSpec(Q=zero_like(dy.A, T, len(xs), len(xs)), q=zero_like(dy.A, T, len(xs)),
+                      Qf=zero_like(dy.A, len(xs), len(xs)), qf=zero_like(dy.A, len(xs)),
+                      P=zero_like(dy.A, T, len(us), len(xs)), R=zero_like(dy.A, T, len(us), len(us)),
+                      r=zero_like(dy.A, T, len(us)), A=_take(dy.A, xs, xs), B=_take(dy.B, xs, us),
+                      V=_take(dy.V, xs, vd), F=_take(dy.F, ys, xs), W=_take(dy.W, ys, wd))
+        out.append((System(actor=act, dynamics=dyn), c["cols"], bs))
+    return out
+
+
+def plan(system, d, Sigma0=None):
+    """Decoupling plan of a System for data with d observed dims: list of (sub_system, data columns, belief dims)
+    or None.  Cached on the instance (per d); the model zoo uses the class-level probe pattern."""
+    from lqg_amd import specialize
+    cache = system.__dict__.setdefault("_lqg_decouple", {})
+    key = (d, Sigma0 is not None)
+    if key in cache:
+        return cache[key]
+    dims, masks, _ = specialize.system_pattern(system, d)
+    extra = None
+    if Sigma0 is not None:
+        extra = specialize._any_nz(Sigma0) | specialize._any_nz(Sigma0).T
+    comps = components_from_masks(dims, masks, extra_bb=extra)
+    result = None
+    if comps is not None:
+        first = specialize._first
+        nz = specialize._any_nz
+        # noise-factor column masks come from the instance (cheap) — only used to pick columns, never to drop values
+        result = split_system(system, comps, nz(first(system.actor.V)), nz(first(system.actor.W)),
+                              nz(first(system.dynamics.V)), nz(first(system.dynamics.W)))
+    cache[key] = result
+    return result

@@ -1,0 +1,69 @@
+"""LogLikelihoodPlan — everything `System.log_likelihood(x)` decides per call (decoupling into independent
+components, structure-specialised vs generic library, workspace, argument structs), decided ONCE so that repeated
+evaluations (benchmarks, optimisation loops over the same data) are pure launches.  `System.log_likelihood` builds a
+throw-away plan; bench.py / bench_configs.py keep one."""
+import ctypes as C
+
+import torch
+
+from lqg_amd import _abi, _hip, _hipev
+
+
+class LogLikelihoodPlan:
+    def __init__(self, system, x, Sigma0=None, eps=1e-8, events=False):
+        self.system = system
+        d = x.shape[-1]
+        lib = _abi.load()
+        parts = system.decoupled(d, Sigma0) or [(system, list(range(d)), None)]
+        self.work = []
+        for sub, cols, bs in parts:
+            contiguous = cols == list(range(cols[0], cols[-1] + 1))
+            xs = x[..., cols[0]:cols[-1] + 1] if contiguous else x[..., cols]
+            S0 = Sigma0 if (Sigma0 is None or bs is None) else Sigma0[..., bs, :][..., :, bs]
+            n = xs.shape[-3]
+            ln = _hip.Launch(sub.actor, sub.dynamics, d=len(cols), n_trials=n, Sigma0=S0, eps=eps)
+            ln.require_gpu()
+            xb, is_b = _hip._prep_x(ln, xs)
+            nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
+            ev = None
+            if events:
+                ev = [_hipev.Event() for _ in range(4)]
+                for i in range(4):
+                    ln.p.phase_events[i] = ev[i].h
+            sp = _hip.specialised_entry(ln, sub, len(cols))
+            self.work.append(dict(ln=ln, x=xb, traj=ln.traj(xb, is_b), ll=ln.empty(n), nbytes=nbytes, ev=ev,
+                                  ws=torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=ln.device),
+                                  entry=sp or lib.lqg_log_likelihood, specialised=sp is not None, n=n,
+                                  dims=(sub.xdim, sub.bdim, sub.udim, sub.ydim, len(cols))))
+        self.lib = lib
+        self.device = self.work[0]["ln"].device
+        self.ll = self.work[0]["ll"]
+
+    @property
+    def description(self):
+        w = self.work
+        kind = "structure-specialised (k_riccati_sp + k_forward_sp)" if all(k["specialised"] for k in w) else \
+            "generic dense (k_riccati + k_forward" + (" + k_trial)" if w[0]["n"] > 1 else ")")
+        if len(w) > 1:
+            kind += f", {len(w)} decoupled components of dims (x,b,u,y,d)={w[0]['dims']}"
+        return kind
+
+    def run(self):
+        """Launch the whole evaluation on the current stream; returns ll[(B,) n] (a buffer owned by the plan)."""
+        with torch.cuda.device(self.device):
+            for wk in self.work:
+                ln = wk["ln"]
+                args = (C.byref(ln.p), wk["traj"], C.c_void_p(wk["ll"].data_ptr()), wk["n"] if ln.batched else 0, 1,
+                        C.c_void_p(wk["ws"].data_ptr()), wk["nbytes"], ln.stream())
+                if wk["entry"](*args) != 0:
+                    if wk["specialised"]:      # the specialised library refused: use the generic one
+                        wk["entry"], wk["specialised"] = self.lib.lqg_log_likelihood, False
+                    _abi.check(self.lib.lqg_log_likelihood(*args), "lqg_log_likelihood")
+            for wk in self.work[1:]:
+                self.ll.add_(wk["ll"])         # log p(x) = sum over independent components
+        return self.ll
+
+    def phase_ms(self):
+        """(riccati, forward, trial) milliseconds of the last run, summed over components (events=True only)."""
+        self.work[-1]["ev"][3].synchronize()
+        return tuple(sum(wk["ev"][i].elapsed_ms(wk["ev"][i + 1]) for wk in self.work) for i in range(3))

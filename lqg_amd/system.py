@@ -139,6 +139,7 @@ class System:
 
         new = System.__new__(type(self))
         new.__dict__.update(self.__dict__)
+        new.__dict__.pop("_lqg_decouple", None)      # cached sub-systems hold tensors of the old dtype / device
         same = self.actor is self.dynamics
         new.actor = conv(self.actor)
         new.dynamics = new.actor if same else conv(self.dynamics)
@@ -184,7 +185,31 @@ class System:
 
     def log_likelihood(self, x, Sigma0=None):
         """log p(x_{1:T} | x_0) per trial: x[n, T+1, d] -> [n] (lqg/system.py:246-248).  Fused HIP path."""
-        return _hip.log_likelihood(self.actor, self.dynamics, x, Sigma0=Sigma0, system=self)
+        from lqg_amd.plan import LogLikelihoodPlan
+        return LogLikelihoodPlan(self, x, Sigma0=Sigma0).run()
+
+    def decoupled(self, d, Sigma0=None):
+        """Independent components of this system for data with d observed dims ([(sub_system, data columns, belief
+        dims)], lqg_amd/decouple.py), or None when it does not decouple (or LQG_NO_DECOUPLE=1)."""
+        import os
+        if os.environ.get("LQG_NO_DECOUPLE") == "1":
+            return None
+        from lqg_amd import _abi, decouple
+        parts = decouple.plan(self, d, Sigma0)
+        if parts is None:
+            return None
+        # every component must be solvable by the generic library too (several trials, moments, ...)
+        import ctypes as C
+        try:
+            lib = _abi.load()
+        except _abi.LqgHipError:
+            return parts
+        for sub, cols, _ in parts:
+            dm = _abi.Dims(sub.xdim, sub.bdim, sub.udim, sub.ydim, len(cols), sub.actor.V.shape[-1],
+                           sub.actor.W.shape[-1], sub.dynamics.V.shape[-1], sub.dynamics.W.shape[-1])
+            if not lib.lqg_dims_supported(_abi.F32, C.byref(dm)):
+                return None
+        return parts
 
     def belief_tracking_distribution(self, x, Sigma0=None):
         """Distribution of the actor's belief given the observed trajectory (lqg/system.py:250-257):

@@ -162,3 +162,28 @@ def test_specialised_path_on_hand_built_system_and_nan_semantics():
     assert abs(float(s64.log_likelihood(x)[0]) / g["ll"][0] - 1) < 1e-10
     bad = lqg_amd.BoundedActor(T=10, action_variability=0.0, device="cuda", dtype=torch.float64)
     assert not torch.isfinite(bad.log_likelihood(torch.zeros(1, 11, 2, dtype=torch.float64, device="cuda"))).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("ctor,kw,gold", [
+    ("SubjectiveActor", dict(dim=2, T=60, action_cost=0.5, sigma_cursor=3.0, subj_noise=1.3, subj_vel_noise=0.7), "subjective2d_T60"),
+    ("BoundedActor", dict(dim=2, T=40, action_cost=0.2), "bounded2d_T40"),
+])
+def test_decoupled_components_sum_to_the_joint_likelihood(ctor, kw, gold, dtype, monkeypatch):
+    """dim=2 zoo models are two independent 1-D models: the component log-likelihoods add up to the reference's
+    joint value (golden) and to the joint kernels' value (lqg_amd/decouple.py)."""
+    import lqg_amd
+
+    g, _, _ = load_golden(gold)
+    m = getattr(lqg_amd, ctor)(device="cuda", dtype=dtype, **kw)
+    parts = m.decoupled(4)
+    assert parts is not None and len(parts) == 2
+    tol = TOL[dtype]["ll"]
+    for xs in (g["x"], g["x"][:1]):                       # several trials (operator stream) and one trial (fused)
+        x = torch.as_tensor(xs, dtype=dtype, device="cuda")
+        ll = m.log_likelihood(x)
+        assert np.abs(np_(ll) / g["ll"][:len(xs)] - 1).max() < tol
+        monkeypatch.setenv("LQG_NO_DECOUPLE", "1")
+        ll_joint = m.log_likelihood(x)
+        monkeypatch.delenv("LQG_NO_DECOUPLE")
+        assert np.abs(np_(ll) / np_(ll_joint) - 1).max() < tol

@@ -91,3 +91,34 @@ def test_workload_generators_are_seeded():
     for k, (lo, hi) in workload.RANGES.items():
         assert float(pa[k].min()) >= lo and float(pa[k].max()) <= hi
     assert (a.xdim, a.bdim, a.udim, a.ydim, a.n_systems) == (4, 6, 2, 4, 16)
+
+
+def test_decoupling_plan_of_the_model_zoo():
+    """dim=2 models split into two 1-D components; coupled models do not."""
+    from lqg_amd import decouple
+    m = lqg_amd.SubjectiveActor(dim=2, T=5, device="cpu", dtype=torch.float64)
+    plan = decouple.plan(m, 4)
+    assert [(s.xdim, s.bdim, s.udim, s.ydim, cols, bs) for s, cols, bs in plan] == \
+        [(2, 3, 1, 2, [0, 1], [0, 1, 4]), (2, 3, 1, 2, [2, 3], [2, 3, 5])]
+    one = lqg_amd.SubjectiveActor(dim=1, T=5, device="cpu", dtype=torch.float64)
+    for f in ("A", "B", "F", "V", "W", "Q", "R"):
+        assert torch.equal(getattr(plan[0][0].actor, f), getattr(one.actor, f)), f
+        if f in ("A", "B", "F", "V", "W"):
+            assert torch.equal(getattr(plan[1][0].dynamics, f), getattr(one.dynamics, f)), f
+    assert decouple.plan(lqg_amd.BoundedActor(dim=1, T=5, device="cpu"), 2) is None
+    assert decouple.plan(lqg_amd.PointMassBoundedActor(T=5, device="cpu"), 2) is None     # coupled through the cost
+    # a full Sigma0 couples the beliefs of the two axes: no decoupling
+    assert decouple.plan(m, 4, Sigma0=torch.ones(6, 6, dtype=torch.float64)) is None
+
+
+def test_pattern_extraction_of_the_model_zoo():
+    from lqg_amd import specialize
+    dims, masks, key = specialize.class_pattern(lqg_amd.SubjectiveActor, 4, dim=2)
+    assert dims == dict(x=4, b=6, u=2, y=4, d=4) and len(key) == 16
+    assert not masks["DB"].any()                              # Fd Bd - Fa Ba cancels exactly
+    assert masks["Aa"].sum() == 8 and masks["Fa"].sum() == 4 and masks["N3"].sum() == 4
+    src = specialize.generate_source(key, dims, masks)
+    assert "lqg_log_likelihood_sp" in src and "lqg::Mask<6, 6> Aa" in src
+    # a parameter that happens to be zero must not narrow the cached class mask
+    z = lqg_amd.SubjectiveActor(dim=2, T=3, subj_vel_noise=0.0, device="cpu")
+    assert specialize.system_pattern(z, 4)[2] == key
