@@ -60,8 +60,9 @@ def up_to_date():
     return os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read().strip() == source_hash()
 
 
-def _newest_src():
-    return max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS + ["lqg_abi.hip", "lqg_inst.hip"])
+def _newest_src(src):
+    """Newest mtime among the headers and the one source file an object is compiled from."""
+    return max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS + [src])
 
 
 def _compile(job):
@@ -108,9 +109,8 @@ def build(force=False, workers=None, verbose=True):
             print(f"[lqg_amd.build] {LIB} is up to date", flush=True)
         return LIB
     os.makedirs(OBJ, exist_ok=True)
-    newest = _newest_src()
     todo = [j for j in jobs() if force or not os.path.exists(os.path.join(OBJ, j[0]))
-            or os.path.getmtime(os.path.join(OBJ, j[0])) < newest]
+            or os.path.getmtime(os.path.join(OBJ, j[0])) < _newest_src(j[1])]
     workers = workers or min(8, os.cpu_count() or 1)
     if todo:
         if verbose:

@@ -297,9 +297,9 @@ int lqg_log_likelihood(const lqg_problem* p, lqg_traj x, void* ll, int64_t ll_sb
                        size_t workspace_bytes, void* stream) {
   static const char* who = "lqg_log_likelihood";
   if (int rc = check_full(p, who)) return rc;
+  if (p->n_sys == 0 || p->n_trials == 0) return 0;   // empty batch: nothing to do (pointers may be NULL)
   if (!x.ptr) return fail(LQG_ERR_NULL, "%s: x.ptr is NULL", who);
   if (!ll) return fail(LQG_ERR_NULL, "%s: ll is NULL", who);
-  if (p->n_sys == 0 || p->n_trials == 0) return 0;
   const lqg_traj no_mu{nullptr, 0, 0, 0, 0};
   const lqg_view no_sig{nullptr, 0, 0, 0, 0};
   const GainOutputs none{};

@@ -50,6 +50,8 @@ class LogLikelihoodPlan:
 
     def run(self):
         """Launch the whole evaluation on the current stream; returns ll[(B,) n] (a buffer owned by the plan)."""
+        if self.work[0]["n"] == 0:
+            return self.ll                     # no trials: nothing to launch
         with torch.cuda.device(self.device):
             for wk in self.work:
                 ln = wk["ln"]

@@ -6,8 +6,6 @@ may carry a leading axis of B systems (parameter candidates); results then gain 
 `x` may be `[n, T+1, d]` (the same trials scored under every candidate — the reference's
 `vmap(ll)(sigmas)`, notebooks/Tutorial.ipynb cell 38) or `[B, n, T+1, d]`.
 """
-import math
-
 import torch
 
 from lqg_amd import _hip
@@ -127,11 +125,16 @@ class System:
         """Move / cast both specs (torch `.to` semantics)."""
         from lqg_amd.utils import mark_zero
 
+        def move(t):
+            # keep stride-0 (expanded) axes expanded: convert one slice and re-expand, never materialise T copies
+            idx = tuple(slice(0, 1) if (st == 0 and sz > 1) else slice(None) for st, sz in zip(t.stride(), t.shape))
+            return t[idx].to(*args, **kwargs).expand(t.shape)
+
         def conv(spec):
             out = {}
             for f in LQGSpec._fields:
                 t = getattr(spec, f)
-                t2 = t.to(*args, **kwargs)
+                t2 = move(t)
                 if getattr(t, "_lqg_zero", False):
                     mark_zero(t2)
                 out[f] = t2
@@ -169,7 +172,6 @@ class System:
     def conditional_moments(self, x, Sigma0=None):
         """p(x_{t+1}, xhat_{t+1} | x_{1:t}) for ONE trajectory x[T+1, d] -> mu[T, m], Sigma[T, m, m]
         (lqg/system.py:142-235).  With B systems: x[B, T+1, d] -> mu[B, T, m], Sigma[B, T, m, m]."""
-        batched = self.n_systems is not None
         xx = x.unsqueeze(-3)
         mu, Sig = _hip.conditional_moments(self.actor, self.dynamics, xx, Sigma0=Sigma0)
         return mu.squeeze(-3), Sig

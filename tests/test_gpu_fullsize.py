@@ -1,0 +1,103 @@
+"""-m gpu: size-independent properties at BASELINE.json's full sizes (where the CPU oracle cannot follow) plus the
+edge cases of the boundary (empty batches, T = 1, one trial, shared vs per-system trials)."""
+import numpy as np
+import pytest
+import torch
+
+import lqg_amd
+from lqg_amd import _hip, workload
+from gpu_common import np_
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def headline():
+    B, T = 1 << 18, 500                                   # BASELINE headline / config 5 shape, full batch
+    system, _ = workload.headline_system(B, T, seed=1234, device=DEV, dtype=torch.float32)
+    x = workload.pack_trials(workload.simulate_one_trial_each(system, seed=99))
+    return system, x
+
+
+def test_full_batch_all_paths_agree(headline, monkeypatch):
+    """2^18 solves: every fp32 path (decoupled + specialised, specialised joint, generic dense joint) against the fp64
+    path (itself within 1e-14 of the oracle): 99.9 % of the systems within the north-star 1e-6, worst case < 5e-6
+    (measured: median 3e-8, p99.9 7e-7, max 1.7e-6 — the tail are candidates whose |ll| is small); the three fp64
+    paths agree to 1e-11."""
+    system, x = headline
+    s64, x64 = system.to(torch.float64), x.double()
+
+    def check32(ll, ref):
+        r = (ll.double() / ref - 1).abs().flatten()
+        assert float(torch.quantile(r[: 1 << 18], 0.999)) < 1e-6 and float(r.max()) < 5e-6
+
+    ref = s64.log_likelihood(x64).clone()                 # decoupled + specialised, fp64
+    check32(system.log_likelihood(x), ref)
+    monkeypatch.setenv("LQG_NO_DECOUPLE", "1")
+    ref_joint = s64.log_likelihood(x64).clone()
+    check32(system.log_likelihood(x), ref)
+    monkeypatch.setenv("LQG_NO_SPECIALIZE", "1")
+    ref_gen = s64.log_likelihood(x64).clone()
+    check32(system.log_likelihood(x), ref)
+    assert ref.shape == (1 << 18, 1) and torch.isfinite(ref).all()
+    assert float((ref_joint / ref - 1).abs().max()) < 1e-11 and float((ref_gen / ref - 1).abs().max()) < 1e-11
+    # checksum of checksums: the fp64 objectives of the extreme paths agree to 1e-12 rel
+    assert abs(float(_hip.sum_trials(ref.view(1, -1)) / _hip.sum_trials(ref_gen.view(1, -1))) - 1) < 1e-12
+
+
+def test_full_batch_permutation_and_sharding_invariance(headline):
+    """Systems are independent: evaluating a shard gives exactly the shard of the full result; the objective is the
+    sum of shard objectives (what the multi-GPU path relies on)."""
+    system, x = headline
+    B = system.n_systems
+    ll = system.log_likelihood(x).clone()
+    lo, hi = B // 4, B // 2
+    sub = workload.slice_system(system, lo, hi)
+    ll_sub = sub.log_likelihood(x[lo:hi])
+    assert torch.equal(ll_sub, ll[lo:hi])                 # bitwise: a lane's arithmetic does not depend on its neighbours
+    total = _hip.sum_trials(ll.view(1, -1))
+    parts = sum(_hip.sum_trials(ll[a:b].reshape(1, -1)) for a, b in ((0, lo), (lo, hi), (hi, B)))
+    assert abs(float(parts / total) - 1) < 1e-12
+
+
+def test_config3_shape_objective_is_sum_of_trials():
+    """4096 candidates x 1024 shared trials (config 3 shape, shortened horizon): [B, n] result, fp64 objective equals
+    the sum over trials, shared x == explicitly replicated x."""
+    Bc, n, T = 4096, 1024, 120
+    m, _ = workload.bounded_system(Bc, T, seed=5, device=DEV, dtype=torch.float32)
+    truth = lqg_amd.BoundedActor(T=T, sigma_target=20.0, sigma_cursor=3.0, action_cost=0.3, device=DEV)
+    x = truth.simulate(13, n=n)
+    ll = m.log_likelihood(x)
+    assert ll.shape == (Bc, n) and torch.isfinite(ll).all()
+    obj = _hip.sum_trials(ll)
+    assert obj.dtype == torch.float64 and obj.shape == (Bc,)
+    assert float(((obj - ll.double().sum(-1)).abs() / obj.abs()).max()) < 1e-10
+    few = m.log_likelihood(x[:3].unsqueeze(0).expand(Bc, 3, T + 1, 2).contiguous())    # per-system copies of the trials
+    assert torch.equal(few, ll[:, :3])
+
+
+def test_metamorphic_bounded_equals_subjective_at_scale():
+    """Likelihood analogue of the reference's tests/lqg_test.py:69-93 over 4096 candidates."""
+    B, T = 4096, 200
+    p = workload.sample_params(("action_variability", "sigma_target", "sigma_cursor", "action_cost"), B, 3, DEV, torch.float64)
+    b = lqg_amd.BoundedActor(T=T, device=DEV, dtype=torch.float64, **p)
+    s = lqg_amd.SubjectiveActor(T=T, subj_noise=1.0, subj_vel_noise=0.0, device=DEV, dtype=torch.float64, **p)
+    x = workload.simulate_one_trial_each(b, seed=1)
+    assert float((b.log_likelihood(x) / s.log_likelihood(x) - 1).abs().max()) < 1e-9
+
+
+def test_edge_cases_of_the_boundary():
+    m = lqg_amd.BoundedActor(T=1, device=DEV, dtype=torch.float64)                 # single step
+    x = m.simulate(0, n=5)
+    assert x.shape == (5, 2, 2) and torch.isfinite(m.log_likelihood(x)).all()
+    mu, Sig = m.conditional_moments(x[0])
+    assert mu.shape == (1, 4) and Sig.shape == (1, 4, 4)
+    m = lqg_amd.BoundedActor(T=50, device=DEV)
+    assert m.log_likelihood(torch.zeros(0, 51, 2, device=DEV)).shape == (0,)        # no trials: nothing launched
+    with pytest.raises(lqg_amd._abi.LqgHipError, match="T\\+1"):
+        m.log_likelihood(torch.zeros(3, 50, 2, device=DEV))                        # wrong number of rows
+    with pytest.raises(lqg_amd._abi.LqgHipError, match="no kernel instantiation"):
+        lqg_amd.LQG(torch.eye(7, device=DEV), torch.ones(7, 3, device=DEV), torch.eye(7, device=DEV),
+                    torch.eye(7, device=DEV), torch.eye(7, device=DEV), torch.eye(7, device=DEV),
+                    torch.eye(3, device=DEV), T=4).conditional_moments(torch.zeros(5, 7, device=DEV))
