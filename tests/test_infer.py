@@ -63,3 +63,27 @@ def test_max_likelihood_improves_and_approaches_truth():
     nll_true = -float(m.log_likelihood(x).sum())
     assert float(losses[-1]) < nll_true + 5.0                              # at least as good as the truth (+slack)
     assert abs(params["sigma_target"] - 12.0) < 4.0 and abs(params["action_variability"] - 0.4) < 0.15
+
+
+@pytest.mark.gpu
+def test_value_and_grad_matches_oracle_finite_differences(oracle_lib):
+    """The batched finite-difference gradient against an independent central difference of the fp64 CPU oracle
+    (the reference's `grad(ll)(28.)`, Tutorial cell 42, differentiates the same function)."""
+    import lqg_np as O
+    from lqg_amd.infer import value_and_grad
+    true = dict(sigma_target=25.0, action_variability=0.5, action_cost=0.05, sigma_cursor=1.0)
+    m = lqg_amd.BoundedActor(T=120, device="cuda", dtype=torch.float64, **true)
+    x = m.simulate(7, n=8)
+    fixed = dict(action_variability=0.5, action_cost=0.05, sigma_cursor=1.0)
+    val, grad = value_and_grad(x, lqg_amd.BoundedActor, dict(sigma_target=28.0), **fixed)
+
+    def oracle_obj(sig):
+        A, B = np.eye(2), (1.0 / 60) * np.array([[0.0], [1.0]])
+        spec = O.time_stack_spec(A, B, np.eye(2), np.diag([1.0, 0.5]), np.diag([sig, 1.0]),
+                                 np.array([[1.0, -1.0], [-1.0, 1.0]]), np.eye(1) * 0.05, 120)
+        return float(oracle_lib.log_likelihood(spec, spec, x.cpu().numpy()).sum())
+
+    h = 1e-4
+    ref_grad = (oracle_obj(28.0 + h) - oracle_obj(28.0 - h)) / (2 * h)
+    assert abs(val / oracle_obj(28.0) - 1) < 1e-11
+    assert abs(grad["sigma_target"] / ref_grad - 1) < 1e-5
