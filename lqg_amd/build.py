@@ -39,8 +39,13 @@ def jobs():
     js = [("abi.o", "lqg_abi.hip", [])]
     for fam, tuples in dims_lists().items():
         for t in tuples:
-            name = f"{fam.lower()}_{'_'.join(map(str, t))}.o"
-            js.append((name, "lqg_inst.hip", [f"-DLQG_INST_{fam}={','.join(map(str, t))}"]))
+            for dt in ("F32", "F64"):
+                base = f"{fam.lower()}_{'_'.join(map(str, t))}_{dt.lower()}"
+                defs = [f"-DLQG_INST_{fam}={','.join(map(str, t))}", f"-DLQG_INST_{dt}"]
+                if fam == "FORWARD":          # the 8 k_forward variants of a (dims, dtype) are split over four units
+                    js += [(f"{base}_v{v}.o", "lqg_inst.hip", defs + [f"-DLQG_INST_VARIANT={v}"]) for v in range(4)]
+                else:
+                    js.append((base + ".o", "lqg_inst.hip", defs))
     return js
 
 
@@ -117,7 +122,7 @@ def build(force=False, workers=None, verbose=True):
             print(f"[lqg_amd.build] compiling {len(todo)} translation units for {ARCH} with {workers} workers",
                   flush=True)
         # biggest kernels first so the tail of the parallel build is short
-        todo.sort(key=lambda j: -sum(int(v) ** 3 for v in re.findall(r"\d+", " ".join(j[2]))))
+        todo.sort(key=lambda j: -sum(int(v) ** 3 for v in re.findall(r"\d+", j[2][0] if j[2] else "")) * (4 if "FORWARD" in " ".join(j[2]) else 1))
         with cf.ThreadPoolExecutor(workers) as ex:
             for name, rc, err in ex.map(_compile, todo):
                 if rc != 0:

@@ -97,6 +97,16 @@ hipError_t launch_kalman(const lqg_problem* p, lqg_view K, hipStream_t st) {
   return hipGetLastError();
 }
 
+// k_forward has 8 instantiations per (dtype, dims): TI x FUSED x MAT.  They are split over four functions (by FUSED
+// and TI) so that lqg_inst.hip can compile them in separate translation units (the m = 20 kernels take ~90 s each).
+template <typename R, int NX, int NB, int NU, int NY, int ND, bool FUSED, bool TI>
+hipError_t launch_forward_v(const lqg::ForwardArgs<R>& k, long n_sys, bool mat, hipStream_t st) {
+  const dim3 grid(blocks_for(n_sys)), block(LQG_BLOCK);
+  if (mat) hipLaunchKernelGGL((lqg::k_forward<R, NX, NB, NU, NY, ND, TI, FUSED, true>), grid, block, 0, st, k);
+  else hipLaunchKernelGGL((lqg::k_forward<R, NX, NB, NU, NY, ND, TI, FUSED, false>), grid, block, 0, st, k);
+  return hipGetLastError();
+}
+
 template <typename R, int NX, int NB, int NU, int NY, int ND>
 hipError_t launch_forward(const lqg_problem* p, const void* Ls, long ldb, bool fused, lqg_traj x, void* ll,
                           long ll_sb, void* ops, lqg_view Sig, lqg_traj mu, lqg_view Kout, hipStream_t st) {
@@ -107,20 +117,13 @@ hipError_t launch_forward(const lqg_problem* p, const void* Ls, long ldb, bool f
                         dv<R>(p->Sigma0), static_cast<const R*>(Ls), ldb, dt<R>(x), static_cast<R*>(ll), ll_sb,
                         static_cast<R*>(ops), dv<R>(Sig), dt<R>(mu), dv<R>(Kout), (long)p->n_sys, p->T,
                         p->dims.nva, p->dims.nwa, p->dims.nvd, p->dims.nwd};
-  const dim3 grid(blocks_for(p->n_sys)), block(LQG_BLOCK);
   const bool ti = forward_ti(p);
   const bool mat = Sig.ptr || mu.ptr || Kout.ptr;
-#define LQG_FWD(TI_, FU_, MA_) \
-  hipLaunchKernelGGL((lqg::k_forward<R, NX, NB, NU, NY, ND, TI_, FU_, MA_>), grid, block, 0, st, k)
-  if (ti) {
-    if (fused) { if (mat) LQG_FWD(true, true, true); else LQG_FWD(true, true, false); }
-    else { if (mat) LQG_FWD(true, false, true); else LQG_FWD(true, false, false); }
-  } else {
-    if (fused) { if (mat) LQG_FWD(false, true, true); else LQG_FWD(false, true, false); }
-    else { if (mat) LQG_FWD(false, false, true); else LQG_FWD(false, false, false); }
-  }
-#undef LQG_FWD
-  return hipGetLastError();
+  const long n = (long)p->n_sys;
+  if (fused) return ti ? launch_forward_v<R, NX, NB, NU, NY, ND, true, true>(k, n, mat, st)
+                       : launch_forward_v<R, NX, NB, NU, NY, ND, true, false>(k, n, mat, st);
+  return ti ? launch_forward_v<R, NX, NB, NU, NY, ND, false, true>(k, n, mat, st)
+            : launch_forward_v<R, NX, NB, NU, NY, ND, false, false>(k, n, mat, st);
 }
 
 #ifndef LQG_TRIALS_PER_LANE
