@@ -23,6 +23,7 @@ import torch
 import lqg_amd
 from lqg_amd import _abi, _hip, _hipev, workload
 from lqg_amd.system import Actor, System
+from bench import PEAK_FP32_TFLOPS, PEAK_FP64_TFLOPS, PEAK_HBM_GBS, algorithmic_bytes_per_solve, algorithmic_flops_per_step
 
 
 def hand2d_system(T, device, dtype, cursor_noise=0.1):
@@ -115,8 +116,21 @@ def main():
         ll, ph = timed_loglik(system, x, args.reps)
         B = system.n_systems or 1
         n = x.shape[-3]
+        dm = dict(x=system.xdim, b=system.bdim, u=system.udim, y=system.ydim, d=x.shape[-1])
+        fl = algorithmic_flops_per_step(**dm)                       # SURVEY.md §8(d), reference formulation
+        T_ = system.T
+        alg_flops = B * T_ * (fl["total"] - fl["mean"] - fl["logprob"]) + B * n * T_ * (fl["mean"] + fl["logprob"])
+        w_ = 4 if dtype_name == "f32" else 8
+        alg_bytes = B * (algorithmic_bytes_per_solve(T=T_, w=w_, **dm) - w_ * (T_ + 1) * dm["d"]) + \
+            (1 if x.dim() == 3 else B) * n * w_ * (T_ + 1) * dm["d"] + B * n * w_
+        peak = PEAK_FP32_TFLOPS if dtype_name == "f32" else PEAK_FP64_TFLOPS
         out = dict(config=cfg, workload=name, dtype=dtype_name, systems=B, trials_per_system=n, T=system.T,
-                   dims=dict(x=system.xdim, b=system.bdim, u=system.udim, y=system.ydim, d=x.shape[-1]), **ph,
+                   dims=dm, **ph,
+                   algorithmic=dict(tflops=alg_flops / (ph["total_ms"] * 1e-3) / 1e12,
+                                    frac_vector_peak=alg_flops / (ph["total_ms"] * 1e-3) / 1e12 / peak,
+                                    hbm_gbs=alg_bytes / (ph["total_ms"] * 1e-3) / 1e9,
+                                    frac_hbm_peak=alg_bytes / (ph["total_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                    note="M1 accounting of SURVEY.md 8(d): reference-formulation flops, inputs-once bytes"),
                    solves_per_s=B / (ph["total_ms"] * 1e-3),
                    trial_evals_per_s=B * n / (ph["total_ms"] * 1e-3),
                    all_finite=bool(torch.isfinite(ll).all()),

@@ -207,23 +207,6 @@ def specialised_entry(ln, system, d):
     return None if lib is None else lib.lqg_log_likelihood_sp
 
 
-def log_likelihood(actor, dynamics, x, Sigma0=None, eps=1e-8, system=None):
-    """x[n,T+1,d] | [B,n,T+1,d] -> ll[(B,)n].  `system` (the owning System) enables the structure-specialised path."""
-    d, n = x.shape[-1], x.shape[-3]
-    ln = Launch(actor, dynamics, d=d, n_trials=n, Sigma0=Sigma0, eps=eps)
-    lib = ln.require_gpu()
-    x, xb = _prep_x(ln, x)
-    ll = ln.empty(n)
-    with torch.cuda.device(ln.device):
-        ws, nbytes = ln.workspace(lib, _abi.OP_LOG_LIKELIHOOD)
-        args = (C.byref(ln.p), ln.traj(x, xb), C.c_void_p(ll.data_ptr()), n if ln.batched else 0, 1,
-                C.c_void_p(ws.data_ptr()), nbytes, ln.stream())
-        sp = specialised_entry(ln, system, d)
-        if sp is None or sp(*args) != 0:
-            _abi.check(lib.lqg_log_likelihood(*args), "lqg_log_likelihood")
-    return ll
-
-
 def sum_trials(ll):
     """ll[(B,)n] -> fp64 sums [(B,)] with a fixed reduction tree (lqg_sum_trials)."""
     lib = _abi.load()
