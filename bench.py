@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--layout", default="packed", choices=["packed", "reference"],
                     help="trajectory layout in HBM: packed = [T+1][d][B] (batch fastest), reference = [B][T+1][d]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stack", action="store_true",
+                    help="launch decoupled components separately instead of stacked into one launch")
     ap.add_argument("--cpu-sample", type=int, default=0, help="solves in the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
 
@@ -101,7 +103,7 @@ def main():
     #     when one exists (lqg_amd/specialize.py; LQG_NO_SPECIALIZE=1 forces the generic dense kernels).
     # Both are exact and both are derived from the spec DATA, not from the model's name.
     from lqg_amd.plan import LogLikelihoodPlan
-    plan = LogLikelihoodPlan(system, x, events=True)
+    plan = LogLikelihoodPlan(system, x, events=True, stack=not args.no_stack)
     ll = plan.ll
     fwd_name = plan.description
     sp_all = all(wk["specialised"] for wk in plan.work)
@@ -161,12 +163,14 @@ def main():
     # PMC-derived figures of the dominant kernel, collected in separate rocprofv3 --pmc passes of this same command and
     # committed under profiles/ (FETCH_SIZE x2 gfx950 correction, calibrated there): HBM bytes and VALU instructions
     traffic = executed = None
-    n_launch = len(plan.work)                       # forward-kernel launches per step (one per decoupled component)
+    n_launch = len(plan.work)                       # forward-kernel launches per step
     pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(pmc_path):
         try:
             pj = json.load(open(pmc_path))
             key = f"{'k_forward_sp' if sp_all else 'k_forward'}_x{n_launch}_{args.dtype}_log2B{args.log2_batch}"
+            if plan.n_stacked > 1:
+                key = f"k_forward_sp_stacked{plan.n_stacked}_{args.dtype}_log2B{args.log2_batch}"
             if n_launch == 1 and key not in pj:
                 key = f"k_forward_{args.dtype}_log2B{args.log2_batch}"
             rec = pj.get(key, {})

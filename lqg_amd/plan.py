@@ -10,11 +10,21 @@ from lqg_amd import _abi, _hip, _hipev
 
 
 class LogLikelihoodPlan:
-    def __init__(self, system, x, Sigma0=None, eps=1e-8, events=False, concurrent=False):
+    def __init__(self, system, x, Sigma0=None, eps=1e-8, events=False, concurrent=False, stack=False):
+        """stack=True (persistent plans over a fixed dataset): decoupled components that share dims and sparsity
+        pattern are concatenated along the system axis and solved by ONE launch of C*B systems (twice the waves in
+        flight per SIMD at the headline shape); costs a one-time re-packing copy of x, so it is off for the throw-away
+        plan of System.log_likelihood."""
         self.system = system
         d = x.shape[-1]
         lib = _abi.load()
         parts = system.decoupled(d, Sigma0) or [(system, list(range(d)), None)]
+        self.n_stacked = 1
+        if stack and len(parts) > 1 and Sigma0 is None:
+            stacked = _stack_components(parts, x)
+            if stacked is not None:
+                self.n_stacked = len(parts)
+                parts, x = [(stacked[0], list(range(stacked[1].shape[-1])), None)], stacked[1]
         self.work = []
         for sub, cols, bs in parts:
             contiguous = cols == list(range(cols[0], cols[-1] + 1))
@@ -38,6 +48,10 @@ class LogLikelihoodPlan:
         self.lib = lib
         self.device = self.work[0]["ln"].device
         self.ll = self.work[0]["ll"]
+        if self.n_stacked > 1:                 # [C*B, n] of the stacked launch -> per-solve sum over the C components
+            self._ll_stacked = self.ll
+            self.ll = torch.empty((self.ll.shape[0] // self.n_stacked,) + tuple(self.ll.shape[1:]),
+                                  dtype=self.ll.dtype, device=self.ll.device)
         # concurrent=True runs the independent components on side streams: with B = 2^18 one launch is 4 waves per
         # SIMD, two in flight give the SIMDs twice the waves to hide latencies behind (measured +4 % at the headline
         # shape; off by default so that per-kernel timings stay attributable)
@@ -52,6 +66,8 @@ class LogLikelihoodPlan:
             "generic dense (k_riccati + k_forward" + (" + k_trial)" if w[0]["n"] > 1 else ")")
         if len(w) > 1:
             kind += f", {len(w)} decoupled components of dims (x,b,u,y,d)={w[0]['dims']}"
+        if self.n_stacked > 1:
+            kind += f", {self.n_stacked} decoupled components of dims (x,b,u,y,d)={w[0]['dims']} stacked into one launch"
         return kind
 
     def run(self):
@@ -79,9 +95,66 @@ class LogLikelihoodPlan:
                 main.wait_event(ev)
             for wk in self.work[1:]:
                 self.ll.add_(wk["ll"])         # log p(x) = sum over independent components
+            if self.n_stacked > 1:
+                torch.sum(self._ll_stacked.view(self.n_stacked, *self.ll.shape), dim=0, out=self.ll)
         return self.ll
 
     def phase_ms(self):
         """(riccati, forward, trial) milliseconds of the last run, summed over components (events=True only)."""
         self.work[-1]["ev"][3].synchronize()
         return tuple(sum(wk["ev"][i].elapsed_ms(wk["ev"][i + 1]) for wk in self.work) for i in range(3))
+
+
+def _stack_components(parts, x):
+    """Concatenate decoupled components of identical shape and sparsity pattern along the system axis:
+    returns (stacked System of C*B systems, x re-packed as [C*B, 1, T+1, d_c]) or None when they do not match."""
+    from lqg_amd import specialize, workload
+    from lqg_amd.spec import LQGSpec
+    from lqg_amd.system import System
+    from lqg_amd.utils import mark_zero
+
+    subs = [p[0] for p in parts]
+    B = subs[0].n_systems
+    if B is None or x.dim() != 4 or x.shape[1] != 1 or x.shape[0] != B:
+        return None
+    shapes = {(s.xdim, s.bdim, s.udim, s.ydim, len(c)) for s, c, _ in parts}
+    keys = {specialize.system_pattern(s, len(c))[2] for s, c, _ in parts}
+    if len(shapes) != 1 or len(keys) != 1:
+        return None
+    T = subs[0].T
+
+    def cat(name, which):
+        ts = []
+        for s in subs:
+            t = getattr(getattr(s, which), name)
+            if getattr(t, "_lqg_zero", False):
+                return t                                    # known-zero affine terms stay shared NULLs
+            notime = name in ("Qf", "qf")
+            vec = name in ("q", "qf", "r")
+            base_nd = (1 if vec else 2) + (0 if notime else 1)
+            if not notime:
+                tax = -(2 if vec else 3)
+                if t.stride(tax) != 0 and t.shape[tax] > 1:
+                    return None                             # time-varying: not stacked
+                t = t.select(tax, 0)
+                base_nd -= 1
+            if t.dim() == base_nd:
+                t = t.expand(B, *t.shape)
+            ts.append(t)
+        out = torch.cat(ts, dim=0)
+        if name not in ("Qf", "qf"):
+            nd = 1 if name in ("q", "r") else 2
+            out = out.unsqueeze(-(nd + 1)).expand(*out.shape[:-nd], T, *out.shape[-nd:])
+        return out
+
+    fields = {}
+    for which in ("actor", "dynamics"):
+        vals = {}
+        for f in LQGSpec._fields:
+            v = cat(f, which)
+            if v is None:
+                return None
+            vals[f] = v
+        fields[which] = LQGSpec(**vals)
+    xs = torch.cat([x[..., c[0]:c[-1] + 1] for _, c, _ in parts], dim=0)      # [C*B, 1, T+1, d_c]
+    return System(actor=fields["actor"], dynamics=fields["dynamics"]), workload.pack_trials(xs)

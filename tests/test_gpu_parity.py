@@ -187,3 +187,18 @@ def test_decoupled_components_sum_to_the_joint_likelihood(ctor, kw, gold, dtype,
         ll_joint = m.log_likelihood(x)
         monkeypatch.delenv("LQG_NO_DECOUPLE")
         assert np.abs(np_(ll) / np_(ll_joint) - 1).max() < tol
+
+
+def test_stacked_plan_equals_separate_components():
+    """LogLikelihoodPlan(stack=True): both decoupled components in one launch — same numbers."""
+    import lqg_amd
+    from lqg_amd import workload
+    from lqg_amd.plan import LogLikelihoodPlan
+    sys_, _ = workload.headline_system(1000, 80, seed=3, device="cuda", dtype=torch.float64)
+    x = workload.pack_trials(workload.simulate_one_trial_each(sys_, seed=4))
+    a = LogLikelihoodPlan(sys_, x).run().clone()
+    plan = LogLikelihoodPlan(sys_, x, stack=True)
+    assert plan.n_stacked == 2 and len(plan.work) == 1
+    b = plan.run()
+    assert a.shape == b.shape == (1000, 1)
+    assert float((a / b - 1).abs().max()) < 1e-13
