@@ -117,10 +117,10 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
   if (a.Sigma0.p) load_sym<R, NB>(a.Sigma0.p + s * a.Sigma0.sb, a.Sigma0.sr, a.Sigma0.sc, P);
   else load_gram<R, NB>(a.aV.p + s * a.aV.sb, a.aV.sr, a.aV.sc, a.nva, P);
 
-  R Sg[M * M], muO[O], muR[RR];
+  R Sg[M * M], xprev[O], dO[O], muR[RR];   // observed mean = xprev + dO (deviation form, see k_forward)
   double acc = 0.0;
   const R* xp = a.x.p + s * a.x.sb;
-  LQG_UNROLL for (int i = 0; i < O; ++i) muO[i] = xp[i * a.x.sd];
+  LQG_UNROLL for (int i = 0; i < O; ++i) { xprev[i] = xp[i * a.x.sd]; dO[i] = R(0); }
   LQG_UNROLL for (int i = 0; i < RR; ++i) muR[i] = R(0);
   const R kLogNorm = R(0.5 * ND * 1.8378770664093453);
 
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
     R zz = R(0);
     LQG_UNROLL for (int i = 0; i < O; ++i) {
       R v = R(0);
-      LQG_UNROLL for (int j = 0; j <= i; ++j) v += Li[i * O + j] * (xt[j] - muO[j]);
+      LQG_UNROLL for (int j = 0; j <= i; ++j) v += Li[i * O + j] * ((xt[j] - xprev[j]) - dO[j]);
       w[i] = v;
       zz += v * v;
     }
@@ -192,9 +192,15 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
       cvec[O + p] = v;
     }
     R mn[M];
-    LQG_UNROLL for (int i = 0; i < M; ++i) mn[i] = R(0);
-    matvec_acc(Fj, cvec, mn);
-    LQG_UNROLL for (int i = 0; i < O; ++i) muO[i] = mn[i];
+    LQG_UNROLL for (int i = 0; i < M; ++i) {                 // rows < O as deviation from x_t: ((Fj - I) cvec)[i]
+      R v = R(0);
+      LQG_UNROLL for (int j = 0; j < M; ++j) {
+        if (i < O && i == j) v += (Fj.mask(i, i) ? Fj.v[i * M + i] - R(1) : R(-1)) * cvec[j];
+        else if (Fj.mask(i, j)) v += Fj.v[i * M + j] * cvec[j];
+      }
+      mn[i] = v;
+    }
+    LQG_UNROLL for (int i = 0; i < O; ++i) { dO[i] = mn[i]; xprev[i] = xt[i]; }
     LQG_UNROLL for (int p = 0; p < RR; ++p) muR[p] = mn[O + p];
     // ---- Sigma' = F2 C F2^T + GG,  C = Srr - U2 U2^T                    system.py:223-230
     Mat<R, RR, RR> C;

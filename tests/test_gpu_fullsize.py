@@ -22,15 +22,15 @@ def headline():
 
 def test_full_batch_all_paths_agree(headline, monkeypatch):
     """2^18 solves: every fp32 path (decoupled + specialised, specialised joint, generic dense joint) against the fp64
-    path (itself within 1e-14 of the oracle): 99.9 % of the systems within the north-star 1e-6, worst case < 5e-6
-    (measured: median 3e-8, p99.9 7e-7, max 1.7e-6 — the tail are candidates whose |ll| is small); the three fp64
-    paths agree to 1e-11."""
+    path (itself within 1e-14 of the oracle): EVERY system within the north-star 1e-6 (measured: median 3e-8,
+    p99.9 1.9e-7, max 5.7e-7 with the deviation-form innovation; 1.6e-6 without it); the three fp64 paths agree to
+    1e-11."""
     system, x = headline
     s64, x64 = system.to(torch.float64), x.double()
 
     def check32(ll, ref):
         r = (ll.double() / ref - 1).abs().flatten()
-        assert float(torch.quantile(r[: 1 << 18], 0.999)) < 1e-6 and float(r.max()) < 5e-6
+        assert float(torch.quantile(r[: 1 << 18], 0.999)) < 5e-7 and float(r.max()) < 1e-6
 
     ref = s64.log_likelihood(x64).clone()                 # decoupled + specialised, fp64
     check32(system.log_likelihood(x), ref)
