@@ -521,35 +521,41 @@ struct TrialArgs {
 // wave-uniform: `ops_all` is a direct `const __restrict__` kernel argument so that the compiler can prove the loads
 // read-only and issue them as SCALAR loads (s_load_dwordx*, operands consumed straight from SGPRs); x is read with
 // one trial per lane.
-template <typename R, int M, int ND, int TPL>
+// STORE_MU is a template flag so that the log-likelihood instantiation carries no store code / output addressing.
+// The data pointers advance incrementally (one 64-bit add per trial per step instead of a multiply-add chain), and
+// in fp32 the per-step densities are summed in fp32 over chunks of kAccChunk steps before entering the fp64 total.
+template <typename R, int M, int ND, int TPL, bool STORE_MU>
 __global__ void __launch_bounds__(LQG_BLOCK) k_trial(const R* __restrict__ ops_all, const TrialArgs<R> a) {
   constexpr int O = ND, RR = M - ND;
+  constexpr int kAccChunk = 8;
   using Ops = TrialOps<M, ND>;
   const long sys = blockIdx.y;
   const long n0 = (long)blockIdx.x * (LQG_BLOCK * TPL) + threadIdx.x;
-  const R* __restrict__ ops = ops_all + sys * (long)(a.T + 1) * Ops::N;
-  const R* xp[TPL];
+  const R* __restrict__ op = ops_all + sys * (long)(a.T + 1) * Ops::N;
+  const R* xr[TPL];
   bool live[TPL];
   R xprev[TPL][O], dO[TPL][O], muR[TPL][RR];   // observed mean = xprev + dO (deviation form, see k_forward)
   double acc[TPL];
+  R part[TPL];
   LQG_UNROLL for (int k = 0; k < TPL; ++k) {
     long n = n0 + (long)k * LQG_BLOCK;
     live[k] = n < a.n_trials;
     n = live[k] ? n : (a.n_trials - 1);
-    xp[k] = a.x.p + sys * a.x.sb + n * a.x.sn;
-    LQG_UNROLL for (int i = 0; i < O; ++i) { xprev[k][i] = xp[k][i * a.x.sd]; dO[k][i] = R(0); }
+    xr[k] = a.x.p + sys * a.x.sb + n * a.x.sn;
+    LQG_UNROLL for (int i = 0; i < O; ++i) { xprev[k][i] = xr[k][i * a.x.sd]; dO[k][i] = R(0); }
     LQG_UNROLL for (int i = 0; i < RR; ++i) muR[k][i] = R(0);
     acc[k] = 0.0;
+    part[k] = R(0);
   }
   for (int t = 0; t <= a.T; ++t) {
-    const R* __restrict__ op = ops + (long)t * Ops::N;
     R Li[O * (O + 1) / 2];
     LQG_UNROLL for (int i = 0; i < O * (O + 1) / 2; ++i) Li[i] = op[Ops::L_OFF + i];
     const R hlc = op[Ops::H_OFF];
+    const bool flush = ((t & (kAccChunk - 1)) == 0) || t == a.T;
     LQG_UNROLL for (int k = 0; k < TPL; ++k) {
-      const R* xr = xp[k] + (long)t * a.x.st;
       R xt[O], w[O];
-      LQG_UNROLL for (int i = 0; i < O; ++i) xt[i] = xr[i * a.x.sd];
+      LQG_UNROLL for (int i = 0; i < O; ++i) xt[i] = xr[k][i * a.x.sd];
+      xr[k] += a.x.st;
       R zz = R(0);
       {
         int e = 0;
@@ -560,7 +566,8 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial(const R* __restrict__ ops_a
           zz += v * v;
         }
       }
-      if (t > 0) acc[k] -= (double)(R(0.5) * zz + hlc);
+      if (t > 0) part[k] += R(0.5) * zz + hlc;
+      if (flush) { acc[k] -= (double)part[k]; part[k] = R(0); }
       if (t < a.T) {
         R c[RR];
         LQG_UNROLL for (int p = 0; p < RR; ++p) {
@@ -577,13 +584,14 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial(const R* __restrict__ ops_a
         }
         LQG_UNROLL for (int i = 0; i < O; ++i) { dO[k][i] = mn[i]; xprev[k][i] = xt[i]; }
         LQG_UNROLL for (int p = 0; p < RR; ++p) muR[k][p] = mn[O + p];
-        if (a.mu.p && live[k]) {
+        if (STORE_MU && live[k]) {
           long n = n0 + (long)k * LQG_BLOCK;
           R* dst = const_cast<R*>(a.mu.p) + sys * a.mu.sb + n * a.mu.sn + (long)t * a.mu.st;
           LQG_UNROLL for (int i = 0; i < M; ++i) dst[i * a.mu.sd] = (i < O) ? xt[i] + mn[i] : mn[i];
         }
       }
     }
+    op += Ops::N;
   }
   if (a.ll) {
     LQG_UNROLL for (int k = 0; k < TPL; ++k)

@@ -136,7 +136,8 @@ hipError_t launch_trial(const lqg_problem* p, const void* ops, lqg_traj x, lqg_t
   constexpr int TPL = LQG_TRIALS_PER_LANE;
   const long per_block = (long)LQG_BLOCK * TPL;
   const dim3 grid((unsigned)((p->n_trials + per_block - 1) / per_block), (unsigned)p->n_sys), block(LQG_BLOCK);
-  hipLaunchKernelGGL((lqg::k_trial<R, M, ND, TPL>), grid, block, 0, st, static_cast<const R*>(ops), k);
+  if (mu.ptr) hipLaunchKernelGGL((lqg::k_trial<R, M, ND, TPL, true>), grid, block, 0, st, static_cast<const R*>(ops), k);
+  else hipLaunchKernelGGL((lqg::k_trial<R, M, ND, TPL, false>), grid, block, 0, st, static_cast<const R*>(ops), k);
   return hipGetLastError();
 }
 
