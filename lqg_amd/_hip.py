@@ -189,10 +189,10 @@ def solve_materialised(actor, dynamics, x, Sigma0=None, eps=1e-8, out=None):
 def specialised_entry(ln, system, d):
     """The structure-specialised `lqg_log_likelihood_sp` for this launch, or None (lqg_amd/specialize.py).
 
-    Eligible: one trial per system, every spec field time-invariant, no affine cost terms.  LQG_NO_SPECIALIZE=1
-    forces the generic dense library (A/B measurements, tests)."""
+    Eligible: every spec field time-invariant, no affine cost terms.  LQG_NO_SPECIALIZE=1 forces the generic dense
+    library (A/B measurements, tests)."""
     import os
-    if system is None or os.environ.get("LQG_NO_SPECIALIZE") == "1" or ln.p.n_trials != 1:
+    if system is None or os.environ.get("LQG_NO_SPECIALIZE") == "1" or ln.p.n_trials < 1:
         return None
     p = ln.p
     for spec, fields in ((p.actor, ("Q", "R", "A", "B", "V", "F", "W")), (p.dynamics, ("A", "B", "V", "F", "W"))):

@@ -83,11 +83,14 @@ __global__ void __launch_bounds__(LQG_BLOCK, LQG_SP_RIC_WAVES) k_riccati_sp(cons
   }
 }
 
-// ---------------------------------------------------------------- forward sweep, TI, fused single trial, ll only
-template <typename R, int NX, int NB, int NU, int NY, int ND, typename PAT>
+// ---------------------------------------------------------------- forward sweep, TI, log-likelihood only
+// FUSED: the single trial of each system is swept in-lane; !FUSED: the per-step trial operators are written to the
+// operator stream for k_trial (several trials per system), exactly as k_forward does.
+template <typename R, int NX, int NB, int NU, int NY, int ND, typename PAT, bool FUSED>
 __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F32 : LQG_SP_FWD_WAVES_F64)
     k_forward_sp(const ForwardArgs<R> a) {
   constexpr int M = NX + NB, O = ND, RR = M - ND;
+  using Ops = TrialOps<M, ND>;
   const long s = blockIdx.x * (long)LQG_BLOCK + threadIdx.x;
   if (s >= a.n_sys) return;
 
@@ -119,9 +122,12 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
 
   R Sg[M * M], xprev[O], dO[O], muR[RR];   // observed mean = xprev + dO (deviation form, see k_forward)
   double acc = 0.0;
-  const R* xp = a.x.p + s * a.x.sb;
-  LQG_UNROLL for (int i = 0; i < O; ++i) { xprev[i] = xp[i * a.x.sd]; dO[i] = R(0); }
-  LQG_UNROLL for (int i = 0; i < RR; ++i) muR[i] = R(0);
+  const R* xp = nullptr;
+  if (FUSED) {
+    xp = a.x.p + s * a.x.sb;
+    LQG_UNROLL for (int i = 0; i < O; ++i) { xprev[i] = xp[i * a.x.sd]; dO[i] = R(0); }
+    LQG_UNROLL for (int i = 0; i < RR; ++i) muR[i] = R(0);
+  }
   const R kLogNorm = R(0.5 * ND * 1.8378770664093453);
 
   R Li[O * O], U2[RR * O], hl;
@@ -183,25 +189,41 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
     if (t == 0) to_dense(GG, Sg);                                        // Sigma0 := G[0] G[0]^T  system.py:212
     // ---- condition on x_t, score it, propagate the mean                system.py:219-221, 244-248
     condition();
-    innovate(t, t > 0);
-    R cvec[M];
-    LQG_UNROLL for (int j = 0; j < O; ++j) cvec[j] = xt[j];
-    LQG_UNROLL for (int p = 0; p < RR; ++p) {
-      R v = muR[p];
-      LQG_UNROLL for (int j = 0; j < O; ++j) v += U2[p * O + j] * w[j];
-      cvec[O + p] = v;
-    }
-    R mn[M];
-    LQG_UNROLL for (int i = 0; i < M; ++i) {                 // rows < O as deviation from x_t: ((Fj - I) cvec)[i]
-      R v = R(0);
-      LQG_UNROLL for (int j = 0; j < M; ++j) {
-        if (i < O && i == j) v += (Fj.mask(i, i) ? Fj.v[i * M + i] - R(1) : R(-1)) * cvec[j];
-        else if (Fj.mask(i, j)) v += Fj.v[i * M + j] * cvec[j];
+    if (FUSED) {
+      innovate(t, t > 0);
+      R cvec[M];
+      LQG_UNROLL for (int j = 0; j < O; ++j) cvec[j] = xt[j];
+      LQG_UNROLL for (int p = 0; p < RR; ++p) {
+        R v = muR[p];
+        LQG_UNROLL for (int j = 0; j < O; ++j) v += U2[p * O + j] * w[j];
+        cvec[O + p] = v;
       }
-      mn[i] = v;
+      R mn[M];
+      LQG_UNROLL for (int i = 0; i < M; ++i) {                 // rows < O as deviation from x_t: ((Fj - I) cvec)[i]
+        R v = R(0);
+        LQG_UNROLL for (int j = 0; j < M; ++j) {
+          if (i < O && i == j) v += (Fj.mask(i, i) ? Fj.v[i * M + i] - R(1) : R(-1)) * cvec[j];
+          else if (Fj.mask(i, j)) v += Fj.v[i * M + j] * cvec[j];
+        }
+        mn[i] = v;
+      }
+      LQG_UNROLL for (int i = 0; i < O; ++i) { dO[i] = mn[i]; xprev[i] = xt[i]; }
+      LQG_UNROLL for (int p = 0; p < RR; ++p) muR[p] = mn[O + p];
+    } else {
+      R* op = a.ops + ((long)s * (a.T + 1) + t) * Ops::N;
+      LQG_UNROLL for (int i = 0; i < M; ++i)
+        LQG_UNROLL for (int j = 0; j < M; ++j) {
+          const R f = Fj.mask(i, j) ? Fj.v[i * M + j] : R(0);
+          op[Ops::F_OFF + i * M + j] = (i < O && i == j) ? f - R(1) : f;
+        }
+      LQG_UNROLL for (int i = 0; i < RR * O; ++i) op[Ops::U_OFF + i] = U2[i];
+      {
+        int e = 0;
+        LQG_UNROLL for (int i = 0; i < O; ++i)
+          LQG_UNROLL for (int j = 0; j <= i; ++j) op[Ops::L_OFF + (e++)] = Li[i * O + j];
+      }
+      op[Ops::H_OFF] = hl + kLogNorm;
     }
-    LQG_UNROLL for (int i = 0; i < O; ++i) { dO[i] = mn[i]; xprev[i] = xt[i]; }
-    LQG_UNROLL for (int p = 0; p < RR; ++p) muR[p] = mn[O + p];
     // ---- Sigma' = F2 C F2^T + GG,  C = Srr - U2 U2^T                    system.py:223-230
     Mat<R, RR, RR> C;
     LQG_UNROLL for (int p = 0; p < RR; ++p)
@@ -215,8 +237,16 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
     to_dense(mul_nt_sym_add(mul(F2, C), F2, GG), Sg);
   }
   condition();
-  innovate(a.T, true);
-  a.ll[s * a.ll_sb] = (R)acc;
+  if (FUSED) {
+    innovate(a.T, true);
+    a.ll[s * a.ll_sb] = (R)acc;
+  } else {
+    R* op = a.ops + ((long)s * (a.T + 1) + a.T) * Ops::N;
+    int e = 0;
+    LQG_UNROLL for (int i = 0; i < O; ++i)
+      LQG_UNROLL for (int j = 0; j <= i; ++j) op[Ops::L_OFF + (e++)] = Li[i * O + j];
+    op[Ops::H_OFF] = hl + kLogNorm;
+  }
 }
 
 // dense pattern (every constant may be non-zero everywhere): the specialised kernels reduce to the generic ones

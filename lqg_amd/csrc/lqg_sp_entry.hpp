@@ -1,6 +1,7 @@
 // lqg_sp_entry.hpp — host side of a structure-specialised library (one per sparsity pattern, generated and compiled
 // by lqg_amd/specialize.py).  Exposes the SAME contract as lqg_log_likelihood (include/lqg_hip.h) restricted to the
-// hot case it is compiled for: time-invariant specs, no affine cost terms, one trial per system, dims fixed.
+// case it is compiled for: time-invariant specs, no affine cost terms, dims fixed (one trial per system runs fused,
+// several go through the operator stream and the generic k_trial).
 // Anything else is refused with LQG_ERR_ARG / LQG_ERR_DIMS before launching; the caller then uses the generic
 // library.  The pattern's validity for the data (structural zeros really are zero) is the generator's contract.
 #pragma once
@@ -13,12 +14,14 @@ namespace lqg {
 namespace host {
 
 template <typename R, typename PAT, int NX, int NB, int NU, int NY, int ND>
-int run_sp(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, void* workspace, size_t workspace_bytes,
+int run_sp(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll_sn, void* workspace, size_t workspace_bytes,
            hipStream_t st) {
-  const Workspace w = carve(p, false);
+  const bool fused = p->n_trials == 1;
+  const Workspace w = carve(p, !fused);
   if (!workspace || workspace_bytes < w.total) return LQG_ERR_WORKSPACE;
   char* base = static_cast<char*>(workspace);
   R* Ls = reinterpret_cast<R*>(base + w.ls_off);
+  R* ops = fused ? nullptr : reinterpret_cast<R*>(base + w.ops_off);
   auto mark = [&](int i) {
     if (p->phase_events[i]) (void)hipEventRecord(static_cast<hipEvent_t>(p->phase_events[i]), st);
   };
@@ -38,12 +41,17 @@ int run_sp(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, void* workspa
   {
     lqg::ForwardArgs<R> k{dv<R>(a.A), dv<R>(a.B), dv<R>(a.F), dv<R>(a.V), dv<R>(a.W),
                           dv<R>(d.A), dv<R>(d.B), dv<R>(d.F), dv<R>(d.V), dv<R>(d.W),
-                          dv<R>(p->Sigma0), Ls, w.ldb, dt<R>(x), static_cast<R*>(ll), ll_sb, nullptr, dv<R>(none),
+                          dv<R>(p->Sigma0), Ls, w.ldb, dt<R>(x), static_cast<R*>(ll), ll_sb, ops, dv<R>(none),
                           dt<R>(no_traj), dv<R>(none), (long)p->n_sys, p->T,
                           p->dims.nva, p->dims.nwa, p->dims.nvd, p->dims.nwd};
-    hipLaunchKernelGGL((lqg::k_forward_sp<R, NX, NB, NU, NY, ND, PAT>), grid, block, 0, st, k);
+    if (fused) hipLaunchKernelGGL((lqg::k_forward_sp<R, NX, NB, NU, NY, ND, PAT, true>), grid, block, 0, st, k);
+    else hipLaunchKernelGGL((lqg::k_forward_sp<R, NX, NB, NU, NY, ND, PAT, false>), grid, block, 0, st, k);
   }
   mark(2);
+  if (!fused) {   // several trials per system: the generic per-trial sweep over the operator stream
+    hipError_t e = launch_trial<R, NX + NB, ND>(p, ops, x, no_traj, ll, ll_sb, ll_sn, st);
+    if (e != hipSuccess) return (int)e;
+  }
   mark(3);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
@@ -52,17 +60,18 @@ int run_sp(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, void* workspa
 template <typename PAT, int NX, int NB, int NU, int NY, int ND>
 int log_likelihood_sp(const lqg_problem* p, lqg_traj x, void* ll, int64_t ll_sb, int64_t ll_sn, void* workspace,
                       size_t workspace_bytes, void* stream) {
-  (void)ll_sn;
   if (!p || !x.ptr || !ll) return LQG_ERR_NULL;
   const lqg_dims& dm = p->dims;
   if (dm.x != NX || dm.b != NB || dm.u != NU || dm.y != NY || dm.d != ND) return LQG_ERR_DIMS;
-  if (p->n_trials != 1 || p->T < 1) return LQG_ERR_ARG;
+  if (p->n_trials < 1 || p->T < 1) return LQG_ERR_ARG;
   if (!forward_ti(p) || !actor_ti_riccati(p) || affine(p)) return LQG_ERR_ARG;
   if (p->n_sys == 0) return 0;
   if (p->dtype == LQG_F64)
-    return run_sp<double, PAT, NX, NB, NU, NY, ND>(p, x, ll, (long)ll_sb, workspace, workspace_bytes, (hipStream_t)stream);
+    return run_sp<double, PAT, NX, NB, NU, NY, ND>(p, x, ll, (long)ll_sb, (long)ll_sn, workspace, workspace_bytes,
+                                                   (hipStream_t)stream);
   if (p->dtype == LQG_F32)
-    return run_sp<float, PAT, NX, NB, NU, NY, ND>(p, x, ll, (long)ll_sb, workspace, workspace_bytes, (hipStream_t)stream);
+    return run_sp<float, PAT, NX, NB, NU, NY, ND>(p, x, ll, (long)ll_sb, (long)ll_sn, workspace, workspace_bytes,
+                                                  (hipStream_t)stream);
   return LQG_ERR_ARG;
 }
 

@@ -62,8 +62,9 @@ class LogLikelihoodPlan:
     @property
     def description(self):
         w = self.work
-        kind = "structure-specialised (k_riccati_sp + k_forward_sp)" if all(k["specialised"] for k in w) else \
-            "generic dense (k_riccati + k_forward" + (" + k_trial)" if w[0]["n"] > 1 else ")")
+        tail = " + k_trial)" if w[0]["n"] > 1 else ")"
+        kind = ("structure-specialised (k_riccati_sp + k_forward_sp" if all(k["specialised"] for k in w) else
+                "generic dense (k_riccati + k_forward") + tail
         if len(w) > 1:
             kind += f", {len(w)} decoupled components of dims (x,b,u,y,d)={w[0]['dims']}"
         if self.n_stacked > 1:

@@ -151,6 +151,11 @@ def test_structure_specialised_path_matches_golden(ctor, kw, d, gold, dtype, mon
     assert abs(float(ll_sp[0]) / g["ll"][0] - 1) < tol
     assert abs(float(ll_gen[0]) / g["ll"][0] - 1) < tol
     assert abs(float(ll_sp[0]) / float(ll_gen[0]) - 1) < tol
+    # several trials per system: specialised system sweep -> operator stream -> k_trial
+    monkeypatch.delenv("LQG_NO_SPECIALIZE")
+    xs = torch.as_tensor(g["x"], dtype=dtype, device="cuda")
+    assert _hip.specialised_entry(_hip.Launch(m.actor, m.dynamics, d=d, n_trials=xs.shape[0]), m, d) is not None
+    assert np.abs(np_(m.log_likelihood(xs)) / g["ll"] - 1).max() < tol
 
 
 def test_specialised_path_on_hand_built_system_and_nan_semantics():
