@@ -207,3 +207,25 @@ def test_stacked_plan_equals_separate_components():
     b = plan.run()
     assert a.shape == b.shape == (1000, 1)
     assert float((a / b - 1).abs().max()) < 1e-13
+
+
+def test_decoupling_with_interleaved_observed_dims(monkeypatch):
+    """Components whose data columns are not a contiguous range (state order [t1, t2, c1, c2]): the plan gathers
+    the columns; the result equals the joint kernels'."""
+    import lqg_amd
+    from lqg_amd.system import Actor, System
+    base = lqg_amd.BoundedActor(dim=2, T=30, action_cost=0.2, device="cuda", dtype=torch.float64)
+    perm = [0, 2, 1, 3]
+    a = base.actor
+    first = lambda t: t[0]
+    A, B, F, V, W, Q, R = (first(getattr(a, f)) for f in ("A", "B", "F", "V", "W", "Q", "R"))
+    P = torch.eye(4, dtype=torch.float64, device="cuda")[perm]
+    spec = Actor(A=P @ A @ P.T, B=P @ B, F=P @ F @ P.T, V=P @ V @ P.T, W=P @ W @ P.T, Q=P @ Q @ P.T, R=R, T=30)
+    m = System(actor=spec, dynamics=spec)
+    parts = m.decoupled(4)
+    assert parts is not None and sorted(tuple(c) for _, c, _ in parts) == [(0, 2), (1, 3)]
+    x = base.simulate(5, n=6)[..., perm]
+    ll = m.log_likelihood(x)
+    assert float((ll / base.log_likelihood(x[..., perm]) - 1).abs().max()) < 1e-12     # same model, permuted back
+    monkeypatch.setenv("LQG_NO_DECOUPLE", "1")
+    assert float((ll / m.log_likelihood(x) - 1).abs().max()) < 1e-12
