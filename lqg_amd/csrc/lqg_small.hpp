@@ -31,7 +31,13 @@ template <> LQG_DEV float rsqrt_<float>(float v) {
   float y = __builtin_amdgcn_rsqf(v);
   return y * (1.5f - 0.5f * v * y * y);
 }
-template <> LQG_DEV double rsqrt_<double>(double v) { return 1.0 / sqrt(v); }
+// fp64: v_rsq_f64 (~2^-26 relative) + three Newton-Raphson steps (quadratic: full double precision after two, the
+// third absorbs the fma-free evaluation) = 13 instructions instead of the ~80 of an IEEE sqrt + IEEE divide.
+template <> LQG_DEV double rsqrt_<double>(double v) {
+  double y = __builtin_amdgcn_rsq(v);
+  LQG_UNROLL for (int it = 0; it < 3; ++it) y = y * (1.5 - 0.5 * v * y * y);
+  return y;
+}
 template <typename R> LQG_DEV R sqrt_(R v);
 template <> LQG_DEV float sqrt_<float>(float v) { return sqrtf(v); }
 template <> LQG_DEV double sqrt_<double>(double v) { return sqrt(v); }
