@@ -53,8 +53,8 @@ def algorithmic_bytes_per_solve(x, b, u, y, d, T, w):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log2-batch", type=int, default=18, help="solves per GPU per step = 2**this")
     ap.add_argument("--T", type=int, default=500)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
@@ -122,13 +122,15 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    ric_ms, fwd_ms = [], []
+    # one set of phase events per timed step (up to 64), so that per-kernel durations cover the timed region without
+    # any host synchronisation inside it
+    n_ev = min(args.steps, 64)
+    ev_sets = [[[_hipev.Event() for _ in range(4)] for _ in plan.work] for _ in range(n_ev)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for it in range(args.steps):
+        if it < n_ev:
+            plan.use_events(ev_sets[it])
         total = step()
-        r_ms, f_ms, _ = plan.phase_ms()                    # events are re-recorded every step: read them now
-        ric_ms.append(r_ms)
-        fwd_ms.append(f_ms)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -138,6 +140,8 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    ric_ms = [sum(e[0].elapsed_ms(e[1]) for e in es) for es in ev_sets]
+    fwd_ms = [sum(e[1].elapsed_ms(e[2]) for e in es) for es in ev_sets]
 
     ll_host = ll[:, 0].double().cpu().numpy()
     finite = bool(np.isfinite(ll_host).all())

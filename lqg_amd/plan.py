@@ -100,6 +100,14 @@ class LogLikelihoodPlan:
                 torch.sum(self._ll_stacked.view(self.n_stacked, *self.ll.shape), dim=0, out=self.ll)
         return self.ll
 
+    def use_events(self, sets):
+        """Point the library's phase-event hook of every component at its own event set for the NEXT run:
+        `sets[i]` = 4 _hipev.Event for component i (lets a caller keep one set per timed step without syncing)."""
+        for wk, ev in zip(self.work, sets):
+            wk["ev"] = ev
+            for i in range(4):
+                wk["ln"].p.phase_events[i] = ev[i].h
+
     def phase_ms(self):
         """(riccati, forward, trial) milliseconds of the last run, summed over components (events=True only)."""
         self.work[-1]["ev"][3].synchronize()
