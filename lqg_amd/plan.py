@@ -9,6 +9,12 @@ import torch
 from lqg_amd import _abi, _hip, _hipev
 
 
+# Above this much operator-stream workspace a multi-trial evaluation is run as one fused single-trial sweep per
+# trial instead (N x the per-system work, no [system][step][operator] stream): e.g. 2^18 systems x 2 trials at
+# n=6, T=500 would need 71 GB of stream for 2 trials' worth of work.
+OPS_WORKSPACE_LIMIT = 16 << 30
+
+
 class LogLikelihoodPlan:
     def __init__(self, system, x, Sigma0=None, eps=1e-8, events=False, concurrent=False, stack=False):
         """stack=True (persistent plans over a fixed dataset): decoupled components that share dims and sparsity
@@ -35,6 +41,10 @@ class LogLikelihoodPlan:
             ln.require_gpu()
             xb, is_b = _hip._prep_x(ln, xs)
             nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
+            loop_trials = n > 1 and nbytes > OPS_WORKSPACE_LIMIT
+            if loop_trials:                      # one fused sweep per trial: the problem describes ONE trial
+                ln.p.n_trials = 1
+                nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
             ev = None
             if events:
                 ev = [_hipev.Event() for _ in range(4)]
@@ -44,6 +54,7 @@ class LogLikelihoodPlan:
             self.work.append(dict(ln=ln, x=xb, traj=ln.traj(xb, is_b), ll=ln.empty(n), nbytes=nbytes, ev=ev,
                                   ws=torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=ln.device),
                                   entry=sp or lib.lqg_log_likelihood, specialised=sp is not None, n=n,
+                                  loop_trials=loop_trials, is_b=is_b,
                                   dims=(sub.xdim, sub.bdim, sub.udim, sub.ydim, len(cols))))
         self.lib = lib
         self.device = self.work[0]["ln"].device
@@ -84,12 +95,20 @@ class LogLikelihoodPlan:
                 stream = self.side[i - 1] if (i > 0 and self.side) else main
                 if stream is not main:
                     stream.wait_event(self._fork)      # inputs produced on the caller's stream are ready
-                args = (C.byref(ln.p), wk["traj"], C.c_void_p(wk["ll"].data_ptr()), wk["n"] if ln.batched else 0, 1,
-                        C.c_void_p(wk["ws"].data_ptr()), wk["nbytes"], C.c_void_p(stream.cuda_stream))
-                if wk["entry"](*args) != 0:
-                    if wk["specialised"]:      # the specialised library refused: use the generic one
-                        wk["entry"], wk["specialised"] = self.lib.lqg_log_likelihood, False
-                    _abi.check(self.lib.lqg_log_likelihood(*args), "lqg_log_likelihood")
+                ll_sb = wk["n"] if ln.batched else 0
+                trials = range(wk["n"]) if wk["loop_trials"] else (None,)
+                for tr in trials:
+                    traj, llp = wk["traj"], wk["ll"].data_ptr()
+                    if tr is not None:           # view of trial `tr`: same strides, shifted base pointers
+                        esz = wk["x"].element_size()
+                        traj = _abi.Traj(traj.ptr + tr * traj.sn * esz, traj.sb, traj.sn, traj.st, traj.sd)
+                        llp += tr * esz
+                    args = (C.byref(ln.p), traj, C.c_void_p(llp), ll_sb, 1,
+                            C.c_void_p(wk["ws"].data_ptr()), wk["nbytes"], C.c_void_p(stream.cuda_stream))
+                    if wk["entry"](*args) != 0:
+                        if wk["specialised"]:      # the specialised library refused: use the generic one
+                            wk["entry"], wk["specialised"] = self.lib.lqg_log_likelihood, False
+                        _abi.check(self.lib.lqg_log_likelihood(*args), "lqg_log_likelihood")
                 if stream is not main:
                     self._join[i - 1].record(stream)
             for ev in self._join:

@@ -229,3 +229,30 @@ def test_decoupling_with_interleaved_observed_dims(monkeypatch):
     assert float((ll / base.log_likelihood(x[..., perm]) - 1).abs().max()) < 1e-12     # same model, permuted back
     monkeypatch.setenv("LQG_NO_DECOUPLE", "1")
     assert float((ll / m.log_likelihood(x) - 1).abs().max()) < 1e-12
+
+
+def test_per_trial_fallback_when_the_operator_stream_would_be_huge(monkeypatch):
+    """LogLikelihoodPlan switches to one fused sweep per trial when the operator stream would exceed the limit."""
+    import lqg_amd
+    from lqg_amd import plan as plan_mod, workload
+    sys_, _ = workload.headline_system(300, 60, seed=9, device="cuda", dtype=torch.float64)
+    x = torch.cat([workload.simulate_one_trial_each(sys_, seed=s) for s in (1, 2, 3)], dim=1)     # [300, 3, 61, 4]
+    ref = sys_.log_likelihood(x).clone()
+    monkeypatch.setattr(plan_mod, "OPS_WORKSPACE_LIMIT", 1024)
+    p = plan_mod.LogLikelihoodPlan(sys_, x)
+    assert all(wk["loop_trials"] for wk in p.work)
+    got = p.run()
+    assert got.shape == (300, 3) and float((got / ref - 1).abs().max()) < 1e-12
+
+
+def test_joint_m20_kernels_still_agree_with_the_decoupled_path(monkeypatch):
+    """hand2d (m = 20) decouples by default; the joint generic kernels for (10,10,2,4,4) stay covered."""
+    g, actor, dyn = load_golden("hand2d_T40")
+    s = system_from_golden(actor, dyn, torch.float64)
+    x = torch.as_tensor(g["x"], dtype=torch.float64, device="cuda")
+    assert s.decoupled(4) is not None
+    monkeypatch.setenv("LQG_NO_DECOUPLE", "1")
+    monkeypatch.setenv("LQG_NO_SPECIALIZE", "1")
+    assert s.decoupled(4) is None
+    for xs in (x, x[:1]):
+        assert np.abs(np_(s.log_likelihood(xs)) / g["ll"][:len(xs)] - 1).max() < 1e-10
