@@ -101,7 +101,7 @@ int lqg_abi_version(void);
 const char* lqg_last_error(void);
 /* 1 if (dtype, dims) has a compiled instantiation in this build, else 0 */
 int lqg_dims_supported(int32_t dtype, const lqg_dims* dims);
-/* number of GPUs visible / name of the code object target ("gfx950") */
+/* name of the code object target this library was compiled for ("gfx950") */
 const char* lqg_target_arch(void);
 
 /* Replaces lqg.control.lqr.backward(spec, eps) -> Gains(L, l, H)   [lqg/control/lqr.py:16-42]
@@ -132,6 +132,13 @@ int lqg_conditional_moments(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_v
  * x[B,N,T+1,d] -> ll[b*ll_sb + n*ll_sn], one value per (system, trial), dtype of the problem. */
 int lqg_log_likelihood(const lqg_problem* p, lqg_traj x, void* ll, int64_t ll_sb, int64_t ll_sn,
                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* Structure-specialised twin (NOT in liblqg_hip.so): libraries generated per sparsity pattern by
+ * lqg_amd/specialize.py (lqg_amd/csrc/pat/pat_<hash>.so, kernels in csrc/lqg_kernels_sp.hpp) export
+ *     int lqg_log_likelihood_sp(<exactly the argument list of lqg_log_likelihood>);
+ * with the same contract, restricted to time-invariant specs without affine terms and to the dims / pattern
+ * they were compiled for (anything else returns LQG_ERR_ARG / LQG_ERR_DIMS without launching).  They are an
+ * optimisation layer: results are identical to lqg_log_likelihood's up to rounding, and every caller falls back to it. */
 
 /* Everything the reference's path materialises, in ONE pass (two or three kernels instead of the seven that separate
  * lqr.backward + kf.forward + conditional_moments + log_likelihood calls launch — each of which recomputes the gains
