@@ -73,16 +73,8 @@ def declare(lib, prefix="lqg_", with_stream=True):
     return lib
 
 
-def load():
-    """Load liblqg_hip.so (built in-tree by __graft_entry__.build() / lqg_amd/csrc/Makefile)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise LqgHipError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "or `make -C lqg_amd/csrc`. lqg_amd has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+def _bind(path):
+    lib = C.CDLL(path)
     lib.lqg_abi_version.restype = C.c_int
     if lib.lqg_abi_version() != ABI_VERSION:
         raise LqgHipError(f"ABI mismatch: library {lib.lqg_abi_version()} vs binding {ABI_VERSION}")
@@ -99,8 +91,51 @@ def load():
                                          C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     lib.lqg_gaussian_logprob.restype = C.c_int
     declare(lib)
-    _lib = lib
     return lib
+
+
+def load():
+    """Load liblqg_hip.so (built in-tree by __graft_entry__.build() / lqg_amd/csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LqgHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C lqg_amd/csrc`. lqg_amd has no CPU fallback.")
+    _lib = _bind(LIB_PATH)
+    return _lib
+
+
+_dims_libs = {}
+
+
+def library_for(dims):
+    """The library that has kernels for this model shape: liblqg_hip.so when lqg_dims.def lists (x, b, u, y, d),
+    otherwise an auxiliary library with the same C ABI compiled on demand for exactly that shape
+    (lqg_amd.build.build_dims_library; needs hipcc, cached in csrc/dims/).  Never a CPU fallback."""
+    lib = load()
+    key = (dims["x"], dims["b"], dims["u"], dims["y"], dims["d"])
+    dm = Dims(*key, dims.get("nva", 1), dims.get("nwa", 1), dims.get("nvd", 1), dims.get("nwd", 1))
+    if lib.lqg_dims_supported(F32, C.byref(dm)):
+        return lib
+    if key not in _dims_libs:
+        from lqg_amd import build
+        if not os.path.exists(build.HIPCC):
+            raise LqgHipError(f"no kernels for model shape (x,b,u,y,d)={key} in {LIB_PATH} and no hipcc to compile "
+                              "them: add the shape to lqg_amd/csrc/lqg_dims.def and rebuild")
+        _dims_libs[key] = _bind(build.build_dims_library(*key))
+    return _dims_libs[key]
+
+
+def shape_available(x, b, u, y, d):
+    """True when kernels for the shape exist or can be compiled on demand."""
+    lib = load()
+    dm = Dims(x, b, u, y, d, 1, 1, 1, 1)
+    if lib.lqg_dims_supported(F32, C.byref(dm)):
+        return True
+    from lqg_amd import build
+    return os.path.exists(build.HIPCC)
 
 
 def check(rc, what):

@@ -85,7 +85,7 @@ class Launch:
             raise LqgHipError(
                 f"lqg_amd computes on MI355X only: tensors are on '{self.device}'. Move the spec to a cuda "
                 "(ROCm) device; there is no CPU fallback.")
-        return _abi.load()
+        return _abi.library_for(self.dims)
 
     def lead(self):
         return (self.B,) if self.batched else ()

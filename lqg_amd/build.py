@@ -35,13 +35,14 @@ def dims_lists():
     return out
 
 
-def jobs():
-    js = [("abi.o", "lqg_abi.hip", [])]
-    for fam, tuples in dims_lists().items():
+def jobs(lists=None, extra_defs=()):
+    extra_defs = list(extra_defs)
+    js = [("abi.o", "lqg_abi.hip", extra_defs)]
+    for fam, tuples in (lists or dims_lists()).items():
         for t in tuples:
             for dt in ("F32", "F64"):
                 base = f"{fam.lower()}_{'_'.join(map(str, t))}_{dt.lower()}"
-                defs = [f"-DLQG_INST_{fam}={','.join(map(str, t))}", f"-DLQG_INST_{dt}"]
+                defs = [f"-DLQG_INST_{fam}={','.join(map(str, t))}", f"-DLQG_INST_{dt}"] + extra_defs
                 if fam == "FORWARD":          # the 8 k_forward variants of a (dims, dtype) are split over four units
                     js += [(f"{base}_v{v}.o", "lqg_inst.hip", defs + [f"-DLQG_INST_VARIANT={v}"]) for v in range(4)]
                 else:
@@ -106,6 +107,56 @@ def build_variant(out, extra_flags=(), only=None, objdir=None, workers=None, ver
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stderr)
     return out
+
+
+DIMS_DIR = os.path.join(CSRC, "dims")
+
+
+def dims_tag(x, b, u, y, d):
+    return f"{x}_{b}_{u}_{y}_{d}"
+
+
+def build_dims_library(x, b, u, y, d, workers=None, verbose=True):
+    """Auxiliary library with the full C ABI for ONE model shape that lqg_dims.def does not list
+    (csrc/dims/liblqg_hip_<x>_<b>_<u>_<y>_<d>.so): same sources, single-shape instantiation lists.
+    Called on demand by lqg_amd._abi.library_for; cached by a hash of the sources."""
+    tag = dims_tag(x, b, u, y, d)
+    os.makedirs(DIMS_DIR, exist_ok=True)
+    so = os.path.join(DIMS_DIR, f"liblqg_hip_{tag}.so")
+    stamp = so + ".stamp"
+    if os.path.exists(so) and os.path.exists(stamp) and open(stamp).read().strip() == source_hash():
+        return so
+    lists = {"FORWARD": [(x, b, u, y, d)], "RICCATI": [(b, u)], "KALMAN": [(b, y)], "TRIAL": [(x + b, d)],
+             "SIM": [(x, b, u, y)]}
+    deff = os.path.join(DIMS_DIR, f"dims_{tag}.def")
+    with open(deff, "w") as f:
+        f.write(f"// GENERATED by lqg_amd/build.py: instantiation lists of the auxiliary library for shape {tag}\n")
+        for fam, tuples in lists.items():
+            f.write(f"#define LQG_{fam}_DIMS(X) " + " ".join("X(" + ", ".join(map(str, t)) + ")" for t in tuples) + "\n")
+    objdir = os.path.join(DIMS_DIR, f"obj_{tag}")
+    os.makedirs(objdir, exist_ok=True)
+    js = jobs(lists, extra_defs=[f'-DLQG_DIMS_DEF="{deff}"'])
+    if verbose:
+        print(f"[lqg_amd.build] compiling auxiliary library for shape (x,b,u,y,d)=({x},{b},{u},{y},{d}): "
+              f"{len(js)} translation units", flush=True)
+
+    def comp(job):
+        name, src, defs = job
+        r = subprocess.run([HIPCC] + FLAGS + defs + ["-c", os.path.join(CSRC, src), "-o", os.path.join(objdir, name)],
+                           capture_output=True, text=True)
+        return name, r.returncode, r.stderr
+
+    with cf.ThreadPoolExecutor(workers or min(8, os.cpu_count() or 1)) as ex:
+        for name, rc, err in ex.map(comp, js):
+            if rc != 0:
+                raise RuntimeError(f"hipcc failed on {name}:\n{err[-3000:]}")
+    r = subprocess.run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", so] +
+                       [os.path.join(objdir, j[0]) for j in js], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stderr[-3000:])
+    with open(stamp, "w") as f:
+        f.write(source_hash())
+    return so
 
 
 def build(force=False, workers=None, verbose=True):

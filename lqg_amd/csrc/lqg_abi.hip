@@ -9,7 +9,12 @@
 
 #include "../../include/lqg_hip.h"
 #include "lqg_launch.hpp"
-#include "lqg_dims.def"
+// the instantiation lists: lqg_dims.def for the main library; lqg_amd/build.py compiles auxiliary libraries for
+// shapes that are not listed there with -DLQG_DIMS_DEF="<generated single-shape lists>"
+#ifndef LQG_DIMS_DEF
+#define LQG_DIMS_DEF "lqg_dims.def"
+#endif
+#include LQG_DIMS_DEF
 
 // ---------------------------------------------------------------- extern instantiations (defined by lqg_inst.hip)
 #define X(B_, U_)                                                                                              \
@@ -149,8 +154,9 @@ int need(const lqg_view& v, const char* who, const char* name) {
 int unsupported(const lqg_problem* p, const char* who) {
   const lqg_dims& d = p->dims;
   return fail(LQG_ERR_DIMS,
-              "%s: no kernel instantiation for dims (x=%d,b=%d,u=%d,y=%d,d=%d); add it to the LQG_*_DIMS lists in "
-              "lqg_amd/csrc/lqg_abi.hip and rebuild",
+              "%s: no kernel instantiation for dims (x=%d,b=%d,u=%d,y=%d,d=%d) in this library; lqg_amd compiles an "
+              "auxiliary library for new shapes on demand (lqg_amd.build.build_dims_library), or add the shape to "
+              "lqg_amd/csrc/lqg_dims.def and rebuild",
               who, d.x, d.b, d.u, d.y, d.d);
 }
 int done(hipError_t e, const char* who) {

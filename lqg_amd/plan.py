@@ -38,7 +38,7 @@ class LogLikelihoodPlan:
             S0 = Sigma0 if (Sigma0 is None or bs is None) else Sigma0[..., bs, :][..., :, bs]
             n = xs.shape[-3]
             ln = _hip.Launch(sub.actor, sub.dynamics, d=len(cols), n_trials=n, Sigma0=S0, eps=eps)
-            ln.require_gpu()
+            lib = ln.require_gpu()               # liblqg_hip.so, or the auxiliary library of an unlisted shape
             xb, is_b = _hip._prep_x(ln, xs)
             nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
             loop_trials = n > 1 and nbytes > OPS_WORKSPACE_LIMIT
@@ -53,7 +53,8 @@ class LogLikelihoodPlan:
             sp = _hip.specialised_entry(ln, sub, len(cols))
             self.work.append(dict(ln=ln, x=xb, traj=ln.traj(xb, is_b), ll=ln.empty(n), nbytes=nbytes, ev=ev,
                                   ws=torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=ln.device),
-                                  entry=sp or lib.lqg_log_likelihood, specialised=sp is not None, n=n,
+                                  entry=sp or lib.lqg_log_likelihood, generic=lib.lqg_log_likelihood,
+                                  specialised=sp is not None, n=n,
                                   loop_trials=loop_trials, is_b=is_b,
                                   dims=(sub.xdim, sub.bdim, sub.udim, sub.ydim, len(cols))))
         self.lib = lib
@@ -107,8 +108,8 @@ class LogLikelihoodPlan:
                             C.c_void_p(wk["ws"].data_ptr()), wk["nbytes"], C.c_void_p(stream.cuda_stream))
                     if wk["entry"](*args) != 0:
                         if wk["specialised"]:      # the specialised library refused: use the generic one
-                            wk["entry"], wk["specialised"] = self.lib.lqg_log_likelihood, False
-                        _abi.check(self.lib.lqg_log_likelihood(*args), "lqg_log_likelihood")
+                            wk["entry"], wk["specialised"] = wk["generic"], False
+                        _abi.check(wk["generic"](*args), "lqg_log_likelihood")
                 if stream is not main:
                     self._join[i - 1].record(stream)
             for ev in self._join:

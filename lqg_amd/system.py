@@ -200,17 +200,13 @@ class System:
         parts = decouple.plan(self, d, Sigma0)
         if parts is None:
             return None
-        # every component must be solvable by the generic library too (several trials, moments, ...)
-        import ctypes as C
+        # every component must be solvable by a generic library too (several trials, moments, ...)
         try:
-            lib = _abi.load()
+            ok = all(_abi.shape_available(sub.xdim, sub.bdim, sub.udim, sub.ydim, len(cols)) for sub, cols, _ in parts)
         except _abi.LqgHipError:
             return parts
-        for sub, cols, _ in parts:
-            dm = _abi.Dims(sub.xdim, sub.bdim, sub.udim, sub.ydim, len(cols), sub.actor.V.shape[-1],
-                           sub.actor.W.shape[-1], sub.dynamics.V.shape[-1], sub.dynamics.W.shape[-1])
-            if not lib.lqg_dims_supported(_abi.F32, C.byref(dm)):
-                return None
+        if not ok:
+            return None
         return parts
 
     def belief_tracking_distribution(self, x, Sigma0=None):

@@ -97,7 +97,45 @@ def test_edge_cases_of_the_boundary():
     assert m.log_likelihood(torch.zeros(0, 51, 2, device=DEV)).shape == (0,)        # no trials: nothing launched
     with pytest.raises(lqg_amd._abi.LqgHipError, match="T\\+1"):
         m.log_likelihood(torch.zeros(3, 50, 2, device=DEV))                        # wrong number of rows
-    with pytest.raises(lqg_amd._abi.LqgHipError, match="no kernel instantiation"):
-        lqg_amd.LQG(torch.eye(7, device=DEV), torch.ones(7, 3, device=DEV), torch.eye(7, device=DEV),
-                    torch.eye(7, device=DEV), torch.eye(7, device=DEV), torch.eye(7, device=DEV),
-                    torch.eye(3, device=DEV), T=4).conditional_moments(torch.zeros(5, 7, device=DEV))
+
+
+
+def test_unlisted_model_shape_compiles_on_demand(oracle_lib, monkeypatch):
+    """A hand-built model whose shape (x=b=3, u=2, y=2) is not in lqg_dims.def: lqg_amd compiles an auxiliary library
+    for it on first use (lqg_amd.build.build_dims_library) — every entry point works and matches the oracle; without
+    a compiler it fails loudly instead of falling back."""
+    from lqg_amd import _abi, build
+    from lqg_amd.belief import kf
+    from lqg_amd.control import lqr
+    rng = np.random.default_rng(11)
+    A = np.eye(3) + 0.05 * rng.standard_normal((3, 3))
+    B = 0.1 * rng.standard_normal((3, 2))
+    F = rng.standard_normal((2, 3))
+    V = np.diag([1.0, 0.5, 0.7]) + 0.05 * rng.standard_normal((3, 3))
+    W = np.diag([2.0, 3.0])
+    Q = np.diag([1.0, 0.5, 0.2])
+    R = 0.3 * np.eye(2)
+    T = 40
+    import lqg_np as O
+    spec = O.time_stack_spec(A, B, F, V, W, Q, R, T)
+    t64 = lambda a: torch.as_tensor(a, dtype=torch.float64, device=DEV)
+    m = lqg_amd.LQG(t64(A), t64(B), t64(F), t64(V), t64(W), t64(Q), t64(R), T=T)
+    assert not _abi.load().lqg_dims_supported(_abi.F64, _abi.C.byref(_abi.Dims(3, 3, 2, 2, 3, 3, 2, 3, 2)))
+    x = m.simulate(2, n=5)
+    assert x.shape == (5, T + 1, 3)
+    xn = x.cpu().numpy()
+    L, _, H = oracle_lib.riccati_backward(spec)
+    K = oracle_lib.kalman_forward(spec)
+    g = lqr.backward(m.actor)
+    assert np.abs(np_(g.L) - L).max() < 1e-11 and np.abs(np_(kf.forward(m.actor, None)) - K).max() < 1e-11
+    for d in (3, 2):                                                      # full and partial observation
+        ref = oracle_lib.log_likelihood(spec, spec, xn[..., :d])
+        assert np.abs(np_(m.log_likelihood(x[..., :d])) / ref - 1).max() < 1e-10          # several trials
+        assert abs(float(m.log_likelihood(x[:1, :, :d])[0]) / ref[0] - 1) < 1e-10          # one trial (specialised)
+    mu, Sig = m.conditional_moments(x[0])
+    mu_r, Sig_r = oracle_lib.conditional_moments(spec, spec, xn[:1])
+    assert np.abs(np_(mu) - mu_r[0]).max() < 1e-10 and np.abs(np_(Sig) - Sig_r).max() < 1e-10
+    # no compiler and an unknown shape: loud failure, never a fallback
+    monkeypatch.setattr(build, "HIPCC", "/nonexistent/hipcc")
+    with pytest.raises(_abi.LqgHipError, match="no hipcc"):
+        _abi.library_for(dict(x=3, b=4, u=1, y=2, d=3))
