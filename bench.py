@@ -202,12 +202,23 @@ def main():
         actor_np = {f: getattr(system.actor, f) for f in lqg_amd.LQGSpec._fields}
         dyn_np = {f: getattr(system.dynamics, f) for f in lqg_amd.LQGSpec._fields}
 
-        def host(spec_t, sel):
+        def host(spec_t, sel, np_dt=np.float64):
+            """Selected systems as NumPy arrays; a time-invariant (stride-0) time axis stays a stride-0 broadcast."""
             out = {}
+            index = torch.as_tensor(sel)
             for f, t in spec_t.items():
                 nd = workload._batched_ndim(f)
-                tt = t[torch.as_tensor(sel, device=t.device)] if t.dim() == nd else t.expand(len(sel), *t.shape)
-                out[f] = tt.double().cpu().numpy()
+                has_t = f not in ("Qf", "qf")
+                tax = -(2 if f in ("q", "r") else 3)
+                ti = has_t and (t.stride(tax) == 0 or t.shape[tax] == 1)
+                base = t.select(tax, 0) if ti else t
+                nd_b = nd - (1 if ti else 0)
+                base = base[index.to(base.device)] if base.dim() == nd_b else base.expand(len(sel), *base.shape)
+                a = base.cpu().numpy().astype(np_dt)
+                if ti:
+                    k = a.ndim + tax + 1
+                    a = np.broadcast_to(np.expand_dims(a, k), a.shape[:k] + (t.shape[tax],) + a.shape[k:])
+                out[f] = a
             return out
 
         a64, d64 = host(actor_np, idx), host(dyn_np, idx)
@@ -219,19 +230,17 @@ def main():
             ncpu = os.cpu_count() or 1
             OC.lib().lqg_oracle_set_threads(ncpu)
             np_dt = np.float32 if args.dtype == "f32" else np.float64
-            nsamp = args.cpu_sample or 1024
+            nsamp = args.cpu_sample or 16384          # 64 solves per thread on a 256-thread host
             sel = np.arange(nsamp) % B
-            a_s, d_s = host(actor_np, sel), host(dyn_np, sel)
-            a_s = {k: v.astype(np_dt) for k, v in a_s.items()}
-            d_s = {k: v.astype(np_dt) for k, v in d_s.items()}
+            a_s, d_s = host(actor_np, sel, np_dt), host(dyn_np, sel, np_dt)
             x_s = x_ref[torch.as_tensor(sel, device=dev)].cpu().numpy().astype(np_dt)
             OC.log_likelihood({k: v[:8] for k, v in a_s.items()}, {k: v[:8] for k, v in d_s.items()}, x_s[:8], dtype=np_dt)
             tc = time.perf_counter()
             OC.log_likelihood(a_s, d_s, x_s, dtype=np_dt)
             tc1 = time.perf_counter() - tc
-            # scale the sample so that the CPU leg does ~10-20 s of work
+            # repeat the sample so that the CPU leg does ~10-20 s of work
             if tc1 < 8.0 and not args.cpu_sample:
-                rep = int(min(32, max(1, 12.0 / max(tc1, 1e-3))))
+                rep = int(min(16, max(1, 12.0 / max(tc1, 1e-3))))
                 tc = time.perf_counter()
                 for _ in range(rep):
                     OC.log_likelihood(a_s, d_s, x_s, dtype=np_dt)

@@ -148,17 +148,18 @@ static int moments_impl(const lqg_problem* p, const lqg_traj* x, const lqg_traj*
   int rc = check(p);
   if (rc) return rc;
   if (!x || !x->ptr) return LQG_ERR_NULL;
-#pragma omp parallel for schedule(dynamic, 16)
-  for (int64_t s = 0; s < p->n_sys; ++s) {
-    if (p->dtype == LQG_F64) {
-      double* w = (double*)malloc(sizeof(double) * work_reals_f64(p));
-      moments_one_f64(p, s, x, mu, Sigma, ll ? (double*)ll + s * ll_sb : NULL, ll_sn, w);
-      free(w);
-    } else {
-      float* w = (float*)malloc(sizeof(float) * work_reals_f32(p));
-      moments_one_f32(p, s, x, mu, Sigma, ll ? (float*)ll + s * ll_sb : NULL, ll_sn, w);
-      free(w);
+#pragma omp parallel
+  {
+    /* one scratch buffer per thread (not per system: 256 threads hammering malloc would measure the allocator) */
+    void* w = malloc(p->dtype == LQG_F64 ? sizeof(double) * work_reals_f64(p) : sizeof(float) * work_reals_f32(p));
+#pragma omp for schedule(dynamic, 8)
+    for (int64_t s = 0; s < p->n_sys; ++s) {
+      if (p->dtype == LQG_F64)
+        moments_one_f64(p, s, x, mu, Sigma, ll ? (double*)ll + s * ll_sb : NULL, ll_sn, (double*)w);
+      else
+        moments_one_f32(p, s, x, mu, Sigma, ll ? (float*)ll + s * ll_sb : NULL, ll_sn, (float*)w);
     }
+    free(w);
   }
   return 0;
 }
