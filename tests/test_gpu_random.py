@@ -1,0 +1,110 @@
+"""-m gpu: randomised parity of the HIP path against the fp64 C oracle (seeded): random dense stable systems of the
+compiled shapes — time-invariant and time-varying, with and without affine cost terms, partial observation, custom
+Sigma0 — plus the reference-independent pins (brute-force joint Gaussian, DARE steady state) run on the GPU path."""
+import numpy as np
+import pytest
+import scipy.linalg as sla
+import torch
+
+import lqg_amd
+import lqg_np as O
+from gpu_common import np_, to_spec
+from lqg_amd.belief import kf
+from lqg_amd.control import lqr
+
+pytestmark = pytest.mark.gpu
+SHAPES = [(2, 2, 1, 2), (2, 3, 1, 2), (4, 4, 1, 3), (4, 4, 2, 4), (2, 2, 1, 1)]     # (x, b, u, y)
+
+
+def random_system(rng, x, b, u, y, T, time_varying, affine):
+    """Random well-posed actor / dynamics specs (dense matrices: no structure for the specialiser to exploit)."""
+    def stack(fn):
+        return np.stack([fn() for _ in range(T)]) if time_varying else np.broadcast_to(fn(), (T,) + fn().shape).copy()
+
+    def spd(n, lo=0.2):
+        M = rng.standard_normal((n, n))
+        return M @ M.T / n + lo * np.eye(n)
+
+    base = dict(Aa=np.eye(b) * 0.95 + 0.05 * rng.standard_normal((b, b)), Ba=0.3 * rng.standard_normal((b, u)),
+                Fa=rng.standard_normal((y, b)), Va=0.5 * rng.standard_normal((b, b)) + 0.5 * np.eye(b),
+                Wa=np.diag(1.0 + rng.random(y)), Q=spd(b), R=spd(u, 0.5),
+                Ad=np.eye(x) * 0.95 + 0.05 * rng.standard_normal((x, x)), Bd=0.3 * rng.standard_normal((x, u)),
+                Fd=rng.standard_normal((y, x)), Vd=0.5 * rng.standard_normal((x, x)) + 0.7 * np.eye(x),
+                Wd=np.diag(1.0 + rng.random(y)))
+    jit = (lambda M: M * (1 + 0.02 * rng.standard_normal(M.shape))) if time_varying else (lambda M: M)
+    sym = lambda M: 0.5 * (M + M.T)
+    mk = lambda k, s=False: np.stack([sym(jit(base[k])) if s else jit(base[k]) for _ in range(T)]) if time_varying \
+        else np.broadcast_to(base[k], (T,) + base[k].shape).copy()
+    actor = dict(A=mk("Aa"), B=mk("Ba"), F=mk("Fa"), V=mk("Va"), W=mk("Wa"), Q=mk("Q", True), R=mk("R", True),
+                 q=(0.1 * rng.standard_normal((T, b)) if affine else np.zeros((T, b))),
+                 P=(0.05 * rng.standard_normal((T, u, b)) if affine else np.zeros((T, u, b))),
+                 r=(0.1 * rng.standard_normal((T, u)) if affine else np.zeros((T, u))),
+                 Qf=base["Q"] * 1.5, qf=(0.1 * rng.standard_normal(b) if affine else np.zeros(b)))
+    dyn = dict(A=mk("Ad"), B=mk("Bd"), F=mk("Fd"), V=mk("Vd"), W=mk("Wd"), Q=np.zeros((T, x, x)), R=np.zeros((T, u, u)),
+               q=np.zeros((T, x)), P=np.zeros((T, u, x)), r=np.zeros((T, u)), Qf=np.zeros((x, x)), qf=np.zeros(x))
+    return actor, dyn
+
+
+@pytest.mark.parametrize("dtype,tol_ll,tol_m", [(torch.float64, 1e-9, 1e-8), (torch.float32, 2e-5, 5e-4)], ids=["f64", "f32"])
+@pytest.mark.parametrize("case", range(10))
+def test_random_systems_match_the_oracle(oracle_lib, case, dtype, tol_ll, tol_m):
+    rng = np.random.default_rng(1000 + case)
+    x, b, u, y = SHAPES[case % len(SHAPES)]
+    T = int(rng.integers(5, 60))
+    tv, affine = bool(case & 1), bool(case & 2)
+    actor, dyn = random_system(rng, x, b, u, y, T, tv, affine)
+    d = x if case % 3 else max(1, x - 1) if (x, b, u, y) != (4, 4, 2, 4) else x          # sometimes partial observation
+    if (x, d) not in ((2, 2), (4, 4), (4, 2)):
+        d = x
+    S0 = None
+    if case % 4 == 3:
+        M = rng.standard_normal((b, b))
+        S0 = M @ M.T / b + 0.3 * np.eye(b)
+    n = 3
+    X, _, _, _ = oracle_lib.simulate(actor, dyn, rng.standard_normal((n, T, x)), rng.standard_normal((n, T, y)), Sigma0=S0)
+    xs = X[..., :d]
+    ref_ll = oracle_lib.log_likelihood(actor, dyn, xs, S0)
+    ref_mu, ref_Sig = oracle_lib.conditional_moments(actor, dyn, xs, S0)
+    a_t = to_spec(actor, dtype)
+    d_t = to_spec(dyn, dtype)
+    sys_ = lqg_amd.System(actor=a_t, dynamics=d_t)
+    S0t = None if S0 is None else torch.as_tensor(S0, dtype=dtype, device="cuda")
+    xt = torch.as_tensor(xs, dtype=dtype, device="cuda")
+    scale = np.abs(ref_ll).max()
+    assert np.abs(np_(sys_.log_likelihood(xt, Sigma0=S0t)) - ref_ll).max() < tol_ll * scale          # several trials
+    assert abs(float(sys_.log_likelihood(xt[:1], Sigma0=S0t)[0]) - ref_ll[0]) < tol_ll * scale      # one trial
+    mu, Sig = sys_._moments(xt, S0t)
+    assert np.abs(np_(mu) - ref_mu).max() < tol_m * max(1.0, np.abs(ref_mu).max())
+    assert np.abs(np_(Sig) - ref_Sig).max() < tol_m * max(1.0, np.abs(ref_Sig).max())
+    L, l, H = oracle_lib.riccati_backward(actor)
+    g = lqr.backward(a_t)
+    assert np.abs(np_(g.L) - L).max() < tol_m * max(1.0, np.abs(L).max())
+    assert np.abs(np_(g.l) - l).max() < tol_m * max(1.0, np.abs(L).max())
+    K = oracle_lib.kalman_forward(actor, S0)
+    assert np.abs(np_(kf.forward(a_t, S0t)) - K).max() < tol_m * max(1.0, np.abs(K).max())
+
+
+def test_gpu_loglik_equals_brute_force_joint_gaussian():
+    """Reference-independent: the HIP path against log p(x_1..x_T | x_0) of the stacked linear-Gaussian system."""
+    T = 6
+    m = lqg_amd.SubjectiveActor(dim=1, T=T, subj_noise=1.3, subj_vel_noise=0.6, sigma_cursor=1.0, action_cost=0.05,
+                                device="cuda", dtype=torch.float64)
+    x = m.simulate(3, n=2)
+    act = {f: getattr(m.actor, f).cpu().numpy() for f in O.FIELDS}
+    dyn = {f: getattr(m.dynamics, f).cpu().numpy() for f in O.FIELDS}
+    ll = m.log_likelihood(x)
+    for i in range(2):
+        assert abs(float(ll[i]) - O.brute_force_loglik(act, dyn, x[i].cpu().numpy())) < 1e-10
+
+
+def test_gpu_kalman_gain_converges_to_dare():
+    m = lqg_amd.BoundedActor(T=3000, sigma_target=6.0, sigma_cursor=1.0, action_cost=0.05, device="cuda",
+                             dtype=torch.float64)
+    K = kf.forward(m.actor, None)
+    A, F, V, W = (getattr(m.actor, f)[0].cpu().numpy() for f in ("A", "F", "V", "W"))
+    P = sla.solve_discrete_are(A.T, F.T, V @ V.T, W @ W.T)
+    Kss = P @ F.T @ np.linalg.inv(F @ P @ F.T + W @ W.T)
+    assert np.allclose(np_(K[-1]), Kss, rtol=1e-8, atol=1e-12)
+    g = lqr.backward(m.actor)
+    c = (1.0 / 60) / (0.05 + (1.0 / 60) ** 2)
+    assert np.allclose(np_(g.L[-1]), [[c, -c]], rtol=1e-12)                      # closed form of the last gain
