@@ -108,6 +108,14 @@ def load():
 
 
 _dims_libs = {}
+# The kernels keep one system's matrices in registers: beyond these bounds an on-demand build would take hours of
+# hipcc time and spill everything, so such shapes are rejected (a wave-per-system kernel is the fix).
+MAX_STATE, MAX_JOINT, MAX_IO = 10, 20, 4
+
+
+def shape_in_range(x, b, u, y, d):
+    return 1 <= x <= MAX_STATE and 1 <= b <= MAX_STATE and x + b <= MAX_JOINT and 1 <= u <= MAX_IO \
+        and 1 <= y <= MAX_IO and 1 <= d <= x
 
 
 def library_for(dims):
@@ -121,11 +129,30 @@ def library_for(dims):
         return lib
     if key not in _dims_libs:
         from lqg_amd import build
+        if not shape_in_range(*key):
+            raise LqgHipError(f"model shape (x,b,u,y,d)={key} is outside the dims the register-resident kernels serve "
+                              f"(x, b <= {MAX_STATE}, x+b <= {MAX_JOINT}, u, y <= {MAX_IO}, d <= x); there is no CPU path")
         if not os.path.exists(build.HIPCC):
             raise LqgHipError(f"no kernels for model shape (x,b,u,y,d)={key} in {LIB_PATH} and no hipcc to compile "
                               "them: add the shape to lqg_amd/csrc/lqg_dims.def and rebuild")
         _dims_libs[key] = _bind(build.build_dims_library(*key))
     return _dims_libs[key]
+
+
+def observed_dims_with_kernels(dims):
+    """For paths that do not depend on the observed width d (simulate): a d in 1..x whose library already exists —
+    compiled in, loaded, or cached on disk — else min(x, 2), the tracking models' (target, cursor) width."""
+    lib = load()
+    x, b, u, y = dims["x"], dims["b"], dims["u"], dims["y"]
+    from lqg_amd import build
+    order = [dims["d"]] + [d for d in range(1, x + 1) if d != dims["d"]]
+    for d in order:
+        if lib.lqg_dims_supported(F32, C.byref(Dims(x, b, u, y, d, 1, 1, 1, 1))) or (x, b, u, y, d) in _dims_libs:
+            return d
+    for d in order:
+        if os.path.exists(os.path.join(build.DIMS_DIR, f"liblqg_hip_{build.dims_tag(x, b, u, y, d)}.so")):
+            return d
+    return min(x, 2)
 
 
 def shape_available(x, b, u, y, d):
@@ -135,7 +162,7 @@ def shape_available(x, b, u, y, d):
     if lib.lqg_dims_supported(F32, C.byref(dm)):
         return True
     from lqg_amd import build
-    return os.path.exists(build.HIPCC)
+    return shape_in_range(x, b, u, y, d) and os.path.exists(build.HIPCC)
 
 
 def check(rc, what):

@@ -251,6 +251,7 @@ def simulate(actor, dynamics, L, l, K, eps_noise, eta_noise, x0=None, xhat0=None
     """eps_noise[(B,)n,T,x], eta_noise[(B,)n,T,y] -> x[(B,)n,T+1,x] (and xhat, y, u)."""
     n = eps_noise.shape[-3]
     ln = Launch(actor, dynamics, n_trials=n)
+    ln.dims["d"] = ln.p.dims.d = _abi.observed_dims_with_kernels(ln.dims)     # k_simulate does not depend on d
     lib = ln.require_gpu()
     dm = ln.dims
     xs = ln.empty(n, ln.T + 1, dm["x"])

@@ -36,6 +36,7 @@ from lqg.spec import LQGSpec  # noqa: E402
 from lqg.system import LQG, Actor, Dynamics, System  # noqa: E402
 from lqg.tracking import (BoundedActor, OptimalActor, PointMassBoundedActor,  # noqa: E402
                           RelativeObservationBoundedActor, SubjectiveActor)
+from lqg.tracking.delay import TemporalDelayModel  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
 FIELDS = LQGSpec._fields
@@ -155,6 +156,32 @@ def time_varying(T, seed):
     return System(actor=actor, dynamics=dynamics)
 
 
+def tracking_io_case():
+    """lqg.io.load_tracking_data on a small synthetic data.mat (same fields/dtypes as the Bonnen et al. file:
+    sigma uint8 [n], target float64 [n, S], response uint16 [n, S]); inputs and outputs go into one fixture."""
+    import tempfile
+
+    import scipy.io as spio
+    from lqg.io import load_tracking_data
+
+    rng = np.random.default_rng(77)
+    n, S = 12, 400
+    sigma = np.repeat(np.array([11, 13, 17, 21], dtype=np.uint8), 3)[rng.permutation(n)]
+    target = 600.0 + np.cumsum(rng.standard_normal((n, S)) * 3.0, axis=1)
+    response = np.clip(np.round(np.roll(target, 9, axis=1) + rng.standard_normal((n, S)) * 4.0), 0, 65535).astype(np.uint16)
+    out = {"sigma": sigma, "target": target, "response": response}
+    with tempfile.TemporaryDirectory() as tmp:
+        spio.savemat(os.path.join(tmp, "data.mat"), out)
+        for tag, kw in (("default", dict(delay=12, clip=120, subtract_mean=True)),
+                        ("nodelay", dict(delay=0, clip=50, subtract_mean=True)),
+                        ("raw", dict(delay=5, clip=0, subtract_mean=False))):
+            data, sigmas = load_tracking_data(data_path=tmp, **kw)
+            out["data_" + tag], out["sigmas_" + tag] = np.asarray(data), np.asarray(sigmas)
+    os.makedirs(os.path.join(OUT, "io"), exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, "io", "tracking_small.npz"), **out)
+    print("io/tracking_small", {k: v.shape for k, v in out.items() if k.startswith("data_")})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     # BASELINE config 1: tutorial LQG, state dim 2, T=100
@@ -180,6 +207,14 @@ def main():
     S0 = np.array([[2.0, 0.3, 0.1], [0.3, 1.5, 0.2], [0.1, 0.2, 1.0]])
     run_case("timevarying_T30", time_varying(30, seed=5), n=3, d=2, seed=20, Sigma0=S0,
              x0=np.array([0.5, -0.25]))
+    # temporal-delay augmentation (lqg/tracking/delay.py): shift-register states, singular process noise
+    run_case("delay1_bounded_T30", TemporalDelayModel(BoundedActor(T=30, sigma_target=6.0, sigma_cursor=1.0,
+                                                                   action_cost=0.05), delay=1), n=2, d=2, seed=22)
+    run_case("delay2_bounded_T30", TemporalDelayModel(BoundedActor(T=30, sigma_target=6.0, sigma_cursor=1.0,
+                                                                   action_cost=0.05), delay=2), n=2, d=2, seed=23)
+    run_case("delay1_subjective1d_T30", TemporalDelayModel(SubjectiveActor(dim=1, T=30, action_cost=0.5), delay=1),
+             n=2, d=2, seed=24)
+    tracking_io_case()
 
 
 if __name__ == "__main__":

@@ -108,3 +108,25 @@ def test_gpu_kalman_gain_converges_to_dare():
     g = lqr.backward(m.actor)
     c = (1.0 / 60) / (0.05 + (1.0 / 60) ** 2)
     assert np.allclose(np_(g.L[-1]), [[c, -c]], rtol=1e-12)                      # closed form of the last gain
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 1e-5)], ids=["f64", "f32"])
+def test_temporal_delay_model_on_the_hip_path(oracle_lib, dtype, tol):
+    """lqg/tracking/delay.py: a delayed BoundedActor (shape compiled on first use) — likelihood over a candidate
+    axis against the fp64 oracle, and the delay-12 model of the reference rejected loudly (no CPU fallback)."""
+    from lqg_amd.tracking.delay import DelayedSubjectiveActor, TemporalDelayModel
+    sig = torch.tensor([4.0, 8.0, 16.0], dtype=dtype, device="cuda")
+    m = TemporalDelayModel(lqg_amd.BoundedActor(T=80, sigma_target=sig, action_cost=0.1, device="cuda", dtype=dtype), delay=2)
+    one = TemporalDelayModel(lqg_amd.BoundedActor(T=80, sigma_target=8.0, action_cost=0.1, device="cuda", dtype=dtype), delay=2)
+    x = one.simulate(5, n=6)[..., :2]
+    ll = m.log_likelihood(x)
+    assert ll.shape == (3, 6)
+    for c, s in enumerate((4.0, 8.0, 16.0)):
+        ref_m = TemporalDelayModel(lqg_amd.BoundedActor(T=80, sigma_target=s, action_cost=0.1, device="cpu", dtype=torch.float64), delay=2)
+        act = {f: getattr(ref_m.actor, f).numpy().copy() for f in O.FIELDS}
+        dyn = {f: getattr(ref_m.dynamics, f).numpy().copy() for f in O.FIELDS}
+        ref = oracle_lib.log_likelihood(act, dyn, x.double().cpu().numpy())
+        assert np.abs(np_(ll[c]) - ref).max() < tol * np.abs(ref).max()
+    big = DelayedSubjectiveActor(T=20, device="cuda", dtype=dtype)
+    with pytest.raises(RuntimeError, match="outside the dims"):
+        big.log_likelihood(torch.zeros(1, 21, 2, device="cuda", dtype=dtype))
