@@ -23,13 +23,19 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # live registers in k_forward (measured: 42.5 ms -> 12.3 ms per 2^18 solves, profiles/README.md).
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-slp-vectorize"]
 HEADERS = ["lqg_small.hpp", "lqg_kernels.hpp", "lqg_launch.hpp", "lqg_dims.def", "../../include/lqg_hip.h"]
+ADJ_HEADERS = ["lqg_small.hpp", "lqg_adjoint.hpp", "lqg_adjoint_launch.hpp", "../../include/lqg_hip.h"]
+# headers each source depends on (an adjoint-kernel edit must not recompile the forward kernels and vice versa)
+DEPS = {"lqg_inst.hip": HEADERS, "lqg_adjoint_inst.hip": ADJ_HEADERS,
+        "lqg_abi.hip": sorted(set(HEADERS + ADJ_HEADERS))}
+FAMILIES = ("FORWARD", "RICCATI", "KALMAN", "TRIAL", "SIM", "ADJOINT")
+ADJOINT_MAX_JOINT = 10          # on-demand libraries get the gradient sweep only up to x + b = 10 (compile time)
 
 
 def dims_lists():
     """Parse the X-macro lists of lqg_dims.def -> {family: [tuple, ...]}."""
     text = open(os.path.join(CSRC, "lqg_dims.def")).read().replace("\\\n", " ")
     out = {}
-    for fam in ("FORWARD", "RICCATI", "KALMAN", "TRIAL", "SIM"):
+    for fam in FAMILIES:
         m = re.search(r"#define LQG_%s_DIMS\(X\)(.*)" % fam, text)
         out[fam] = [tuple(int(v) for v in t.split(",")) for t in re.findall(r"X\(([^)]*)\)", m.group(1))]
     return out
@@ -43,7 +49,9 @@ def jobs(lists=None, extra_defs=()):
             for dt in ("F32", "F64"):
                 base = f"{fam.lower()}_{'_'.join(map(str, t))}_{dt.lower()}"
                 defs = [f"-DLQG_INST_{fam}={','.join(map(str, t))}", f"-DLQG_INST_{dt}"] + extra_defs
-                if fam == "FORWARD":          # the 8 k_forward variants of a (dims, dtype) are split over four units
+                if fam == "ADJOINT":
+                    js.append((base + ".o", "lqg_adjoint_inst.hip", defs))
+                elif fam == "FORWARD":        # the 8 k_forward variants of a (dims, dtype) are split over four units
                     js += [(f"{base}_v{v}.o", "lqg_inst.hip", defs + [f"-DLQG_INST_VARIANT={v}"]) for v in range(4)]
                 else:
                     js.append((base + ".o", "lqg_inst.hip", defs))
@@ -57,7 +65,7 @@ def source_hash():
     """Content hash of every source that goes into the library (+ compile flags): mtimes do not survive the
     snapshot to the GPU box, the hash does."""
     h = hashlib.sha256(" ".join(FLAGS).encode())
-    for f in sorted(HEADERS + ["lqg_abi.hip", "lqg_inst.hip"]):
+    for f in sorted(set(HEADERS + ADJ_HEADERS + ["lqg_abi.hip", "lqg_inst.hip", "lqg_adjoint_inst.hip"])):
         h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()
 
@@ -68,7 +76,7 @@ def up_to_date():
 
 def _newest_src(src):
     """Newest mtime among the headers and the one source file an object is compiled from."""
-    return max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS + [src])
+    return max(os.path.getmtime(os.path.join(CSRC, h)) for h in DEPS.get(src, HEADERS) + [src])
 
 
 def _compile(job):
@@ -127,7 +135,7 @@ def build_dims_library(x, b, u, y, d, workers=None, verbose=True):
     if os.path.exists(so) and os.path.exists(stamp) and open(stamp).read().strip() == source_hash():
         return so
     lists = {"FORWARD": [(x, b, u, y, d)], "RICCATI": [(b, u)], "KALMAN": [(b, y)], "TRIAL": [(x + b, d)],
-             "SIM": [(x, b, u, y)]}
+             "SIM": [(x, b, u, y)], "ADJOINT": [(x, b, u, y, d)] if x + b <= ADJOINT_MAX_JOINT else []}
     deff = os.path.join(DIMS_DIR, f"dims_{tag}.def")
     with open(deff, "w") as f:
         f.write(f"// GENERATED by lqg_amd/build.py: instantiation lists of the auxiliary library for shape {tag}\n")

@@ -8,6 +8,7 @@
 #include <cstring>
 
 #include "../../include/lqg_hip.h"
+#include "lqg_adjoint_launch.hpp"
 #include "lqg_launch.hpp"
 // the instantiation lists: lqg_dims.def for the main library; lqg_amd/build.py compiles auxiliary libraries for
 // shapes that are not listed there with -DLQG_DIMS_DEF="<generated single-shape lists>"
@@ -53,6 +54,17 @@ LQG_TRIAL_DIMS(X)
       const lqg_problem*, lqg_view, lqg_view, lqg_view, lqg_traj, lqg_traj, lqg_view, lqg_view, lqg_traj,       \
       lqg_traj, lqg_traj, lqg_traj, hipStream_t);
 LQG_SIM_DIMS(X)
+#undef X
+
+#ifndef LQG_ADJOINT_DIMS
+#define LQG_ADJOINT_DIMS(X)
+#endif
+#define X(X_, B_, U_, Y_, D_)                                                                                    \
+  extern template hipError_t lqg::host::launch_adjoint<float, X_, B_, U_, Y_, D_>(                               \
+      const lqg_problem*, lqg_traj, const void*, long, long, void*, long, long, void*, long, void*, hipStream_t); \
+  extern template hipError_t lqg::host::launch_adjoint<double, X_, B_, U_, Y_, D_>(                              \
+      const lqg_problem*, lqg_traj, const void*, long, long, void*, long, long, void*, long, void*, hipStream_t);
+LQG_ADJOINT_DIMS(X)
 #undef X
 
 using namespace lqg::host;
@@ -389,6 +401,63 @@ int lqg_gaussian_logprob(int32_t dtype, int32_t k, int32_t T, int64_t n_sys, int
 #undef LPK
 #undef LP
   return done(hipGetLastError(), who);
+}
+
+int lqg_grad_supported(int32_t dtype, const lqg_dims* dims) {
+  if (!dims || (dtype != LQG_F32 && dtype != LQG_F64)) return 0;
+  const lqg_dims& d = *dims;
+  (void)d;
+#define X(X_, B_, U_, Y_, D_) \
+  if (d.x == X_ && d.b == B_ && d.u == U_ && d.y == Y_ && d.d == D_) return 1;
+  LQG_ADJOINT_DIMS(X)
+#undef X
+  return 0;
+}
+
+int64_t lqg_grad_elements(const lqg_dims* dims) { return dims ? (int64_t)adj_grad_elements(*dims) : 0; }
+
+size_t lqg_grad_workspace_bytes(const lqg_problem* p, int64_t ld) {
+  if (!p || p->T <= 0 || ld <= 0) return 0;
+  const size_t e = p->dtype == LQG_F64 ? 8 : 4;
+  return (size_t)p->T * (size_t)adj_step_reals(p->dims) * (size_t)ld * e;
+}
+
+int lqg_log_likelihood_grad(const lqg_problem* p, lqg_traj x, const void* g, int64_t g_sb, int64_t g_sn, void* ll,
+                            int64_t ll_sb, int64_t ll_sn, void* grad, int64_t ld, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  static const char* who = "lqg_log_likelihood_grad";
+  if (int rc = check_problem(p, who)) return rc;
+  const lqg_spec& a = p->actor;
+  const lqg_spec& dy = p->dynamics;
+  if (need(a.Q, who, "actor.Q") || need(a.Qf, who, "actor.Qf") || need(a.R, who, "actor.R") ||
+      need(a.A, who, "actor.A") || need(a.B, who, "actor.B") || need(a.F, who, "actor.F") ||
+      need(a.V, who, "actor.V") || need(a.W, who, "actor.W") || need(dy.A, who, "dynamics.A") ||
+      need(dy.B, who, "dynamics.B") || need(dy.F, who, "dynamics.F") || need(dy.V, who, "dynamics.V") ||
+      need(dy.W, who, "dynamics.W"))
+    return LQG_ERR_NULL;
+  if (p->n_sys == 0 || p->n_trials == 0) return 0;
+  if (!x.ptr || !grad || !workspace) return fail(LQG_ERR_NULL, "%s: NULL x / grad / workspace", who);
+  if (!(actor_ti_riccati(p) && forward_ti(p)))
+    return fail(LQG_ERR_ARG, "%s: time-varying specs are not supported by the adjoint sweep (every field's st must be 0)",
+                who);
+  if (ld < p->n_sys * p->n_trials) return fail(LQG_ERR_ARG, "%s: ld %lld < n_sys * n_trials", who, (long long)ld);
+  if (workspace_bytes < lqg_grad_workspace_bytes(p, ld))
+    return fail(LQG_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", who, workspace_bytes, lqg_grad_workspace_bytes(p, ld));
+  const lqg_dims& d = p->dims;
+  (void)d;
+  hipStream_t st = (hipStream_t)stream;
+#define X(X_, B_, U_, Y_, D_)                                                                                   \
+  if (d.x == X_ && d.b == B_ && d.u == U_ && d.y == Y_ && d.d == D_)                                           \
+    return done(p->dtype == LQG_F64                                                                             \
+                    ? launch_adjoint<double, X_, B_, U_, Y_, D_>(p, x, g, g_sb, g_sn, ll, ll_sb, ll_sn, grad, ld, \
+                                                                 workspace, st)                                  \
+                    : launch_adjoint<float, X_, B_, U_, Y_, D_>(p, x, g, g_sb, g_sn, ll, ll_sb, ll_sn, grad, ld,  \
+                                                                workspace, st),                                  \
+                who);
+  LQG_ADJOINT_DIMS(X)
+#undef X
+  (void)st;
+  return unsupported(p, who);
 }
 
 }  // extern "C"

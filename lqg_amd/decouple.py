@@ -83,7 +83,9 @@ def _take(t, rows, cols=None, time_axis=True):
     if time_axis and t.dim() > nd and t.stride(tax) == 0 and t.shape[tax] > 1:
         T = t.shape[tax]
         base = _take(t.select(tax, 0), rows, cols, time_axis=False)
-        return base.unsqueeze(tax).expand(*base.shape[:tax + 1 + base.dim()][:base.dim() - nd], T, *base.shape[-nd:])
+        out = base.unsqueeze(tax).expand(*base.shape[:tax + 1 + base.dim()][:base.dim() - nd], T, *base.shape[-nd:])
+        out._lqg_base = base
+        return out
     if cols is None:
         return t[..., rows]
     return t[..., rows, :][..., :, cols]

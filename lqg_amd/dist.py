@@ -48,6 +48,14 @@ def log_likelihood_sum(system, x_local, Sigma0=None, group=None, local_sum=None)
     return part
 
 
+def all_reduce_sum(t, group=None):
+    """Sum a small fp64 vector (objective and its gradient) over the ranks of `group`; identity without a group."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        t = t.contiguous()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 def gather_candidates(local_values, n_total, group=None):
     """Candidate-sharded evaluation: every rank scored its block of candidates (shard_bounds) against all trials;
     concatenate the [n_local] blocks into [n_total] on every rank (all_gather of padded blocks)."""

@@ -1,0 +1,151 @@
+"""Reverse-mode gradients of the trajectory log-likelihood — the torch.autograd face of the HIP adjoint sweep
+(lqg_amd/csrc/lqg_adjoint.hpp, C ABI lqg_log_likelihood_grad).
+
+What the reference gets from jax.grad / jax.value_and_grad of `System.log_likelihood` through all three scans
+(lqg/optim.py:142-147, lqg/infer/utils.py:18,37-39, lqg/infer/mle.py:17-23, notebooks/Tutorial.ipynb cell 40):
+
+    sigma = torch.tensor(6., device="cuda", requires_grad=True)
+    ll = lqg_amd.BoundedActor(T=500, sigma_target=sigma).log_likelihood(x).sum()
+    ll.backward()                      # sigma.grad == d ll / d sigma
+
+`System.log_likelihood` routes here whenever a spec tensor (or Sigma0) requires grad.  The forward value comes from
+the ordinary fused path; backward launches the four adjoint sweeps with the upstream weights and hands the bars of
+the spec matrices to autograd, which chains them through the (torch) model constructors to the parameters.  Systems
+that decouple (every dim=2 model) are differentiated component by component — the gathers of lqg_amd/decouple.py are
+differentiable.  Time-invariant specs only; no CPU fallback.
+"""
+import ctypes as C
+
+import torch
+
+from lqg_amd import _abi, _hip
+
+ACTOR_FIELDS = ("A", "B", "F", "V", "W", "Q", "R")           # time-stacked actor fields that get a gradient
+DYN_FIELDS = ("A", "B", "F", "V", "W")
+
+
+def needs_grad(system, Sigma0=None):
+    if not torch.is_grad_enabled():
+        return False
+    ts = [getattr(system.actor, f) for f in ACTOR_FIELDS + ("Qf",)] + [getattr(system.dynamics, f) for f in DYN_FIELDS]
+    if Sigma0 is not None:
+        ts.append(Sigma0)
+    return any(isinstance(t, torch.Tensor) and t.requires_grad for t in ts)
+
+
+def _time_slice(t, name):
+    """[.., T, r, c] time-invariant field -> its [.., r, c] matrix, staying on the autograd graph."""
+    if t.shape[-3] > 1 and t.stride(-3) != 0:
+        raise NotImplementedError(f"gradients need time-invariant specs (field {name} varies over time): the adjoint "
+                                  "sweep accumulates one bar per matrix (lqg_hip.h: lqg_log_likelihood_grad)")
+    base = getattr(t, "_lqg_base", None)
+    if base is not None and base.shape == t.shape[:-3] + t.shape[-2:]:
+        return base                     # the matrix time_stack expanded: avoids a [.., T, r, c] zero-fill in backward
+    return t.select(-3, 0)
+
+
+def _layout(dm):
+    x, b, u, y = dm["x"], dm["b"], dm["u"], dm["y"]
+    order = [("dA", x, x), ("dB", x, u), ("dF", y, x), ("dVV", x, x), ("dWW", y, y), ("aA", b, b), ("aB", b, u),
+             ("aF", y, b), ("aVV", b, b), ("aWW", y, y), ("aQ", b, b), ("aR", u, u), ("aQf", b, b), ("aS0", b, b),
+             ("aA2", b, b), ("aB2", b, u)]
+    off, out = 0, {}
+    for name, r, c in order:
+        out[name] = (off, r, c)
+        off += r * c
+    return out, off
+
+
+def raw_grad(actor, dynamics, x, g=None, Sigma0=None, eps=1e-8, want_value=True):
+    """Launch the adjoint sweeps.  x[n,T+1,d] or [B,n,T+1,d]; g like the log-likelihood ([n] / [B,n]) or None.
+    Returns (ll or None, {name: [B, N, r, c] per-(system, trial) bars})."""
+    d = x.shape[-1]
+    ln = _hip.Launch(actor, dynamics, d=d, n_trials=x.shape[-3], Sigma0=Sigma0, eps=eps)
+    lib = ln.require_gpu()
+    if not lib.lqg_grad_supported(ln.p.dtype, C.byref(ln.p.dims)):
+        raise _abi.LqgHipError(f"no adjoint kernels for model shape {tuple(ln.dims[k] for k in 'xbuyd')}: add it to "
+                               "LQG_ADJOINT_DIMS in lqg_amd/csrc/lqg_dims.def and rebuild (there is no CPU path)")
+    xx, xb = _hip._prep_x(ln, x)
+    N = xx.shape[-3]
+    lanes = ln.B * N
+    ld = (lanes + 63) // 64 * 64
+    lay, total = _layout(ln.dims)
+    assert total == lib.lqg_grad_elements(C.byref(ln.p.dims))
+    out = torch.empty(total, ld, dtype=ln.dtype, device=ln.device)
+    nbytes = lib.lqg_grad_workspace_bytes(C.byref(ln.p), ld)
+    ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=ln.device)
+    ll = ln.empty(N) if want_value else None
+    if g is not None:
+        g = g.to(dtype=ln.dtype, device=ln.device).expand(ln.lead() + (N,)).contiguous()
+    with torch.cuda.device(ln.device):
+        _abi.check(lib.lqg_log_likelihood_grad(
+            C.byref(ln.p), ln.traj(xx, xb), C.c_void_p(g.data_ptr() if g is not None else None),
+            N if ln.batched else 0, 1, C.c_void_p(ll.data_ptr() if ll is not None else None), N if ln.batched else 0, 1,
+            C.c_void_p(out.data_ptr()), ld, C.c_void_p(ws.data_ptr()), int(nbytes), ln.stream()),
+            "lqg_log_likelihood_grad")
+    bars = {k: out[o:o + r * c, :lanes].reshape(r, c, ln.B, N).permute(2, 3, 0, 1) for k, (o, r, c) in lay.items()}
+    return ll, bars, ln
+
+
+class _LogLikelihood(torch.autograd.Function):
+    """ll = log_likelihood(system, x); inputs are the time-invariant matrices (slices of the spec fields)."""
+
+    @staticmethod
+    def forward(ctx, system, x, Sigma0, *mats):
+        ctx.system, ctx.x, ctx.n_mats = system, x, len(mats)
+        ctx.save_for_backward(*(mats + ((Sigma0,) if Sigma0 is not None else ())))
+        ctx.has_s0 = Sigma0 is not None
+        with torch.no_grad():
+            from lqg_amd.plan import LogLikelihoodPlan
+            return LogLikelihoodPlan(system, x, Sigma0=Sigma0).run()
+
+    @staticmethod
+    def backward(ctx, g):
+        saved = ctx.saved_tensors
+        mats = saved[:ctx.n_mats]
+        S0 = saved[ctx.n_mats] if ctx.has_s0 else None
+        sys_ = ctx.system
+        with torch.no_grad():
+            _, bars, ln = raw_grad(sys_.actor, sys_.dynamics, ctx.x, g=g, Sigma0=S0, want_value=False)
+            tot = {k: v.sum(1) for k, v in bars.items()}                    # over trials -> [B, r, c]
+            sym2 = lambda M: M + M.transpose(-1, -2)
+            first = lambda t: t.select(-3, 0)
+            res = {"aA": tot["aA"] + tot["aA2"], "aB": tot["aB"] + tot["aB2"], "aF": tot["aF"],
+                   "aV": sym2(tot["aVV"]) @ first(sys_.actor.V), "aW": sym2(tot["aWW"]) @ first(sys_.actor.W),
+                   "aQ": tot["aQ"], "aR": 0.5 * sym2(tot["aR"]), "aQf": tot["aQf"],
+                   "dA": tot["dA"], "dB": tot["dB"], "dF": tot["dF"],
+                   "dV": sym2(tot["dVV"]) @ first(sys_.dynamics.V), "dW": sym2(tot["dWW"]) @ first(sys_.dynamics.W)}
+            names = ["a" + f for f in ACTOR_FIELDS] + ["aQf"] + ["d" + f for f in DYN_FIELDS]
+            outs = []
+            for name, m in zip(names, mats):
+                gm = res[name]
+                if m.dim() == 2:                                             # field shared by all systems
+                    gm = gm.sum(0)
+                outs.append(gm.to(m.dtype) if ctx.needs_input_grad[3 + len(outs)] else None)
+            gS0 = None
+            if S0 is not None and ctx.needs_input_grad[2]:
+                gS0 = tot["aS0"] if S0.dim() == 3 else tot["aS0"].sum(0)
+        return (None, None, gS0) + tuple(outs)
+
+
+def _one(system, x, Sigma0):
+    a, dy = system.actor, system.dynamics
+    if not (getattr(a.P, "_lqg_zero", False) or not a.P.requires_grad):
+        raise NotImplementedError("gradient w.r.t. the cross-cost P is not provided")
+    mats = [_time_slice(getattr(a, f), "actor." + f) for f in ACTOR_FIELDS] + [a.Qf] \
+        + [_time_slice(getattr(dy, f), "dynamics." + f) for f in DYN_FIELDS]
+    return _LogLikelihood.apply(system, x, Sigma0, *mats)
+
+
+def log_likelihood(system, x, Sigma0=None):
+    """Differentiable log-likelihood: x[n,T+1,d] (or [B,n,T+1,d]) -> [n] (or [B,n])."""
+    d = x.shape[-1]
+    parts = system.decoupled(d, Sigma0)
+    if parts is None:
+        return _one(system, x, Sigma0)
+    total = None
+    for sub, cols, bs in parts:
+        S0 = None if Sigma0 is None else Sigma0[..., bs, :][..., :, bs]
+        ll = _one(sub, x[..., cols].contiguous(), S0)
+        total = ll if total is None else total + ll
+    return total

@@ -187,6 +187,9 @@ class System:
 
     def log_likelihood(self, x, Sigma0=None):
         """log p(x_{1:T} | x_0) per trial: x[n, T+1, d] -> [n] (lqg/system.py:246-248).  Fused HIP path."""
+        from lqg_amd import grad
+        if grad.needs_grad(self, Sigma0):              # jax.grad(ll): reverse-mode HIP sweep behind torch.autograd
+            return grad.log_likelihood(self, x, Sigma0)
         from lqg_amd.plan import LogLikelihoodPlan
         return LogLikelihoodPlan(self, x, Sigma0=Sigma0).run()
 

@@ -25,7 +25,9 @@ def mark_zero(t):
 
 def time_stack(A: torch.Tensor, T: int):
     """lqg/utils.py:6-7.  A[r, c] -> [T, r, c] (or [B, r, c] -> [B, T, r, c]) as a stride-0 view."""
-    return A.unsqueeze(-3).expand(*A.shape[:-2], T, *A.shape[-2:])
+    out = A.unsqueeze(-3).expand(*A.shape[:-2], T, *A.shape[-2:])
+    out._lqg_base = A                  # lets lqg_amd.grad differentiate w.r.t. the matrix without a T-fold zero-fill
+    return out
 
 
 def time_stack_spec(A, B, F, V, W, Q, R, T: int) -> LQGSpec:

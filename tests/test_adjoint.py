@@ -1,0 +1,213 @@
+"""Reverse-mode gradient of the log-likelihood (jax.grad in lqg/optim.py:142-147).
+
+CPU (-m "not gpu"): the NumPy restatement of the adjoint sweep (oracle/lqg_adjoint_np.py) is pinned against
+torch.autograd of the literal torch restatement (oracle/lqg_torch_ref.py, itself checked against the golden vectors
+here) and against central finite differences of the golden-pinned C oracle.
+GPU (-m gpu): the HIP sweeps through the C ABI against that restatement, and end to end through torch.autograd and the
+model constructors against finite differences of the fp64 HIP forward path."""
+import numpy as np
+import pytest
+import torch
+
+import lqg_adjoint_np as ADJ
+import lqg_torch_ref as TR
+from conftest import load_golden
+
+SYM = ("Q", "Qf")
+
+
+def _cut(spec, T):
+    return {k: (v[:T] if (v.ndim == 3 or (v.ndim == 2 and k in ("q", "r"))) else v) for k, v in spec.items()}
+
+
+@pytest.mark.parametrize("name,T", [("subjective1d_T50", 50), ("pointmass_d2_T50", 20), ("timevarying_T30", 30),
+                                    ("tutorial_lqg_T100", 100), ("delay1_bounded_T30", 30)])
+def test_numpy_adjoint_matches_torch_autograd(name, T):
+    g, actor, dyn = load_golden(name)
+    actor, dyn, x = _cut(actor, T), _cut(dyn, T), g["x"][:2, :T + 1]
+    S0 = g.get("Sigma0")
+    w = np.array([0.7, 1.3])
+    a = {k: torch.tensor(v, requires_grad=True) for k, v in actor.items()}
+    d = {k: torch.tensor(v, requires_grad=True) for k, v in dyn.items()}
+    S0t = None if S0 is None else torch.tensor(S0, requires_grad=True)
+    ll = TR.log_likelihood(a, d, torch.tensor(x), S0t)
+    if T == actor["A"].shape[0] and T == g["x"].shape[1] - 1:
+        assert np.abs(ll.detach().numpy() - g["ll"][:2]).max() < 1e-10 * np.abs(g["ll"]).max()   # the torch restatement is pinned
+    (ll * torch.tensor(w)).sum().backward()
+    ll2, ga, gd, S0b = ADJ.loglik_grad(actor, dyn, x, w, S0)
+    assert np.abs(ll2 - ll.detach().numpy()).max() < 1e-10 * np.abs(ll2).max()
+    for who, mine, ref in (("actor", ga, a), ("dyn", gd, d)):
+        for k, v in mine.items():
+            r = ref[k].grad.numpy()
+            if k in SYM:
+                r = 0.5 * (r + np.swapaxes(r, -1, -2))
+            assert np.abs(v - r).max() < 1e-7 * max(np.abs(r).max(), 1e-3), (who, k)
+    if S0 is not None:
+        r = S0t.grad.numpy()
+        assert np.abs(S0b - 0.5 * (r + r.T)).max() < 1e-9
+
+
+def test_numpy_adjoint_matches_finite_differences_of_the_c_oracle(oracle_lib):
+    g, actor, dyn = load_golden("subjective1d_T50")
+    x = g["x"]
+    w = np.linspace(0.5, 1.5, x.shape[0])
+    _, ga, gd, _ = ADJ.loglik_grad(actor, dyn, x, w)
+    f = lambda a, d: float((oracle_lib.log_likelihood(a, d, x) * w).sum())
+    h = 1e-6
+    for who, spec, grads in (("dyn", dyn, gd), ("actor", actor, ga)):
+        for k, (i, j) in (("A", (0, 1)), ("B", (1, 0)), ("F", (1, 1)), ("V", (1, 1)), ("W", (0, 0))):
+            Mp, Mm = spec[k].copy(), spec[k].copy()
+            Mp[:, i, j] += h
+            Mm[:, i, j] -= h
+            sp, sm = dict(spec, **{k: Mp}), dict(spec, **{k: Mm})
+            fd = (f(actor, sp) - f(actor, sm)) / (2 * h) if who == "dyn" else (f(sp, dyn) - f(sm, dyn)) / (2 * h)
+            an = grads[k][:, i, j].sum()
+            assert abs(fd - an) < 2e-6 * max(1.0, abs(an)), (who, k, fd, an)
+
+
+# ------------------------------------------------------------------------------------------------------------ GPU
+gpu = pytest.mark.gpu
+TI_CASES = ["bounded_T100", "optimal_T30", "relobs_T40", "subjective1d_T50", "pointmass_d2_T50", "pointmass_d4_T50",
+            "tutorial_lqg_T100"]
+
+
+def _ti(spec):
+    """Golden specs are materialised [T, ...] stacks of one matrix: re-express them as stride-0 views."""
+    return spec._replace(**{f: getattr(spec, f)[:1].expand_as(getattr(spec, f))
+                            for f in ("A", "B", "F", "V", "W", "Q", "R", "q", "P", "r")})
+
+
+@gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-8), (torch.float32, 2e-4)], ids=["f64", "f32"])
+@pytest.mark.parametrize("name", TI_CASES)
+def test_hip_adjoint_matches_the_restatement(name, dtype, tol):
+    from gpu_common import system_from_golden
+    from lqg_amd import grad as G
+    if name == "pointmass_d4_T50" and dtype == torch.float32:
+        pytest.skip("full point-mass state observed: cond(Sigma_oo) ~ 5e8 is beyond fp32 for the adjoint's plain "
+                    "(non-deviation-form) forward recompute; gradients of this model are fp64-only (DESIGN.md §10)")
+    g, actor, dyn = load_golden(name)
+    x = g["x"]
+    w = np.linspace(0.5, 1.5, x.shape[0])
+    ll_ref, ga, gd, _ = ADJ.loglik_grad(actor, dyn, x, w)
+    s = system_from_golden(actor, dyn, dtype)
+    ll, bars, _ = G.raw_grad(_ti(s.actor), _ti(s.dynamics), torch.as_tensor(x, dtype=dtype, device="cuda"),
+                             g=torch.as_tensor(w, dtype=dtype, device="cuda"))
+    assert np.abs(ll.double().cpu().numpy() - g["ll"]).max() < max(tol * 1e-1, 1e-10) * np.abs(g["ll"]).max()
+    tot = {k: v.sum(1)[0].double().cpu().numpy() for k, v in bars.items()}
+    sym2 = lambda M: M + M.T
+    got = {"dA": tot["dA"], "dB": tot["dB"], "dF": tot["dF"], "dV": sym2(tot["dVV"]) @ dyn["V"][0],
+           "dW": sym2(tot["dWW"]) @ dyn["W"][0], "aA": tot["aA"] + tot["aA2"], "aB": tot["aB"] + tot["aB2"],
+           "aF": tot["aF"], "aV": sym2(tot["aVV"]) @ actor["V"][0], "aW": sym2(tot["aWW"]) @ actor["W"][0],
+           "aQ": tot["aQ"], "aR": tot["aR"], "aQf": tot["aQf"]}
+    ref = {"d" + k: v.sum(0) for k, v in gd.items()}
+    ref.update({"a" + k: (v.sum(0) if v.ndim == 3 else v) for k, v in ga.items()})
+    scale = max(np.abs(v).max() for v in ref.values())
+    for k, r in ref.items():
+        assert np.abs(got[k] - r).max() < tol * max(np.abs(r).max(), 1e-3 * scale), k
+
+
+def _fd(make, x, names, h=1e-6):
+    """Central differences of sum(ll) w.r.t. scalar model parameters through the fp64 HIP forward path."""
+    out = {}
+    base = {k: v for k, v in names.items()}
+    for k in names:
+        vals = []
+        for s in (+1, -1):
+            kw = dict(base)
+            kw[k] = base[k] * (1 + s * h)
+            with torch.no_grad():
+                vals.append(float(make(**kw).log_likelihood(x).sum()))
+        out[k] = (vals[0] - vals[1]) / (2 * h * base[k])
+    return out
+
+
+@gpu
+@pytest.mark.parametrize("ctor,kw,params,d", [
+    ("BoundedActor", dict(T=120), dict(sigma_target=6.0, sigma_cursor=1.5, action_cost=0.05, action_variability=0.4), 2),
+    ("SubjectiveActor", dict(T=100, dim=1), dict(subj_noise=1.2, subj_vel_noise=0.6, sigma_target=5.0, sigma_cursor=2.0,
+                                                 action_cost=0.3, action_variability=0.5), 2),
+    ("SubjectiveActor", dict(T=60, dim=2), dict(subj_noise=1.2, subj_vel_noise=0.6, sigma_target=5.0, action_cost=0.3), 4),
+    ("BoundedActor", dict(T=60, dim=2), dict(sigma_target=6.0, action_cost=0.1), 4),
+    ("RelativeObservationBoundedActor", dict(T=80), dict(sigma=4.0, action_cost=0.2), 2),
+    ("PointMassBoundedActor", dict(T=60), dict(sigma_target=5.0, sigma_cursor=1.0, action_cost=0.02, action_variability=0.5), 2),
+])
+def test_autograd_through_the_model_constructors_matches_finite_differences(ctor, kw, params, d):
+    """`jax.grad(lambda theta: Model(**theta).log_likelihood(x).sum())` of the reference, via torch.autograd."""
+    import lqg_amd
+    cls = getattr(lqg_amd, ctor)
+    make = lambda **p: cls(device="cuda", dtype=torch.float64, **kw, **p)
+    with torch.no_grad():
+        x = make(**params).simulate(3, n=5)[..., :d].contiguous()
+    theta = {k: torch.tensor(v, dtype=torch.float64, device="cuda", requires_grad=True) for k, v in params.items()}
+    model = make(**theta)
+    ll = model.log_likelihood(x)
+    with torch.no_grad():
+        assert torch.allclose(ll.detach(), make(**params).log_likelihood(x), rtol=1e-12)
+    ll.sum().backward()
+    fd = _fd(make, x, params)
+    for k in params:
+        an = float(theta[k].grad)
+        assert abs(an - fd[k]) < 1e-5 * max(1.0, abs(fd[k])), (k, an, fd[k])
+
+
+@gpu
+def test_candidate_axis_gradients_and_upstream_weights():
+    import lqg_amd
+    sig = torch.tensor([3.0, 6.0, 12.0], dtype=torch.float64, device="cuda", requires_grad=True)
+    cost = torch.tensor(0.1, dtype=torch.float64, device="cuda", requires_grad=True)
+    with torch.no_grad():
+        x = lqg_amd.BoundedActor(T=80, sigma_target=6.0, device="cuda", dtype=torch.float64).simulate(1, n=4)
+    w = torch.tensor([[1.0, 0.5, 2.0, 0.0], [0.3, 0.3, 0.3, 0.3], [1.0, -1.0, 1.0, -1.0]], dtype=torch.float64, device="cuda")
+    ll = lqg_amd.BoundedActor(T=80, sigma_target=sig, action_cost=cost, device="cuda", dtype=torch.float64).log_likelihood(x)
+    assert ll.shape == (3, 4)
+    (ll * w).sum().backward()
+    g_sig, g_cost = sig.grad.clone(), float(cost.grad)
+    tot_cost = 0.0
+    for c in range(3):
+        s1 = torch.tensor(float(sig[c].detach()), dtype=torch.float64, device="cuda", requires_grad=True)
+        c1 = torch.tensor(0.1, dtype=torch.float64, device="cuda", requires_grad=True)
+        l1 = lqg_amd.BoundedActor(T=80, sigma_target=s1, action_cost=c1, device="cuda", dtype=torch.float64).log_likelihood(x)
+        (l1 * w[c]).sum().backward()
+        assert abs(float(s1.grad) - float(g_sig[c])) < 1e-9 * max(1.0, abs(float(s1.grad)))
+        tot_cost += float(c1.grad)
+    assert abs(tot_cost - g_cost) < 1e-9 * max(1.0, abs(g_cost))             # a shared parameter sums over systems
+
+
+@gpu
+def test_sigma0_gradient_and_unsupported_inputs():
+    import lqg_amd
+    m = lqg_amd.SubjectiveActor(dim=1, T=40, device="cuda", dtype=torch.float64)
+    with torch.no_grad():
+        x = m.simulate(2, n=3)
+    S0 = torch.tensor([[2.0, 0.3, 0.1], [0.3, 1.5, 0.2], [0.1, 0.2, 1.0]], dtype=torch.float64, device="cuda", requires_grad=True)
+    m.log_likelihood(x, Sigma0=S0).sum().backward()
+    an = S0.grad.cpu().numpy()
+    h = 1e-6
+    for (i, j) in ((0, 0), (0, 1), (2, 1)):
+        E = torch.zeros(3, 3, dtype=torch.float64, device="cuda")
+        E[i, j] += 0.5
+        E[j, i] += 0.5
+        with torch.no_grad():
+            fd = float(m.log_likelihood(x, Sigma0=S0.detach() + h * E).sum() - m.log_likelihood(x, Sigma0=S0.detach() - h * E).sum()) / (2 * h)
+        assert abs(fd - 0.5 * (an[i, j] + an[j, i])) < 1e-6 * max(1.0, abs(fd))
+    # time-varying specs: refused, not silently wrong
+    A = m.actor.A.clone() * torch.linspace(1.0, 1.01, 40, dtype=torch.float64, device="cuda")[:, None, None]
+    A.requires_grad_(True)
+    tv = lqg_amd.System(actor=m.actor._replace(A=A), dynamics=m.dynamics)
+    with pytest.raises(NotImplementedError, match="time-invariant"):
+        tv.log_likelihood(x)
+
+
+@gpu
+def test_value_and_grad_adjoint_agrees_with_finite_difference_method():
+    import lqg_amd
+    from lqg_amd.infer import gradient
+    with torch.no_grad():
+        x = lqg_amd.BoundedActor(T=150, sigma_target=8.0, action_cost=0.2, device="cuda", dtype=torch.float64).simulate(4, n=10)
+    p = dict(sigma_target=6.0, sigma_cursor=2.0, action_cost=0.3, action_variability=0.4)
+    v1, g1 = gradient.value_and_grad(x, lqg_amd.BoundedActor, p, method="adjoint")
+    v2, g2 = gradient.value_and_grad(x, lqg_amd.BoundedActor, p, method="fd")
+    assert abs(v1 - v2) < 1e-9 * abs(v2)
+    for k in p:
+        assert abs(g1[k] - g2[k]) < 1e-5 * max(1.0, abs(g2[k])), k
