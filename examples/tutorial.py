@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The flow of the reference's notebooks/Tutorial.ipynb on MI355X with `lqg_amd` as the drop-in:
 build an LQG from matrices (cell 14) -> simulate trials -> likelihood sweep over sigma_target, the reference's
-`vmap(ll)(sigmas)` (cell 38) -> its gradient `grad(ll)(28.)` (cell 42, here by batched finite differences) ->
+`vmap(ll)(sigmas)` (cell 38) -> its gradient `grad(ll)(28.)` (cell 42: reverse-mode HIP sweep via torch.autograd) ->
 maximum likelihood (lqg/infer/mle.py) -> belief tracking (cell 52).    usage: python examples/tutorial.py"""
 import os
 import sys
@@ -41,7 +41,11 @@ print(f"sweep over 50 sigmas x 50 trials x T={T}: {1e3 * (time.perf_counter() - 
 
 # --- cell 42: d/d sigma at 28
 val, grad = value_and_grad(x, lqg.BoundedActor, dict(sigma_target=28.0), **fixed)
-print(f"ll(28) = {val:.4f}, d ll / d sigma = {grad['sigma_target']:.6f}")
+print(f"ll(28) = {val:.4f}, d ll / d sigma = {grad['sigma_target']:.6f}  (adjoint sweep)")
+sigma = torch.tensor(28.0, device=dev, dtype=dt_, requires_grad=True)              # the same thing, spelled like jax.grad
+lqg.BoundedActor(T=T, sigma_target=sigma, device=dev, dtype=dt_, **fixed).log_likelihood(x).sum().backward()
+_, grad_fd = value_and_grad(x, lqg.BoundedActor, dict(sigma_target=28.0), method="fd", **fixed)
+print(f"torch.autograd: {float(sigma.grad):.6f}; finite differences: {grad_fd['sigma_target']:.6f}")
 
 # --- lqg/infer/mle.py: Adam on the log-likelihood (two free parameters)
 t0 = time.perf_counter()

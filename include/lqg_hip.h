@@ -191,13 +191,16 @@ int lqg_gaussian_logprob(int32_t dtype, int32_t k, int32_t T, int64_t n_sys, int
  *   | actor A[b,b], B[b,u] (second part: ADD to the first; the Riccati sweep writes it separately)
  * With Sigma0.ptr NULL (default V V') the Sigma0 bar is already folded into the actor's VV bar.
  * g: upstream weights (NULL = all 1), element [s*g_sb + n*g_sn]; ll (optional): the value, as lqg_log_likelihood.
- * workspace: lqg_grad_workspace_bytes(p, ld) bytes (the kept forward state, [T][per-step reals][ld]). */
+ * workspace: lqg_grad_workspace_bytes(p, ld) bytes (the kept forward state, [T][per-step reals][ld]).
+ * phases: 1 = forward sweeps only (fill the workspace, write ll — what an autograd forward() runs), 2 = reverse sweeps
+ * only (consume the workspace a phase-1 call with the same problem, x and ld left, write grad — backward(), where g
+ * first becomes known), 3 = both in one call. */
 int lqg_grad_supported(int32_t dtype, const lqg_dims* dims);
 int64_t lqg_grad_elements(const lqg_dims* dims);
 size_t lqg_grad_workspace_bytes(const lqg_problem* p, int64_t ld);
 int lqg_log_likelihood_grad(const lqg_problem* p, lqg_traj x, const void* g, int64_t g_sb, int64_t g_sn, void* ll,
                             int64_t ll_sb, int64_t ll_sn, void* grad, int64_t ld, void* workspace,
-                            size_t workspace_bytes, void* stream);
+                            size_t workspace_bytes, int32_t phases, void* stream);
 
 #ifdef __cplusplus
 }

@@ -97,7 +97,7 @@ def _bind(path):
         lib.lqg_grad_workspace_bytes.restype = C.c_size_t
         lib.lqg_log_likelihood_grad.argtypes = [C.POINTER(Problem), Traj, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                                 C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t,
-                                                C.c_void_p]
+                                                C.c_int32, C.c_void_p]
         lib.lqg_log_likelihood_grad.restype = C.c_int
     declare(lib)
     return lib

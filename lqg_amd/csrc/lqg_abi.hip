@@ -61,9 +61,9 @@ LQG_SIM_DIMS(X)
 #endif
 #define X(X_, B_, U_, Y_, D_)                                                                                    \
   extern template hipError_t lqg::host::launch_adjoint<float, X_, B_, U_, Y_, D_>(                               \
-      const lqg_problem*, lqg_traj, const void*, long, long, void*, long, long, void*, long, void*, hipStream_t); \
+      const lqg_problem*, lqg_traj, const void*, long, long, void*, long, long, void*, long, void*, int, hipStream_t); \
   extern template hipError_t lqg::host::launch_adjoint<double, X_, B_, U_, Y_, D_>(                              \
-      const lqg_problem*, lqg_traj, const void*, long, long, void*, long, long, void*, long, void*, hipStream_t);
+      const lqg_problem*, lqg_traj, const void*, long, long, void*, long, long, void*, long, void*, int, hipStream_t);
 LQG_ADJOINT_DIMS(X)
 #undef X
 
@@ -424,8 +424,9 @@ size_t lqg_grad_workspace_bytes(const lqg_problem* p, int64_t ld) {
 
 int lqg_log_likelihood_grad(const lqg_problem* p, lqg_traj x, const void* g, int64_t g_sb, int64_t g_sn, void* ll,
                             int64_t ll_sb, int64_t ll_sn, void* grad, int64_t ld, void* workspace,
-                            size_t workspace_bytes, void* stream) {
+                            size_t workspace_bytes, int32_t phases, void* stream) {
   static const char* who = "lqg_log_likelihood_grad";
+  if (phases < 1 || phases > 3) return fail(LQG_ERR_ARG, "%s: phases must be 1 (forward), 2 (reverse) or 3 (both)", who);
   if (int rc = check_problem(p, who)) return rc;
   const lqg_spec& a = p->actor;
   const lqg_spec& dy = p->dynamics;
@@ -436,7 +437,7 @@ int lqg_log_likelihood_grad(const lqg_problem* p, lqg_traj x, const void* g, int
       need(dy.W, who, "dynamics.W"))
     return LQG_ERR_NULL;
   if (p->n_sys == 0 || p->n_trials == 0) return 0;
-  if (!x.ptr || !grad || !workspace) return fail(LQG_ERR_NULL, "%s: NULL x / grad / workspace", who);
+  if (!x.ptr || !workspace || ((phases & 2) && !grad)) return fail(LQG_ERR_NULL, "%s: NULL x / grad / workspace", who);
   if (!(actor_ti_riccati(p) && forward_ti(p)))
     return fail(LQG_ERR_ARG, "%s: time-varying specs are not supported by the adjoint sweep (every field's st must be 0)",
                 who);
@@ -450,9 +451,9 @@ int lqg_log_likelihood_grad(const lqg_problem* p, lqg_traj x, const void* g, int
   if (d.x == X_ && d.b == B_ && d.u == U_ && d.y == Y_ && d.d == D_)                                           \
     return done(p->dtype == LQG_F64                                                                             \
                     ? launch_adjoint<double, X_, B_, U_, Y_, D_>(p, x, g, g_sb, g_sn, ll, ll_sb, ll_sn, grad, ld, \
-                                                                 workspace, st)                                  \
+                                                                 workspace, phases, st)                                  \
                     : launch_adjoint<float, X_, B_, U_, Y_, D_>(p, x, g, g_sb, g_sn, ll, ll_sb, ll_sn, grad, ld,  \
-                                                                workspace, st),                                  \
+                                                                workspace, phases, st),                                  \
                 who);
   LQG_ADJOINT_DIMS(X)
 #undef X

@@ -6,11 +6,11 @@ namespace lqg {
 namespace host {
 #ifdef LQG_INST_F32
 template hipError_t launch_adjoint<float, LQG_INST_ADJOINT>(const lqg_problem*, lqg_traj, const void*, long, long,
-                                                            void*, long, long, void*, long, void*, hipStream_t);
+                                                            void*, long, long, void*, long, void*, int, hipStream_t);
 #endif
 #ifdef LQG_INST_F64
 template hipError_t launch_adjoint<double, LQG_INST_ADJOINT>(const lqg_problem*, lqg_traj, const void*, long, long,
-                                                             void*, long, long, void*, long, void*, hipStream_t);
+                                                             void*, long, long, void*, long, void*, int, hipStream_t);
 #endif
 }  // namespace host
 }  // namespace lqg

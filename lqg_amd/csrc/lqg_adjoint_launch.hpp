@@ -25,7 +25,7 @@ inline long adj_grad_elements(const lqg_dims& d) {
 
 template <typename R, int NX, int NB, int NU, int NY, int ND>
 hipError_t launch_adjoint(const lqg_problem* p, lqg_traj x, const void* g, long g_sb, long g_sn, void* ll, long ll_sb,
-                          long ll_sn, void* grad, long ld, void* ws, hipStream_t stream) {
+                          long ll_sn, void* grad, long ld, void* ws, int phases, hipStream_t stream) {
   using Lay = lqg::adj::Layout<NX, NB, NU, NY>;
   static_assert(Lay::STEP > 0 && Lay::TOTAL > 0, "layout");
   lqg::adj::AdjArgs<R> a;
@@ -47,10 +47,14 @@ hipError_t launch_adjoint(const lqg_problem* p, lqg_traj x, const void* g, long 
   a.nva = p->dims.nva; a.nwa = p->dims.nwa; a.nvd = p->dims.nvd; a.nwd = p->dims.nwd;
   a.eps = (R)p->eps;
   const unsigned nb = (unsigned)((a.n_lanes + LQG_BLOCK - 1) / LQG_BLOCK);
-  hipLaunchKernelGGL((lqg::adj::k_adj_riccati<R, NX, NB, NU, NY, ND>), dim3(nb), dim3(LQG_BLOCK), 0, stream, a);
-  hipLaunchKernelGGL((lqg::adj::k_adj_forward<R, NX, NB, NU, NY, ND>), dim3(nb), dim3(LQG_BLOCK), 0, stream, a);
-  hipLaunchKernelGGL((lqg::adj::k_adj_reverse<R, NX, NB, NU, NY, ND>), dim3(nb), dim3(LQG_BLOCK), 0, stream, a);
-  hipLaunchKernelGGL((lqg::adj::k_adj_riccati_rev<R, NX, NB, NU, NY, ND>), dim3(nb), dim3(LQG_BLOCK), 0, stream, a);
+  if (phases & 1) {   // forward sweeps: fill the workspace, write the value
+    hipLaunchKernelGGL((lqg::adj::k_adj_riccati<R, NX, NB, NU, NY, ND>), dim3(nb), dim3(LQG_BLOCK), 0, stream, a);
+    hipLaunchKernelGGL((lqg::adj::k_adj_forward<R, NX, NB, NU, NY, ND>), dim3(nb), dim3(LQG_BLOCK), 0, stream, a);
+  }
+  if (phases & 2) {   // reverse sweeps: consume the workspace, write the bars
+    hipLaunchKernelGGL((lqg::adj::k_adj_reverse<R, NX, NB, NU, NY, ND>), dim3(nb), dim3(LQG_BLOCK), 0, stream, a);
+    hipLaunchKernelGGL((lqg::adj::k_adj_riccati_rev<R, NX, NB, NU, NY, ND>), dim3(nb), dim3(LQG_BLOCK), 0, stream, a);
+  }
   return hipGetLastError();
 }
 

@@ -8,9 +8,9 @@ What the reference gets from jax.grad / jax.value_and_grad of `System.log_likeli
     ll = lqg_amd.BoundedActor(T=500, sigma_target=sigma).log_likelihood(x).sum()
     ll.backward()                      # sigma.grad == d ll / d sigma
 
-`System.log_likelihood` routes here whenever a spec tensor (or Sigma0) requires grad.  The forward value comes from
-the ordinary fused path; backward launches the four adjoint sweeps with the upstream weights and hands the bars of
-the spec matrices to autograd, which chains them through the (torch) model constructors to the parameters.  Systems
+`System.log_likelihood` routes here whenever a spec tensor (or Sigma0) requires grad.  forward() runs the first two
+sweeps (Riccati, forward: they keep the per-step state and return the value), backward() the two adjoint sweeps with
+the upstream weights, and hands the bars of the spec matrices to autograd, which chains them through the (torch) model constructors to the parameters.  Systems
 that decouple (every dim=2 model) are differentiated component by component — the gathers of lqg_amd/decouple.py are
 differentiable.  Time-invariant specs only; no CPU fallback.
 """
@@ -56,35 +56,59 @@ def _layout(dm):
     return out, off
 
 
+class Sweep:
+    """One adjoint evaluation in two phases sharing the kept forward state: `forward()` (Riccati + forward sweep, returns
+    the log-likelihood) and `reverse(g)` (the two adjoint sweeps with upstream weights g, returns the bars).  The
+    workspace lives as long as this object (an autograd node keeps it between forward and backward)."""
+
+    def __init__(self, actor, dynamics, x, Sigma0=None, eps=1e-8):
+        d = x.shape[-1]
+        ln = _hip.Launch(actor, dynamics, d=d, n_trials=x.shape[-3], Sigma0=Sigma0, eps=eps)
+        self.lib = ln.require_gpu()
+        if not self.lib.lqg_grad_supported(ln.p.dtype, C.byref(ln.p.dims)):
+            raise _abi.LqgHipError(f"no adjoint kernels for model shape {tuple(ln.dims[k] for k in 'xbuyd')}: add it to "
+                                   "LQG_ADJOINT_DIMS in lqg_amd/csrc/lqg_dims.def and rebuild (there is no CPU path)")
+        self.ln = ln
+        self.x, self.xb = _hip._prep_x(ln, x)
+        self.N = self.x.shape[-3]
+        self.lanes = ln.B * self.N
+        self.ld = (self.lanes + 63) // 64 * 64
+        self.lay, self.total = _layout(ln.dims)
+        assert self.total == self.lib.lqg_grad_elements(C.byref(ln.p.dims))
+        self.nbytes = int(self.lib.lqg_grad_workspace_bytes(C.byref(ln.p), self.ld))
+        self.ws = torch.empty(max(self.nbytes, 256), dtype=torch.uint8, device=ln.device)
+
+    def _call(self, phases, g, ll, out):
+        ln, N = self.ln, self.N
+        ptr = lambda t: C.c_void_p(t.data_ptr() if t is not None else None)
+        with torch.cuda.device(ln.device):
+            _abi.check(self.lib.lqg_log_likelihood_grad(
+                C.byref(ln.p), ln.traj(self.x, self.xb), ptr(g), N if ln.batched else 0, 1, ptr(ll),
+                N if ln.batched else 0, 1, ptr(out), self.ld, ptr(self.ws), self.nbytes, phases, ln.stream()),
+                "lqg_log_likelihood_grad")
+
+    def forward(self):
+        ll = self.ln.empty(self.N)
+        self._call(1, None, ll, None)
+        return ll
+
+    def reverse(self, g=None):
+        """-> {name: [B, N, r, c]} per-(system, trial) bars (lqg_hip.h: order of the gradient elements)."""
+        ln = self.ln
+        if g is not None:
+            g = g.to(dtype=ln.dtype, device=ln.device).expand(ln.lead() + (self.N,)).contiguous()
+        out = torch.empty(self.total, self.ld, dtype=ln.dtype, device=ln.device)
+        self._call(2, g, None, out)
+        return {k: out[o:o + r * c, :self.lanes].reshape(r, c, ln.B, self.N).permute(2, 3, 0, 1)
+                for k, (o, r, c) in self.lay.items()}
+
+
 def raw_grad(actor, dynamics, x, g=None, Sigma0=None, eps=1e-8, want_value=True):
-    """Launch the adjoint sweeps.  x[n,T+1,d] or [B,n,T+1,d]; g like the log-likelihood ([n] / [B,n]) or None.
-    Returns (ll or None, {name: [B, N, r, c] per-(system, trial) bars})."""
-    d = x.shape[-1]
-    ln = _hip.Launch(actor, dynamics, d=d, n_trials=x.shape[-3], Sigma0=Sigma0, eps=eps)
-    lib = ln.require_gpu()
-    if not lib.lqg_grad_supported(ln.p.dtype, C.byref(ln.p.dims)):
-        raise _abi.LqgHipError(f"no adjoint kernels for model shape {tuple(ln.dims[k] for k in 'xbuyd')}: add it to "
-                               "LQG_ADJOINT_DIMS in lqg_amd/csrc/lqg_dims.def and rebuild (there is no CPU path)")
-    xx, xb = _hip._prep_x(ln, x)
-    N = xx.shape[-3]
-    lanes = ln.B * N
-    ld = (lanes + 63) // 64 * 64
-    lay, total = _layout(ln.dims)
-    assert total == lib.lqg_grad_elements(C.byref(ln.p.dims))
-    out = torch.empty(total, ld, dtype=ln.dtype, device=ln.device)
-    nbytes = lib.lqg_grad_workspace_bytes(C.byref(ln.p), ld)
-    ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=ln.device)
-    ll = ln.empty(N) if want_value else None
-    if g is not None:
-        g = g.to(dtype=ln.dtype, device=ln.device).expand(ln.lead() + (N,)).contiguous()
-    with torch.cuda.device(ln.device):
-        _abi.check(lib.lqg_log_likelihood_grad(
-            C.byref(ln.p), ln.traj(xx, xb), C.c_void_p(g.data_ptr() if g is not None else None),
-            N if ln.batched else 0, 1, C.c_void_p(ll.data_ptr() if ll is not None else None), N if ln.batched else 0, 1,
-            C.c_void_p(out.data_ptr()), ld, C.c_void_p(ws.data_ptr()), int(nbytes), ln.stream()),
-            "lqg_log_likelihood_grad")
-    bars = {k: out[o:o + r * c, :lanes].reshape(r, c, ln.B, N).permute(2, 3, 0, 1) for k, (o, r, c) in lay.items()}
-    return ll, bars, ln
+    """Both phases at once.  x[n,T+1,d] or [B,n,T+1,d]; g like the log-likelihood ([n] / [B,n]) or None.
+    Returns (ll, {name: [B, N, r, c] per-(system, trial) bars}, launch)."""
+    sw = Sweep(actor, dynamics, x, Sigma0=Sigma0, eps=eps)
+    ll = sw.forward()
+    return ll, sw.reverse(g), sw.ln
 
 
 class _LogLikelihood(torch.autograd.Function):
@@ -92,12 +116,12 @@ class _LogLikelihood(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, system, x, Sigma0, *mats):
-        ctx.system, ctx.x, ctx.n_mats = system, x, len(mats)
+        ctx.system, ctx.n_mats = system, len(mats)
         ctx.save_for_backward(*(mats + ((Sigma0,) if Sigma0 is not None else ())))
         ctx.has_s0 = Sigma0 is not None
         with torch.no_grad():
-            from lqg_amd.plan import LogLikelihoodPlan
-            return LogLikelihoodPlan(system, x, Sigma0=Sigma0).run()
+            ctx.sweep = Sweep(system.actor, system.dynamics, x, Sigma0=Sigma0)
+            return ctx.sweep.forward()
 
     @staticmethod
     def backward(ctx, g):
@@ -106,7 +130,8 @@ class _LogLikelihood(torch.autograd.Function):
         S0 = saved[ctx.n_mats] if ctx.has_s0 else None
         sys_ = ctx.system
         with torch.no_grad():
-            _, bars, ln = raw_grad(sys_.actor, sys_.dynamics, ctx.x, g=g, Sigma0=S0, want_value=False)
+            bars = ctx.sweep.reverse(g)
+            ctx.sweep = None                                                 # release the kept forward state
             tot = {k: v.sum(1) for k, v in bars.items()}                    # over trials -> [B, r, c]
             sym2 = lambda M: M + M.transpose(-1, -2)
             first = lambda t: t.select(-3, 0)

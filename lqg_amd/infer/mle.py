@@ -1,10 +1,13 @@
 """Maximum likelihood — the role of lqg/infer/mle.py:14-25 (NumPyro SVI with an empty guide = Adam on the
 log-likelihood of positive-constrained parameters).
 
-The reference differentiates the likelihood with JAX reverse mode.  This round has no adjoint sweep (SURVEY.md §8f
-rank 1), so the gradient is taken by CENTRAL FINITE DIFFERENCES in the unconstrained (log) space and evaluated as ONE
-batched candidate sweep of 2P+1 systems through the fused HIP path — derivative-free use of the same kernels.
-fp64 is used throughout (a finite difference of an fp32 likelihood is noise).  `candidate_search` is the
+The reference differentiates the likelihood with JAX reverse mode.  Two gradient methods are provided:
+method="fd" (default): CENTRAL FINITE DIFFERENCES in the unconstrained (log) space evaluated as ONE batched candidate
+sweep of 2P+1 systems through the fused HIP path — for ONE parameter vector this is the faster of the two on MI355X
+(all 2P+1 candidates x trials run in parallel: 1.6 ms per evaluation at T=500, 50 trials, P=4);
+method="adjoint": the reverse-mode HIP sweep behind torch.autograd (lqg_amd/grad.py; 2.8 ms per evaluation on the same
+workload — one lane walks one trial's 500 steps four times — but exact, and P-independent / 3x cheaper per gradient when
+many parameter vectors are differentiated at once).  fp64 is used throughout.  `candidate_search` is the
 derivative-free population evaluation of BASELINE config 3 (thousands of candidates x shared trials).
 """
 import torch
@@ -21,7 +24,7 @@ def candidate_search(x, model=BoundedActor, candidates=None, process_noise=1.0, 
 
 
 def max_likelihood(x, model=BoundedActor, process_noise=1.0, dt=1.0 / 60, steps=2_000, step_size=0.01, fd_step=1e-4,
-                   group=None, **fixed):
+                   group=None, method="fd", **fixed):
     """Adam on the negative log-likelihood of the positive parameters of `model` (defaults as in the reference:
     2000 steps, step size 0.01, initial values = constructor defaults).  Returns (params, losses) like
     `svi.run` in lqg/infer/mle.py:23-25: params = dict name -> fitted value, losses[steps] = -log p(x | params)."""
@@ -33,13 +36,22 @@ def max_likelihood(x, model=BoundedActor, process_noise=1.0, dt=1.0 / 60, steps=
     b1, b2, eps = 0.9, 0.999, 1e-8
     eye = torch.eye(P, dtype=torch.float64, device=x.device)
     losses = torch.empty(steps, dtype=torch.float64)
+    if method not in ("fd", "adjoint"):
+        raise ValueError(f"method must be 'fd' or 'adjoint', got {method!r}")
     for it in range(steps):
-        # one sweep over 2P+1 candidates: z, z + h e_i, z - h e_i
-        Z = torch.cat([z[None], z[None] + fd_step * eye, z[None] - fd_step * eye])
-        cand = {k: torch.exp(Z[:, i]) for i, k in enumerate(names)}
-        obj = log_likelihood_objective(x, model, cand, process_noise=process_noise, dt=dt, group=group, **fixed)
-        loss = -obj[0]
-        grad = -(obj[1:P + 1] - obj[P + 1:]) / (2 * fd_step)
+        if method == "adjoint":
+            from lqg_amd.infer.gradient import value_and_grad
+            theta = {k: float(torch.exp(z[i])) for i, k in enumerate(names)}
+            val, g = value_and_grad(x, model, theta, process_noise=process_noise, dt=dt, group=group, **fixed)
+            loss = torch.tensor(-val, dtype=torch.float64, device=x.device)
+            grad = -torch.tensor([g[k] * theta[k] for k in names], dtype=torch.float64, device=x.device)   # d/d log
+        else:
+            # one sweep over 2P+1 candidates: z, z + h e_i, z - h e_i
+            Z = torch.cat([z[None], z[None] + fd_step * eye, z[None] - fd_step * eye])
+            cand = {k: torch.exp(Z[:, i]) for i, k in enumerate(names)}
+            obj = log_likelihood_objective(x, model, cand, process_noise=process_noise, dt=dt, group=group, **fixed)
+            loss = -obj[0]
+            grad = -(obj[1:P + 1] - obj[P + 1:]) / (2 * fd_step)
         losses[it] = loss
         m1 = b1 * m1 + (1 - b1) * grad
         m2 = b2 * m2 + (1 - b2) * grad * grad

@@ -211,3 +211,18 @@ def test_value_and_grad_adjoint_agrees_with_finite_difference_method():
     assert abs(v1 - v2) < 1e-9 * abs(v2)
     for k in p:
         assert abs(g1[k] - g2[k]) < 1e-5 * max(1.0, abs(g2[k])), k
+
+
+@gpu
+def test_max_likelihood_with_adjoint_gradients_follows_the_finite_difference_path():
+    import lqg_amd
+    from lqg_amd.infer import max_likelihood
+    with torch.no_grad():
+        x = lqg_amd.BoundedActor(T=100, sigma_target=12.0, action_variability=0.4, action_cost=0.1, sigma_cursor=2.0,
+                                 device="cuda", dtype=torch.float64).simulate(11, n=12)
+    kw = dict(steps=25, step_size=0.05, action_cost=0.1, sigma_cursor=2.0)
+    p1, l1 = max_likelihood(x, lqg_amd.BoundedActor, method="adjoint", **kw)
+    p2, l2 = max_likelihood(x, lqg_amd.BoundedActor, method="fd", **kw)
+    assert torch.allclose(l1, l2, rtol=1e-6) and float(l1[-1]) < float(l1[0])
+    for k in p1:
+        assert abs(p1[k] - p2[k]) < 1e-4 * abs(p2[k])
