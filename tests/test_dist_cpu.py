@@ -59,6 +59,19 @@ def _worker(rank, world, port, out_dir):
     loc = OC.log_likelihood(a_loc, d_loc, np.broadcast_to(x, (hi - lo,) + x.shape)).sum(-1) if hi > lo else np.zeros(0)
     allv = ld.gather_candidates(torch.from_numpy(np.ascontiguousarray(loc)), 3)
     assert np.allclose(allv.numpy(), full, rtol=1e-12)
+    # objective + gradient with the trials sharded (lqg_amd.infer.value_and_grad, method="adjoint"): every rank
+    # differentiates its shard (here with the NumPy restatement of the adjoint sweep), ONE all-reduce of [1 + P] numbers
+    import lqg_adjoint_np as ADJ
+    xm = mine.numpy()
+    if xm.shape[0]:
+        ll_loc, ga, gd, _ = ADJ.loglik_grad(actor, dyn, xm)
+        vec = torch.tensor([ll_loc.sum(), ga["W"].sum(0)[0, 0], gd["V"].sum(0)[1, 1]], dtype=torch.float64)
+    else:
+        vec = torch.zeros(3, dtype=torch.float64)
+    vec = ld.all_reduce_sum(vec)
+    ll_all, ga, gd, _ = ADJ.loglik_grad(actor, dyn, x)
+    ref = np.array([ll_all.sum(), ga["W"].sum(0)[0, 0], gd["V"].sum(0)[1, 1]])
+    assert np.allclose(vec.numpy(), ref, rtol=1e-10), (vec, ref)
     np.save(os.path.join(out_dir, f"r{rank}.npy"), total.numpy())
     dist.destroy_process_group()
 
