@@ -110,6 +110,7 @@ class Launch:
 
 def riccati_backward(spec: LQGSpec, eps=1e-8):
     ln = Launch(spec, eps=eps)
+    ln.dims["d"] = ln.p.dims.d = _abi.observed_dims_with_kernels(ln.dims)     # k_riccati does not depend on d
     lib = ln.require_gpu()
     dm = ln.dims
     L, l, H = ln.empty(ln.T, dm["u"], dm["b"]), ln.empty(ln.T, dm["u"]), ln.empty(ln.T, dm["u"], dm["u"])
@@ -121,6 +122,7 @@ def riccati_backward(spec: LQGSpec, eps=1e-8):
 
 def kalman_forward(spec: LQGSpec, Sigma0=None):
     ln = Launch(spec, Sigma0=Sigma0)
+    ln.dims["d"] = ln.p.dims.d = _abi.observed_dims_with_kernels(ln.dims)     # k_kalman does not depend on d
     lib = ln.require_gpu()
     K = ln.empty(ln.T, ln.dims["b"], ln.dims["y"])
     with torch.cuda.device(ln.device):

@@ -133,11 +133,21 @@ template <typename R, int M, int ND>
 hipError_t launch_trial(const lqg_problem* p, const void* ops, lqg_traj x, lqg_traj mu, void* ll, long ll_sb,
                         long ll_sn, hipStream_t st) {
   lqg::TrialArgs<R> k{dt<R>(x), dt<R>(mu), static_cast<R*>(ll), ll_sb, ll_sn, (long)p->n_trials, p->T};
-  constexpr int TPL = LQG_TRIALS_PER_LANE;
-  const long per_block = (long)LQG_BLOCK * TPL;
+  // Trials per lane: 4 amortises the per-step operator (scalar) loads when there are trials to spare; with fewer than
+  // ~2 waves per SIMD at that packing (one system with 10^4..10^5 trials: BASELINE configs 2 and 4) the sweep is
+  // latency-bound and one trial per lane puts 4x the waves in flight.
+  const long lanes4 = (long)p->n_sys * ((p->n_trials + 4 * LQG_BLOCK - 1) / (4 * LQG_BLOCK)) * LQG_BLOCK;
+  const bool wide = lanes4 >= 2L * 1024 * 64;
+  const long per_block = (long)LQG_BLOCK * (wide ? LQG_TRIALS_PER_LANE : 1);
   const dim3 grid((unsigned)((p->n_trials + per_block - 1) / per_block), (unsigned)p->n_sys), block(LQG_BLOCK);
-  if (mu.ptr) hipLaunchKernelGGL((lqg::k_trial<R, M, ND, TPL, true>), grid, block, 0, st, static_cast<const R*>(ops), k);
-  else hipLaunchKernelGGL((lqg::k_trial<R, M, ND, TPL, false>), grid, block, 0, st, static_cast<const R*>(ops), k);
+  const R* o = static_cast<const R*>(ops);
+  if (wide) {
+    if (mu.ptr) hipLaunchKernelGGL((lqg::k_trial<R, M, ND, LQG_TRIALS_PER_LANE, true>), grid, block, 0, st, o, k);
+    else hipLaunchKernelGGL((lqg::k_trial<R, M, ND, LQG_TRIALS_PER_LANE, false>), grid, block, 0, st, o, k);
+  } else {
+    if (mu.ptr) hipLaunchKernelGGL((lqg::k_trial<R, M, ND, 1, true>), grid, block, 0, st, o, k);
+    else hipLaunchKernelGGL((lqg::k_trial<R, M, ND, 1, false>), grid, block, 0, st, o, k);
+  }
   return hipGetLastError();
 }
 
