@@ -183,7 +183,7 @@ def loglik_grad(actor, dyn, x, g=None, Sigma0=None, eps=1e-8):
         tot = bar if tot is None else {k: tot[k] + bar[k] for k in bar}
         Qfb, S0b = Qfb + qf, S0b + s0
     ga = {"A": tot["aA"], "B": tot["aB"], "F": tot["aF"], "Q": tot["aQ"], "R": tot["aR"], "Qf": Qfb,
-          "V": 2.0 * np.einsum("tij,tjk->tik", tot["aVV"] + np.swapaxes(tot["aVV"], 1, 2), actor["V"]) * 0.5,
+          "V": np.einsum("tij,tjk->tik", tot["aVV"] + np.swapaxes(tot["aVV"], 1, 2), actor["V"]),
           "W": np.einsum("tij,tjk->tik", tot["aWW"] + np.swapaxes(tot["aWW"], 1, 2), actor["W"])}
     gd = {"A": tot["dA"], "B": tot["dB"], "F": tot["dF"],
           "V": np.einsum("tij,tjk->tik", tot["dVV"] + np.swapaxes(tot["dVV"], 1, 2), dyn["V"]),
