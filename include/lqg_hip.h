@@ -179,14 +179,16 @@ int lqg_gaussian_logprob(int32_t dtype, int32_t k, int32_t T, int64_t n_sys, int
  * Replaces jax.grad / jax.value_and_grad of System.log_likelihood, which every inference driver of the reference takes
  * through all three scans [lqg/optim.py:142-147 `jit(grad(fun))`, lqg/infer/utils.py:18,37-39, lqg/infer/mle.py:17-23,
  * notebooks/Tutorial.ipynb cell 40 `grad(ll)`]:  for the objective  J = sum_{s,n} g[s,n] * ll[s,n]  it returns
- * dJ/d(spec matrix) PER (system, trial) pair — the caller sums over the trial axis — for TIME-INVARIANT specs (every
- * field's st == 0; the whole model zoo).  Gradients are taken w.r.t. the dynamics' A, B, F, VV = V V', WW = W W' and the
+ * dJ/d(spec matrix) PER (system, trial) pair — the caller sums over the trial axis.  With TIME-INVARIANT specs (every
+ * field's st == 0; the whole model zoo) there is ONE accumulated bar per matrix; if any field varies over time the bars
+ * are per step (lqg_grad_slabs(p) == T slabs instead of 1).  Gradients are taken w.r.t. the dynamics' A, B, F, VV = V V', WW = W W' and the
  * actor's A, B, F, VV, WW, Q, R, Qf (+ Sigma0 when given); chain VVbar to V as (VVbar + VVbar') V.  q, r, qf, P get none
  * (the likelihood ignores the affine gain).  Bars of symmetric quantities (VV, WW, Q, Qf, Sigma0) are symmetrised;
  * the eigenvalue-floor shift of lqr.py:27-28 is held constant (it is 0 whenever R + B'SB > eps).
  *
- * grad: [lqg_grad_elements(dims)][ld] reals of the problem dtype, ld >= n_sys * n_trials (lane = s * n_trials + n),
- * consecutive row-major matrices in this order:
+ * grad: [lqg_grad_slabs(p)][lqg_grad_elements(dims)][ld] reals of the problem dtype, ld >= n_sys * n_trials
+ * (lane = s * n_trials + n); slab t holds the bars of the step-t matrices (slab 0 also Qf and Sigma0, which have no time
+ * axis); within a slab, consecutive row-major matrices in this order:
  *   dyn A[x,x] B[x,u] F[y,x] VV[x,x] WW[y,y] | actor A[b,b] B[b,u] F[y,b] VV[b,b] WW[y,y] Q[b,b] R[u,u] Qf[b,b] Sigma0[b,b]
  *   | actor A[b,b], B[b,u] (second part: ADD to the first; the Riccati sweep writes it separately)
  * With Sigma0.ptr NULL (default V V') the Sigma0 bar is already folded into the actor's VV bar.
@@ -197,6 +199,7 @@ int lqg_gaussian_logprob(int32_t dtype, int32_t k, int32_t T, int64_t n_sys, int
  * first becomes known), 3 = both in one call. */
 int lqg_grad_supported(int32_t dtype, const lqg_dims* dims);
 int64_t lqg_grad_elements(const lqg_dims* dims);
+int32_t lqg_grad_slabs(const lqg_problem* p);
 size_t lqg_grad_workspace_bytes(const lqg_problem* p, int64_t ld);
 int lqg_log_likelihood_grad(const lqg_problem* p, lqg_traj x, const void* g, int64_t g_sb, int64_t g_sn, void* ll,
                             int64_t ll_sb, int64_t ll_sn, void* grad, int64_t ld, void* workspace,

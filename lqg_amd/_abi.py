@@ -93,6 +93,7 @@ def _bind(path):
     if hasattr(lib, "lqg_log_likelihood_grad"):
         lib.lqg_grad_supported.argtypes, lib.lqg_grad_supported.restype = [C.c_int32, C.POINTER(Dims)], C.c_int
         lib.lqg_grad_elements.argtypes, lib.lqg_grad_elements.restype = [C.POINTER(Dims)], C.c_int64
+        lib.lqg_grad_slabs.argtypes, lib.lqg_grad_slabs.restype = [C.POINTER(Problem)], C.c_int32
         lib.lqg_grad_workspace_bytes.argtypes = [C.POINTER(Problem), C.c_int64]
         lib.lqg_grad_workspace_bytes.restype = C.c_size_t
         lib.lqg_log_likelihood_grad.argtypes = [C.POINTER(Problem), Traj, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,

@@ -416,6 +416,8 @@ int lqg_grad_supported(int32_t dtype, const lqg_dims* dims) {
 
 int64_t lqg_grad_elements(const lqg_dims* dims) { return dims ? (int64_t)adj_grad_elements(*dims) : 0; }
 
+int32_t lqg_grad_slabs(const lqg_problem* p) { return !p ? 0 : (adj_time_invariant(p) ? 1 : p->T); }
+
 size_t lqg_grad_workspace_bytes(const lqg_problem* p, int64_t ld) {
   if (!p || p->T <= 0 || ld <= 0) return 0;
   const size_t e = p->dtype == LQG_F64 ? 8 : 4;
@@ -438,9 +440,6 @@ int lqg_log_likelihood_grad(const lqg_problem* p, lqg_traj x, const void* g, int
     return LQG_ERR_NULL;
   if (p->n_sys == 0 || p->n_trials == 0) return 0;
   if (!x.ptr || !workspace || ((phases & 2) && !grad)) return fail(LQG_ERR_NULL, "%s: NULL x / grad / workspace", who);
-  if (!(actor_ti_riccati(p) && forward_ti(p)))
-    return fail(LQG_ERR_ARG, "%s: time-varying specs are not supported by the adjoint sweep (every field's st must be 0)",
-                who);
   if (ld < p->n_sys * p->n_trials) return fail(LQG_ERR_ARG, "%s: ld %lld < n_sys * n_trials", who, (long long)ld);
   if (workspace_bytes < lqg_grad_workspace_bytes(p, ld))
     return fail(LQG_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", who, workspace_bytes, lqg_grad_workspace_bytes(p, ld));

@@ -15,8 +15,9 @@
 // Noise enters through the Gram matrices VV = V V', WW = W W' (the host chains VVbar, WWbar to V, W).  Adjoints of
 // the symmetric carries (Sigma, P, S) are symmetrised every step: the antisymmetric part is invisible to symmetric
 // perturbations but grows geometrically and destroys the result by cancellation otherwise.  The eigenvalue-floor
-// shift (lqr.py:27-28) is held constant.  Time-invariant specs only.  q, r, qf, P get no gradient (the likelihood
-// ignores the affine gain l).
+// shift (lqr.py:27-28) is held constant.  q, r, qf, P get no gradient (the likelihood ignores the affine gain l).
+// TI = true: time-invariant specs, loaded once, ONE accumulated bar per matrix (slab 0 of the output).  TI = false: specs
+// loaded every step, one bar per matrix PER STEP (slab t); Qf and Sigma0 bars always go to slab 0.
 #pragma once
 #include "lqg_small.hpp"
 
@@ -160,17 +161,17 @@ template <typename R, int NX, int NB, int NU, int NY>
 struct Spec {
   R Ad[NX * NX], Bd[NX * NU], Fd[NY * NX], VVd[NX * NX], WWd[NY * NY];
   R Aa[NB * NB], Ba[NB * NU], Fa[NY * NB], VVa[NB * NB], WWa[NY * NY];
-  LQG_DEV void load(const AdjArgs<R>& a, long s) {
-    load_mat<R, NX, NX>(a.dA.p + s * a.dA.sb, a.dA.sr, a.dA.sc, Ad);
-    load_mat<R, NX, NU>(a.dB.p + s * a.dB.sb, a.dB.sr, a.dB.sc, Bd);
-    load_mat<R, NY, NX>(a.dF.p + s * a.dF.sb, a.dF.sr, a.dF.sc, Fd);
-    load_gram<R, NX>(a.dV.p + s * a.dV.sb, a.dV.sr, a.dV.sc, a.nvd, VVd);
-    load_gram<R, NY>(a.dW.p + s * a.dW.sb, a.dW.sr, a.dW.sc, a.nwd, WWd);
-    load_mat<R, NB, NB>(a.A.p + s * a.A.sb, a.A.sr, a.A.sc, Aa);
-    load_mat<R, NB, NU>(a.B.p + s * a.B.sb, a.B.sr, a.B.sc, Ba);
-    load_mat<R, NY, NB>(a.F.p + s * a.F.sb, a.F.sr, a.F.sc, Fa);
-    load_gram<R, NB>(a.V.p + s * a.V.sb, a.V.sr, a.V.sc, a.nva, VVa);
-    load_gram<R, NY>(a.W.p + s * a.W.sb, a.W.sr, a.W.sc, a.nwa, WWa);
+  LQG_DEV void load(const AdjArgs<R>& a, long s, long t = 0) {
+    load_mat<R, NX, NX>(a.dA.p + s * a.dA.sb + t * a.dA.st, a.dA.sr, a.dA.sc, Ad);
+    load_mat<R, NX, NU>(a.dB.p + s * a.dB.sb + t * a.dB.st, a.dB.sr, a.dB.sc, Bd);
+    load_mat<R, NY, NX>(a.dF.p + s * a.dF.sb + t * a.dF.st, a.dF.sr, a.dF.sc, Fd);
+    load_gram<R, NX>(a.dV.p + s * a.dV.sb + t * a.dV.st, a.dV.sr, a.dV.sc, a.nvd, VVd);
+    load_gram<R, NY>(a.dW.p + s * a.dW.sb + t * a.dW.st, a.dW.sr, a.dW.sc, a.nwd, WWd);
+    load_mat<R, NB, NB>(a.A.p + s * a.A.sb + t * a.A.st, a.A.sr, a.A.sc, Aa);
+    load_mat<R, NB, NU>(a.B.p + s * a.B.sb + t * a.B.st, a.B.sr, a.B.sc, Ba);
+    load_mat<R, NY, NB>(a.F.p + s * a.F.sb + t * a.F.st, a.F.sr, a.F.sc, Fa);
+    load_gram<R, NB>(a.V.p + s * a.V.sb + t * a.V.st, a.V.sr, a.V.sc, a.nva, VVa);
+    load_gram<R, NY>(a.W.p + s * a.W.sb + t * a.W.st, a.W.sr, a.W.sc, a.nwa, WWa);
   }
 };
 
@@ -211,22 +212,26 @@ struct RicStep {
   }
 };
 
-template <typename R, int NX, int NB, int NU, int NY, int ND>
+template <typename R, int NX, int NB, int NU, int NY, int ND, bool TI>
 __global__ void __launch_bounds__(LQG_BLOCK, 1) k_adj_riccati(const AdjArgs<R> a) {
   using Lay = Layout<NX, NB, NU, NY>;
   const long i = blockIdx.x * (long)LQG_BLOCK + threadIdx.x;
   if (i >= a.n_lanes) return;
   const long s = i / a.n_trials;
   R A[NB * NB], B[NB * NU], Q[NB * NB], Rm[NU * NU], P[NU * NB], S[NB * NB];
-  load_mat<R, NB, NB>(a.A.p + s * a.A.sb, a.A.sr, a.A.sc, A);
-  load_mat<R, NB, NU>(a.B.p + s * a.B.sb, a.B.sr, a.B.sc, B);
-  load_sym<R, NB>(a.Q.p + s * a.Q.sb, a.Q.sr, a.Q.sc, Q);
-  load_sym<R, NU>(a.Rm.p + s * a.Rm.sb, a.Rm.sr, a.Rm.sc, Rm);
-  zero<R, NU * NB>(P);
-  if (a.P.p) load_mat<R, NU, NB>(a.P.p + s * a.P.sb, a.P.sr, a.P.sc, P);
+  auto load_step = [&](long t) {
+    load_mat<R, NB, NB>(a.A.p + s * a.A.sb + t * a.A.st, a.A.sr, a.A.sc, A);
+    load_mat<R, NB, NU>(a.B.p + s * a.B.sb + t * a.B.st, a.B.sr, a.B.sc, B);
+    load_sym<R, NB>(a.Q.p + s * a.Q.sb + t * a.Q.st, a.Q.sr, a.Q.sc, Q);
+    load_sym<R, NU>(a.Rm.p + s * a.Rm.sb + t * a.Rm.st, a.Rm.sr, a.Rm.sc, Rm);
+    zero<R, NU * NB>(P);
+    if (a.P.p) load_mat<R, NU, NB>(a.P.p + s * a.P.sb + t * a.P.st, a.P.sr, a.P.sc, P);
+  };
+  if (TI) load_step(0);
   load_sym<R, NB>(a.Qf.p + s * a.Qf.sb, a.Qf.sr, a.Qf.sc, S);
   RicStep<R, NB, NU> st;
   for (int t = a.T - 1; t >= 0; --t) {
+    if (!TI) load_step(t);
     R* w = a.ws + ((long)t * Lay::STEP) * a.ld + i;
     store_tri<R, NB>(w + Lay::S_OFF * a.ld, a.ld, S);
     st.compute(S, A, B, Rm, P, a.eps);
@@ -352,7 +357,7 @@ struct FwdStep {
   }
 };
 
-template <typename R, int NX, int NB, int NU, int NY, int ND>
+template <typename R, int NX, int NB, int NU, int NY, int ND, bool TI>
 __global__ void __launch_bounds__(LQG_BLOCK, 1) k_adj_forward(const AdjArgs<R> a) {
   using Lay = Layout<NX, NB, NU, NY>;
   constexpr int M = NX + NB;
@@ -371,6 +376,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, 1) k_adj_forward(const AdjArgs<R> a
   double ll = 0.0;
   FwdStep<R, NX, NB, NU, NY, ND> f;
   for (int t = 0; t < a.T; ++t) {
+    if (!TI && t > 0) sp.load(a, s, t);
     R* w = a.ws + ((long)t * Lay::STEP) * a.ld + i;
     load_flat<R, NU * NB>(w + Lay::L_OFF * a.ld, a.ld, L);
     f.system(sp, P, L);
@@ -395,7 +401,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, 1) k_adj_forward(const AdjArgs<R> a
   if (a.ll) a.ll[s * a.ll_sb + n * a.ll_sn] = (R)ll;
 }
 
-template <typename R, int NX, int NB, int NU, int NY, int ND>
+template <typename R, int NX, int NB, int NU, int NY, int ND, bool TI>
 __global__ void __launch_bounds__(LQG_BLOCK, 1) k_adj_reverse(const AdjArgs<R> a) {
   using Lay = Layout<NX, NB, NU, NY>;
   constexpr int M = NX + NB;
@@ -414,7 +420,25 @@ __global__ void __launch_bounds__(LQG_BLOCK, 1) k_adj_reverse(const AdjArgs<R> a
   R mub[M], Sigb[M * M], Pb[NB * NB];
   zero<R, M>(mub); zero<R, M * M>(Sigb); zero<R, NB * NB>(Pb);
   FwdStep<R, NX, NB, NU, NY, ND> f;
+  auto store_bars = [&](long slab) {
+    R* o = a.out + slab * (long)Lay::TOTAL * a.ld + i;
+    store_flat<R, NX * NX>(o + Lay::DA * a.ld, a.ld, bdA);
+    store_flat<R, NX * NU>(o + Lay::DB * a.ld, a.ld, bdB);
+    store_flat<R, NY * NX>(o + Lay::DF * a.ld, a.ld, bdF);
+    store_flat<R, NX * NX>(o + Lay::DVV * a.ld, a.ld, bdVV);
+    store_flat<R, NY * NY>(o + Lay::DWW * a.ld, a.ld, bdWW);
+    store_flat<R, NB * NB>(o + Lay::AA * a.ld, a.ld, baA);
+    store_flat<R, NB * NU>(o + Lay::AB * a.ld, a.ld, baB);
+    store_flat<R, NY * NB>(o + Lay::AF * a.ld, a.ld, baF);
+    store_flat<R, NB * NB>(o + Lay::AVV * a.ld, a.ld, baVV);
+    store_flat<R, NY * NY>(o + Lay::AWW * a.ld, a.ld, baWW);
+  };
   for (int t = a.T - 1; t >= 0; --t) {
+    if (!TI) {
+      sp.load(a, s, t);
+      zero<R, NX * NX>(bdA); zero<R, NX * NU>(bdB); zero<R, NY * NX>(bdF); zero<R, NX * NX>(bdVV); zero<R, NY * NY>(bdWW);
+      zero<R, NB * NB>(baA); zero<R, NB * NU>(baB); zero<R, NY * NB>(baF); zero<R, NB * NB>(baVV); zero<R, NY * NY>(baWW);
+    }
     R* w = a.ws + ((long)t * Lay::STEP) * a.ld + i;
     R P0[NB * NB], Sig[M * M], mu[M], L[NU * NB], xt[ND], x1[ND];
     load_flat<R, NU * NB>(w + Lay::L_OFF * a.ld, a.ld, L);
@@ -583,40 +607,45 @@ __global__ void __launch_bounds__(LQG_BLOCK, 1) k_adj_reverse(const AdjArgs<R> a
       mtm_acc<R, NB, NB, NB>(sp.Aa, PA, Pb);
       symmetrise<R, NB>(Pb);
     }
+    if (t == 0 && !a.Sigma0.p) {                                       // default Sigma0 = V_0 V_0'  system.py:160
+      LQG_UNROLL for (int k = 0; k < NB * NB; ++k) baVV[k] += Pb[k];
+    }
+    if (!TI) store_bars(t);
   }
-  R* o = a.out + i;
-  store_flat<R, NX * NX>(o + Lay::DA * a.ld, a.ld, bdA);
-  store_flat<R, NX * NU>(o + Lay::DB * a.ld, a.ld, bdB);
-  store_flat<R, NY * NX>(o + Lay::DF * a.ld, a.ld, bdF);
-  store_flat<R, NX * NX>(o + Lay::DVV * a.ld, a.ld, bdVV);
-  store_flat<R, NY * NY>(o + Lay::DWW * a.ld, a.ld, bdWW);
-  store_flat<R, NB * NB>(o + Lay::AA * a.ld, a.ld, baA);
-  store_flat<R, NB * NU>(o + Lay::AB * a.ld, a.ld, baB);
-  store_flat<R, NY * NB>(o + Lay::AF * a.ld, a.ld, baF);
-  if (!a.Sigma0.p) {                                                   // default Sigma0 = V V'  system.py:160
-    LQG_UNROLL for (int k = 0; k < NB * NB; ++k) baVV[k] += Pb[k];
-  }
-  store_flat<R, NB * NB>(o + Lay::AVV * a.ld, a.ld, baVV);
-  store_flat<R, NY * NY>(o + Lay::AWW * a.ld, a.ld, baWW);
-  store_flat<R, NB * NB>(o + Lay::AS0 * a.ld, a.ld, Pb);
+  if (TI) store_bars(0);
+  store_flat<R, NB * NB>(a.out + i + Lay::AS0 * a.ld, a.ld, Pb);
 }
 
-template <typename R, int NX, int NB, int NU, int NY, int ND>
+template <typename R, int NX, int NB, int NU, int NY, int ND, bool TI>
 __global__ void __launch_bounds__(LQG_BLOCK, 1) k_adj_riccati_rev(const AdjArgs<R> a) {
   using Lay = Layout<NX, NB, NU, NY>;
   const long i = blockIdx.x * (long)LQG_BLOCK + threadIdx.x;
   if (i >= a.n_lanes) return;
   const long s = i / a.n_trials;
   R A[NB * NB], B[NB * NU], Rm[NU * NU], P[NU * NB];
-  load_mat<R, NB, NB>(a.A.p + s * a.A.sb, a.A.sr, a.A.sc, A);
-  load_mat<R, NB, NU>(a.B.p + s * a.B.sb, a.B.sr, a.B.sc, B);
-  load_sym<R, NU>(a.Rm.p + s * a.Rm.sb, a.Rm.sr, a.Rm.sc, Rm);
-  zero<R, NU * NB>(P);
-  if (a.P.p) load_mat<R, NU, NB>(a.P.p + s * a.P.sb, a.P.sr, a.P.sc, P);
+  auto load_step = [&](long t) {
+    load_mat<R, NB, NB>(a.A.p + s * a.A.sb + t * a.A.st, a.A.sr, a.A.sc, A);
+    load_mat<R, NB, NU>(a.B.p + s * a.B.sb + t * a.B.st, a.B.sr, a.B.sc, B);
+    load_sym<R, NU>(a.Rm.p + s * a.Rm.sb + t * a.Rm.st, a.Rm.sr, a.Rm.sc, Rm);
+    zero<R, NU * NB>(P);
+    if (a.P.p) load_mat<R, NU, NB>(a.P.p + s * a.P.sb + t * a.P.st, a.P.sr, a.P.sc, P);
+  };
+  if (TI) load_step(0);
   R bA[NB * NB], bB[NB * NU], bQ[NB * NB], bR[NU * NU], Sb[NB * NB];
   zero<R, NB * NB>(bA); zero<R, NB * NU>(bB); zero<R, NB * NB>(bQ); zero<R, NU * NU>(bR); zero<R, NB * NB>(Sb);
+  auto store_bars = [&](long slab) {
+    R* o = a.out + slab * (long)Lay::TOTAL * a.ld + i;
+    store_flat<R, NB * NB>(o + Lay::AA2 * a.ld, a.ld, bA);
+    store_flat<R, NB * NU>(o + Lay::AB2 * a.ld, a.ld, bB);
+    store_flat<R, NB * NB>(o + Lay::AQ * a.ld, a.ld, bQ);
+    store_flat<R, NU * NU>(o + Lay::AR * a.ld, a.ld, bR);
+  };
   RicStep<R, NB, NU> st;
   for (int t = 0; t < a.T; ++t) {
+    if (!TI) {
+      load_step(t);
+      zero<R, NB * NB>(bA); zero<R, NB * NU>(bB); zero<R, NB * NB>(bQ); zero<R, NU * NU>(bR);
+    }
     const R* w = a.ws + ((long)t * Lay::STEP) * a.ld + i;
     R S[NB * NB], Lb[NU * NB];
     load_tri<R, NB>(w + Lay::S_OFF * a.ld, a.ld, S);
@@ -654,13 +683,10 @@ __global__ void __launch_bounds__(LQG_BLOCK, 1) k_adj_riccati_rev(const AdjArgs<
     mmt_acc<R, NB, NB, NB>(X1, A, Sb);
     mmt_acc<R, NB, NU, NB>(X2, B, Sb);
     symmetrise<R, NB>(Sb);
+    if (!TI) store_bars(t);
   }
-  R* o = a.out + i;
-  store_flat<R, NB * NB>(o + Lay::AA2 * a.ld, a.ld, bA);
-  store_flat<R, NB * NU>(o + Lay::AB2 * a.ld, a.ld, bB);
-  store_flat<R, NB * NB>(o + Lay::AQ * a.ld, a.ld, bQ);
-  store_flat<R, NU * NU>(o + Lay::AR * a.ld, a.ld, bR);
-  store_flat<R, NB * NB>(o + Lay::AQF * a.ld, a.ld, Sb);
+  if (TI) store_bars(0);
+  store_flat<R, NB * NB>(a.out + i + Lay::AQF * a.ld, a.ld, Sb);
 }
 
 }  // namespace adj

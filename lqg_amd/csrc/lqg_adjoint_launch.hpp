@@ -23,6 +23,17 @@ inline long adj_grad_elements(const lqg_dims& d) {
          + 6L * d.b * d.b + 2L * d.b * d.u + (long)d.y * d.b + (long)d.u * d.u;  // aA aVV aQ aQf aS0 aA2 aB aB2 aF aR
 }
 
+inline bool adj_ti(const lqg_view& v, int T) { return v.ptr == nullptr || v.st == 0 || T <= 1; }
+// true when every field the gradient sweep reads is time-invariant (one accumulated bar per matrix)
+inline bool adj_time_invariant(const lqg_problem* p) {
+  const lqg_spec& a = p->actor;
+  const lqg_spec& d = p->dynamics;
+  const int T = p->T;
+  return adj_ti(a.Q, T) && adj_ti(a.P, T) && adj_ti(a.R, T) && adj_ti(a.A, T) && adj_ti(a.B, T) && adj_ti(a.F, T) &&
+         adj_ti(a.V, T) && adj_ti(a.W, T) && adj_ti(d.A, T) && adj_ti(d.B, T) && adj_ti(d.F, T) && adj_ti(d.V, T) &&
+         adj_ti(d.W, T);
+}
+
 template <typename R, int NX, int NB, int NU, int NY, int ND>
 hipError_t launch_adjoint(const lqg_problem* p, lqg_traj x, const void* g, long g_sb, long g_sn, void* ll, long ll_sb,
                           long ll_sn, void* grad, long ld, void* ws, int phases, hipStream_t stream) {
@@ -47,14 +58,18 @@ hipError_t launch_adjoint(const lqg_problem* p, lqg_traj x, const void* g, long 
   a.nva = p->dims.nva; a.nwa = p->dims.nwa; a.nvd = p->dims.nvd; a.nwd = p->dims.nwd;
   a.eps = (R)p->eps;
   const unsigned nb = (unsigned)((a.n_lanes + LQG_BLOCK - 1) / LQG_BLOCK);
+#define LQG_ADJ_LAUNCH(K_, TI_) \
+  hipLaunchKernelGGL((lqg::adj::K_<R, NX, NB, NU, NY, ND, TI_>), dim3(nb), dim3(LQG_BLOCK), 0, stream, a)
+  const bool ti = adj_time_invariant(p);
   if (phases & 1) {   // forward sweeps: fill the workspace, write the value
-    hipLaunchKernelGGL((lqg::adj::k_adj_riccati<R, NX, NB, NU, NY, ND>), dim3(nb), dim3(LQG_BLOCK), 0, stream, a);
-    hipLaunchKernelGGL((lqg::adj::k_adj_forward<R, NX, NB, NU, NY, ND>), dim3(nb), dim3(LQG_BLOCK), 0, stream, a);
+    if (ti) { LQG_ADJ_LAUNCH(k_adj_riccati, true); LQG_ADJ_LAUNCH(k_adj_forward, true); }
+    else { LQG_ADJ_LAUNCH(k_adj_riccati, false); LQG_ADJ_LAUNCH(k_adj_forward, false); }
   }
-  if (phases & 2) {   // reverse sweeps: consume the workspace, write the bars
-    hipLaunchKernelGGL((lqg::adj::k_adj_reverse<R, NX, NB, NU, NY, ND>), dim3(nb), dim3(LQG_BLOCK), 0, stream, a);
-    hipLaunchKernelGGL((lqg::adj::k_adj_riccati_rev<R, NX, NB, NU, NY, ND>), dim3(nb), dim3(LQG_BLOCK), 0, stream, a);
+  if (phases & 2) {   // reverse sweeps: consume the workspace, write the bars (one slab, or one per step)
+    if (ti) { LQG_ADJ_LAUNCH(k_adj_reverse, true); LQG_ADJ_LAUNCH(k_adj_riccati_rev, true); }
+    else { LQG_ADJ_LAUNCH(k_adj_reverse, false); LQG_ADJ_LAUNCH(k_adj_riccati_rev, false); }
   }
+#undef LQG_ADJ_LAUNCH
   return hipGetLastError();
 }
 

@@ -12,7 +12,7 @@ What the reference gets from jax.grad / jax.value_and_grad of `System.log_likeli
 sweeps (Riccati, forward: they keep the per-step state and return the value), backward() the two adjoint sweeps with
 the upstream weights, and hands the bars of the spec matrices to autograd, which chains them through the (torch) model constructors to the parameters.  Systems
 that decouple (every dim=2 model) are differentiated component by component — the gathers of lqg_amd/decouple.py are
-differentiable.  Time-invariant specs only; no CPU fallback.
+differentiable.  Time-invariant specs get one bar per matrix, time-varying specs one per step; no CPU fallback.
 """
 import ctypes as C
 
@@ -33,11 +33,12 @@ def needs_grad(system, Sigma0=None):
     return any(isinstance(t, torch.Tensor) and t.requires_grad for t in ts)
 
 
+def _varies(t):
+    return t.shape[-3] > 1 and t.stride(-3) != 0
+
+
 def _time_slice(t, name):
     """[.., T, r, c] time-invariant field -> its [.., r, c] matrix, staying on the autograd graph."""
-    if t.shape[-3] > 1 and t.stride(-3) != 0:
-        raise NotImplementedError(f"gradients need time-invariant specs (field {name} varies over time): the adjoint "
-                                  "sweep accumulates one bar per matrix (lqg_hip.h: lqg_log_likelihood_grad)")
     base = getattr(t, "_lqg_base", None)
     if base is not None and base.shape == t.shape[:-3] + t.shape[-2:]:
         return base                     # the matrix time_stack expanded: avoids a [.., T, r, c] zero-fill in backward
@@ -75,6 +76,7 @@ class Sweep:
         self.ld = (self.lanes + 63) // 64 * 64
         self.lay, self.total = _layout(ln.dims)
         assert self.total == self.lib.lqg_grad_elements(C.byref(ln.p.dims))
+        self.slabs = int(self.lib.lqg_grad_slabs(C.byref(ln.p)))          # 1 (time-invariant) or T (bars per step)
         self.nbytes = int(self.lib.lqg_grad_workspace_bytes(C.byref(ln.p), self.ld))
         self.ws = torch.empty(max(self.nbytes, 256), dtype=torch.uint8, device=ln.device)
 
@@ -93,14 +95,18 @@ class Sweep:
         return ll
 
     def reverse(self, g=None):
-        """-> {name: [B, N, r, c]} per-(system, trial) bars (lqg_hip.h: order of the gradient elements)."""
+        """-> {name: [B, N, r, c]} per-(system, trial) bars (lqg_hip.h: order of the gradient elements); with
+        time-varying specs [B, N, T, r, c] (aQf and aS0, which have no time axis, stay [B, N, r, c])."""
         ln = self.ln
         if g is not None:
             g = g.to(dtype=ln.dtype, device=ln.device).expand(ln.lead() + (self.N,)).contiguous()
-        out = torch.empty(self.total, self.ld, dtype=ln.dtype, device=ln.device)
+        out = torch.empty(self.slabs, self.total, self.ld, dtype=ln.dtype, device=ln.device)
         self._call(2, g, None, out)
-        return {k: out[o:o + r * c, :self.lanes].reshape(r, c, ln.B, self.N).permute(2, 3, 0, 1)
-                for k, (o, r, c) in self.lay.items()}
+        bars = {}
+        for k, (o, r, c) in self.lay.items():
+            v = out[:, o:o + r * c, :self.lanes].reshape(self.slabs, r, c, ln.B, self.N).permute(3, 4, 0, 1, 2)
+            bars[k] = v[:, :, 0] if (self.slabs == 1 or k in ("aQf", "aS0")) else v
+        return bars
 
 
 def raw_grad(actor, dynamics, x, g=None, Sigma0=None, eps=1e-8, want_value=True):
@@ -117,6 +123,7 @@ class _LogLikelihood(torch.autograd.Function):
     @staticmethod
     def forward(ctx, system, x, Sigma0, *mats):
         ctx.system, ctx.n_mats = system, len(mats)
+        ctx.time_varying = mats[0].dim() == system.actor.A.dim()        # full [.., T, r, c] fields were passed
         ctx.save_for_backward(*(mats + ((Sigma0,) if Sigma0 is not None else ())))
         ctx.has_s0 = Sigma0 is not None
         with torch.no_grad():
@@ -132,9 +139,10 @@ class _LogLikelihood(torch.autograd.Function):
         with torch.no_grad():
             bars = ctx.sweep.reverse(g)
             ctx.sweep = None                                                 # release the kept forward state
-            tot = {k: v.sum(1) for k, v in bars.items()}                    # over trials -> [B, r, c]
+            tot = {k: v.sum(1) for k, v in bars.items()}                    # over trials -> [B, (T,) r, c]
             sym2 = lambda M: M + M.transpose(-1, -2)
-            first = lambda t: t.select(-3, 0)
+            tv = ctx.time_varying
+            first = (lambda t: t) if tv else (lambda t: t.select(-3, 0))
             res = {"aA": tot["aA"] + tot["aA2"], "aB": tot["aB"] + tot["aB2"], "aF": tot["aF"],
                    "aV": sym2(tot["aVV"]) @ first(sys_.actor.V), "aW": sym2(tot["aWW"]) @ first(sys_.actor.W),
                    "aQ": tot["aQ"], "aR": 0.5 * sym2(tot["aR"]), "aQf": tot["aQf"],
@@ -144,7 +152,7 @@ class _LogLikelihood(torch.autograd.Function):
             outs = []
             for name, m in zip(names, mats):
                 gm = res[name]
-                if m.dim() == 2:                                             # field shared by all systems
+                if m.dim() == (3 if (tv and name != "aQf") else 2):          # field shared by all systems
                     gm = gm.sum(0)
                 outs.append(gm.to(m.dtype) if ctx.needs_input_grad[3 + len(outs)] else None)
             gS0 = None
@@ -157,8 +165,12 @@ def _one(system, x, Sigma0):
     a, dy = system.actor, system.dynamics
     if not (getattr(a.P, "_lqg_zero", False) or not a.P.requires_grad):
         raise NotImplementedError("gradient w.r.t. the cross-cost P is not provided")
-    mats = [_time_slice(getattr(a, f), "actor." + f) for f in ACTOR_FIELDS] + [a.Qf] \
-        + [_time_slice(getattr(dy, f), "dynamics." + f) for f in DYN_FIELDS]
+    if any(_varies(getattr(a, f)) for f in ACTOR_FIELDS) or any(_varies(getattr(dy, f)) for f in DYN_FIELDS):
+        # time-varying specs: the sweep returns one bar per step; the fields themselves are the autograd inputs
+        mats = [getattr(a, f) for f in ACTOR_FIELDS] + [a.Qf] + [getattr(dy, f) for f in DYN_FIELDS]
+    else:
+        mats = [_time_slice(getattr(a, f), "actor." + f) for f in ACTOR_FIELDS] + [a.Qf] \
+            + [_time_slice(getattr(dy, f), "dynamics." + f) for f in DYN_FIELDS]
     return _LogLikelihood.apply(system, x, Sigma0, *mats)
 
 

@@ -175,7 +175,7 @@ def test_candidate_axis_gradients_and_upstream_weights():
 
 
 @gpu
-def test_sigma0_gradient_and_unsupported_inputs():
+def test_sigma0_gradient():
     import lqg_amd
     m = lqg_amd.SubjectiveActor(dim=1, T=40, device="cuda", dtype=torch.float64)
     with torch.no_grad():
@@ -191,12 +191,43 @@ def test_sigma0_gradient_and_unsupported_inputs():
         with torch.no_grad():
             fd = float(m.log_likelihood(x, Sigma0=S0.detach() + h * E).sum() - m.log_likelihood(x, Sigma0=S0.detach() - h * E).sum()) / (2 * h)
         assert abs(fd - 0.5 * (an[i, j] + an[j, i])) < 1e-6 * max(1.0, abs(fd))
-    # time-varying specs: refused, not silently wrong
-    A = m.actor.A.clone() * torch.linspace(1.0, 1.01, 40, dtype=torch.float64, device="cuda")[:, None, None]
-    A.requires_grad_(True)
-    tv = lqg_amd.System(actor=m.actor._replace(A=A), dynamics=m.dynamics)
-    with pytest.raises(NotImplementedError, match="time-invariant"):
-        tv.log_likelihood(x)
+
+
+@gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-8), (torch.float32, 5e-4)], ids=["f64", "f32"])
+def test_time_varying_specs_get_one_bar_per_step(dtype, tol):
+    """Every field time-varying, custom Sigma0 (golden case timevarying_T30): HIP per-step bars against the restatement,
+    then through torch.autograd with the full [T, r, c] fields as leaves."""
+    from gpu_common import system_from_golden
+    from lqg_amd import grad as G
+    g, actor, dyn = load_golden("timevarying_T30")
+    x, S0 = g["x"], g["Sigma0"]
+    w = np.linspace(0.5, 1.5, x.shape[0])
+    _, ga, gd, S0b = ADJ.loglik_grad(actor, dyn, x, w, S0)
+    s = system_from_golden(actor, dyn, dtype)
+    xt = torch.as_tensor(x, dtype=dtype, device="cuda")
+    S0t = torch.as_tensor(S0, dtype=dtype, device="cuda")
+    ll, bars, _ = G.raw_grad(s.actor, s.dynamics, xt, g=torch.as_tensor(w, dtype=dtype, device="cuda"), Sigma0=S0t)
+    assert np.abs(ll.double().cpu().numpy() - g["ll"]).max() < max(tol * 1e-1, 1e-10) * np.abs(g["ll"]).max()
+    tot = {k: v.sum(1)[0].double().cpu().numpy() for k, v in bars.items()}
+    assert tot["dA"].shape == (30, 2, 2) and tot["aQf"].shape == (3, 3)
+    sym2 = lambda M: M + np.swapaxes(M, -1, -2)
+    got = {"dA": tot["dA"], "dB": tot["dB"], "dF": tot["dF"], "dV": sym2(tot["dVV"]) @ dyn["V"], "dW": sym2(tot["dWW"]) @ dyn["W"],
+           "aA": tot["aA"] + tot["aA2"], "aB": tot["aB"] + tot["aB2"], "aF": tot["aF"], "aV": sym2(tot["aVV"]) @ actor["V"],
+           "aW": sym2(tot["aWW"]) @ actor["W"], "aQ": tot["aQ"], "aR": tot["aR"], "aQf": tot["aQf"]}
+    ref = {"d" + k: v for k, v in gd.items()}
+    ref.update({"a" + k: v for k, v in ga.items()})
+    scale = max(np.abs(v).max() for v in ref.values())
+    for k, r in ref.items():
+        assert np.abs(got[k] - r).max() < tol * max(np.abs(r).max(), 1e-3 * scale), k
+    assert np.abs(tot["aS0"] - S0b).max() < tol * max(np.abs(S0b).max(), 1e-3)
+    if dtype == torch.float64:                       # autograd: leaves are the time-varying fields themselves
+        A = s.actor.A.clone().requires_grad_(True)
+        Wd = s.dynamics.W.clone().requires_grad_(True)
+        sys2 = type(s)(actor=s.actor._replace(A=A), dynamics=s.dynamics._replace(W=Wd))
+        (sys2.log_likelihood(xt, Sigma0=S0t) * torch.as_tensor(w, device="cuda")).sum().backward()
+        assert np.abs(A.grad.cpu().numpy() - ga["A"]).max() < 1e-8 * np.abs(ga["A"]).max()
+        assert np.abs(Wd.grad.cpu().numpy() - gd["W"]).max() < 1e-8 * max(np.abs(gd["W"]).max(), 1e-3)
 
 
 @gpu
