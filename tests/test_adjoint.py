@@ -257,3 +257,24 @@ def test_max_likelihood_with_adjoint_gradients_follows_the_finite_difference_pat
     assert torch.allclose(l1, l2, rtol=1e-6) and float(l1[-1]) < float(l1[0])
     for k in p1:
         assert abs(p1[k] - p2[k]) < 1e-4 * abs(p2[k])
+
+
+@gpu
+def test_fp32_gradients_track_fp64_on_the_decoupled_headline_model():
+    """SubjectiveActor(dim=2) (two decoupled 1-D components), a batch of candidates: fp32 parameter gradients against fp64."""
+    import lqg_amd
+    names = ("sigma_target", "subj_noise", "subj_vel_noise", "action_cost")
+    base = dict(sigma_target=[4.0, 8.0, 16.0, 30.0], subj_noise=[1.0, 1.5, 0.7, 1.2], subj_vel_noise=[0.5, 0.8, 0.4, 1.0],
+                action_cost=[0.05, 0.2, 0.5, 1.0])
+    with torch.no_grad():
+        x = lqg_amd.SubjectiveActor(dim=2, T=200, device="cuda", dtype=torch.float64).simulate(9, n=6)
+    grads = {}
+    for dtype in (torch.float64, torch.float32):
+        theta = {k: torch.tensor(base[k], dtype=dtype, device="cuda", requires_grad=True) for k in names}
+        ll = lqg_amd.SubjectiveActor(dim=2, T=200, device="cuda", dtype=dtype, **theta).log_likelihood(x.to(dtype))
+        assert ll.shape == (4, 6) and ll.dtype == dtype
+        ll.sum().backward()
+        grads[dtype] = {k: theta[k].grad.double().cpu().numpy() for k in names}
+    for k in names:
+        ref = grads[torch.float64][k]
+        assert np.abs(grads[torch.float32][k] - ref).max() < 2e-3 * max(np.abs(ref).max(), 1.0), k
