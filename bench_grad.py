@@ -38,11 +38,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--log2-lanes", type=int, default=16)
+    ap.add_argument("--sweep-only", action="store_true", help="skip the single-parameter-vector workload (profiling)")
     args = ap.parse_args()
     dt = torch.float64 if args.dtype == "f64" else torch.float32
     dev = torch.device("cuda", 0)
 
     # ---- eval: one parameter vector, 50 trials of 500 steps
+    if not args.sweep_only:
+        eval_workload(args, dev)
+    sweep_workload(args, dev, dt)
+
+
+def eval_workload(args, dev):
     true = dict(sigma_target=25.0, sigma_cursor=1.0, action_cost=0.05, action_variability=0.5)
     with torch.no_grad():
         x = lqg_amd.BoundedActor(T=500, device=dev, dtype=torch.float64, **true).simulate(0, n=50)
@@ -57,6 +64,9 @@ def main():
                           "config": {"workload": "BoundedActor T=500 x=b=2, 50 trials, 4 parameters, one parameter vector"},
                           "grad_vs_fd_max_rel": err, "baseline_note": "BASELINE.md derived ~54 evals/s (JAX CPU, not comparable)"}))
 
+
+
+def sweep_workload(args, dev, dt):
     # ---- sweep: B lanes, one (system, trial) each
     B = 1 << args.log2_lanes
     sig = torch.linspace(5.0, 50.0, B, device=dev, dtype=dt)
