@@ -72,6 +72,15 @@ def _worker(rank, world, port, out_dir):
     ll_all, ga, gd, _ = ADJ.loglik_grad(actor, dyn, x)
     ref = np.array([ll_all.sum(), ga["W"].sum(0)[0, 0], gd["V"].sum(0)[1, 1]])
     assert np.allclose(vec.numpy(), ref, rtol=1e-10), (vec, ref)
+    # lqg_amd.optim.minimize with a process group (row a12): each rank holds a shard of the objective's data; value and
+    # gradient are all-reduced inside the driver, so every rank walks the same L-BFGS path to the same optimum
+    from lqg_amd.optim import minimize
+    data = torch.arange(1.0, 9.0, dtype=torch.float64)                       # 8 "trials"
+    lo8, hi8 = ld.shard_bounds(8, rank, world)
+    mine8 = data[lo8:hi8]
+    res = minimize(lambda p: ((mine8 - p["m"]) ** 2).sum() + 0.0 * p["s"], dict(m=torch.zeros((), dtype=torch.float64),
+                   s=torch.ones((), dtype=torch.float64)), method="L-BFGS-B", group=dist.group.WORLD)
+    assert abs(float(res.x["m"]) - float(data.mean())) < 1e-6 and abs(res.fun - float(((data - data.mean()) ** 2).sum())) < 1e-8
     np.save(os.path.join(out_dir, f"r{rank}.npy"), total.numpy())
     dist.destroy_process_group()
 
