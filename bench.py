@@ -12,7 +12,6 @@ the summed log-likelihood (the objective of lqg.infer / lqg.optim), issued once 
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys

@@ -7,11 +7,9 @@ Units: solve = one system + one trajectory end to end; trial-ev
 already-solved system.   usage: python bench_configs.py [--configs 1,2,3,4,5] [--reps 5]
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
-import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -21,7 +19,7 @@ import numpy as np
 import torch
 
 import lqg_amd
-from lqg_amd import _abi, _hip, _hipev, workload
+from lqg_amd import _hip, workload
 from lqg_amd.system import Actor, System
 from bench import PEAK_FP32_TFLOPS, PEAK_FP64_TFLOPS, PEAK_HBM_GBS, algorithmic_bytes_per_solve, algorithmic_flops_per_step
 

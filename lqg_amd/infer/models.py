@@ -3,9 +3,6 @@
 the summed log-likelihood of data x[n, T, d] under `model_type(T=T-1, **params)`."""
 import inspect
 
-import torch
-
-from lqg_amd import _hip
 
 _NOT_INFERRED = ("self", "dim", "dt", "T", "process_noise", "delay", "covar", "device", "dtype")
 

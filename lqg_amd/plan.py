@@ -140,7 +140,6 @@ def _stack_components(parts, x):
     from lqg_amd import specialize, workload
     from lqg_amd.spec import LQGSpec
     from lqg_amd.system import System
-    from lqg_amd.utils import mark_zero
 
     subs = [p[0] for p in parts]
     B = subs[0].n_systems

@@ -8,7 +8,7 @@ import torch
 
 from lqg_amd.spec import LQGSpec
 from lqg_amd.system import System
-from lqg_amd.tracking import BoundedActor, PointMassBoundedActor, SubjectiveActor
+from lqg_amd.tracking import BoundedActor, SubjectiveActor
 
 # ranges: inside the tutorial slider ranges (notebooks/Tutorial.ipynb:715-724) and the prior scales of
 # lqg/infer/prior.py:7-15
