@@ -79,6 +79,7 @@ class Sweep:
         self.slabs = int(self.lib.lqg_grad_slabs(C.byref(ln.p)))          # 1 (time-invariant) or T (bars per step)
         self.nbytes = int(self.lib.lqg_grad_workspace_bytes(C.byref(ln.p), self.ld))
         self.ws = torch.empty(max(self.nbytes, 256), dtype=torch.uint8, device=ln.device)
+        self.fresh = False              # True while the workspace holds an unconsumed forward state
 
     def _call(self, phases, g, ll, out):
         ln, N = self.ln, self.N
@@ -92,6 +93,7 @@ class Sweep:
     def forward(self):
         ll = self.ln.empty(self.N)
         self._call(1, None, ll, None)
+        self.fresh = True
         return ll
 
     def reverse(self, g=None):
@@ -101,7 +103,10 @@ class Sweep:
         if g is not None:
             g = g.to(dtype=ln.dtype, device=ln.device).expand(ln.lead() + (self.N,)).contiguous()
         out = torch.empty(self.slabs, self.total, self.ld, dtype=ln.dtype, device=ln.device)
+        if not self.fresh:              # a second backward (retain_graph): the reverse sweep overwrote L_t with Lbar_t
+            self.forward()
         self._call(2, g, None, out)
+        self.fresh = False
         bars = {}
         for k, (o, r, c) in self.lay.items():
             v = out[:, o:o + r * c, :self.lanes].reshape(self.slabs, r, c, ln.B, self.N).permute(3, 4, 0, 1, 2)
@@ -138,7 +143,6 @@ class _LogLikelihood(torch.autograd.Function):
         sys_ = ctx.system
         with torch.no_grad():
             bars = ctx.sweep.reverse(g)
-            ctx.sweep = None                                                 # release the kept forward state
             tot = {k: v.sum(1) for k, v in bars.items()}                    # over trials -> [B, (T,) r, c]
             sym2 = lambda M: M + M.transpose(-1, -2)
             tv = ctx.time_varying

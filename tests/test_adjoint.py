@@ -161,8 +161,12 @@ def test_candidate_axis_gradients_and_upstream_weights():
     w = torch.tensor([[1.0, 0.5, 2.0, 0.0], [0.3, 0.3, 0.3, 0.3], [1.0, -1.0, 1.0, -1.0]], dtype=torch.float64, device="cuda")
     ll = lqg_amd.BoundedActor(T=80, sigma_target=sig, action_cost=cost, device="cuda", dtype=torch.float64).log_likelihood(x)
     assert ll.shape == (3, 4)
-    (ll * w).sum().backward()
+    (ll * w).sum().backward(retain_graph=True)
     g_sig, g_cost = sig.grad.clone(), float(cost.grad)
+    sig.grad = None
+    (ll * w).sum().backward()                                                # a second backward re-runs the forward sweeps
+    assert torch.allclose(sig.grad, g_sig, rtol=1e-12)
+    cost.grad = cost.grad - g_cost
     tot_cost = 0.0
     for c in range(3):
         s1 = torch.tensor(float(sig[c].detach()), dtype=torch.float64, device="cuda", requires_grad=True)
