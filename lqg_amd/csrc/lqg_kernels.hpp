@@ -30,6 +30,9 @@
 #define LQG_BLOCK 64
 #endif
 // minimum waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument)
+#ifndef LQG_TRIAL_PREFETCH
+#define LQG_TRIAL_PREFETCH 1
+#endif
 #ifndef LQG_FWD_WAVES
 #define LQG_FWD_WAVES 1
 #endif
@@ -547,6 +550,17 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial(const R* __restrict__ ops_a
     acc[k] = 0.0;
     part[k] = R(0);
   }
+#if LQG_TRIAL_PREFETCH
+  // software pipeline of the data stream, depth D = LQG_TRIAL_PREFETCH: while step t computes, rows t+1 .. t+D are in
+  // flight (row indices clamped to T).  xq[k][0] is the row of the current step.
+  constexpr int D = LQG_TRIAL_PREFETCH;
+  R xq[TPL][D][O];
+  LQG_UNROLL for (int k = 0; k < TPL; ++k)
+    LQG_UNROLL for (int j = 0; j < D; ++j) {
+      const long row = (j < a.T) ? j : a.T;
+      LQG_UNROLL for (int i = 0; i < O; ++i) xq[k][j][i] = xr[k][row * a.x.st + i * a.x.sd];
+    }
+#endif
   for (int t = 0; t <= a.T; ++t) {
     R Li[O * (O + 1) / 2];
     LQG_UNROLL for (int i = 0; i < O * (O + 1) / 2; ++i) Li[i] = op[Ops::L_OFF + i];
@@ -554,8 +568,18 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial(const R* __restrict__ ops_a
     const bool flush = ((t & (kAccChunk - 1)) == 0) || t == a.T;
     LQG_UNROLL for (int k = 0; k < TPL; ++k) {
       R xt[O], w[O];
+#if LQG_TRIAL_PREFETCH
+      LQG_UNROLL for (int i = 0; i < O; ++i) xt[i] = xq[k][0][i];
+      LQG_UNROLL for (int j = 0; j + 1 < D; ++j)
+        LQG_UNROLL for (int i = 0; i < O; ++i) xq[k][j][i] = xq[k][j + 1][i];
+      {
+        const long row = (t + D < a.T) ? (long)(t + D) : (long)a.T;
+        LQG_UNROLL for (int i = 0; i < O; ++i) xq[k][D - 1][i] = xr[k][row * a.x.st + i * a.x.sd];
+      }
+#else
       LQG_UNROLL for (int i = 0; i < O; ++i) xt[i] = xr[k][i * a.x.sd];
       xr[k] += a.x.st;
+#endif
       R zz = R(0);
       {
         int e = 0;
