@@ -16,7 +16,7 @@ OPS_WORKSPACE_LIMIT = 16 << 30
 
 
 class LogLikelihoodPlan:
-    def __init__(self, system, x, Sigma0=None, eps=1e-8, events=False, concurrent=False, stack=False):
+    def __init__(self, system, x, Sigma0=None, eps=1e-8, events=False, concurrent=None, stack=False):
         """stack=True (persistent plans over a fixed dataset): decoupled components that share dims and sparsity
         pattern are concatenated along the system axis and solved by ONE launch of C*B systems (twice the waves in
         flight per SIMD at the headline shape); costs a one-time re-packing copy of x, so it is off for the throw-away
@@ -64,9 +64,13 @@ class LogLikelihoodPlan:
             self._ll_stacked = self.ll
             self.ll = torch.empty((self.ll.shape[0] // self.n_stacked,) + tuple(self.ll.shape[1:]),
                                   dtype=self.ll.dtype, device=self.ll.device)
-        # concurrent=True runs the independent components on side streams: with B = 2^18 one launch is 4 waves per
-        # SIMD, two in flight give the SIMDs twice the waves to hide latencies behind (measured +4 % at the headline
-        # shape; off by default so that per-kernel timings stay attributable)
+        # concurrent=True runs the independent components on side streams.  With few systems (one parameter vector, a
+        # handful of candidates) each per-system sweep is a single latency-bound wave and the components simply overlap:
+        # the default (None) turns it on below 2^14 systems (config 4: 8.2 -> ~5 ms wall).  At B = 2^18 two launches in
+        # flight give +4 % (the bench stacks the components into one launch instead).
+        if concurrent is None:
+            n_sys = self.work[0]["ln"].B
+            concurrent = len(self.work) > 1 and n_sys < (1 << 14)
         self.side = [torch.cuda.Stream(device=self.device) for _ in self.work[1:]] if concurrent else []
         self._fork = torch.cuda.Event() if self.side else None
         self._join = [torch.cuda.Event() for _ in self.side]
@@ -130,7 +134,8 @@ class LogLikelihoodPlan:
 
     def phase_ms(self):
         """(riccati, forward, trial) milliseconds of the last run, summed over components (events=True only)."""
-        self.work[-1]["ev"][3].synchronize()
+        for wk in self.work:                       # components may run on different streams
+            wk["ev"][3].synchronize()
         return tuple(sum(wk["ev"][i].elapsed_ms(wk["ev"][i + 1]) for wk in self.work) for i in range(3))
 
 
