@@ -127,15 +127,16 @@ hipError_t launch_forward(const lqg_problem* p, const void* Ls, long ldb, bool f
 }
 
 #ifndef LQG_TRIALS_PER_LANE
-#define LQG_TRIALS_PER_LANE 4
+#define LQG_TRIALS_PER_LANE 2
 #endif
 template <typename R, int M, int ND>
 hipError_t launch_trial(const lqg_problem* p, const void* ops, lqg_traj x, lqg_traj mu, void* ll, long ll_sb,
                         long ll_sn, hipStream_t st) {
   lqg::TrialArgs<R> k{dt<R>(x), dt<R>(mu), static_cast<R*>(ll), ll_sb, ll_sn, (long)p->n_trials, p->T};
-  // Trials per lane: 4 amortises the per-step operator (scalar) loads when there are trials to spare; with fewer than
-  // ~2 waves per SIMD at that packing (one system with 10^4..10^5 trials: BASELINE configs 2 and 4) the sweep is
-  // latency-bound and one trial per lane puts 4x the waves in flight.
+  // Trials per lane: a few trials per lane amortise the per-step operator (scalar) loads when there are trials to spare
+  // (2 measured best with the pipelined data loads: 2 / 4 / 8 -> 2.20 / 2.31 / 2.57 ms on config 5); with fewer than ~2
+  // waves per SIMD at 4 per lane (one system with 10^4..10^5 trials: BASELINE configs 2 and 4) the sweep is
+  // latency-bound and one trial per lane puts the most waves in flight.
   const long lanes4 = (long)p->n_sys * ((p->n_trials + 4 * LQG_BLOCK - 1) / (4 * LQG_BLOCK)) * LQG_BLOCK;
   const bool wide = lanes4 >= 2L * 1024 * 64;
   const long per_block = (long)LQG_BLOCK * (wide ? LQG_TRIALS_PER_LANE : 1);
