@@ -84,11 +84,14 @@ __global__ void __launch_bounds__(LQG_BLOCK, LQG_SP_RIC_WAVES) k_riccati_sp(cons
 }
 
 // ---------------------------------------------------------------- forward sweep, TI, log-likelihood only
-// FUSED: the single trial of each system is swept in-lane; !FUSED: the per-step trial operators are written to the
-// operator stream for k_trial (several trials per system), exactly as k_forward does.
-template <typename R, int NX, int NB, int NU, int NY, int ND, typename PAT, bool FUSED>
+// NTR >= 1 (fused): the NTR trials of each system are swept in-lane (1: the headline; 2: two identical decoupled
+// components solved as ONE system with two trials, lqg_amd/plan.py); NTR == 0: the per-step trial operators are written
+// to the operator stream for k_trial (many trials per system), exactly as k_forward does.  ll_sn: trial stride of ll.
+template <typename R, int NX, int NB, int NU, int NY, int ND, typename PAT, int NTR>
 __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F32 : LQG_SP_FWD_WAVES_F64)
-    k_forward_sp(const ForwardArgs<R> a) {
+    k_forward_sp(const ForwardArgs<R> a, const long ll_sn) {
+  constexpr bool FUSED = NTR > 0;
+  constexpr int NT = FUSED ? NTR : 1;
   constexpr int M = NX + NB, O = ND, RR = M - ND;
   using Ops = TrialOps<M, ND>;
   const long s = blockIdx.x * (long)LQG_BLOCK + threadIdx.x;
@@ -120,13 +123,16 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
   if (a.Sigma0.p) load_sym<R, NB>(a.Sigma0.p + s * a.Sigma0.sb, a.Sigma0.sr, a.Sigma0.sc, P);
   else load_gram<R, NB>(a.aV.p + s * a.aV.sb, a.aV.sr, a.aV.sc, a.nva, P);
 
-  R Sg[M * M], xprev[O], dO[O], muR[RR];   // observed mean = xprev + dO (deviation form, see k_forward)
-  double acc = 0.0;
+  R Sg[M * M], xprev[NT][O], dO[NT][O], muR[NT][RR];   // observed mean = xprev + dO (deviation form, see k_forward)
+  double acc[NT];
   const R* xp = nullptr;
+  LQG_UNROLL for (int k = 0; k < NT; ++k) acc[k] = 0.0;
   if (FUSED) {
     xp = a.x.p + s * a.x.sb;
-    LQG_UNROLL for (int i = 0; i < O; ++i) { xprev[i] = xp[i * a.x.sd]; dO[i] = R(0); }
-    LQG_UNROLL for (int i = 0; i < RR; ++i) muR[i] = R(0);
+    LQG_UNROLL for (int k = 0; k < NT; ++k) {
+      LQG_UNROLL for (int i = 0; i < O; ++i) { xprev[k][i] = xp[k * a.x.sn + i * a.x.sd]; dO[k][i] = R(0); }
+      LQG_UNROLL for (int i = 0; i < RR; ++i) muR[k][i] = R(0);
+    }
   }
   const R kLogNorm = R(0.5 * ND * 1.8378770664093453);
 
@@ -148,17 +154,17 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
       }
   };
   R w[O], xt[O];
-  auto innovate = [&](int k, bool score) {
-    const R* xr = xp + (long)k * a.x.st;
+  auto innovate = [&](int n, int row, bool score) {        // trial n, data row `row`
+    const R* xr = xp + n * a.x.sn + (long)row * a.x.st;
     LQG_UNROLL for (int i = 0; i < O; ++i) xt[i] = xr[i * a.x.sd];
     R zz = R(0);
     LQG_UNROLL for (int i = 0; i < O; ++i) {
       R v = R(0);
-      LQG_UNROLL for (int j = 0; j <= i; ++j) v += Li[i * O + j] * ((xt[j] - xprev[j]) - dO[j]);
+      LQG_UNROLL for (int j = 0; j <= i; ++j) v += Li[i * O + j] * ((xt[j] - xprev[n][j]) - dO[n][j]);
       w[i] = v;
       zz += v * v;
     }
-    if (score) acc -= (double)(R(0.5) * zz + hl + kLogNorm);
+    if (score) acc[n] -= (double)(R(0.5) * zz + hl + kLogNorm);
   };
 
   for (int t = 0; t < a.T; ++t) {
@@ -190,25 +196,27 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
     // ---- condition on x_t, score it, propagate the mean                system.py:219-221, 244-248
     condition();
     if (FUSED) {
-      innovate(t, t > 0);
-      R cvec[M];
-      LQG_UNROLL for (int j = 0; j < O; ++j) cvec[j] = xt[j];
-      LQG_UNROLL for (int p = 0; p < RR; ++p) {
-        R v = muR[p];
-        LQG_UNROLL for (int j = 0; j < O; ++j) v += U2[p * O + j] * w[j];
-        cvec[O + p] = v;
-      }
-      R mn[M];
-      LQG_UNROLL for (int i = 0; i < M; ++i) {                 // rows < O as deviation from x_t: ((Fj - I) cvec)[i]
-        R v = R(0);
-        LQG_UNROLL for (int j = 0; j < M; ++j) {
-          if (i < O && i == j) v += (Fj.mask(i, i) ? Fj.v[i * M + i] - R(1) : R(-1)) * cvec[j];
-          else if (Fj.mask(i, j)) v += Fj.v[i * M + j] * cvec[j];
+      LQG_UNROLL for (int n = 0; n < NT; ++n) {
+        innovate(n, t, t > 0);
+        R cvec[M];
+        LQG_UNROLL for (int j = 0; j < O; ++j) cvec[j] = xt[j];
+        LQG_UNROLL for (int p = 0; p < RR; ++p) {
+          R v = muR[n][p];
+          LQG_UNROLL for (int j = 0; j < O; ++j) v += U2[p * O + j] * w[j];
+          cvec[O + p] = v;
         }
-        mn[i] = v;
+        R mn[M];
+        LQG_UNROLL for (int i = 0; i < M; ++i) {               // rows < O as deviation from x_t: ((Fj - I) cvec)[i]
+          R v = R(0);
+          LQG_UNROLL for (int j = 0; j < M; ++j) {
+            if (i < O && i == j) v += (Fj.mask(i, i) ? Fj.v[i * M + i] - R(1) : R(-1)) * cvec[j];
+            else if (Fj.mask(i, j)) v += Fj.v[i * M + j] * cvec[j];
+          }
+          mn[i] = v;
+        }
+        LQG_UNROLL for (int i = 0; i < O; ++i) { dO[n][i] = mn[i]; xprev[n][i] = xt[i]; }
+        LQG_UNROLL for (int p = 0; p < RR; ++p) muR[n][p] = mn[O + p];
       }
-      LQG_UNROLL for (int i = 0; i < O; ++i) { dO[i] = mn[i]; xprev[i] = xt[i]; }
-      LQG_UNROLL for (int p = 0; p < RR; ++p) muR[p] = mn[O + p];
     } else {
       R* op = a.ops + ((long)s * (a.T + 1) + t) * Ops::N;
       LQG_UNROLL for (int i = 0; i < M; ++i)
@@ -238,8 +246,10 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
   }
   condition();
   if (FUSED) {
-    innovate(a.T, true);
-    a.ll[s * a.ll_sb] = (R)acc;
+    LQG_UNROLL for (int n = 0; n < NT; ++n) {
+      innovate(n, a.T, true);
+      a.ll[s * a.ll_sb + n * ll_sn] = (R)acc[n];
+    }
   } else {
     R* op = a.ops + ((long)s * (a.T + 1) + a.T) * Ops::N;
     int e = 0;

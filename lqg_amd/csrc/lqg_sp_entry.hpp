@@ -1,7 +1,7 @@
 // lqg_sp_entry.hpp — host side of a structure-specialised library (one per sparsity pattern, generated and compiled
 // by lqg_amd/specialize.py).  Exposes the SAME contract as lqg_log_likelihood (include/lqg_hip.h) restricted to the
-// case it is compiled for: time-invariant specs, no affine cost terms, dims fixed (one trial per system runs fused,
-// several go through the operator stream and the generic k_trial).
+// case it is compiled for: time-invariant specs, no affine cost terms, dims fixed (one or two trials per system run
+// fused in-lane, more go through the operator stream and the generic k_trial).
 // Anything else is refused with LQG_ERR_ARG / LQG_ERR_DIMS before launching; the caller then uses the generic
 // library.  The pattern's validity for the data (structural zeros really are zero) is the generator's contract.
 #pragma once
@@ -16,7 +16,7 @@ namespace host {
 template <typename R, typename PAT, int NX, int NB, int NU, int NY, int ND>
 int run_sp(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll_sn, void* workspace, size_t workspace_bytes,
            hipStream_t st) {
-  const bool fused = p->n_trials == 1;
+  const bool fused = p->n_trials <= 2;
   const Workspace w = carve(p, !fused);
   if (!workspace || workspace_bytes < w.total) return LQG_ERR_WORKSPACE;
   char* base = static_cast<char*>(workspace);
@@ -44,8 +44,9 @@ int run_sp(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll_sn, v
                           dv<R>(p->Sigma0), Ls, w.ldb, dt<R>(x), static_cast<R*>(ll), ll_sb, ops, dv<R>(none),
                           dt<R>(no_traj), dv<R>(none), (long)p->n_sys, p->T,
                           p->dims.nva, p->dims.nwa, p->dims.nvd, p->dims.nwd};
-    if (fused) hipLaunchKernelGGL((lqg::k_forward_sp<R, NX, NB, NU, NY, ND, PAT, true>), grid, block, 0, st, k);
-    else hipLaunchKernelGGL((lqg::k_forward_sp<R, NX, NB, NU, NY, ND, PAT, false>), grid, block, 0, st, k);
+    if (p->n_trials == 1) hipLaunchKernelGGL((lqg::k_forward_sp<R, NX, NB, NU, NY, ND, PAT, 1>), grid, block, 0, st, k, ll_sn);
+    else if (p->n_trials == 2) hipLaunchKernelGGL((lqg::k_forward_sp<R, NX, NB, NU, NY, ND, PAT, 2>), grid, block, 0, st, k, ll_sn);
+    else hipLaunchKernelGGL((lqg::k_forward_sp<R, NX, NB, NU, NY, ND, PAT, 0>), grid, block, 0, st, k, ll_sn);
   }
   mark(2);
   if (!fused) {   // several trials per system: the generic per-trial sweep over the operator stream

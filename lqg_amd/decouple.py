@@ -127,6 +127,63 @@ def split_system(system, comps, vmask_a, wmask_a, vmask_d, wmask_d):
     return out
 
 
+_ZOO_GROUPS = {}        # (class, zoo structure, d) -> groups of identical components (a property of the constructor)
+
+
+def _same_spec(sa, sb):
+    """True when two sub-systems have bit-identical specs (values AND time structure)."""
+    for which in ("actor", "dynamics"):
+        for f in LQGSpec._fields:
+            ta, tb = getattr(getattr(sa, which), f), getattr(getattr(sb, which), f)
+            za, zb = getattr(ta, "_lqg_zero", False), getattr(tb, "_lqg_zero", False)
+            if za and zb:
+                continue
+            if za != zb or ta.shape != tb.shape:
+                return False
+            notime = f in ("Qf", "qf")
+            if not notime:
+                tax = -(2 if f in ("q", "r") else 3)
+                ia, ib = ta.stride(tax) == 0 or ta.shape[tax] == 1, tb.stride(tax) == 0 or tb.shape[tax] == 1
+                if ia != ib:
+                    return False
+                if ia:
+                    ta, tb = ta.select(tax, 0), tb.select(tax, 0)
+            if not torch.equal(ta, tb):
+                return False
+    return True
+
+
+def identical_groups(system, d, parts, Sigma0=None):
+    """Partition the components into groups with bit-identical specs: such components are the SAME system observed on
+    different data columns (every dim=2 model of the zoo is block_diag of one 1-D model with shared parameters), so the
+    per-system sweeps are done once and the components become trials (lqg_amd/plan.py).  For the exact zoo classes the
+    grouping is a property of the constructor and is cached per class; otherwise it is decided from the data."""
+    if parts is None or len(parts) < 2 or Sigma0 is not None:
+        return [[i] for i in range(len(parts or []))]
+    import lqg_amd
+    zoo = (lqg_amd.BoundedActor, lqg_amd.OptimalActor, lqg_amd.RelativeObservationBoundedActor, lqg_amd.SubjectiveActor)
+    zs = getattr(system, "_zoo_structure", None) if type(system) in zoo else None
+    key = (type(system), tuple(sorted(zs.items())), d) if zs is not None else None
+    if key is not None and key in _ZOO_GROUPS:
+        return _ZOO_GROUPS[key]
+    cache = system.__dict__.setdefault("_lqg_groups", {})
+    if d in cache:
+        return cache[d]
+    groups = []
+    for i, (sub, cols, _) in enumerate(parts):
+        for g in groups:
+            ref, rcols, _ = parts[g[0]]
+            if len(rcols) == len(cols) and _same_spec(ref, sub):
+                g.append(i)
+                break
+        else:
+            groups.append([i])
+    cache[d] = groups
+    if key is not None:
+        _ZOO_GROUPS[key] = groups
+    return groups
+
+
 def plan(system, d, Sigma0=None):
     """Decoupling plan of a System for data with d observed dims: list of (sub_system, data columns, belief dims)
     or None.  Cached on the instance (per d); the model zoo uses the class-level probe pattern."""

@@ -3,6 +3,7 @@ components, structure-specialised vs generic library, workspace, argument struct
 evaluations (benchmarks, optimisation loops over the same data) are pure launches.  `System.log_likelihood` builds a
 throw-away plan; bench.py / bench_configs.py keep one."""
 import ctypes as C
+import os
 
 import torch
 
@@ -16,7 +17,7 @@ OPS_WORKSPACE_LIMIT = 16 << 30
 
 
 class LogLikelihoodPlan:
-    def __init__(self, system, x, Sigma0=None, eps=1e-8, events=False, concurrent=None, stack=False):
+    def __init__(self, system, x, Sigma0=None, eps=1e-8, events=False, concurrent=None, stack=False, merge=True):
         """stack=True (persistent plans over a fixed dataset): decoupled components that share dims and sparsity
         pattern are concatenated along the system axis and solved by ONE launch of C*B systems (twice the waves in
         flight per SIMD at the headline shape); costs a one-time re-packing copy of x, so it is off for the throw-away
@@ -25,22 +26,43 @@ class LogLikelihoodPlan:
         d = x.shape[-1]
         lib = _abi.load()
         parts = system.decoupled(d, Sigma0) or [(system, list(range(d)), None)]
+        # merge=True: decoupled components with bit-identical specs are ONE system observed on different data columns
+        # (every dim=2 zoo model): the per-system sweeps run once and the components become trials of that system
+        self.merged = []
+        if merge and len(parts) > 1 and os.environ.get("LQG_NO_MERGE") != "1":
+            from lqg_amd import decouple
+            merged_parts, merged_x = [], []
+            for g in decouple.identical_groups(system, d, parts, Sigma0):
+                merged_parts.append(parts[g[0]])
+                merged_x.append(_trial_stack(x, [parts[i][1] for i in g]) if len(g) > 1 else None)
+                self.merged.append(len(g))
+            if any(m > 1 for m in self.merged):
+                parts = merged_parts
+            else:
+                self.merged, merged_x = [], []
         self.n_stacked = 1
-        if stack and len(parts) > 1 and Sigma0 is None:
+        if stack and len(parts) > 1 and Sigma0 is None and not self.merged:
             stacked = _stack_components(parts, x)
             if stacked is not None:
                 self.n_stacked = len(parts)
                 parts, x = [(stacked[0], list(range(stacked[1].shape[-1])), None)], stacked[1]
         self.work = []
-        for sub, cols, bs in parts:
+        for ip, (sub, cols, bs) in enumerate(parts):
             contiguous = cols == list(range(cols[0], cols[-1] + 1))
             xs = x[..., cols[0]:cols[-1] + 1] if contiguous else x[..., cols]
+            if self.merged and merged_x[ip] is not None:
+                xs = merged_x[ip]                # [(B,) G*n, T+1, d_c]: the group's components as trials
             S0 = Sigma0 if (Sigma0 is None or bs is None) else Sigma0[..., bs, :][..., :, bs]
             n = xs.shape[-3]
             ln = _hip.Launch(sub.actor, sub.dynamics, d=len(cols), n_trials=n, Sigma0=S0, eps=eps)
             lib = ln.require_gpu()               # liblqg_hip.so, or the auxiliary library of an unlisted shape
             xb, is_b = _hip._prep_x(ln, xs)
             nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
+            sp = _hip.specialised_entry(ln, sub, len(cols))
+            if sp is not None and n == 2:        # the specialised library sweeps two trials in-lane: no operator stream
+                ln.p.n_trials = 1
+                nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
+                ln.p.n_trials = 2
             loop_trials = n > 1 and nbytes > OPS_WORKSPACE_LIMIT
             if loop_trials:                      # one fused sweep per trial: the problem describes ONE trial
                 ln.p.n_trials = 1
@@ -50,16 +72,18 @@ class LogLikelihoodPlan:
                 ev = [_hipev.Event() for _ in range(4)]
                 for i in range(4):
                     ln.p.phase_events[i] = ev[i].h
-            sp = _hip.specialised_entry(ln, sub, len(cols))
             self.work.append(dict(ln=ln, x=xb, traj=ln.traj(xb, is_b), ll=ln.empty(n), nbytes=nbytes, ev=ev,
                                   ws=torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=ln.device),
                                   entry=sp or lib.lqg_log_likelihood, generic=lib.lqg_log_likelihood,
                                   specialised=sp is not None, n=n,
-                                  loop_trials=loop_trials, is_b=is_b,
+                                  loop_trials=loop_trials, is_b=is_b, group=(self.merged[ip] if self.merged else 1),
                                   dims=(sub.xdim, sub.bdim, sub.udim, sub.ydim, len(cols))))
         self.lib = lib
         self.device = self.work[0]["ln"].device
         self.ll = self.work[0]["ll"]
+        if self.merged:                        # [.., G*n] per work item -> [.., n]: sum over the G merged components
+            n0 = x.shape[-3]
+            self.ll = torch.empty(tuple(self.ll.shape[:-1]) + (n0,), dtype=self.ll.dtype, device=self.ll.device)
         if self.n_stacked > 1:                 # [C*B, n] of the stacked launch -> per-solve sum over the C components
             self._ll_stacked = self.ll
             self.ll = torch.empty((self.ll.shape[0] // self.n_stacked,) + tuple(self.ll.shape[1:]),
@@ -78,13 +102,17 @@ class LogLikelihoodPlan:
     @property
     def description(self):
         w = self.work
-        tail = " + k_trial)" if w[0]["n"] > 1 else ")"
+        in_lane = w[0]["n"] == 1 or (w[0]["n"] == 2 and w[0]["specialised"])
+        tail = ")" if in_lane else " + k_trial)"
         kind = ("structure-specialised (k_riccati_sp + k_forward_sp" if all(k["specialised"] for k in w) else
                 "generic dense (k_riccati + k_forward") + tail
         if len(w) > 1:
             kind += f", {len(w)} decoupled components of dims (x,b,u,y,d)={w[0]['dims']}"
         if self.n_stacked > 1:
             kind += f", {self.n_stacked} decoupled components of dims (x,b,u,y,d)={w[0]['dims']} stacked into one launch"
+        if self.merged and max(self.merged) > 1:
+            kind += (f"; {max(self.merged)} identical decoupled components of dims (x,b,u,y,d)={w[0]['dims']} solved as ONE "
+                     "system with the components as in-lane trials")
         return kind
 
     def run(self):
@@ -113,13 +141,26 @@ class LogLikelihoodPlan:
                     if wk["entry"](*args) != 0:
                         if wk["specialised"]:      # the specialised library refused: use the generic one
                             wk["entry"], wk["specialised"] = wk["generic"], False
+                        need = self.lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
+                        if need > wk["nbytes"]:    # (the in-lane two-trial sweep needed no operator stream)
+                            wk["ws"] = torch.empty(int(need), dtype=torch.uint8, device=ln.device)
+                            wk["nbytes"] = need
+                            args = args[:5] + (C.c_void_p(wk["ws"].data_ptr()), wk["nbytes"]) + args[7:]
                         _abi.check(wk["generic"](*args), "lqg_log_likelihood")
                 if stream is not main:
                     self._join[i - 1].record(stream)
             for ev in self._join:
                 main.wait_event(ev)
-            for wk in self.work[1:]:
-                self.ll.add_(wk["ll"])         # log p(x) = sum over independent components
+            if self.merged:
+                for i, wk in enumerate(self.work):
+                    part = wk["ll"].view(*wk["ll"].shape[:-1], wk["group"], -1)
+                    if i == 0:
+                        torch.sum(part, dim=-2, out=self.ll)
+                    else:
+                        self.ll.add_(part.sum(-2))
+            else:
+                for wk in self.work[1:]:
+                    self.ll.add_(wk["ll"])     # log p(x) = sum over independent components
             if self.n_stacked > 1:
                 torch.sum(self._ll_stacked.view(self.n_stacked, *self.ll.shape), dim=0, out=self.ll)
         return self.ll
@@ -137,6 +178,17 @@ class LogLikelihoodPlan:
         for wk in self.work:                       # components may run on different streams
             wk["ev"][3].synchronize()
         return tuple(sum(wk["ev"][i].elapsed_ms(wk["ev"][i + 1]) for wk in self.work) for i in range(3))
+
+
+def _trial_stack(x, cols_list):
+    """Data columns of G identical components as G*n trials of one system: x[(B,) n, T+1, d] -> [(B,) G*n, T+1, d_c],
+    re-laid so that the system index (or, without one, the trial index) is the fastest-varying one in HBM."""
+    comps = [x[..., c] for c in cols_list]
+    st = torch.stack(comps, dim=-4)                                   # [(B,) G, n, T+1, d_c]
+    st = st.reshape(*st.shape[:-4], st.shape[-4] * st.shape[-3], *st.shape[-2:])
+    if st.dim() == 4:
+        return st.permute(1, 2, 3, 0).contiguous().permute(3, 0, 1, 2)    # storage [G*n][T+1][d_c][B]
+    return st.permute(1, 2, 0).contiguous().permute(2, 0, 1)              # storage [T+1][d_c][G*n]
 
 
 def _stack_components(parts, x):

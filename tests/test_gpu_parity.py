@@ -201,12 +201,52 @@ def test_stacked_plan_equals_separate_components():
     from lqg_amd.plan import LogLikelihoodPlan
     sys_, _ = workload.headline_system(1000, 80, seed=3, device="cuda", dtype=torch.float64)
     x = workload.pack_trials(workload.simulate_one_trial_each(sys_, seed=4))
-    a = LogLikelihoodPlan(sys_, x).run().clone()
-    plan = LogLikelihoodPlan(sys_, x, stack=True)
+    a = LogLikelihoodPlan(sys_, x, merge=False).run().clone()
+    plan = LogLikelihoodPlan(sys_, x, stack=True, merge=False)
     assert plan.n_stacked == 2 and len(plan.work) == 1
     b = plan.run()
     assert a.shape == b.shape == (1000, 1)
     assert float((a / b - 1).abs().max()) < 1e-13
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 2e-6)], ids=["f64", "f32"])
+@pytest.mark.parametrize("n_trials", [1, 3])
+def test_identical_components_are_solved_once(dtype, tol, n_trials):
+    """Both axes of a dim=2 zoo model are the SAME 1-D system (shared parameters): the plan solves it once with the
+    axes as trials (two in-lane trials for one trajectory, the operator stream for more) == separate components."""
+    from lqg_amd import workload
+    from lqg_amd.plan import LogLikelihoodPlan
+    sys_, _ = workload.headline_system(96, 80, seed=33, device="cuda", dtype=dtype)
+    with torch.no_grad():
+        x = sys_.simulate(6, n=n_trials)[..., :4].contiguous()
+    sep = LogLikelihoodPlan(sys_, x, merge=False).run().clone()
+    plan = LogLikelihoodPlan(sys_, x)
+    assert plan.merged == [2] and len(plan.work) == 1 and plan.work[0]["n"] == 2 * n_trials
+    got = plan.run()
+    assert got.shape == sep.shape == (96, n_trials)
+    assert relerr(np_(got), np_(sep)) < tol
+    assert relerr(np_(sys_.log_likelihood(x)), np_(sep)) < tol          # the default path of System.log_likelihood
+    xs = x[0]                                                           # trials shared by all systems ([n, T+1, d])
+    assert relerr(np_(LogLikelihoodPlan(sys_, xs).run()), np_(LogLikelihoodPlan(sys_, xs, merge=False).run())) < tol
+
+
+def test_components_with_different_parameters_are_not_merged():
+    """The merge is decided from the DATA for non-zoo systems: same structure, one axis with a different noise level."""
+    import lqg_amd
+    from lqg_amd.plan import LogLikelihoodPlan
+    m = lqg_amd.SubjectiveActor(dim=2, T=60, device="cuda", dtype=torch.float64)
+    twin = lqg_amd.System(actor=m.actor, dynamics=m.dynamics)           # plain System: grouping decided from the data
+    with torch.no_grad():
+        x = m.simulate(3, n=2)
+    assert LogLikelihoodPlan(twin, x).merged == [2]
+    W0 = m.actor.W[0].clone()
+    W0[2, 2] *= 1.7                                                      # the second axis sees the target more noisily
+    W = W0.expand(60, 4, 4)                                              # still time-invariant (stride-0 time axis)
+    odd = lqg_amd.System(actor=m.actor._replace(W=W), dynamics=m.dynamics._replace(W=W))
+    plan = LogLikelihoodPlan(odd, x)
+    assert plan.merged == [] and len(plan.work) == 2
+    joint = LogLikelihoodPlan(odd, x, merge=False).run().clone()
+    assert relerr(np_(plan.run()), np_(joint)) < 1e-13
 
 
 def test_decoupling_with_interleaved_observed_dims(monkeypatch):
