@@ -175,7 +175,9 @@ def main():
             key = f"{'k_forward_sp' if sp_all else 'k_forward'}_x{n_launch}_{args.dtype}_log2B{args.log2_batch}"
             if plan.n_stacked > 1:
                 key = f"k_forward_sp_stacked{plan.n_stacked}_{args.dtype}_log2B{args.log2_batch}"
-            if n_launch == 1 and key not in pj:
+            if plan.merged and max(plan.merged) > 1:
+                key = f"k_forward_sp_merged{max(plan.merged)}_{args.dtype}_log2B{args.log2_batch}"
+            elif n_launch == 1 and key not in pj and not sp_all:
                 key = f"k_forward_{args.dtype}_log2B{args.log2_batch}"
             rec = pj.get(key, {})
             traffic = rec.get("hbm_bytes_per_launch")
@@ -294,7 +296,7 @@ def main():
                                       "~20x fewer, so this frac exceeds 1 - `executed.valu_issue_frac` is the utilisation"},
                      "note": "M1 is VALU-issue-bound, not HBM- or MFMA-bound (MFMA deliberately unused: contractions are "
                              "<= 6x6 per lane). traffic > algorithmic bytes because the control gains L_t travel from the "
-                             "backward to the forward sweep through HBM (12 kB/solve), which M1's figure does not count"},
+                             "backward to the forward sweep through HBM (6 kB/solve), which M1's figure does not count"},
         "cpu_baseline": cpu, "parity": parity, "all_finite": finite,
         "objective_sum": float(total.item()),
     }
