@@ -80,3 +80,26 @@ def test_connected_graph_is_not_split():
     dims, masks, _ = _assemble(rng, [(2, 2, 1, 1), (2, 2, 1, 1)], [1, 1])
     masks["Q"][0, dims["b"] - 1] = masks["Q"][dims["b"] - 1, 0] = True       # a cost term couples the two beliefs
     assert components_from_masks(dims, masks) is None
+
+
+def test_identical_components_are_grouped_from_class_or_data():
+    """decouple.identical_groups: both axes of a dim=2 zoo model are one 1-D system (grouped); a plain System with the same
+    specs is grouped from the data; changing one axis' parameter un-groups it; an explicit Sigma0 disables merging."""
+    import torch
+    import lqg_amd
+    from lqg_amd import decouple
+    m = lqg_amd.SubjectiveActor(dim=2, T=12, device="cpu", dtype=torch.float64)
+    parts = m.decoupled(4)
+    assert parts is not None and len(parts) == 2
+    assert decouple.identical_groups(m, 4, parts) == [[0, 1]]
+    twin = lqg_amd.System(actor=m.actor, dynamics=m.dynamics)
+    assert decouple.identical_groups(twin, 4, twin.decoupled(4)) == [[0, 1]]
+    W0 = m.actor.W[0].clone()
+    W0[3, 3] *= 2.0
+    W = W0.expand(12, 4, 4)
+    odd = lqg_amd.System(actor=m.actor._replace(W=W), dynamics=m.dynamics._replace(W=W))
+    assert decouple.identical_groups(odd, 4, odd.decoupled(4)) == [[0], [1]]
+    S0 = torch.eye(6, dtype=torch.float64)
+    assert decouple.identical_groups(m, 4, parts, Sigma0=S0) == [[0], [1]]
+    one = lqg_amd.BoundedActor(dim=1, T=12, device="cpu")
+    assert one.decoupled(2) is None and decouple.identical_groups(one, 2, None) == []
