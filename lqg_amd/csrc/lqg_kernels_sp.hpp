@@ -84,10 +84,33 @@ __global__ void __launch_bounds__(LQG_BLOCK, LQG_SP_RIC_WAVES) k_riccati_sp(cons
 }
 
 // ---------------------------------------------------------------- forward sweep, TI, log-likelihood only
+// Structural mask of the loop-carried Kalman covariance P_t: the least fixed point of the mask recursion of kf.py:10-14
+// started from mask(V V^T) (the default Sigma0).  For the tracking models the cursor state is filtered independently of
+// (target, velocity): P keeps 2 structural zeros, F P F' + W W' is DIAGONAL (inverted without a Cholesky), K has 3 of 6
+// entries, and the sparsity propagates into the joint system and G G^T through the mask algebra.  DENSE (an explicit
+// Sigma0 is supplied at run time): the mask is full.
+template <typename PAT, int NB, int NY, bool DENSE>
+constexpr Mask<NB, NB> kalman_state_mask() {
+  if (DENSE) return mask_full<NB, NB>();
+  Mask<NB, NB> P = mask_or(PAT::VVa, mask_t(PAT::VVa));
+  for (int it = 0; it <= NB * NB; ++it) {
+    const auto Pp = mask_or(mask_mul(mask_mul(PAT::Aa, P), mask_t(PAT::Aa)), PAT::VVa);
+    const auto FP = mask_mul(PAT::Fa, Pp);
+    const auto G = mask_or(mask_mul(FP, mask_t(PAT::Fa)), PAT::WWa);
+    const auto Gi = mask_is_diag(G) ? G : mask_full<NY, NY>();
+    const auto K = mask_mul(mask_t(FP), Gi);
+    auto Pn = mask_or(Pp, mask_mul(K, FP));
+    Pn = mask_or(mask_or(Pn, mask_t(Pn)), P);
+    if (mask_eq(Pn, P)) break;
+    P = Pn;
+  }
+  return P;
+}
+
 // NTR >= 1 (fused): the NTR trials of each system are swept in-lane (1: the headline; 2: two identical decoupled
 // components solved as ONE system with two trials, lqg_amd/plan.py); NTR == 0: the per-step trial operators are written
 // to the operator stream for k_trial (many trials per system), exactly as k_forward does.  ll_sn: trial stride of ll.
-template <typename R, int NX, int NB, int NU, int NY, int ND, typename PAT, int NTR>
+template <typename R, int NX, int NB, int NU, int NY, int ND, typename PAT, int NTR, bool DENSE_P>
 __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F32 : LQG_SP_FWD_WAVES_F64)
     k_forward_sp(const ForwardArgs<R> a, const long ll_sn) {
   constexpr bool FUSED = NTR > 0;
@@ -119,9 +142,15 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
     return Out{fad, db, n2, n3};
   }();
 
-  R P[NB * NB];
-  if (a.Sigma0.p) load_sym<R, NB>(a.Sigma0.p + s * a.Sigma0.sb, a.Sigma0.sr, a.Sigma0.sc, P);
-  else load_gram<R, NB>(a.aV.p + s * a.aV.sb, a.aV.sr, a.aV.sc, a.nva, P);
+  constexpr auto PMASK = kalman_state_mask<PAT, NB, NY, DENSE_P>();
+  Mat<R, NB, NB, PMASK> Pm;                     // loop-carried Kalman covariance, structural zeros in the type
+  {
+    R P0[NB * NB];
+    if (DENSE_P && a.Sigma0.p) load_sym<R, NB>(a.Sigma0.p + s * a.Sigma0.sb, a.Sigma0.sr, a.Sigma0.sc, P0);
+    else load_gram<R, NB>(a.aV.p + s * a.aV.sb, a.aV.sr, a.aV.sc, a.nva, P0);
+    LQG_UNROLL for (int i = 0; i < NB * NB; ++i)
+      if (PMASK.b[i]) Pm.v[i] = P0[i];
+  }
 
   R Sg[M * M], xprev[NT][O], dO[NT][O], muR[NT][RR];   // observed mean = xprev + dO (deviation form, see k_forward)
   double acc[NT];
@@ -169,17 +198,12 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
 
   for (int t = 0; t < a.T; ++t) {
     // ---- Kalman step                                                   kf.py:10-14
-    const auto Pm = from_dense<R, NB, NB>(P);
     const auto AP = mul(Aa, Pm);
     const auto Pp = mul_nt_sym_add(AP, Aa, VVa);
     const auto FP = mul(Fa, Pp);
-    R Gk[NY * NY], Lc[NY * NY], dinv[NY], Lt[NY * NY], Gi[NY * NY];
-    to_dense(mul_nt_sym_add(FP, Fa, WWa), Gk);
-    chol_lower<R, NY>(Gk, Lc, dinv);
-    tri_inverse_lower<R, NY>(Lc, dinv, Lt);
-    spd_inverse_from_tri<R, NY>(Lt, Gi);
-    const auto K = mul_tn(FP, from_dense<R, NY, NY>(Gi));                // K = (F Pp)^T Gk^-1
-    to_dense(sym_sub_mul(Pp, K, FP), P);                                 // P = Pp - K F Pp
+    const auto Gi = spd_inverse_masked(mul_nt_sym_add(FP, Fa, WWa));     // (F Pp F' + W W')^-1
+    const auto K = mul_tn(FP, Gi);                                       // K = (F Pp)^T Gk^-1
+    assign_state(Pm, sym_sub_mul(Pp, K, FP));                            // P = Pp - K F Pp
     // ---- control gain L_t
     Mat<R, NU, NB> L;
     {

@@ -44,9 +44,14 @@ int run_sp(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll_sn, v
                           dv<R>(p->Sigma0), Ls, w.ldb, dt<R>(x), static_cast<R*>(ll), ll_sb, ops, dv<R>(none),
                           dt<R>(no_traj), dv<R>(none), (long)p->n_sys, p->T,
                           p->dims.nva, p->dims.nwa, p->dims.nvd, p->dims.nwd};
-    if (p->n_trials == 1) hipLaunchKernelGGL((lqg::k_forward_sp<R, NX, NB, NU, NY, ND, PAT, 1>), grid, block, 0, st, k, ll_sn);
-    else if (p->n_trials == 2) hipLaunchKernelGGL((lqg::k_forward_sp<R, NX, NB, NU, NY, ND, PAT, 2>), grid, block, 0, st, k, ll_sn);
-    else hipLaunchKernelGGL((lqg::k_forward_sp<R, NX, NB, NU, NY, ND, PAT, 0>), grid, block, 0, st, k, ll_sn);
+    // DENSE_P: an explicit Sigma0 may be dense, so the Kalman covariance cannot carry the structural mask derived from V V'
+#define LQG_SP_FWD(NTR_, DP_) \
+  hipLaunchKernelGGL((lqg::k_forward_sp<R, NX, NB, NU, NY, ND, PAT, NTR_, DP_>), grid, block, 0, st, k, ll_sn)
+    const bool dense_p = p->Sigma0.ptr != nullptr;
+    if (p->n_trials == 1) { if (dense_p) LQG_SP_FWD(1, true); else LQG_SP_FWD(1, false); }
+    else if (p->n_trials == 2) { if (dense_p) LQG_SP_FWD(2, true); else LQG_SP_FWD(2, false); }
+    else { if (dense_p) LQG_SP_FWD(0, true); else LQG_SP_FWD(0, false); }
+#undef LQG_SP_FWD
   }
   mark(2);
   if (!fused) {   // several trials per system: the generic per-trial sweep over the operator stream

@@ -88,6 +88,20 @@ constexpr Mask<M, NC> mask_cols(const Mask<M, N>& a) {
   return r;
 }
 
+template <int N>
+constexpr bool mask_is_diag(const Mask<N, N>& a) {
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j)
+      if (i != j && a(i, j)) return false;
+  return true;
+}
+template <int M, int N>
+constexpr bool mask_eq(const Mask<M, N>& a, const Mask<M, N>& b) {
+  for (int i = 0; i < M * N; ++i)
+    if (a.b[i] != b.b[i]) return false;
+  return true;
+}
+
 template <typename R, int M, int N, Mask<M, N> MK = mask_full<M, N>()>
 struct Mat {
   R v[M * N];
@@ -318,6 +332,43 @@ LQG_DEV auto cols(const Mat<R, M, N, MK>& a) {
     LQG_UNROLL for (int j = 0; j < NC; ++j) if (MR(i, j)) r.v[i * NC + j] = a.v[i * N + C0 + j];
   return r;
 }
+// reciprocal: hardware estimate + Newton steps (the IEEE division expands to ~10 instructions)
+template <typename R> LQG_DEV R rcp_(R v);
+template <> LQG_DEV float rcp_<float>(float v) {
+  float r = __builtin_amdgcn_rcpf(v);
+  return r * (2.0f - v * r);
+}
+template <> LQG_DEV double rcp_<double>(double v) {
+  double r = __builtin_amdgcn_rcp(v);
+  r = r * (2.0 - v * r);
+  return r * (2.0 - v * r);
+}
+// inverse of a symmetric positive-definite matrix: a structurally DIAGONAL one is inverted entry by entry (and stays
+// diagonal in the type), anything else goes through the dense Cholesky kernels
+template <typename R, int N, Mask<N, N> MK>
+LQG_DEV auto spd_inverse_masked(const Mat<R, N, N, MK>& a) {
+  if constexpr (mask_is_diag(MK)) {
+    Mat<R, N, N, MK> r;
+    LQG_UNROLL for (int i = 0; i < N; ++i)
+      if (MK(i, i)) r.v[i * N + i] = rcp_<R>(a.v[i * N + i]);
+    return r;
+  } else {
+    R G[N * N], Lc[N * N], dinv[N], Lt[N * N], Gi[N * N];
+    to_dense(a, G);
+    chol_lower<R, N>(G, Lc, dinv);
+    tri_inverse_lower<R, N>(Lc, dinv, Lt);
+    spd_inverse_from_tri<R, N>(Lt, Gi);
+    return from_dense<R, N, N>(Gi);
+  }
+}
+// assign into a loop-carried matrix of FIXED mask MD (a fixed point of the recursion: the result's mask is a subset)
+template <typename R, int M, int N, Mask<M, N> MD, Mask<M, N> MS>
+LQG_DEV void assign_state(Mat<R, M, N, MD>& dst, const Mat<R, M, N, MS>& src) {
+  static_assert(mask_eq(mask_or(MD, MS), MD), "loop-carried mask is not a fixed point of the recursion");
+  LQG_UNROLL for (int i = 0; i < M * N; ++i)
+    if (MD.b[i]) dst.v[i] = MS.b[i] ? src.v[i] : R(0);
+}
+
 // y = A x with dense vectors
 template <typename R, int M, int N, Mask<M, N> MK>
 LQG_DEV void matvec_acc(const Mat<R, M, N, MK>& a, const R (&x)[N], R (&y)[M]) {
