@@ -10,6 +10,9 @@
 //
 // Reference parity: lqg/control/lqr.py:16-42, lqg/belief/kf.py:6-21, lqg/system.py:167-248 (as lqg_kernels.hpp).
 #pragma once
+#ifndef LQG_SP_PREFETCH
+#define LQG_SP_PREFETCH 1
+#endif
 #include "lqg_kernels.hpp"
 #include "lqg_sparse.hpp"
 
@@ -183,9 +186,23 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
       }
   };
   R w[O], xt[O];
+#if LQG_SP_PREFETCH
+  // software pipeline of the two per-step HBM streams: the rows of step t+1 are requested at the top of step t
+  R xnx[NT][O], Lnx[NU * NB];
+  if (FUSED) {
+    LQG_UNROLL for (int k = 0; k < NT; ++k)
+      LQG_UNROLL for (int i = 0; i < O; ++i) xnx[k][i] = xprev[k][i];
+  }
+  LQG_UNROLL for (int e = 0; e < NU * NB; ++e) Lnx[e] = a.Ls[e * a.ldb + s];
+#endif
   auto innovate = [&](int n, int row, bool score) {        // trial n, data row `row`
+#if LQG_SP_PREFETCH
+    (void)row;
+    LQG_UNROLL for (int i = 0; i < O; ++i) xt[i] = xnx[n][i];
+#else
     const R* xr = xp + n * a.x.sn + (long)row * a.x.st;
     LQG_UNROLL for (int i = 0; i < O; ++i) xt[i] = xr[i * a.x.sd];
+#endif
     R zz = R(0);
     LQG_UNROLL for (int i = 0; i < O; ++i) {
       R v = R(0);
@@ -206,10 +223,14 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
     assign_state(Pm, sym_sub_mul(Pp, K, FP));                            // P = Pp - K F Pp
     // ---- control gain L_t
     Mat<R, NU, NB> L;
+#if LQG_SP_PREFETCH
+    LQG_UNROLL for (int e = 0; e < NU * NB; ++e) L.v[e] = Lnx[e];
+#else
     {
       const R* src = a.Ls + (long)t * (NU * NB) * a.ldb + s;
       LQG_UNROLL for (int e = 0; e < NU * NB; ++e) L.v[e] = src[e * a.ldb];
     }
+#endif
     // ---- joint dynamics                                                system.py:167-187
     const auto BK = add(Ba, mul(K, DB));
     const auto Fj = block2x2(Ad, mul(Bd, L), mul(K, FAd), add(sub(Aa, mul(K, FAa)), mul(BK, L)));
@@ -266,6 +287,20 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
         C.v[q * RR + p] = v;
       }
     const auto F2 = cols<O, RR>(Fj);
+#if LQG_SP_PREFETCH
+    {   // requests for step t+1 (row t+1 of x always exists; the last step re-reads its own gain row), issued BEFORE the
+        // Sigma update below so that ~100 FMAs stand between the loads and the loop back-edge
+      const int tn = (t + 1 < a.T) ? t + 1 : t;
+      const R* src = a.Ls + (long)tn * (NU * NB) * a.ldb + s;
+      LQG_UNROLL for (int e = 0; e < NU * NB; ++e) Lnx[e] = src[e * a.ldb];
+      if (FUSED) {
+        LQG_UNROLL for (int k = 0; k < NT; ++k) {
+          const R* xr = xp + k * a.x.sn + (long)(t + 1) * a.x.st;
+          LQG_UNROLL for (int i = 0; i < O; ++i) xnx[k][i] = xr[i * a.x.sd];
+        }
+      }
+    }
+#endif
     to_dense(mul_nt_sym_add(mul(F2, C), F2, GG), Sg);
   }
   condition();
