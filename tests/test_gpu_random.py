@@ -130,3 +130,27 @@ def test_temporal_delay_model_on_the_hip_path(oracle_lib, dtype, tol):
     big = DelayedSubjectiveActor(T=20, device="cuda", dtype=dtype)
     with pytest.raises(RuntimeError, match="outside the dims"):
         big.log_likelihood(torch.zeros(1, 21, 2, device="cuda", dtype=dtype))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 2e-6)], ids=["f64", "f32"])
+@pytest.mark.parametrize("ctor,kw,d", [("SubjectiveActor", dict(dim=1), 2), ("BoundedActor", dict(dim=1), 2),
+                                       ("SubjectiveActor", dict(dim=2), 4), ("PointMassBoundedActor", {}, 2)])
+def test_explicit_dense_sigma0_on_the_specialised_path(oracle_lib, ctor, kw, d, dtype, tol):
+    """An explicit (dense) Sigma0 selects the DENSE_P variant of the specialised forward kernel — the Kalman covariance
+    cannot carry the structural mask derived from V V' — for one, two and several trials; against the fp64 oracle."""
+    m = getattr(lqg_amd, ctor)(T=70, device="cuda", dtype=dtype, **kw)
+    b = m.bdim
+    rng = np.random.default_rng(5)
+    M = rng.standard_normal((b, b))
+    S0 = M @ M.T / b + 0.5 * np.eye(b)                                  # dense: couples every belief state
+    S0t = torch.as_tensor(S0, dtype=dtype, device="cuda")
+    with torch.no_grad():
+        x = m.simulate(8, n=5)[..., :d].contiguous()
+    act = {f: getattr(m.actor, f).double().cpu().numpy().copy() for f in O.FIELDS}
+    dyn = {f: getattr(m.dynamics, f).double().cpu().numpy().copy() for f in O.FIELDS}
+    ref = oracle_lib.log_likelihood(act, dyn, x.double().cpu().numpy(), S0)
+    for n in (1, 2, 5):
+        got = np_(m.log_likelihood(x[:n], Sigma0=S0t))
+        assert np.abs(got - ref[:n]).max() < tol * np.abs(ref).max(), n
+    assert np.abs(np_(m.log_likelihood(x)) - oracle_lib.log_likelihood(act, dyn, x.double().cpu().numpy())).max() \
+        < tol * np.abs(ref).max()                                       # and the default Sigma0 = V V' on the same data
