@@ -144,9 +144,17 @@ class System:
         new.__dict__.update(self.__dict__)
         new.__dict__.pop("_lqg_decouple", None)      # cached sub-systems hold tensors of the old dtype / device
         same = self.actor is self.dynamics
-        new.actor = conv(self.actor)
-        new.dynamics = new.actor if same else conv(self.dynamics)
+        new.__dict__["actor"] = conv(self.actor)     # (not through __setattr__: a cast keeps the structure)
+        new.__dict__["dynamics"] = new.__dict__["actor"] if same else conv(self.dynamics)
         return new
+
+    def __setattr__(self, name, value):
+        """Replacing a spec AFTER construction voids everything derived from the old one: the class-level structure of a
+        zoo model (sparsity pattern, identical axes) and the cached decoupling / specialisation decisions."""
+        if name in ("actor", "dynamics") and name in self.__dict__:
+            for k in ("_zoo_structure", "_lqg_decouple", "_lqg_patterns", "_lqg_groups"):
+                self.__dict__.pop(k, None)
+        object.__setattr__(self, name, value)
 
     # ---- simulation (lqg/system.py:62-140)
     def simulate(self, rng_key=None, n=1, x0=None, xhat0=None, Sigma0=None, return_all=False):

@@ -103,3 +103,22 @@ def test_identical_components_are_grouped_from_class_or_data():
     assert decouple.identical_groups(m, 4, parts, Sigma0=S0) == [[0], [1]]
     one = lqg_amd.BoundedActor(dim=1, T=12, device="cpu")
     assert one.decoupled(2) is None and decouple.identical_groups(one, 2, None) == []
+
+
+def test_replacing_a_spec_voids_the_class_level_structure():
+    """A zoo model whose spec is swapped after construction must not keep its class-derived pattern / identical-axes
+    decision (they would be silently wrong for the new spec)."""
+    import torch
+    import lqg_amd
+    from lqg_amd import decouple
+    m = lqg_amd.SubjectiveActor(dim=2, T=12, device="cpu", dtype=torch.float64)
+    assert decouple.identical_groups(m, 4, m.decoupled(4)) == [[0, 1]] and hasattr(m, "_zoo_structure")
+    W0 = m.actor.W[0].clone()
+    W0[3, 3] *= 2.0
+    W = W0.expand(12, 4, 4)
+    m.actor = m.actor._replace(W=W)
+    m.dynamics = m.dynamics._replace(W=W)
+    assert not hasattr(m, "_zoo_structure") and "_lqg_decouple" not in m.__dict__
+    assert decouple.identical_groups(m, 4, m.decoupled(4)) == [[0], [1]]
+    m64 = lqg_amd.BoundedActor(dim=2, T=5, device="cpu").to(torch.float64)          # a cast keeps the structure
+    assert hasattr(m64, "_zoo_structure") and m64.actor.A.dtype == torch.float64
