@@ -30,6 +30,9 @@
 #define LQG_BLOCK 64
 #endif
 // minimum waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument)
+#ifndef LQG_TRIAL_OPS_PREFETCH
+#define LQG_TRIAL_OPS_PREFETCH 1
+#endif
 #ifndef LQG_TRIAL_PREFETCH
 #define LQG_TRIAL_PREFETCH 1
 #endif
@@ -561,10 +564,25 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial(const R* __restrict__ ops_a
       LQG_UNROLL for (int i = 0; i < O; ++i) xq[k][j][i] = xr[k][row * a.x.st + i * a.x.sd];
     }
 #endif
+  // Double-buffered operator block: step t+1's block is requested (scalar loads) while step t computes.  Only when both
+  // blocks fit comfortably in SGPRs (<= 32 dwords per block: n=2 models in fp32 — config 3: 5.1 -> 4.5 ms); larger blocks
+  // spill and lose (m=5 in fp64: 3.2 -> 3.9 ms).
+  constexpr bool PF = LQG_TRIAL_OPS_PREFETCH && (Ops::N * (int)(sizeof(R) / 4) <= 32);
+  constexpr int NPF = PF ? Ops::N : 1;
+  R opn[NPF], opc[NPF];
+  if (PF) {
+    LQG_UNROLL for (int i = 0; i < NPF; ++i) opn[i] = op[i];
+  }
   for (int t = 0; t <= a.T; ++t) {
+    if (PF) {
+      LQG_UNROLL for (int i = 0; i < NPF; ++i) opc[i] = opn[i];
+      const R* __restrict__ nx = op + ((t < a.T) ? Ops::N : 0);
+      LQG_UNROLL for (int i = 0; i < NPF; ++i) opn[i] = nx[i];
+    }
+#define LQG_OP(i_) (PF ? opc[PF ? (i_) : 0] : op[i_])
     R Li[O * (O + 1) / 2];
-    LQG_UNROLL for (int i = 0; i < O * (O + 1) / 2; ++i) Li[i] = op[Ops::L_OFF + i];
-    const R hlc = op[Ops::H_OFF];
+    LQG_UNROLL for (int i = 0; i < O * (O + 1) / 2; ++i) Li[i] = LQG_OP(Ops::L_OFF + i);
+    const R hlc = LQG_OP(Ops::H_OFF);
     const bool flush = ((t & (kAccChunk - 1)) == 0) || t == a.T;
     LQG_UNROLL for (int k = 0; k < TPL; ++k) {
       R xt[O], w[O];
@@ -596,14 +614,14 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial(const R* __restrict__ ops_a
         R c[RR];
         LQG_UNROLL for (int p = 0; p < RR; ++p) {
           R v = muR[k][p];
-          LQG_UNROLL for (int j = 0; j < O; ++j) v += op[Ops::U_OFF + p * O + j] * w[j];
+          LQG_UNROLL for (int j = 0; j < O; ++j) v += LQG_OP(Ops::U_OFF + p * O + j) * w[j];
           c[p] = v;
         }
         R mn[M];
         LQG_UNROLL for (int i = 0; i < M; ++i) {
           R v = R(0);
-          LQG_UNROLL for (int j = 0; j < O; ++j) v += op[Ops::F_OFF + i * M + j] * xt[j];
-          LQG_UNROLL for (int p = 0; p < RR; ++p) v += op[Ops::F_OFF + i * M + O + p] * c[p];
+          LQG_UNROLL for (int j = 0; j < O; ++j) v += LQG_OP(Ops::F_OFF + i * M + j) * xt[j];
+          LQG_UNROLL for (int p = 0; p < RR; ++p) v += LQG_OP(Ops::F_OFF + i * M + O + p) * c[p];
           mn[i] = v;
         }
         LQG_UNROLL for (int i = 0; i < O; ++i) { dO[k][i] = mn[i]; xprev[k][i] = xt[i]; }
@@ -616,6 +634,7 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial(const R* __restrict__ ops_a
       }
     }
     op += Ops::N;
+#undef LQG_OP
   }
   if (a.ll) {
     LQG_UNROLL for (int k = 0; k < TPL; ++k)
