@@ -154,3 +154,30 @@ def test_explicit_dense_sigma0_on_the_specialised_path(oracle_lib, ctor, kw, d, 
         assert np.abs(got - ref[:n]).max() < tol * np.abs(ref).max(), n
     assert np.abs(np_(m.log_likelihood(x)) - oracle_lib.log_likelihood(act, dyn, x.double().cpu().numpy())).max() \
         < tol * np.abs(ref).max()                                       # and the default Sigma0 = V V' on the same data
+
+
+@pytest.mark.parametrize("ctor,dim,names", [
+    ("BoundedActor", 1, ("action_variability", "action_cost", "sigma_target", "sigma_cursor")),
+    ("BoundedActor", 2, ("action_variability", "action_cost", "sigma_target", "sigma_cursor")),
+    ("OptimalActor", 2, ("action_variability", "sigma_target", "sigma_cursor")),
+    ("RelativeObservationBoundedActor", 2, ("action_variability", "sigma", "action_cost")),
+    ("SubjectiveActor", 1, ("action_variability", "action_cost", "subj_noise", "subj_vel_noise", "sigma_target", "sigma_cursor")),
+    ("SubjectiveActor", 2, ("action_variability", "action_cost", "subj_noise", "subj_vel_noise", "sigma_target", "sigma_cursor")),
+])
+def test_zoo_models_over_wide_parameter_ranges(oracle_lib, ctor, dim, names):
+    """Every structural shortcut of the default path (class-level sparsity pattern, decoupling, identical axes solved once,
+    loop-carried Kalman mask) on 48 candidates drawn log-uniformly over four decades, fp64, against the literal C oracle."""
+    rng = np.random.default_rng(sum(map(ord, ctor)) * 10 + dim)            # deterministic per case
+    C_ = 48
+    cand = {k: torch.as_tensor(10.0 ** rng.uniform(-1.5, 2.0, C_), dtype=torch.float64, device="cuda") for k in names}
+    m = getattr(lqg_amd, ctor)(dim=dim, T=60, device="cuda", dtype=torch.float64, **cand)
+    d = 2 * dim
+    with torch.no_grad():
+        x = m.simulate(17, n=2)[..., :d].contiguous()                  # [C, 2, T+1, d]
+    ll = np_(m.log_likelihood(x))
+    assert ll.shape == (C_, 2) and np.isfinite(ll).all()
+    F = O.FIELDS
+    host = lambda spec: {f: (getattr(spec, f) if getattr(spec, f).dim() == (3 if f in ("Qf",) else (2 if f == "qf" else (3 if f in ("q", "r") else 4)))
+                             else getattr(spec, f).expand(C_, *getattr(spec, f).shape)).double().cpu().numpy().copy() for f in F}
+    ref = oracle_lib.log_likelihood(host(m.actor), host(m.dynamics), x.cpu().numpy())
+    assert np.abs(ll / ref - 1).max() < 1e-9
