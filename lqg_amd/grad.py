@@ -184,9 +184,25 @@ def log_likelihood(system, x, Sigma0=None):
     parts = system.decoupled(d, Sigma0)
     if parts is None:
         return _one(system, x, Sigma0)
+    # Identical axes of a ZOO model are one system observed on several data columns: one sweep with the axes as trials.
+    # Only for the exact zoo classes — there every block is the same FUNCTION of the parameters by construction, so
+    # routing all of the gradient through the first block's entries is exact; components of an arbitrary System that merely
+    # hold equal values may depend on different leaves and are differentiated one by one.
+    import lqg_amd
+    from lqg_amd import decouple
+    from lqg_amd.plan import _trial_stack
+    zoo = (lqg_amd.BoundedActor, lqg_amd.OptimalActor, lqg_amd.RelativeObservationBoundedActor, lqg_amd.SubjectiveActor)
+    by_class = type(system) in zoo and getattr(system, "_zoo_structure", None) is not None and Sigma0 is None
+    groups = decouple.identical_groups(system, d, parts, Sigma0) if by_class else [[i] for i in range(len(parts))]
     total = None
-    for sub, cols, bs in parts:
-        S0 = None if Sigma0 is None else Sigma0[..., bs, :][..., :, bs]
-        ll = _one(sub, x[..., cols].contiguous(), S0)
+    for g in groups:
+        sub, cols, bs = parts[g[0]]
+        if len(g) > 1:
+            xm = _trial_stack(x, [parts[i][1] for i in g])                  # [(B,) G*n, T+1, d_c]
+            ll = _one(sub, xm, None)
+            ll = ll.view(*ll.shape[:-1], len(g), -1).sum(-2)
+        else:
+            S0 = None if Sigma0 is None else Sigma0[..., bs, :][..., :, bs]
+            ll = _one(sub, x[..., cols].contiguous(), S0)
         total = ll if total is None else total + ll
     return total
