@@ -213,7 +213,9 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
     if (score) acc[n] -= (double)(R(0.5) * zz + hl + kLogNorm);
   };
 
-  for (int t = 0; t < a.T; ++t) {
+  // The first step is peeled (templated lambda): it alone initialises Sigma := G_0 G_0^T and skips the score of x_0;
+  // inside one loop the compiler turns those two `t == 0` tests into ~30 v_cndmask per step.
+  auto step = [&]<bool FIRST>(int t) {
     // ---- Kalman step                                                   kf.py:10-14
     const auto AP = mul(Aa, Pm);
     const auto Pp = mul_nt_sym_add(AP, Aa, VVa);
@@ -237,12 +239,12 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
     // ---- joint noise covariance                                        system.py:190-207
     const auto KN2 = mul(K, N2);
     const auto GG = block2x2(N1, transpose(KN2), KN2, mul_nt_sym_add(mul(K, N3), K, Mat<R, NB, NB, mask_none<NB, NB>()>{}));
-    if (t == 0) to_dense(GG, Sg);                                        // Sigma0 := G[0] G[0]^T  system.py:212
+    if constexpr (FIRST) to_dense(GG, Sg);                               // Sigma0 := G[0] G[0]^T  system.py:212
     // ---- condition on x_t, score it, propagate the mean                system.py:219-221, 244-248
     condition();
     if (FUSED) {
       LQG_UNROLL for (int n = 0; n < NT; ++n) {
-        innovate(n, t, t > 0);
+        innovate(n, t, !FIRST);
         R cvec[M];
         LQG_UNROLL for (int j = 0; j < O; ++j) cvec[j] = xt[j];
         LQG_UNROLL for (int p = 0; p < RR; ++p) {
@@ -251,24 +253,13 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
           cvec[O + p] = v;
         }
         R mn[M];
-        LQG_UNROLL for (int i = 0; i < M; ++i) {               // rows < O as deviation from x_t: ((Fj - I) cvec)[i]
-          R v = R(0);
-          LQG_UNROLL for (int j = 0; j < M; ++j) {
-            if (i < O && i == j) v += (Fj.mask(i, i) ? Fj.v[i * M + i] - R(1) : R(-1)) * cvec[j];
-            else if (Fj.mask(i, j)) v += Fj.v[i * M + j] * cvec[j];
-          }
-          mn[i] = v;
-        }
+        dev_matvec_row<O, 0>(Fj, cvec, mn);                    // rows < O as deviation from x_t: ((Fj - I) cvec)[i]
         LQG_UNROLL for (int i = 0; i < O; ++i) { dO[n][i] = mn[i]; xprev[n][i] = xt[i]; }
         LQG_UNROLL for (int p = 0; p < RR; ++p) muR[n][p] = mn[O + p];
       }
     } else {
       R* op = a.ops + ((long)s * (a.T + 1) + t) * Ops::N;
-      LQG_UNROLL for (int i = 0; i < M; ++i)
-        LQG_UNROLL for (int j = 0; j < M; ++j) {
-          const R f = Fj.mask(i, j) ? Fj.v[i * M + j] : R(0);
-          op[Ops::F_OFF + i * M + j] = (i < O && i == j) ? f - R(1) : f;
-        }
+      store_dev_dense<O, 0>(Fj, op + Ops::F_OFF);
       LQG_UNROLL for (int i = 0; i < RR * O; ++i) op[Ops::U_OFF + i] = U2[i];
       {
         int e = 0;
@@ -302,7 +293,9 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
     }
 #endif
     to_dense(mul_nt_sym_add(mul(F2, C), F2, GG), Sg);
-  }
+  };
+  step.template operator()<true>(0);
+  for (int t = 1; t < a.T; ++t) step.template operator()<false>(t);
   condition();
   if (FUSED) {
     LQG_UNROLL for (int n = 0; n < NT; ++n) {

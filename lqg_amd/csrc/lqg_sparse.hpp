@@ -361,12 +361,61 @@ LQG_DEV auto spd_inverse_masked(const Mat<R, N, N, MK>& a) {
     return from_dense<R, N, N>(Gi);
   }
 }
+// element I of assign_state, as a compile-time recursion so that both mask tests are `if constexpr` (inside an unrolled
+// loop the compiler left the mask bytes as run-time loads + v_cndmask)
+template <int I, typename R, int M, int N, Mask<M, N> MD, Mask<M, N> MS>
+LQG_DEV void assign_state_at(Mat<R, M, N, MD>& dst, const Mat<R, M, N, MS>& src) {
+  if constexpr (I < M * N) {
+    if constexpr (MD.b[I]) {
+      if constexpr (MS.b[I]) dst.v[I] = src.v[I];
+      else dst.v[I] = R(0);
+    }
+    assign_state_at<I + 1>(dst, src);
+  }
+}
 // assign into a loop-carried matrix of FIXED mask MD (a fixed point of the recursion: the result's mask is a subset)
 template <typename R, int M, int N, Mask<M, N> MD, Mask<M, N> MS>
 LQG_DEV void assign_state(Mat<R, M, N, MD>& dst, const Mat<R, M, N, MS>& src) {
   static_assert(mask_eq(mask_or(MD, MS), MD), "loop-carried mask is not a fixed point of the recursion");
-  LQG_UNROLL for (int i = 0; i < M * N; ++i)
-    if (MD.b[i]) dst.v[i] = MS.b[i] ? src.v[i] : R(0);
+  assign_state_at<0>(dst, src);
+}
+
+// y = (A - [[I_O, 0], [0, 0]]) x  (the deviation form of the mean update, lqg_kernels.hpp), every mask test resolved at
+// compile time by recursion over (row, column): inside unrolled loops the compiler left some of them as run-time loads of
+// the mask bytes followed by v_cndmask chains.
+template <int O, int I, int J, typename R, int M, Mask<M, M> MK>
+LQG_DEV void dev_matvec_term(const Mat<R, M, M, MK>& a, const R (&x)[M], R& v) {
+  if constexpr (J < M) {
+    if constexpr (I < O && I == J) {
+      if constexpr (MK.b[I * M + I]) v += (a.v[I * M + I] - R(1)) * x[J];
+      else v -= x[J];
+    } else if constexpr (MK.b[I * M + J]) {
+      v += a.v[I * M + J] * x[J];
+    }
+    dev_matvec_term<O, I, J + 1>(a, x, v);
+  }
+}
+template <int O, int I, typename R, int M, Mask<M, M> MK>
+LQG_DEV void dev_matvec_row(const Mat<R, M, M, MK>& a, const R (&x)[M], R (&y)[M]) {
+  if constexpr (I < M) {
+    R v = R(0);
+    dev_matvec_term<O, I, 0>(a, x, v);
+    y[I] = v;
+    dev_matvec_row<O, I + 1>(a, x, y);
+  }
+}
+
+// dense row-major image of A - [[I_O, 0], [0, 0]] at p (the operator stream's F block), masks resolved at compile time
+template <int O, int I, typename R, int M, Mask<M, M> MK>
+LQG_DEV void store_dev_dense(const Mat<R, M, M, MK>& a, R* __restrict__ p) {
+  if constexpr (I < M * M) {
+    constexpr int r = I / M, c = I % M;
+    R f = R(0);
+    if constexpr (MK.b[I]) f = a.v[I];
+    if constexpr (r < O && r == c) f -= R(1);
+    p[I] = f;
+    store_dev_dense<O, I + 1>(a, p);
+  }
 }
 
 // y = A x with dense vectors
