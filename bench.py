@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — LQG solves/sec (Riccati + Kalman + log-likelihood), n=6, T=500, on N MI355X.
 
-One "step" = one pass of the hot path (lqg_log_likelihood through the C ABI: k_riccati -> k_forward fused
+One "step" = one pass of the hot path (lqg_log_likelihood through the C ABI: Riccati sweep -> forward sweep fused
 with the per-trial density) over one batch of B independent (candidate, trajectory) pairs per GPU; inputs are
 resident in HBM before the timed region.  Workload = BASELINE.json headline / config 5 shape:
 SubjectiveActor(dim=2) (x=4, b=6, u=2, y=4, d=4), T=500, synthetic candidates, trajectories
@@ -9,28 +9,33 @@ simulated from the model.  Weak scaling: every rank owns B solves; the only coll
 the summed log-likelihood (the objective of lqg.infer / lqg.optim), issued once per step.
 
     python bench.py [--gpus N --steps K --warmup W --log2-batch 20 --dtype f32|f64]
+    python bench.py --gpus 8                 # bare: starts 8 ranks itself (torch.distributed.run), relays rank 0's line
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --config 3 [--gpus N]    # BASELINE config 3: 4096 candidates x 1024 trials, trial axis split
+                                             # over the ranks, all-reduce of the [4096] fp64 objective (strong scaling)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector == FP32 matrix (MFMA f32) peak
 PEAK_FP64_TFLOPS = 78.6    # datasheet FP64 vector == FP64 matrix peak
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+COPY_HBM_GBS = 6290.0      # MI355X_MICROARCH.md: measured device copy rate
+VALU_WAVE_INSTS_PER_S = 1024 * 2.4e9 / 2    # 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
 def algorithmic_flops_per_step(x, b, u, y, d):
     """flops of ONE time step of the reference's formulation (2mnk per matmul, no symmetry
-    exploitation, no hoisting) — the 'algorithmic' figure the roofline uses."""
+    exploitation, no hoisting) — the 'algorithmic' figure of the flop view."""
     m, o = x + b, d
     ric = (4 * u * b * b + 2 * u * u * b + 2 * u * b + 10.67 * u ** 3 + 2 * u * u * (b + 1) + 4 * b ** 3
            + 2 * u * u * b + 4 * u * b * b + 2 * b * b + 6 * u * b + 2 * u * u)
@@ -49,11 +54,13 @@ def algorithmic_bytes_per_solve(x, b, u, y, d, T, w):
     return w * ((T + 1) * d + (3 * b * b + b * u + y * b + y * y + u * u) + (2 * x * x + x * u + y * x + y * y) + 1)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=5, choices=[3, 5],
+                    help="5 = the headline (BASELINE metric); 3 = candidate search, trial axis split over the ranks")
     ap.add_argument("--log2-batch", type=int, default=20,
                     help="solves per GPU per step = 2**this (2^20: 14.7 GB resident; 2^18 fills each SIMD with exactly 4 waves "
                          "and runs ~12 %% slower per solve)")
@@ -62,53 +69,158 @@ def main():
     ap.add_argument("--layout", default="packed", choices=["packed", "reference"],
                     help="trajectory layout in HBM: packed = [T+1][d][B] (batch fastest), reference = [B][T+1][d]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary legs (fp64 headline, dense generic n=6)")
     ap.add_argument("--no-stack", action="store_true",
                     help="launch decoupled components separately instead of stacked into one launch")
     ap.add_argument("--cpu-sample", type=int, default=0, help="solves in the CPU baseline sample (0 = auto)")
-    args = ap.parse_args()
+    return ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1 or "RANK" in os.environ:      # under torchrun the collective path is exercised even at world == 1
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
 
-    import lqg_amd
-    from lqg_amd import _abi, _hip, _hipev, workload
+def launch_ranks(args):
+    """`python bench.py --gpus N` run bare: start N ranks as CHILD processes (one per GPU, torch.distributed.run) and
+    relay their output.  Nothing in this process has touched the GPU (no HIP call, no torch.cuda.is_available()), and it
+    never execs: it waits for the children and exits with their code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
 
-    dtype = torch.float32 if args.dtype == "f32" else torch.float64
-    w = 4 if args.dtype == "f32" else 8
-    B, T = 1 << args.log2_batch, args.T
-    lib = _abi.load()
 
-    # ---- synthetic workload, resident in HBM
-    system, params = workload.headline_system(B, T, seed=1234 + rank, device=dev, dtype=dtype)
-    dm = dict(x=system.xdim, b=system.bdim, u=system.udim, y=system.ydim, d=system.xdim)
-    x_ref = workload.simulate_one_trial_each(system, seed=99 + 7919 * rank)            # [B,1,T+1,d]
-    x = workload.pack_trials(x_ref) if args.layout == "packed" else x_ref
+def pmc_record(kernel, pattern_key, dtype, log2_batch):
+    """The PMC-derived HBM bytes / VALU instructions of `kernel`, but only if the committed profile was taken on
+    exactly these kernels: same library source hash, same sparsity-pattern library, dtype and batch."""
+    try:
+        from lqg_amd import build, specialize
+        pj = json.load(open(PMC_FILE))
+        for rec in pj.get("records", []):
+            if (rec.get("kernel") == kernel and rec.get("dtype") == dtype and rec.get("log2_batch") == log2_batch
+                    and rec.get("pattern_key") == pattern_key and rec.get("source_hash") == build.source_hash()
+                    and rec.get("sp_headers_hash") == specialize._headers_hash()):
+                return rec
+    except Exception:
+        pass
+    return None
+
+
+class Timer:
+    """Per-step durations on the launch stream without host synchronisation: one event pair per step."""
+
+    def __init__(self, torch, n):
+        self.ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+
+    def ms(self):
+        return [a.elapsed_time(b) for a, b in self.ev]
+
+
+def timed_steps(torch, dist, step, steps, warmup, before_step=None):
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+    out = None
+    for _ in range(warmup):
+        out = step()
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    tm = Timer(torch, steps)
+    t0 = time.perf_counter()
+    for it in range(steps):
+        if before_step is not None:
+            before_step(it)
+        tm.ev[it][0].record()
+        out = step()
+        tm.ev[it][1].record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    mine = time.perf_counter() - t0
+    elapsed, per_rank = mine, [mine]
+    if dist is not None:
+        t = torch.tensor([mine], dtype=torch.float64, device="cuda")
+        allt = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(allt, t)
+        per_rank = [float(v.item()) for v in allt]
+        elapsed = max(per_rank)
+    return out, elapsed, per_rank, tm.ms()
 
-    # The hot path exactly as lqg_amd.System.log_likelihood runs it (lqg_amd/plan.py), decided once:
-    # (1) if the model's interaction graph splits into independent components (every dim=2 zoo model is two 1-D
-    #     models) each component is solved on its own and the log-likelihoods add (lqg_amd/decouple.py;
-    #     LQG_NO_DECOUPLE=1 disables); (2) each solve uses the structure-specialised library of its sparsity pattern
-    #     when one exists (lqg_amd/specialize.py; LQG_NO_SPECIALIZE=1 forces the generic dense kernels).
-    # Both are exact and both are derived from the spec DATA, not from the model's name.
+
+def allreduce_us(torch, dist, n, reps=50):
+    """Mean latency of the path's one collective: all-reduce of n fp64 values (RCCL over xGMI)."""
+    if dist is None:
+        return None
+    v = torch.zeros(n, dtype=torch.float64, device="cuda")
+    for _ in range(5):
+        dist.all_reduce(v)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dist.all_reduce(v)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def host_specs(torch, np, workload, LQGSpec, system, sel, np_dt):
+    """Selected systems of both specs as NumPy arrays; a time-invariant (stride-0) time axis stays a stride-0 broadcast."""
+    def host(spec):
+        out = {}
+        index = torch.as_tensor(sel)
+        for f in LQGSpec._fields:
+            t = getattr(spec, f)
+            nd = workload._batched_ndim(f)
+            has_t = f not in ("Qf", "qf")
+            tax = -(2 if f in ("q", "r") else 3)
+            ti = has_t and (t.stride(tax) == 0 or t.shape[tax] == 1)
+            base = t.select(tax, 0) if ti else t
+            nd_b = nd - (1 if ti else 0)
+            base = base[index.to(base.device)] if base.dim() == nd_b else base.expand(len(sel), *base.shape)
+            a = base.cpu().numpy().astype(np_dt)
+            if ti:
+                k = a.ndim + tax + 1
+                a = np.broadcast_to(np.expand_dims(a, k), a.shape[:k] + (t.shape[tax],) + a.shape[k:])
+            out[f] = a
+        return out
+    return host(system.actor), host(system.dynamics)
+
+
+def headline_leg(torch, dist, args, dev, rank, world, dtype_name, log2_batch, steps, warmup, env=None, cpu=False):
+    """One measurement of the headline workload; returns the dict rank 0 prints (None on other ranks)."""
+    import numpy as np
+    import lqg_amd
+    from lqg_amd import _hip, _hipev, workload
     from lqg_amd.plan import LogLikelihoodPlan
-    plan = LogLikelihoodPlan(system, x, events=True, stack=not args.no_stack)
+
+    saved = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        dtype = torch.float32 if dtype_name == "f32" else torch.float64
+        w = 4 if dtype_name == "f32" else 8
+        B, T = 1 << log2_batch, args.T
+        system, _ = workload.headline_system(B, T, seed=1234 + rank, device=dev, dtype=dtype)
+        dm = dict(x=system.xdim, b=system.bdim, u=system.udim, y=system.ydim, d=system.xdim)
+        x_ref = workload.simulate_one_trial_each(system, seed=99 + 7919 * rank)            # [B,1,T+1,d]
+        x = workload.pack_trials(x_ref) if args.layout == "packed" else x_ref
+        torch.cuda.synchronize()
+        # The hot path exactly as lqg_amd.System.log_likelihood runs it (lqg_amd/plan.py), decided once:
+        # (1) a model whose interaction graph splits into independent components is solved per component (every dim=2
+        #     zoo model is two 1-D models; identical components become trials of ONE system), LQG_NO_DECOUPLE=1 disables;
+        # (2) each solve uses the structure-specialised library of its sparsity pattern (LQG_NO_SPECIALIZE=1 forces the
+        #     generic dense kernels).  Both are exact and derived from the spec DATA, not from the model's name.
+        plan = LogLikelihoodPlan(system, x, events=True, stack=not args.no_stack)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     ll = plan.ll
-    fwd_name = plan.description
     sp_all = all(wk["specialised"] for wk in plan.work)
-    total = torch.zeros((), dtype=torch.float64, device=dev)
 
     def step():
         plan.run()
@@ -117,141 +229,92 @@ def main():
             dist.all_reduce(s)                             # the one collective of the path (RCCL over xGMI)
         return s
 
-    for _ in range(args.warmup):
-        total = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # one set of phase events per timed step (up to 64), so that per-kernel durations cover the timed region without
-    # any host synchronisation inside it
-    n_ev = min(args.steps, 64)
+    n_ev = min(steps, 64)
     ev_sets = [[[_hipev.Event() for _ in range(4)] for _ in plan.work] for _ in range(n_ev)]
-    t0 = time.perf_counter()
-    for it in range(args.steps):
-        if it < n_ev:
-            plan.use_events(ev_sets[it])
-        total = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    total, elapsed, per_rank, step_ms = timed_steps(
+        torch, dist, step, steps, warmup, before_step=lambda it: plan.use_events(ev_sets[it]) if it < n_ev else None)
     ric_ms = [sum(e[0].elapsed_ms(e[1]) for e in es) for es in ev_sets]
     fwd_ms = [sum(e[1].elapsed_ms(e[2]) for e in es) for es in ev_sets]
-
     ll_host = ll[:, 0].double().cpu().numpy()
-    finite = bool(np.isfinite(ll_host).all())
-
+    ar_us = allreduce_us(torch, dist, 1)
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
+        return None
 
-    solves = float(B) * world * args.steps
-    value = solves / elapsed
-    ms_per_step = elapsed / args.steps * 1e3
     fl = algorithmic_flops_per_step(**dm)
-    flops_solve = fl["total"] * T
     bytes_solve = algorithmic_bytes_per_solve(T=T, w=w, **dm)
-    fwd_avg_ms = float(np.mean(fwd_ms))
-    ric_avg_ms = float(np.mean(ric_ms))
-    peak = PEAK_FP32_TFLOPS if args.dtype == "f32" else PEAK_FP64_TFLOPS
-    # dominant kernel = k_forward: Kalman + joint + Sigma recursion + mean + log-density for B solves per launch
-    fwd_flops_launch = (fl["total"] - fl["riccati"]) * T * B
-    achieved_tflops = fwd_flops_launch / (fwd_avg_ms * 1e-3) / 1e12
-    hbm_gbs = bytes_solve * B / ((fwd_avg_ms + ric_avg_ms) * 1e-3) / 1e9
-    # PMC-derived figures of the dominant kernel, collected in separate rocprofv3 --pmc passes of this same command and
-    # committed under profiles/ (FETCH_SIZE x2 gfx950 correction, calibrated there): HBM bytes and VALU instructions
-    traffic = executed = None
+    fwd_avg_ms, ric_avg_ms = float(np.mean(fwd_ms)), float(np.mean(ric_ms))
     n_launch = len(plan.work)                       # forward-kernel launches per step
-    alg_gbs = bytes_solve * B / (fwd_avg_ms * n_launch * 1e-3) / 1e9     # algorithmic bytes of one step / forward-kernel time
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(pmc_path):
-        try:
-            pj = json.load(open(pmc_path))
-            key = f"{'k_forward_sp' if sp_all else 'k_forward'}_x{n_launch}_{args.dtype}_log2B{args.log2_batch}"
-            if plan.n_stacked > 1:
-                key = f"k_forward_sp_stacked{plan.n_stacked}_{args.dtype}_log2B{args.log2_batch}"
-            if plan.merged and max(plan.merged) > 1:
-                key = f"k_forward_sp_merged{max(plan.merged)}_{args.dtype}_log2B{args.log2_batch}"
-            elif n_launch == 1 and key not in pj and not sp_all:
-                key = f"k_forward_{args.dtype}_log2B{args.log2_batch}"
-            rec = pj.get(key, {})
-            traffic = rec.get("hbm_bytes_per_launch")
-            if "valu_wave_insts_per_launch" in rec:
-                rate = rec["valu_wave_insts_per_launch"] * n_launch / (fwd_avg_ms * 1e-3)
-                executed = {"valu_wave_insts_per_launch": rec["valu_wave_insts_per_launch"],
-                            "valu_issue_frac": rate / (1024 * 2.4e9 / 2),
-                            "note": "wave64 VALU instructions issued per second / (1024 SIMDs x 2.4 GHz / 2 cycles)"}
-        except Exception:
-            traffic = None
-    if traffic is not None:
-        hbm_gbs = traffic * n_launch / (fwd_avg_ms * 1e-3) / 1e9    # measured bytes of the forward launches / their time
-
-    # ---- parity spot check against the CPU oracle (not timed)
-    parity = None
-    cpu = None
+    alg_gbs = bytes_solve * B / (fwd_avg_ms * 1e-3) / 1e9     # algorithmic bytes of one step / forward-kernel time
+    kernel = ("k_forward_sp" if sp_all else "k_forward") + \
+        (f"<merged{max(plan.merged)}>" if plan.merged and max(plan.merged) > 1 else "") + f"x{n_launch}"
+    pkey = plan.work[0].get("pattern_key") if sp_all else "generic"
+    rec = pmc_record(kernel, pkey, dtype_name, log2_batch)
+    traffic = rec["hbm_bytes_per_launch"] if rec else None
+    limits = {"note": "which side binds the dominant kernel: measured HBM bytes/s against the guide's achievable copy rate "
+                      "vs wave64 VALU instructions issued/s against 1024 SIMDs x 2.4 GHz / 2 cycles"}
+    if rec:
+        limits["hbm_frac_of_copy_rate"] = traffic / (fwd_avg_ms * 1e-3) / 1e9 / COPY_HBM_GBS
+        limits["hbm_frac_of_peak"] = traffic / (fwd_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS
+        if rec.get("valu_wave_insts_per_launch"):
+            limits["valu_issue_frac"] = rec["valu_wave_insts_per_launch"] / (fwd_avg_ms * 1e-3) / VALU_WAVE_INSTS_PER_S
+            limits["valu_insts_per_step_per_wave"] = rec.get("valu_insts_per_step_per_wave")
+        limits["profile"] = rec.get("profile")
+    solves = float(B) * world * steps
+    out = {
+        "metric": "LQG solves/sec (Riccati+Kalman+loglik), n=6 T=500",
+        "value": solves / elapsed, "unit": "solves/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "ms_per_step_min": float(np.min(step_ms)),
+        "ms_per_step_median": float(np.median(step_ms)), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
+        "config": {"workload": f"SubjectiveActor(dim=2) x=4 b=6 u=2 y=4 d=4, T={T}, {B} independent "
+                               f"(candidate, trajectory) solves per GPU per step (BASELINE config 5 / headline shape)",
+                   "solves_per_gpu": B, "T": T, "trajectory_layout": args.layout, "path": plan.description,
+                   "parallelism": f"candidate-sharded x{world}, all-reduce of the summed log-likelihood"},
+        "world_size": world if dist is None else dist.get_world_size(),
+        "per_rank_solves_per_s": [float(B) * steps / t for t in per_rank], "allreduce_us": ar_us,
+        # Contract form: achieved = ALGORITHMIC bytes per launch (mode M1: trajectory in, specs in, one
+        # scalar out) / the dominant kernel's HIP-event time; traffic = PMC bytes of that launch (null unless the
+        # committed profile was taken on exactly this build).
+        "roofline": {"bound": "hbm", "achieved": alg_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": alg_gbs / PEAK_HBM_GBS, "traffic": traffic,
+                     "kernel": "forward sweep (Kalman + joint system + Sigma recursion + mean + log-density) of: "
+                               + plan.description,
+                     "kernel_ms": fwd_avg_ms, "riccati_kernel_ms": ric_avg_ms,
+                     "algorithmic_bytes_per_solve": bytes_solve, "algorithmic_bytes_per_launch": bytes_solve * B,
+                     "kernel_launches_per_step": n_launch, "limits": limits,
+                     "algorithmic_flops_per_solve": fl["total"] * T},
+        "all_finite": bool(np.isfinite(ll_host).all()), "objective_sum": float(total.item()),
+    }
+    # ---- parity spot check against the CPU oracle (not timed) and, on the main leg, the CPU baseline
     try:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle as OC
         OC.build()
         ns = 64
         idx = np.linspace(0, B - 1, ns).astype(np.int64)
-        sub = workload.slice_system  # noqa
-        actor_np = {f: getattr(system.actor, f) for f in lqg_amd.LQGSpec._fields}
-        dyn_np = {f: getattr(system.dynamics, f) for f in lqg_amd.LQGSpec._fields}
-
-        def host(spec_t, sel, np_dt=np.float64):
-            """Selected systems as NumPy arrays; a time-invariant (stride-0) time axis stays a stride-0 broadcast."""
-            out = {}
-            index = torch.as_tensor(sel)
-            for f, t in spec_t.items():
-                nd = workload._batched_ndim(f)
-                has_t = f not in ("Qf", "qf")
-                tax = -(2 if f in ("q", "r") else 3)
-                ti = has_t and (t.stride(tax) == 0 or t.shape[tax] == 1)
-                base = t.select(tax, 0) if ti else t
-                nd_b = nd - (1 if ti else 0)
-                base = base[index.to(base.device)] if base.dim() == nd_b else base.expand(len(sel), *base.shape)
-                a = base.cpu().numpy().astype(np_dt)
-                if ti:
-                    k = a.ndim + tax + 1
-                    a = np.broadcast_to(np.expand_dims(a, k), a.shape[:k] + (t.shape[tax],) + a.shape[k:])
-                out[f] = a
-            return out
-
-        a64, d64 = host(actor_np, idx), host(dyn_np, idx)
+        a64, d64 = host_specs(torch, np, workload, lqg_amd.LQGSpec, system, idx, np.float64)
         x64 = x_ref[torch.as_tensor(idx, device=dev)].double().cpu().numpy()
         ref = OC.log_likelihood(a64, d64, x64, dtype=np.float64)[:, 0]
-        got = ll_host[idx]
-        parity = dict(samples=int(ns), max_rel_err_vs_fp64_oracle=float(np.abs(got / ref - 1).max()))
-        if not args.no_cpu_baseline and world == 1:
+        out["parity"] = dict(samples=int(ns), max_rel_err_vs_fp64_oracle=float(np.abs(ll_host[idx] / ref - 1).max()))
+        if cpu:
             ncpu = os.cpu_count() or 1
             OC.lib().lqg_oracle_set_threads(ncpu)
-            np_dt = np.float32 if args.dtype == "f32" else np.float64
+            np_dt = np.float32 if dtype_name == "f32" else np.float64
             nsamp = args.cpu_sample or 16384          # 64 solves per thread on a 256-thread host
             sel = np.arange(nsamp) % B
-            a_s, d_s = host(actor_np, sel, np_dt), host(dyn_np, sel, np_dt)
+            a_s, d_s = host_specs(torch, np, workload, lqg_amd.LQGSpec, system, sel, np_dt)
             x_s = x_ref[torch.as_tensor(sel, device=dev)].cpu().numpy().astype(np_dt)
             OC.log_likelihood({k: v[:8] for k, v in a_s.items()}, {k: v[:8] for k, v in d_s.items()}, x_s[:8], dtype=np_dt)
             tc = time.perf_counter()
             OC.log_likelihood(a_s, d_s, x_s, dtype=np_dt)
             tc1 = time.perf_counter() - tc
-            # repeat the sample so that the CPU leg does ~10-20 s of work
-            if tc1 < 8.0 and not args.cpu_sample:
-                rep = int(min(16, max(1, 12.0 / max(tc1, 1e-3))))
+            nrep = 1
+            if tc1 < 8.0 and not args.cpu_sample:     # repeat the sample so that the CPU leg does ~10-20 s of work
+                nrep = int(min(16, max(1, 12.0 / max(tc1, 1e-3))))
                 tc = time.perf_counter()
-                for _ in range(rep):
+                for _ in range(nrep):
                     OC.log_likelihood(a_s, d_s, x_s, dtype=np_dt)
-                tc1 = (time.perf_counter() - tc) / rep
-                nrep = rep
-            else:
-                nrep = 1
+                tc1 = (time.perf_counter() - tc) / nrep
             model = ""
             try:
                 for line in open("/proc/cpuinfo"):
@@ -260,49 +323,130 @@ def main():
                         break
             except OSError:
                 pass
-            cpu = dict(value=nsamp / tc1, unit="solves/s", cores=OC.lib().lqg_oracle_max_threads(), kind="port",
-                       sample=f"{nsamp} solves of the same workload ({args.dtype}, T={T}) x {nrep} repetitions, "
-                              f"oracle/lqg_oracle.c with OpenMP over systems", cpu_model=model,
-                       host_cpu_count=ncpu)
+            out["cpu_baseline"] = dict(
+                value=nsamp / tc1, unit="solves/s", cores=OC.lib().lqg_oracle_max_threads(), kind="port",
+                sample=f"{nsamp} solves of the same workload ({dtype_name}, T={T}) x {nrep} repetitions, "
+                       f"oracle/lqg_oracle.c (literal dense restatement) with OpenMP over systems",
+                cpu_model=model, host_cpu_count=ncpu)
     except Exception as e:  # the oracle is a checker: its absence must not break the measurement
-        parity = dict(error=repr(e))
+        out["parity"] = dict(error=repr(e))
+    return out
 
-    out = {
-        "metric": "LQG solves/sec (Riccati+Kalman+loglik), n=6 T=500",
-        "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"SubjectiveActor(dim=2) x=4 b=6 u=2 y=4 d=4, T={T}, {B} independent "
-                               f"(candidate, trajectory) solves per GPU per step (BASELINE config 5 / headline shape)",
-                   "solves_per_gpu": B, "T": T, "trajectory_layout": args.layout,
-                   "path": fwd_name,
-                   "parallelism": f"candidate-sharded x{world}, all-reduce of the summed log-likelihood"},
-        # Contract form: bound in {hbm, mfma}; achieved = ALGORITHMIC bytes per launch (mode M1: trajectory
-        # in, specs in, one scalar out) / the dominant kernel's HIP-event time.  The kernel is VALU-issue-bound (SURVEY 8d
-        # says so by construction for M1), so the honest reading is in `valu` (flop view, executed-instruction issue rate)
-        # and `hbm_measured` (PMC bytes / time: how busy HBM really is, incl. the gain stream L_t between the two sweeps).
-        "roofline": {"bound": "hbm", "achieved": alg_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                     "frac": alg_gbs / PEAK_HBM_GBS, "traffic": traffic,
-                     "kernel": "forward sweep (Kalman + joint system + Sigma recursion + mean + log-density) of: " + fwd_name,
-                     "kernel_ms": fwd_avg_ms, "riccati_kernel_ms": ric_avg_ms,
-                     "algorithmic_bytes_per_solve": bytes_solve, "algorithmic_bytes_per_launch": bytes_solve * B,
-                     "kernel_launches_per_step": n_launch,
-                     "hbm_measured": {"achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                      "frac": hbm_gbs / PEAK_HBM_GBS,
-                                      "basis": "PMC traffic of the forward launches / their time" if traffic is not None
-                                      else "algorithmic bytes (M1) / (riccati + forward time)"},
-                     "valu": {"achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s", "frac": achieved_tflops / peak,
-                              "algorithmic_flops_per_solve": flops_solve, "executed": executed,
-                              "note": "ALGORITHMIC flops of the reference formulation (SURVEY.md 8d: dense, no symmetry, "
-                                      "no hoisting) / kernel time; the structure-specialised + decoupled kernels execute "
-                                      "~20x fewer, so this frac exceeds 1 - `executed.valu_issue_frac` is the utilisation"},
-                     "note": "M1 is VALU-issue-bound, not HBM- or MFMA-bound (MFMA deliberately unused: contractions are "
-                             "<= 6x6 per lane). traffic > algorithmic bytes because the control gains L_t travel from the "
-                             "backward to the forward sweep through HBM (6 kB/solve), which M1's figure does not count"},
-        "cpu_baseline": cpu, "parity": parity, "all_finite": finite,
-        "objective_sum": float(total.item()),
+
+def config3(torch, dist, args, dev, rank, world):
+    """BASELINE config 3 / SURVEY §8(e): 4096 parameter candidates x 1024 data.mat-shaped trials (1068 rows).  The TRIAL
+    axis is split over the ranks (every rank holds all candidates and 1024/N trials: x is read once per rank, the
+    4096 per-system sweeps are replicated); one all-reduce of the [4096] fp64 objective per step.  Strong scaling."""
+    import numpy as np
+    import lqg_amd
+    from lqg_amd import _hip, workload
+    from lqg_amd.plan import LogLikelihoodPlan
+
+    dtype = torch.float32 if args.dtype == "f32" else torch.float64
+    Bc, Nt, T = 4096, 1024, 1067
+    if Nt % world:
+        raise SystemExit(f"--config 3: {Nt} trials do not split over {world} ranks")
+    system, _ = workload.bounded_system(Bc, T, seed=5, device=dev, dtype=dtype)       # the same candidates on every rank
+    truth = lqg_amd.BoundedActor(T=T, sigma_target=20.0, sigma_cursor=3.0, action_cost=0.3, action_variability=0.5,
+                                 device=dev, dtype=dtype)
+    x_all = truth.simulate(13, n=Nt)                                                  # same seed: same data on every rank
+    lo = rank * (Nt // world)
+    x = workload.pack_trials(x_all[lo:lo + Nt // world].contiguous())
+    plan = LogLikelihoodPlan(system, x, events=True)
+
+    def step():
+        obj = _hip.sum_trials(plan.run())            # [4096] fp64 partial objective of this rank's trials
+        if dist is not None:
+            dist.all_reduce(obj)
+        return obj
+
+    obj, elapsed, per_rank, step_ms = timed_steps(torch, dist, step, args.steps, args.warmup)
+    ph = plan.phase_ms()
+    ar_us = allreduce_us(torch, dist, Bc)
+    if rank != 0:
+        return None
+    w = 4 if args.dtype == "f32" else 8
+    evals = float(Bc) * Nt * args.steps
+    bytes_launch = (Nt // world) * (T + 1) * 2 * w            # the data rows; operators come from the scalar cache
+    return {
+        "metric": "trial-evals/sec (candidate search: 4096 candidates x 1024 trials, T=1067)",
+        "value": evals / elapsed, "unit": "trial-evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_min": float(np.min(step_ms)),
+        "ms_per_step_median": float(np.median(step_ms)), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "BASELINE config 3: BoundedActor x=b=2 u=1 y=2 d=2, data.mat-shaped trials (1068 rows), "
+                               f"{Bc} candidates x {Nt} shared trials; objective = sum over trials per candidate",
+                   "candidates": Bc, "trials": Nt, "trials_per_rank": Nt // world, "T": T, "path": plan.description,
+                   "parallelism": f"trial-split x{world}, all-reduce of the [{Bc}] fp64 objective"},
+        "world_size": world if dist is None else dist.get_world_size(),
+        "per_rank_s": per_rank, "allreduce_us": ar_us,
+        "phase_ms": {"riccati": ph[0], "forward": ph[1], "trial": ph[2]},
+        "roofline": {"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                     "kernel": "k_trial (per-trial mean recursion + density over the operator stream)",
+                     "note": "the per-trial sweep reads each data row once per CANDIDATE BLOCK from L2/HBM and its operators "
+                             f"from the scalar cache; algorithmic bytes of the data alone = {bytes_launch} B per rank — "
+                             "the sweep is VALU-bound (bench_configs.py carries the per-config accounting)"},
+        "best_candidate": int(obj.argmax()), "objective_max": float(obj.max()),
     }
-    print(json.dumps(out))
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))               # before anything touches the GPU
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1 or "RANK" in os.environ:      # under torchrun the collective path is exercised even at world == 1
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    if args.config == 3:
+        out = config3(torch, dist, args, dev, rank, world)
+    else:
+        out = headline_leg(torch, dist, args, dev, rank, world, args.dtype, args.log2_batch, args.steps, args.warmup,
+                           cpu=(world == 1 and not args.no_cpu_baseline))
+        if world == 1 and not args.no_extra and out is not None:
+            # secondary legs, outside the headline's timed region (same workload generator, same timing protocol)
+            extra = {}
+            other = "f64" if args.dtype == "f32" else "f32"
+            torch.cuda.empty_cache()
+            leg = headline_leg(torch, None, args, dev, 0, 1, other, args.log2_batch, min(args.steps, 10), 2)
+            extra[f"headline_{other}"] = {k: leg[k] for k in ("value", "unit", "ms_per_step", "dtype", "parity", "roofline")}
+            extra[f"headline_{other}"]["path"] = leg["config"]["path"]
+            torch.cuda.empty_cache()
+            for dn in ("f32", "f64"):
+                leg = headline_leg(torch, None, args, dev, 0, 1, dn, 17, min(args.steps, 5), 1,
+                                   env={"LQG_NO_SPECIALIZE": "1", "LQG_NO_DECOUPLE": "1"})
+                r = leg["roofline"]
+                # dense joint n=6 (m=10) kernel: VALU-bound; executed-instruction figures come from the ISA of
+                # k_forward<R,4,6,2,4,4,TI,FUSED> (profiles/README.md), the algorithmic flop rate from SURVEY 8(d)
+                fl_rate = r["algorithmic_flops_per_solve"] * leg["value"] / 1e12
+                extra[f"dense_generic_{dn}"] = {
+                    "value": leg["value"], "unit": leg["unit"], "ms_per_step": leg["ms_per_step"], "dtype": dn,
+                    "solves_per_gpu": 1 << 17, "path": leg["config"]["path"], "parity": leg.get("parity"),
+                    "env": "LQG_NO_SPECIALIZE=1 LQG_NO_DECOUPLE=1",
+                    "roofline": {"bound": "valu", "achieved": fl_rate, "unit": "TFLOP/s (algorithmic, SURVEY 8d)",
+                                 "peak": PEAK_FP32_TFLOPS if dn == "f32" else PEAK_FP64_TFLOPS,
+                                 "frac": fl_rate / (PEAK_FP32_TFLOPS if dn == "f32" else PEAK_FP64_TFLOPS),
+                                 "kernel_ms": r["kernel_ms"], "riccati_kernel_ms": r["riccati_kernel_ms"]}}
+                torch.cuda.empty_cache()
+            out["extra"] = extra
+    if rank == 0 and out is not None:
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

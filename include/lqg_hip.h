@@ -101,6 +101,26 @@ int lqg_abi_version(void);
 const char* lqg_last_error(void);
 /* 1 if (dtype, dims) has a compiled instantiation in this build, else 0 */
 int lqg_dims_supported(int32_t dtype, const lqg_dims* dims);
+/* Per kernel FAMILY: lqr.backward only depends on (b, u), kf.forward on (b, y), simulate on (x, b, u, y), the per-trial
+ * sweep on (x + b, d); the fused forward sweep and the gradient on the full (x, b, u, y, d).  1 if this library holds
+ * the family's instantiation for `dims` (fields the family ignores are not looked at), else 0. */
+#define LQG_FAMILY_FORWARD  0
+#define LQG_FAMILY_RICCATI  1
+#define LQG_FAMILY_KALMAN   2
+#define LQG_FAMILY_TRIAL    3
+#define LQG_FAMILY_SIMULATE 4
+#define LQG_FAMILY_ADJOINT  5
+int lqg_kernel_supported(int32_t family, const lqg_dims* dims);
+/* Two kernel strategies serve every entry point below.  LANE: one system per lane, matrices in registers, kernels
+ * instantiated per model shape (lqg_kernel_supported) — the throughput path for >= 10^4 systems.  COOP: one
+ * workgroup per system, matrices staged in LDS, dimensions are run-time arguments (any x, b; u, y, d <= 6) — for few
+ * systems (one parameter vector x many trials) and for shapes no lane kernel holds (x + b > 20: the reference's
+ * DelayedSubjectiveActor, lqg/tracking/delay.py:44-51).  lqg_strategy(p) tells which one THIS library runs for p
+ * (environment LQG_COOP=0/1 overrides the default rule); lqg_workspace_bytes accounts for it. */
+#define LQG_STRATEGY_LANE 0
+#define LQG_STRATEGY_COOP 1
+int lqg_coop_supported(const lqg_dims* dims);
+int lqg_strategy(const lqg_problem* p);
 /* name of the code object target this library was compiled for ("gfx950") */
 const char* lqg_target_arch(void);
 

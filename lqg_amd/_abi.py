@@ -9,6 +9,9 @@ import os
 ABI_VERSION = 1
 F32, F64 = 0, 1
 OP_LOG_LIKELIHOOD, OP_CONDITIONAL_MOMENTS = 0, 1
+FAM_FORWARD, FAM_RICCATI, FAM_KALMAN, FAM_TRIAL, FAM_SIMULATE, FAM_ADJOINT = range(6)
+# which of (x, b, u, y, d) a kernel family is instantiated on (include/lqg_hip.h: lqg_kernel_supported)
+_FAMILY_KEYS = {FAM_FORWARD: "xbuyd", FAM_RICCATI: "bu", FAM_KALMAN: "by", FAM_SIMULATE: "xbuy", FAM_ADJOINT: "xbuyd"}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # LQG_HIP_LIB selects a variant build of the same library (developer A/B kernel experiments); never a fallback
@@ -81,6 +84,9 @@ def _bind(path):
     lib.lqg_last_error.restype = C.c_char_p
     lib.lqg_target_arch.restype = C.c_char_p
     lib.lqg_dims_supported.argtypes, lib.lqg_dims_supported.restype = [C.c_int32, C.POINTER(Dims)], C.c_int
+    lib.lqg_kernel_supported.argtypes, lib.lqg_kernel_supported.restype = [C.c_int32, C.POINTER(Dims)], C.c_int
+    lib.lqg_coop_supported.argtypes, lib.lqg_coop_supported.restype = [C.POINTER(Dims)], C.c_int
+    lib.lqg_strategy.argtypes, lib.lqg_strategy.restype = [C.POINTER(Problem)], C.c_int
     lib.lqg_workspace_bytes.argtypes, lib.lqg_workspace_bytes.restype = [C.POINTER(Problem), C.c_int32], C.c_size_t
     lib.lqg_sum_trials.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                    C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -128,17 +134,58 @@ def shape_in_range(x, b, u, y, d):
         and 1 <= y <= MAX_IO and 1 <= d <= x
 
 
-def library_for(dims):
-    """The library that has kernels for this model shape: liblqg_hip.so when lqg_dims.def lists (x, b, u, y, d),
-    otherwise an auxiliary library with the same C ABI compiled on demand for exactly that shape
-    (lqg_amd.build.build_dims_library; needs hipcc, cached in csrc/dims/).  Never a CPU fallback."""
+def _dims_struct(dims):
+    return Dims(dims["x"], dims["b"], dims["u"], dims["y"], dims["d"], dims.get("nva", 1), dims.get("nwa", 1),
+                dims.get("nvd", 1), dims.get("nwd", 1))
+
+
+# Below this many systems per call a shape without lane kernels runs on the cooperative run-time-dims kernels of the
+# main library (no compile); above it an auxiliary lane-kernel library is compiled once (8-30 s) and cached.
+JIT_MIN_SYSTEMS = 4096
+STRATEGY_LANE, STRATEGY_COOP = 0, 1
+
+
+def library_for(dims, family=FAM_FORWARD, n_sys=None):
+    """The library that holds the kernels of `family` for this model shape.  lqr.backward only depends on (b, u),
+    kf.forward on (b, y), simulate on (x, b, u, y) — they are resolved per FAMILY, so e.g. the Riccati sweep of a
+    SubjectiveActor's actor spec (b=6, u=2) is served by the main library whatever x, y, d are.  Order: lane kernels of
+    liblqg_hip.so; auxiliary libraries already loaded or cached on disk; the COOPERATIVE kernels of liblqg_hip.so
+    (run-time dims: any x, b with u, y, d <= 6 — no compile) for small batches, shapes beyond the lane kernels' range
+    (x + b > 20) or when no compiler is there; finally an auxiliary lane-kernel library compiled on demand for exactly
+    this shape (lqg_amd.build.build_dims_library; needs hipcc).  Never a CPU fallback."""
     lib = load()
-    key = (dims["x"], dims["b"], dims["u"], dims["y"], dims["d"])
-    dm = Dims(*key, dims.get("nva", 1), dims.get("nwa", 1), dims.get("nvd", 1), dims.get("nwd", 1))
-    if lib.lqg_dims_supported(F32, C.byref(dm)):
+    dm = _dims_struct(dims)
+    if lib.lqg_kernel_supported(family, C.byref(dm)):
         return lib
+    for aux in _dims_libs.values():
+        if aux.lqg_kernel_supported(family, C.byref(dm)):
+            return aux
+    from lqg_amd import build
+    key0 = (dims["x"], dims["b"], dims["u"], dims["y"], dims["d"] if 1 <= dims["d"] <= dims["x"] else min(dims["x"], 2))
+    coop_ok = family in (FAM_FORWARD, FAM_RICCATI, FAM_KALMAN) and lib.lqg_coop_supported(C.byref(dm))
+    can_jit = shape_in_range(*key0) and os.path.exists(build.HIPCC) and os.environ.get("LQG_JIT", "1") != "0"
+    big = n_sys is not None and n_sys >= JIT_MIN_SYSTEMS
+    names = "xbuyd"
+    want = {k: dims[k] for k in _FAMILY_KEYS[family]}
+    ddir = build.cache_dir(build.DIMS_DIR, "dims")
+    for f in sorted(os.listdir(ddir)) if os.path.isdir(ddir) else ():
+        if not (f.startswith("liblqg_hip_") and f.endswith(".so")):
+            continue
+        try:
+            tup = tuple(int(v) for v in f[len("liblqg_hip_"):-3].split("_"))
+        except ValueError:
+            continue
+        if len(tup) != 5 or any(tup[names.index(k)] != v for k, v in want.items()):
+            continue
+        if tup not in _dims_libs and build.stamped(os.path.join(ddir, f), build.source_hash()):
+            _dims_libs[tup] = _bind(os.path.join(ddir, f))
+            return _dims_libs[tup]
+    if coop_ok and not (can_jit and big):
+        return lib                                  # cooperative kernels: the main library decides per call (lqg_strategy)
+    key = (dims["x"], dims["b"], dims["u"], dims["y"], dims["d"])
+    if family != FAM_FORWARD and not (1 <= key[4] <= key[0]):
+        key = key[:4] + (min(key[0], 2),)           # d is irrelevant to this family: the tracking models' width
     if key not in _dims_libs:
-        from lqg_amd import build
         if not shape_in_range(*key):
             raise LqgHipError(f"model shape (x,b,u,y,d)={key} is outside the dims the register-resident kernels serve "
                               f"(x, b <= {MAX_STATE}, x+b <= {MAX_JOINT}, u, y <= {MAX_IO}, d <= x); there is no CPU path")
@@ -149,27 +196,11 @@ def library_for(dims):
     return _dims_libs[key]
 
 
-def observed_dims_with_kernels(dims):
-    """For paths that do not depend on the observed width d (simulate): a d in 1..x whose library already exists —
-    compiled in, loaded, or cached on disk — else min(x, 2), the tracking models' (target, cursor) width."""
-    lib = load()
-    x, b, u, y = dims["x"], dims["b"], dims["u"], dims["y"]
-    from lqg_amd import build
-    order = [dims["d"]] + [d for d in range(1, x + 1) if d != dims["d"]]
-    for d in order:
-        if lib.lqg_dims_supported(F32, C.byref(Dims(x, b, u, y, d, 1, 1, 1, 1))) or (x, b, u, y, d) in _dims_libs:
-            return d
-    for d in order:
-        if os.path.exists(os.path.join(build.DIMS_DIR, f"liblqg_hip_{build.dims_tag(x, b, u, y, d)}.so")):
-            return d
-    return min(x, 2)
-
-
 def shape_available(x, b, u, y, d):
-    """True when kernels for the shape exist or can be compiled on demand."""
+    """True when kernels for the shape exist (lane or cooperative) or can be compiled on demand."""
     lib = load()
     dm = Dims(x, b, u, y, d, 1, 1, 1, 1)
-    if lib.lqg_dims_supported(F32, C.byref(dm)):
+    if lib.lqg_dims_supported(F32, C.byref(dm)) or lib.lqg_coop_supported(C.byref(dm)):
         return True
     from lqg_amd import build
     return shape_in_range(x, b, u, y, d) and os.path.exists(build.HIPCC)

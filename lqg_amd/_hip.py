@@ -80,12 +80,12 @@ class Launch:
         self.p = p
 
     # ---- helpers
-    def require_gpu(self):
+    def require_gpu(self, family=_abi.FAM_FORWARD):
         if self.device.type != "cuda":
             raise LqgHipError(
                 f"lqg_amd computes on MI355X only: tensors are on '{self.device}'. Move the spec to a cuda "
                 "(ROCm) device; there is no CPU fallback.")
-        return _abi.library_for(self.dims)
+        return _abi.library_for(self.dims, family, n_sys=self.B)
 
     def lead(self):
         return (self.B,) if self.batched else ()
@@ -110,8 +110,7 @@ class Launch:
 
 def riccati_backward(spec: LQGSpec, eps=1e-8):
     ln = Launch(spec, eps=eps)
-    ln.dims["d"] = ln.p.dims.d = _abi.observed_dims_with_kernels(ln.dims)     # k_riccati does not depend on d
-    lib = ln.require_gpu()
+    lib = ln.require_gpu(_abi.FAM_RICCATI)          # k_riccati is instantiated per (b, u) only
     dm = ln.dims
     L, l, H = ln.empty(ln.T, dm["u"], dm["b"]), ln.empty(ln.T, dm["u"]), ln.empty(ln.T, dm["u"], dm["u"])
     with torch.cuda.device(ln.device):
@@ -122,8 +121,7 @@ def riccati_backward(spec: LQGSpec, eps=1e-8):
 
 def kalman_forward(spec: LQGSpec, Sigma0=None):
     ln = Launch(spec, Sigma0=Sigma0)
-    ln.dims["d"] = ln.p.dims.d = _abi.observed_dims_with_kernels(ln.dims)     # k_kalman does not depend on d
-    lib = ln.require_gpu()
+    lib = ln.require_gpu(_abi.FAM_KALMAN)           # k_kalman is instantiated per (b, y) only
     K = ln.empty(ln.T, ln.dims["b"], ln.dims["y"])
     with torch.cuda.device(ln.device):
         _abi.check(lib.lqg_kalman_forward(C.byref(ln.p), ln.view(K), ln.stream()), "lqg_kalman_forward")
@@ -196,6 +194,8 @@ def specialised_entry(ln, system, d):
     import os
     if system is None or os.environ.get("LQG_NO_SPECIALIZE") == "1" or ln.p.n_trials < 1:
         return None
+    if _abi.load().lqg_strategy(C.byref(ln.p)) == _abi.STRATEGY_COOP:
+        return None             # few systems of a large joint dimension: the cooperative kernels of the main library
     p = ln.p
     for spec, fields in ((p.actor, ("Q", "R", "A", "B", "V", "F", "W")), (p.dynamics, ("A", "B", "V", "F", "W"))):
         for f in fields:
@@ -253,8 +253,7 @@ def simulate(actor, dynamics, L, l, K, eps_noise, eta_noise, x0=None, xhat0=None
     """eps_noise[(B,)n,T,x], eta_noise[(B,)n,T,y] -> x[(B,)n,T+1,x] (and xhat, y, u)."""
     n = eps_noise.shape[-3]
     ln = Launch(actor, dynamics, n_trials=n)
-    ln.dims["d"] = ln.p.dims.d = _abi.observed_dims_with_kernels(ln.dims)     # k_simulate does not depend on d
-    lib = ln.require_gpu()
+    lib = ln.require_gpu(_abi.FAM_SIMULATE)         # k_simulate is instantiated per (x, b, u, y) only
     dm = ln.dims
     xs = ln.empty(n, ln.T + 1, dm["x"])
     xh = ln.empty(n, ln.T + 1, dm["b"]) if return_all else None

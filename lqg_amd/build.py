@@ -6,6 +6,8 @@ travels to the GPU box).  Incremental: an object is rebuilt only when a source i
 """
 import argparse
 import concurrent.futures as cf
+import contextlib
+import fcntl
 import hashlib
 import os
 import re
@@ -22,10 +24,12 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # live registers in k_forward (measured: 42.5 ms -> 12.3 ms per 2^18 solves, profiles/README.md).
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-slp-vectorize"]
 HEADERS = ["lqg_small.hpp", "lqg_kernels.hpp", "lqg_launch.hpp", "lqg_dims.def", "../../include/lqg_hip.h"]
+COOP_HEADERS = ["lqg_small.hpp", "lqg_kernels.hpp", "lqg_launch.hpp", "lqg_coop.hpp", "lqg_coop_launch.hpp",
+                "../../include/lqg_hip.h"]
 ADJ_HEADERS = ["lqg_small.hpp", "lqg_adjoint.hpp", "lqg_adjoint_launch.hpp", "../../include/lqg_hip.h"]
 # headers each source depends on (an adjoint-kernel edit must not recompile the forward kernels and vice versa)
-DEPS = {"lqg_inst.hip": HEADERS, "lqg_adjoint_inst.hip": ADJ_HEADERS,
-        "lqg_abi.hip": sorted(set(HEADERS + ADJ_HEADERS))}
+DEPS = {"lqg_inst.hip": HEADERS, "lqg_adjoint_inst.hip": ADJ_HEADERS, "lqg_coop_inst.hip": COOP_HEADERS,
+        "lqg_abi.hip": sorted(set(HEADERS + ADJ_HEADERS + ["lqg_coop_launch.hpp"]))}
 FAMILIES = ("FORWARD", "RICCATI", "KALMAN", "TRIAL", "SIM", "ADJOINT")
 ADJOINT_MAX_JOINT = 10          # on-demand libraries get the gradient sweep only up to x + b = 10 (compile time)
 
@@ -42,7 +46,7 @@ def dims_lists():
 
 def jobs(lists=None, extra_defs=()):
     extra_defs = list(extra_defs)
-    js = [("abi.o", "lqg_abi.hip", extra_defs)]
+    js = [("abi.o", "lqg_abi.hip", extra_defs), ("coop.o", "lqg_coop_inst.hip", extra_defs)]
     for fam, tuples in (lists or dims_lists()).items():
         for t in tuples:
             for dt in ("F32", "F64"):
@@ -64,7 +68,8 @@ def source_hash():
     """Content hash of every source that goes into the library (+ compile flags): mtimes do not survive the
     snapshot to the GPU box, the hash does."""
     h = hashlib.sha256(" ".join(FLAGS).encode())
-    for f in sorted(set(HEADERS + ADJ_HEADERS + ["lqg_abi.hip", "lqg_inst.hip", "lqg_adjoint_inst.hip"])):
+    for f in sorted(set(HEADERS + ADJ_HEADERS + COOP_HEADERS + ["lqg_abi.hip", "lqg_inst.hip", "lqg_adjoint_inst.hip",
+                                                                "lqg_coop_inst.hip"])):
         h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()
 
@@ -116,7 +121,49 @@ def build_variant(out, extra_flags=(), only=None, objdir=None, workers=None, ver
     return out
 
 
-DIMS_DIR = os.path.join(CSRC, "dims")
+def cache_dir(preferred, name):
+    """`preferred` (in-tree, so that the libraries travel with the snapshot) when it can be written, else a per-user
+    cache directory (read-only installs)."""
+    try:
+        os.makedirs(preferred, exist_ok=True)
+        if os.access(preferred, os.W_OK):
+            return preferred
+    except OSError:
+        pass
+    alt = os.path.join(os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"), "lqg_amd", name)
+    os.makedirs(alt, exist_ok=True)
+    return alt
+
+
+@contextlib.contextmanager
+def locked(target):
+    """Exclusive inter-process lock for producing `target` (several ranks of one node may ask for the same library at
+    the same time): the first one in compiles, the others block here and then find the finished, stamped file."""
+    with open(target + ".lock", "w") as f:
+        fcntl.flock(f, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(f, fcntl.LOCK_UN)
+
+
+def atomic_write(path, text):
+    tmp = f"{path}.tmp.{os.getpid()}"
+    with open(tmp, "w") as f:
+        f.write(text)
+    os.replace(tmp, path)
+
+
+def stamped(so, want):
+    """True when `so` exists with a stamp equal to `want` (the stamp is written after the library is in place)."""
+    stamp = so + ".stamp"
+    try:
+        return os.path.exists(so) and open(stamp).read().strip() == want
+    except OSError:
+        return False
+
+
+DIMS_DIR = os.environ.get("LQG_DIMS_DIR") or os.path.join(CSRC, "dims")
 
 
 def dims_tag(x, b, u, y, d):
@@ -125,44 +172,49 @@ def dims_tag(x, b, u, y, d):
 
 def build_dims_library(x, b, u, y, d, workers=None, verbose=True):
     """Auxiliary library with the full C ABI for ONE model shape that lqg_dims.def does not list
-    (csrc/dims/liblqg_hip_<x>_<b>_<u>_<y>_<d>.so): same sources, single-shape instantiation lists.
-    Called on demand by lqg_amd._abi.library_for; cached by a hash of the sources."""
+    (<dims dir>/liblqg_hip_<x>_<b>_<u>_<y>_<d>.so): same sources, single-shape instantiation lists.
+    Called on demand by lqg_amd._abi.library_for; cached by a hash of the sources.  Safe under concurrent callers
+    (ranks of one node): inter-process lock, link to a temporary name, atomic rename, stamp last."""
     tag = dims_tag(x, b, u, y, d)
-    os.makedirs(DIMS_DIR, exist_ok=True)
-    so = os.path.join(DIMS_DIR, f"liblqg_hip_{tag}.so")
-    stamp = so + ".stamp"
-    if os.path.exists(so) and os.path.exists(stamp) and open(stamp).read().strip() == source_hash():
+    ddir = cache_dir(DIMS_DIR, "dims")
+    so = os.path.join(ddir, f"liblqg_hip_{tag}.so")
+    want = source_hash()
+    if stamped(so, want):
         return so
-    lists = {"FORWARD": [(x, b, u, y, d)], "RICCATI": [(b, u)], "KALMAN": [(b, y)], "TRIAL": [(x + b, d)],
-             "SIM": [(x, b, u, y)], "ADJOINT": [(x, b, u, y, d)] if x + b <= ADJOINT_MAX_JOINT else []}
-    deff = os.path.join(DIMS_DIR, f"dims_{tag}.def")
-    with open(deff, "w") as f:
-        f.write(f"// GENERATED by lqg_amd/build.py: instantiation lists of the auxiliary library for shape {tag}\n")
+    with locked(so):
+        if stamped(so, want):                      # another process built it while this one waited for the lock
+            return so
+        lists = {"FORWARD": [(x, b, u, y, d)], "RICCATI": [(b, u)], "KALMAN": [(b, y)], "TRIAL": [(x + b, d)],
+                 "SIM": [(x, b, u, y)], "ADJOINT": [(x, b, u, y, d)] if x + b <= ADJOINT_MAX_JOINT else []}
+        deff = os.path.join(ddir, f"dims_{tag}.def")
+        text = f"// GENERATED by lqg_amd/build.py: instantiation lists of the auxiliary library for shape {tag}\n"
         for fam, tuples in lists.items():
-            f.write(f"#define LQG_{fam}_DIMS(X) " + " ".join("X(" + ", ".join(map(str, t)) + ")" for t in tuples) + "\n")
-    objdir = os.path.join(DIMS_DIR, f"obj_{tag}")
-    os.makedirs(objdir, exist_ok=True)
-    js = jobs(lists, extra_defs=[f'-DLQG_DIMS_DEF="{deff}"'])
-    if verbose:
-        print(f"[lqg_amd.build] compiling auxiliary library for shape (x,b,u,y,d)=({x},{b},{u},{y},{d}): "
-              f"{len(js)} translation units", flush=True)
+            text += f"#define LQG_{fam}_DIMS(X) " + " ".join("X(" + ", ".join(map(str, t)) + ")" for t in tuples) + "\n"
+        atomic_write(deff, text)
+        objdir = os.path.join(ddir, f"obj_{tag}")
+        os.makedirs(objdir, exist_ok=True)
+        js = jobs(lists, extra_defs=[f'-DLQG_DIMS_DEF="{deff}"'])
+        if verbose:
+            print(f"[lqg_amd.build] compiling auxiliary library for shape (x,b,u,y,d)=({x},{b},{u},{y},{d}): "
+                  f"{len(js)} translation units", flush=True)
 
-    def comp(job):
-        name, src, defs = job
-        r = subprocess.run([HIPCC] + FLAGS + defs + ["-c", os.path.join(CSRC, src), "-o", os.path.join(objdir, name)],
-                           capture_output=True, text=True)
-        return name, r.returncode, r.stderr
+        def comp(job):
+            name, src, defs = job
+            r = subprocess.run([HIPCC] + FLAGS + defs + ["-c", os.path.join(CSRC, src), "-o", os.path.join(objdir, name)],
+                               capture_output=True, text=True)
+            return name, r.returncode, r.stderr
 
-    with cf.ThreadPoolExecutor(workers or min(8, os.cpu_count() or 1)) as ex:
-        for name, rc, err in ex.map(comp, js):
-            if rc != 0:
-                raise RuntimeError(f"hipcc failed on {name}:\n{err[-3000:]}")
-    r = subprocess.run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", so] +
-                       [os.path.join(objdir, j[0]) for j in js], capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("link failed:\n" + r.stderr[-3000:])
-    with open(stamp, "w") as f:
-        f.write(source_hash())
+        with cf.ThreadPoolExecutor(workers or min(8, os.cpu_count() or 1)) as ex:
+            for name, rc, err in ex.map(comp, js):
+                if rc != 0:
+                    raise RuntimeError(f"hipcc failed on {name}:\n{err[-3000:]}")
+        tmp = f"{so}.tmp.{os.getpid()}"
+        r = subprocess.run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] +
+                           [os.path.join(objdir, j[0]) for j in js], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stderr[-3000:])
+        os.replace(tmp, so)
+        atomic_write(so + ".stamp", want)
     return so
 
 

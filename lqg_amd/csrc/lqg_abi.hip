@@ -5,10 +5,12 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/lqg_hip.h"
 #include "lqg_adjoint_launch.hpp"
+#include "lqg_coop_launch.hpp"
 #include "lqg_launch.hpp"
 // the instantiation lists: lqg_dims.def for the main library; lqg_amd/build.py compiles auxiliary libraries for
 // shapes that are not listed there with -DLQG_DIMS_DEF="<generated single-shape lists>"
@@ -151,6 +153,28 @@ bool has_forward(const lqg_dims& d) {
   return false;
 }
 
+// ---- strategy: lane-per-system kernels (register-resident, instantiated per shape) or the cooperative
+// workgroup-per-system kernels (lqg_coop.hpp: run-time dims, LDS-staged).  LQG_COOP=1 forces the cooperative path
+// wherever it is defined, LQG_COOP=0 restricts it to shapes without a lane instantiation; default: shapes without an
+// instantiation, and few systems of a large enough joint dimension (a lane would walk the recursion alone).
+#ifndef LQG_COOP_MAX_SYS
+#define LQG_COOP_MAX_SYS 512
+#endif
+#ifndef LQG_COOP_MIN_M
+#define LQG_COOP_MIN_M 8
+#endif
+int coop_mode() {
+  const char* e = getenv("LQG_COOP");
+  return (e && *e) ? atoi(e) : -1;
+}
+bool use_coop(const lqg_problem* p) {
+  if (!coop_supported(p->dims)) return false;
+  if (!has_forward(p->dims)) return true;
+  const int mode = coop_mode();
+  if (mode >= 0) return mode == 1;
+  return p->n_sys <= LQG_COOP_MAX_SYS && p->dims.x + p->dims.b >= LQG_COOP_MIN_M;
+}
+
 int check_problem(const lqg_problem* p, const char* who) {
   if (!p) return fail(LQG_ERR_NULL, "%s: problem is NULL", who);
   if (p->dtype != LQG_F32 && p->dtype != LQG_F64) return fail(LQG_ERR_ARG, "%s: bad dtype %d", who, p->dtype);
@@ -189,7 +213,7 @@ int check_full(const lqg_problem* p, const char* who) {
     return LQG_ERR_NULL;
   if (p->dims.d < 1 || p->dims.d > p->dims.x)
     return fail(LQG_ERR_DIMS, "%s: observed dims d=%d must be in [1, x=%d]", who, p->dims.d, p->dims.x);
-  if (!has_forward(p->dims)) return unsupported(p, who);
+  if (!has_forward(p->dims) && !coop_supported(p->dims)) return unsupported(p, who);
   return 0;
 }
 
@@ -202,7 +226,16 @@ struct GainOutputs {
 // more trials go through the per-system operator stream and k_trial.
 template <typename R>
 int run_moments(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_view Sigma, void* ll, long ll_sb, long ll_sn,
+                const GainOutputs& g, void* workspace, size_t workspace_bytes, hipStream_t st, const char* who);
+
+template <typename R>
+int run_coop(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_view Sigma, void* ll, long ll_sb, long ll_sn,
+             const GainOutputs& g, void* workspace, size_t workspace_bytes, hipStream_t st, const char* who);
+
+template <typename R>
+int run_moments(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_view Sigma, void* ll, long ll_sb, long ll_sn,
                 const GainOutputs& g, void* workspace, size_t workspace_bytes, hipStream_t st, const char* who) {
+  if (use_coop(p)) return run_coop<R>(p, x, mu, Sigma, ll, ll_sb, ll_sn, g, workspace, workspace_bytes, st, who);
   const bool fused = p->n_trials == 1;
   const Workspace w = carve(p, !fused);
   if (!workspace || workspace_bytes < w.total)
@@ -232,6 +265,38 @@ int run_moments(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_view Sigma, v
   return done(e, who);
 }
 
+// The same three phases on the cooperative kernels: Riccati -> forward sweep (always through the operator stream) ->
+// per-trial sweep (the instantiated k_trial when the shape has one, else the run-time-dims k_coop_trial).
+template <typename R>
+int run_coop(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_view Sigma, void* ll, long ll_sb, long ll_sn,
+             const GainOutputs& g, void* workspace, size_t workspace_bytes, hipStream_t st, const char* who) {
+  const Workspace w = carve(p, true);
+  const size_t arena_bytes = coop_arena_bytes(p, false, false);
+  if (!workspace || workspace_bytes < w.total + arena_bytes)
+    return fail(LQG_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B", who, workspace_bytes, w.total + arena_bytes);
+  char* base = static_cast<char*>(workspace);
+  void* Ls = base + w.ls_off;
+  void* ops = base + w.ops_off;
+  void* arena = arena_bytes ? base + w.total : nullptr;
+  auto mark = [&](int i) {
+    if (p->phase_events[i]) (void)hipEventRecord(static_cast<hipEvent_t>(p->phase_events[i]), st);
+  };
+  mark(0);
+  hipError_t e = coop_riccati<R>(p, g.L, g.l, g.H, Ls, arena, st);
+  if (e != hipSuccess) return done(e, who);
+  mark(1);
+  e = coop_forward<R>(p, Ls, ops, Sigma, g.K, arena, st);
+  if (e != hipSuccess) return done(e, who);
+  mark(2);
+  if (p->n_trials > 0 && (ll || mu.ptr)) {
+    bool found;
+    e = dispatch_trial<R>(p, ops, x, mu, ll, ll_sb, ll_sn, st, &found);
+    if (!found) e = coop_trial<R>(p, ops, x, mu, ll, ll_sb, ll_sn, st);
+  }
+  mark(3);
+  return done(e, who);
+}
+
 }  // namespace
 
 extern "C" {
@@ -239,6 +304,40 @@ extern "C" {
 int lqg_abi_version(void) { return LQG_ABI_VERSION; }
 const char* lqg_last_error(void) { return g_err; }
 const char* lqg_target_arch(void) { return "gfx950"; }
+
+int lqg_coop_supported(const lqg_dims* dims) { return dims && coop_supported(*dims) ? 1 : 0; }
+int lqg_strategy(const lqg_problem* p) { return p && use_coop(p) ? LQG_STRATEGY_COOP : LQG_STRATEGY_LANE; }
+
+int lqg_kernel_supported(int32_t family, const lqg_dims* dims) {
+  if (!dims) return 0;
+  const lqg_dims& d = *dims;
+  (void)d;
+  switch (family) {
+    case LQG_FAMILY_FORWARD: return has_forward(d) ? 1 : 0;
+    case LQG_FAMILY_RICCATI:
+#define X(B_, U_) if (d.b == B_ && d.u == U_) return 1;
+      LQG_RICCATI_DIMS(X)
+#undef X
+      return 0;
+    case LQG_FAMILY_KALMAN:
+#define X(B_, Y_) if (d.b == B_ && d.y == Y_) return 1;
+      LQG_KALMAN_DIMS(X)
+#undef X
+      return 0;
+    case LQG_FAMILY_TRIAL:
+#define X(M_, D_) if (d.x + d.b == M_ && d.d == D_) return 1;
+      LQG_TRIAL_DIMS(X)
+#undef X
+      return 0;
+    case LQG_FAMILY_SIMULATE:
+#define X(X_, B_, U_, Y_) if (d.x == X_ && d.b == B_ && d.u == U_ && d.y == Y_) return 1;
+      LQG_SIM_DIMS(X)
+#undef X
+      return 0;
+    case LQG_FAMILY_ADJOINT: return lqg_grad_supported(LQG_F64, dims);
+    default: return 0;
+  }
+}
 
 int lqg_dims_supported(int32_t dtype, const lqg_dims* dims) {
   if (!dims || (dtype != LQG_F32 && dtype != LQG_F64)) return 0;
@@ -253,11 +352,17 @@ int lqg_riccati_backward(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view 
       need(a.A, who, "actor.A") || need(a.B, who, "actor.B") || need(L, who, "L"))
     return LQG_ERR_NULL;
   if (p->n_sys == 0) return 0;
-  bool found;
-  hipError_t e = p->dtype == LQG_F64
-                     ? dispatch_riccati<double>(p, L, l, H, nullptr, 0, (hipStream_t)stream, &found)
-                     : dispatch_riccati<float>(p, L, l, H, nullptr, 0, (hipStream_t)stream, &found);
-  if (!found) return unsupported(p, who);
+  bool found = false;
+  hipError_t e = hipSuccess;
+  const bool can_coop = coop_supported(p->dims) && coop_fits_lds(p, false, true);
+  if (!(coop_mode() == 1 && can_coop))
+    e = p->dtype == LQG_F64 ? dispatch_riccati<double>(p, L, l, H, nullptr, 0, (hipStream_t)stream, &found)
+                            : dispatch_riccati<float>(p, L, l, H, nullptr, 0, (hipStream_t)stream, &found);
+  if (!found) {                 // no (b, u) instantiation: the cooperative run-time-dims kernel (working set in LDS)
+    if (!can_coop) return unsupported(p, who);
+    e = p->dtype == LQG_F64 ? coop_riccati<double>(p, L, l, H, nullptr, nullptr, (hipStream_t)stream)
+                            : coop_riccati<float>(p, L, l, H, nullptr, nullptr, (hipStream_t)stream);
+  }
   return done(e, who);
 }
 
@@ -269,16 +374,25 @@ int lqg_kalman_forward(const lqg_problem* p, lqg_view K, void* stream) {
       need(a.W, who, "actor.W") || need(K, who, "K"))
     return LQG_ERR_NULL;
   if (p->n_sys == 0) return 0;
-  bool found;
-  hipError_t e = p->dtype == LQG_F64 ? dispatch_kalman<double>(p, K, (hipStream_t)stream, &found)
-                                     : dispatch_kalman<float>(p, K, (hipStream_t)stream, &found);
-  if (!found) return unsupported(p, who);
+  bool found = false;
+  hipError_t e = hipSuccess;
+  const bool can_coop = coop_supported(p->dims) && coop_fits_lds(p, true, false);
+  if (!(coop_mode() == 1 && can_coop))
+    e = p->dtype == LQG_F64 ? dispatch_kalman<double>(p, K, (hipStream_t)stream, &found)
+                            : dispatch_kalman<float>(p, K, (hipStream_t)stream, &found);
+  if (!found) {                 // no (b, y) instantiation: the cooperative run-time-dims kernel (working set in LDS)
+    if (!can_coop) return unsupported(p, who);
+    const lqg_view none{nullptr, 0, 0, 0, 0};
+    e = p->dtype == LQG_F64 ? coop_forward<double>(p, nullptr, nullptr, none, K, nullptr, (hipStream_t)stream)
+                            : coop_forward<float>(p, nullptr, nullptr, none, K, nullptr, (hipStream_t)stream);
+  }
   return done(e, who);
 }
 
 size_t lqg_workspace_bytes(const lqg_problem* p, int32_t op) {
   if (!p) return 0;
   (void)op;   // every op runs fused (no operator stream) when there is one trial per system
+  if (use_coop(p)) return carve(p, true).total + coop_arena_bytes(p, false, false);
   return carve(p, p->n_trials != 1).total;
 }
 

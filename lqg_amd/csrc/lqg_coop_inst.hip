@@ -1,0 +1,147 @@
+// lqg_coop_inst.hip — the cooperative kernels of lqg_coop.hpp and their launch wrappers: ONE translation unit for every
+// model shape (dimensions are run-time arguments), both dtypes, LDS and global-arena variants, 64- and 256-lane
+// workgroups.
+#include "lqg_coop.hpp"
+#include "lqg_coop_launch.hpp"
+#include "lqg_launch.hpp"
+
+namespace lqg {
+namespace host {
+
+namespace {
+constexpr size_t kLdsLimit = 160 * 1024 - 512;     // gfx950: 160 KB LDS per CU
+constexpr size_t kLdsDefault = 64 * 1024;          // above this the kernel needs the dynamic-LDS attribute raised
+
+inline size_t esz(const lqg_problem* p) { return p->dtype == LQG_F64 ? 8 : 4; }
+inline long ric_reals(const lqg_problem* p) { return coop::riccati_arena_reals(p->dims.b, p->dims.u); }
+inline long fwd_reals(const lqg_problem* p, bool kalman_only) {
+  return kalman_only ? coop::kalman_arena_reals(p->dims.b, p->dims.y)
+                     : coop::forward_arena_reals(p->dims.x, p->dims.b, p->dims.u, p->dims.y, p->dims.d);
+}
+// one wave per system while a step's largest product has at most two elements per lane, else four waves
+inline int block_for(int elems) { return elems <= 128 ? 64 : 256; }
+
+template <typename K>
+hipError_t raise_lds(K kernel, size_t bytes) {
+  if (bytes <= kLdsDefault) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <typename R>
+coop::Args<R> make_args(const lqg_problem* p) {
+  const lqg_spec& a = p->actor;
+  const lqg_spec& d = p->dynamics;
+  coop::Args<R> k{};
+  k.aQ = dv<R>(a.Q); k.aq = dv<R>(a.q); k.aQf = dv<R>(a.Qf); k.aqf = dv<R>(a.qf); k.aP = dv<R>(a.P); k.aR = dv<R>(a.R);
+  k.ar = dv<R>(a.r); k.aA = dv<R>(a.A); k.aB = dv<R>(a.B); k.aF = dv<R>(a.F); k.aV = dv<R>(a.V); k.aW = dv<R>(a.W);
+  k.dA = dv<R>(d.A); k.dB = dv<R>(d.B); k.dF = dv<R>(d.F); k.dV = dv<R>(d.V); k.dW = dv<R>(d.W);
+  k.Sigma0 = dv<R>(p->Sigma0);
+  k.n_sys = (long)p->n_sys;
+  k.T = p->T;
+  k.x = p->dims.x; k.b = p->dims.b; k.u = p->dims.u; k.y = p->dims.y; k.d = p->dims.d;
+  k.nva = p->dims.nva; k.nwa = p->dims.nwa; k.nvd = p->dims.nvd; k.nwd = p->dims.nwd;
+  k.nops = (int)ops_reals(p->dims);
+  k.eps = (R)p->eps;
+  return k;
+}
+}  // namespace
+
+bool coop_supported(const lqg_dims& d) {
+  return d.x >= 1 && d.b >= 1 && d.u >= 1 && d.y >= 1 && d.u <= coop::kMaxSmall && d.y <= coop::kMaxSmall &&
+         d.d <= coop::kMaxSmall;
+}
+
+bool coop_fits_lds(const lqg_problem* p, bool kalman_only, bool riccati_only) {
+  const size_t ric = kalman_only ? 0 : (size_t)ric_reals(p) * esz(p);
+  const size_t fwd = riccati_only ? 0 : (size_t)fwd_reals(p, kalman_only) * esz(p);
+  return ric <= kLdsLimit && fwd <= kLdsLimit;
+}
+
+size_t coop_arena_bytes(const lqg_problem* p, bool kalman_only, bool riccati_only) {
+  if (coop_fits_lds(p, kalman_only, riccati_only)) return 0;
+  const long r = kalman_only ? 0 : ric_reals(p), f = riccati_only ? 0 : fwd_reals(p, kalman_only);
+  return (size_t)p->n_sys * (size_t)(r > f ? r : f) * esz(p);
+}
+
+template <typename R>
+hipError_t coop_riccati(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view H, void* Ls, void* arena, hipStream_t st) {
+  coop::Args<R> k = make_args<R>(p);
+  k.L = dv<R>(L); k.l = dv<R>(l); k.H = dv<R>(H);
+  k.Ls = static_cast<R*>(Ls);
+  k.ti = actor_ti_riccati(p) ? 1 : 0;
+  const long reals = ric_reals(p);
+  const size_t lds = (size_t)reals * sizeof(R);
+  const bool global = lds > kLdsLimit;
+  if (global && !arena) return hipErrorInvalidValue;
+  k.arena = static_cast<R*>(arena);
+  k.arena_reals = reals;
+  const dim3 grid((unsigned)p->n_sys);
+  const int block = block_for(p->dims.b * p->dims.b);
+#define LQG_GO(B_, G_)                                                                     \
+  {                                                                                         \
+    auto kern = coop::k_coop_riccati<R, B_, G_>;                                            \
+    if (!(G_)) { hipError_t e = raise_lds(kern, lds); if (e != hipSuccess) return e; }      \
+    hipLaunchKernelGGL(kern, grid, dim3(B_), (G_) ? 0 : lds, st, k);                        \
+  }
+  if (block == 64) { if (global) LQG_GO(64, true) else LQG_GO(64, false) }
+  else { if (global) LQG_GO(256, true) else LQG_GO(256, false) }
+#undef LQG_GO
+  return hipGetLastError();
+}
+
+template <typename R>
+hipError_t coop_forward(const lqg_problem* p, const void* Ls, void* ops, lqg_view Sig, lqg_view K, void* arena,
+                        hipStream_t st) {
+  coop::Args<R> k = make_args<R>(p);
+  k.Sig = dv<R>(Sig); k.K = dv<R>(K);
+  k.Ls = const_cast<R*>(static_cast<const R*>(Ls));
+  k.ops = static_cast<R*>(ops);
+  k.ti = forward_ti(p) ? 1 : 0;
+  const bool kalman_only = !ops && !Sig.ptr;
+  const long reals = fwd_reals(p, kalman_only);
+  const size_t lds = (size_t)reals * sizeof(R);
+  const bool global = lds > kLdsLimit;
+  if (global && !arena) return hipErrorInvalidValue;
+  k.arena = static_cast<R*>(arena);
+  k.arena_reals = reals;
+  const dim3 grid((unsigned)p->n_sys);
+  const int m = p->dims.x + p->dims.b;
+  const int block = block_for(kalman_only ? p->dims.b * p->dims.b : m * m);
+#define LQG_GO(B_, G_)                                                                     \
+  {                                                                                         \
+    auto kern = coop::k_coop_forward<R, B_, G_>;                                            \
+    if (!(G_)) { hipError_t e = raise_lds(kern, lds); if (e != hipSuccess) return e; }      \
+    hipLaunchKernelGGL(kern, grid, dim3(B_), (G_) ? 0 : lds, st, k);                        \
+  }
+  if (block == 64) { if (global) LQG_GO(64, true) else LQG_GO(64, false) }
+  else { if (global) LQG_GO(256, true) else LQG_GO(256, false) }
+#undef LQG_GO
+  return hipGetLastError();
+}
+
+template <typename R>
+hipError_t coop_trial(const lqg_problem* p, const void* ops, lqg_traj x, lqg_traj mu, void* ll, long ll_sb, long ll_sn,
+                      hipStream_t st) {
+  const int m = p->dims.x + p->dims.b, o = p->dims.d, rr = m - o;
+  coop::TrialArgsRT<R> k{dt<R>(x), dt<R>(mu), static_cast<R*>(ll), ll_sb, ll_sn, (long)p->n_trials, p->T, m, o,
+                         (int)ops_reals(p->dims)};
+  constexpr int B = 64;
+  const size_t lds = (size_t)B * (size_t)(4 * o + 2 * rr + m) * sizeof(R);
+  if (lds > kLdsLimit) return hipErrorInvalidValue;
+  auto kern = coop::k_coop_trial<R, B>;
+  hipError_t e = raise_lds(kern, lds);
+  if (e != hipSuccess) return e;
+  const dim3 grid((unsigned)((p->n_trials + B - 1) / B), (unsigned)p->n_sys);
+  hipLaunchKernelGGL(kern, grid, dim3(B), lds, st, static_cast<const R*>(ops), k);
+  return hipGetLastError();
+}
+
+template hipError_t coop_riccati<float>(const lqg_problem*, lqg_view, lqg_view, lqg_view, void*, void*, hipStream_t);
+template hipError_t coop_riccati<double>(const lqg_problem*, lqg_view, lqg_view, lqg_view, void*, void*, hipStream_t);
+template hipError_t coop_forward<float>(const lqg_problem*, const void*, void*, lqg_view, lqg_view, void*, hipStream_t);
+template hipError_t coop_forward<double>(const lqg_problem*, const void*, void*, lqg_view, lqg_view, void*, hipStream_t);
+template hipError_t coop_trial<float>(const lqg_problem*, const void*, lqg_traj, lqg_traj, void*, long, long, hipStream_t);
+template hipError_t coop_trial<double>(const lqg_problem*, const void*, lqg_traj, lqg_traj, void*, long, long, hipStream_t);
+
+}  // namespace host
+}  // namespace lqg

@@ -1,0 +1,30 @@
+// lqg_coop_launch.hpp — host side of the cooperative (workgroup-per-system, run-time dims) kernels of lqg_coop.hpp:
+// strategy decision, workspace accounting and launch wrappers.  Defined once in lqg_coop_inst.hip (one translation
+// unit for every model shape), declared here for lqg_abi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/lqg_hip.h"
+
+namespace lqg {
+namespace host {
+
+// dims the cooperative kernels serve: u, y, d <= 6 (their small factorizations run in registers); x, b unbounded
+bool coop_supported(const lqg_dims& d);
+// bytes of the global working set the cooperative path needs BEHIND the gain scratch + operator stream of carve():
+// 0 when the per-system working set fits LDS
+size_t coop_arena_bytes(const lqg_problem* p, bool kalman_only, bool riccati_only);
+// true when the call can run without any global arena (stand-alone lqr.backward / kf.forward take no workspace)
+bool coop_fits_lds(const lqg_problem* p, bool kalman_only, bool riccati_only);
+
+template <typename R>
+hipError_t coop_riccati(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view H, void* Ls, void* arena, hipStream_t st);
+template <typename R>
+hipError_t coop_forward(const lqg_problem* p, const void* Ls, void* ops, lqg_view Sig, lqg_view K, void* arena,
+                        hipStream_t st);
+template <typename R>
+hipError_t coop_trial(const lqg_problem* p, const void* ops, lqg_traj x, lqg_traj mu, void* ll, long ll_sb, long ll_sn,
+                      hipStream_t st);
+
+}  // namespace host
+}  // namespace lqg

@@ -13,6 +13,8 @@
 #ifndef LQG_SP_PREFETCH
 #define LQG_SP_PREFETCH 1
 #endif
+#include <utility>
+
 #include "lqg_kernels.hpp"
 #include "lqg_sparse.hpp"
 
@@ -31,10 +33,83 @@ namespace lqg {
 #endif
 
 // ---------------------------------------------------------------- Riccati backward, TI, no affine terms
-template <typename R, int NB, int NU, typename PAT>
+// LQG_SP_CHUNK = CK > 0: CHECKPOINTED gains.  The backward sweep keeps only the packed cost-to-go S every CK steps
+// (NB (NB + 1) / 2 reals per CK steps instead of NU NB reals per step); the forward sweep re-runs the CK backward steps of
+// each chunk in registers (the same riccati_step_sp, hence bitwise the same L_t) right before it consumes them.  Trades
+// HBM traffic of the gain stream (written once, read once) for NU-row Riccati work on the forward kernel's VALU.
+// Measured (MI355X, headline shape x=2 b=3 u=1, 2^20 systems, profiles/r02_a_chunk_*.json): fp32 CK = 0 / 4 / 8 / 16 ->
+// 241 / 246 / 253 / 230 M solves/s (the Riccati kernel stops being HBM-write-bound: 1.02 -> 0.69 ms; the forward kernel
+// pays 3.28 -> 3.41 ms for the recompute and drops from 4 to 3 waves per SIMD; at 16 the 48 gain registers cost more);
+// fp64 CK = 0 / 8 -> 113 / 111 M (fp64 VALU runs at half rate: the recompute costs more than the traffic it saves).
+// Hence: 8 in fp32, 0 in fp64, and only for gains of at most 4 reals per step (u b <= 4: every 1-D tracking model).
+// LQG_SP_CHUNK overrides both (A/B builds: scripts/exp_chunk.sh).
+#ifdef LQG_SP_CHUNK
+#define LQG_SP_CHUNK_F32 LQG_SP_CHUNK
+#define LQG_SP_CHUNK_F64 LQG_SP_CHUNK
+#endif
+#ifndef LQG_SP_CHUNK_F32
+#define LQG_SP_CHUNK_F32 8
+#endif
+#ifndef LQG_SP_CHUNK_F64
+#define LQG_SP_CHUNK_F64 0
+#endif
+#ifndef LQG_SP_CHUNK_MAX_GAIN
+#define LQG_SP_CHUNK_MAX_GAIN 4
+#endif
+template <typename R, int NB, int NU>
+constexpr int sp_chunk() {
+  return (NU * NB <= LQG_SP_CHUNK_MAX_GAIN) ? (sizeof(R) == 4 ? LQG_SP_CHUNK_F32 : LQG_SP_CHUNK_F64) : 0;
+}
+
+// one backward step: S <- Q + A'SA + L'HL + L'G + G'L with L = -Ht^-1 G (lqr.py:22-34), L returned
+template <typename R, int NB, int NU, typename MA, typename MB, typename MQ, typename MR>
+LQG_DEV void riccati_step_sp(R (&S)[NB * NB], const MA& A, const MB& Bm, const MQ& Q, const MR& Rm, const R eps,
+                             R (&L)[NU * NB]) {
+  const auto Sm = from_dense<R, NB, NB>(S);
+  const auto SA = mul(Sm, A);
+  const auto SB = mul(Sm, Bm);
+  R H[NU * NU], G[NU * NB];
+  to_dense(mul_tn_sym_add(Bm, SB, Rm), H);                       // H = R + B^T S B     lqr.py:22
+  to_dense(mul_tn(Bm, SA), G);                                   // G = B^T S A         lqr.py:23
+  R ev0 = min_eig_sym<R, NU>(H);
+  R shift = eps - ev0;
+  shift = (shift > R(0)) ? shift : R(0);
+  R Ht[NU * NU];
+  LQG_UNROLL for (int i = 0; i < NU * NU; ++i) Ht[i] = H[i];
+  LQG_UNROLL for (int i = 0; i < NU; ++i) Ht[i * NU + i] += shift;  // lqr.py:27-28
+  R Lc[NU * NU], dinv[NU], Li[NU * NU], Hi[NU * NU];
+  chol_lower<R, NU>(Ht, Lc, dinv);
+  tri_inverse_lower<R, NU>(Lc, dinv, Li);
+  spd_inverse_from_tri<R, NU>(Li, Hi);
+  R W1[NU * NB];
+  LQG_UNROLL for (int i = 0; i < NU; ++i)
+    LQG_UNROLL for (int j = 0; j < NB; ++j) {
+      R acc = R(0);
+      LQG_UNROLL for (int k = 0; k < NU; ++k) acc -= Hi[i * NU + k] * G[k * NB + j];
+      L[i * NB + j] = acc;                                       // L = -Ht^-1 G        lqr.py:30
+    }
+  LQG_UNROLL for (int i = 0; i < NU; ++i)
+    LQG_UNROLL for (int j = 0; j < NB; ++j) {
+      R acc = G[i * NB + j];
+      LQG_UNROLL for (int k = 0; k < NU; ++k) acc += H[i * NU + k] * L[k * NB + j];
+      W1[i * NB + j] = acc;                                      // H L + G (unregularised H)
+    }
+  R Sn[NB * NB];
+  to_dense(mul_tn_sym_add(A, SA, Q), Sn);                        // Q + A^T S A
+  LQG_UNROLL for (int i = 0; i < NB; ++i)
+    LQG_UNROLL for (int j = i; j < NB; ++j) {
+      R acc = Sn[i * NB + j];
+      LQG_UNROLL for (int k = 0; k < NU; ++k) acc += L[k * NB + i] * W1[k * NB + j] + G[k * NB + i] * L[k * NB + j];
+      S[i * NB + j] = acc;                                       // lqr.py:33
+      S[j * NB + i] = acc;
+    }
+}
+
+template <typename R, int NB, int NU, typename PAT, int CK>
 __global__ void __launch_bounds__(LQG_BLOCK, LQG_SP_RIC_WAVES) k_riccati_sp(const RiccatiArgs<R> a) {
   const long s = blockIdx.x * (long)LQG_BLOCK + threadIdx.x;
   if (s >= a.n_sys) return;
+  constexpr int NS = NB * (NB + 1) / 2;
   R S[NB * NB];
   load_sym<R, NB>(a.Qf.p + s * a.Qf.sb, a.Qf.sr, a.Qf.sc, S);
   const auto A = load_masked<R, NB, NB, PAT::Aa>(a.A.p + s * a.A.sb, a.A.sr, a.A.sc);
@@ -43,46 +118,20 @@ __global__ void __launch_bounds__(LQG_BLOCK, LQG_SP_RIC_WAVES) k_riccati_sp(cons
   const auto Rm = load_sym_masked<R, NU, PAT::Rr>(a.Rm.p + s * a.Rm.sb, a.Rm.sr, a.Rm.sc);
 
   for (int t = a.T - 1; t >= 0; --t) {
-    const auto Sm = from_dense<R, NB, NB>(S);
-    const auto SA = mul(Sm, A);
-    const auto SB = mul(Sm, Bm);
-    R H[NU * NU], G[NU * NB];
-    to_dense(mul_tn_sym_add(Bm, SB, Rm), H);                       // H = R + B^T S B     lqr.py:22
-    to_dense(mul_tn(Bm, SA), G);                                   // G = B^T S A         lqr.py:23
-    R ev0 = min_eig_sym<R, NU>(H);
-    R shift = a.eps - ev0;
-    shift = (shift > R(0)) ? shift : R(0);
-    R Ht[NU * NU];
-    LQG_UNROLL for (int i = 0; i < NU * NU; ++i) Ht[i] = H[i];
-    LQG_UNROLL for (int i = 0; i < NU; ++i) Ht[i * NU + i] += shift;  // lqr.py:27-28
-    R Lc[NU * NU], dinv[NU], Li[NU * NU], Hi[NU * NU];
-    chol_lower<R, NU>(Ht, Lc, dinv);
-    tri_inverse_lower<R, NU>(Lc, dinv, Li);
-    spd_inverse_from_tri<R, NU>(Li, Hi);
-    R L[NU * NB], W1[NU * NB];
-    LQG_UNROLL for (int i = 0; i < NU; ++i)
-      LQG_UNROLL for (int j = 0; j < NB; ++j) {
-        R acc = R(0);
-        LQG_UNROLL for (int k = 0; k < NU; ++k) acc -= Hi[i * NU + k] * G[k * NB + j];
-        L[i * NB + j] = acc;                                       // L = -Ht^-1 G        lqr.py:30
+    if constexpr (CK > 0) {
+      if ((t + 1) % CK == 0 || t == a.T - 1) {       // t is the last step of its chunk: keep S_{t+1}
+        R* dst = a.Ls + (long)(t / CK) * NS * a.ldb + s;
+        int e = 0;
+        LQG_UNROLL for (int i = 0; i < NB; ++i)
+          LQG_UNROLL for (int j = i; j < NB; ++j) dst[(e++) * a.ldb] = S[i * NB + j];
       }
-    LQG_UNROLL for (int i = 0; i < NU; ++i)
-      LQG_UNROLL for (int j = 0; j < NB; ++j) {
-        R acc = G[i * NB + j];
-        LQG_UNROLL for (int k = 0; k < NU; ++k) acc += H[i * NU + k] * L[k * NB + j];
-        W1[i * NB + j] = acc;                                      // H L + G (unregularised H)
-      }
-    R Sn[NB * NB];
-    to_dense(mul_tn_sym_add(A, SA, Q), Sn);                        // Q + A^T S A
-    LQG_UNROLL for (int i = 0; i < NB; ++i)
-      LQG_UNROLL for (int j = i; j < NB; ++j) {
-        R acc = Sn[i * NB + j];
-        LQG_UNROLL for (int k = 0; k < NU; ++k) acc += L[k * NB + i] * W1[k * NB + j] + G[k * NB + i] * L[k * NB + j];
-        S[i * NB + j] = acc;                                       // lqr.py:33
-        S[j * NB + i] = acc;
-      }
-    R* dst = a.Ls + (long)t * (NU * NB) * a.ldb + s;
-    LQG_UNROLL for (int e = 0; e < NU * NB; ++e) dst[e * a.ldb] = L[e];
+    }
+    R L[NU * NB];
+    riccati_step_sp<R, NB, NU>(S, A, Bm, Q, Rm, a.eps, L);
+    if constexpr (CK == 0) {
+      R* dst = a.Ls + (long)t * (NU * NB) * a.ldb + s;
+      LQG_UNROLL for (int e = 0; e < NU * NB; ++e) dst[e * a.ldb] = L[e];
+    }
   }
 }
 
@@ -113,9 +162,10 @@ constexpr Mask<NB, NB> kalman_state_mask() {
 // NTR >= 1 (fused): the NTR trials of each system are swept in-lane (1: the headline; 2: two identical decoupled
 // components solved as ONE system with two trials, lqg_amd/plan.py); NTR == 0: the per-step trial operators are written
 // to the operator stream for k_trial (many trials per system), exactly as k_forward does.  ll_sn: trial stride of ll.
-template <typename R, int NX, int NB, int NU, int NY, int ND, typename PAT, int NTR, bool DENSE_P>
+// CK > 0: checkpointed gains (see k_riccati_sp): `rc` carries the actor's cost matrices and the checkpoint stream.
+template <typename R, int NX, int NB, int NU, int NY, int ND, typename PAT, int NTR, bool DENSE_P, int CK>
 __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F32 : LQG_SP_FWD_WAVES_F64)
-    k_forward_sp(const ForwardArgs<R> a, const long ll_sn) {
+    k_forward_sp(const ForwardArgs<R> a, const long ll_sn, const RiccatiArgs<R> rc) {
   constexpr bool FUSED = NTR > 0;
   constexpr int NT = FUSED ? NTR : 1;
   constexpr int M = NX + NB, O = ND, RR = M - ND;
@@ -193,8 +243,39 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
     LQG_UNROLL for (int k = 0; k < NT; ++k)
       LQG_UNROLL for (int i = 0; i < O; ++i) xnx[k][i] = xprev[k][i];
   }
-  LQG_UNROLL for (int e = 0; e < NU * NB; ++e) Lnx[e] = a.Ls[e * a.ldb + s];
+  if constexpr (CK == 0) {
+    LQG_UNROLL for (int e = 0; e < NU * NB; ++e) Lnx[e] = a.Ls[e * a.ldb + s];
+  }
 #endif
+  // ---- checkpointed gains: the chunk's L_t are recomputed backward from the kept S into registers
+  constexpr int CKN = CK > 0 ? CK : 1;
+  constexpr int NS = NB * (NB + 1) / 2;
+  R Lbuf[CKN][NU * NB], Snx[NS];
+  [[maybe_unused]] const auto rQ = [&]() {
+    if constexpr (CK > 0) return load_sym_masked<R, NB, PAT::Q>(rc.Q.p + s * rc.Q.sb, rc.Q.sr, rc.Q.sc);
+    else return 0;
+  }();
+  [[maybe_unused]] const auto rR = [&]() {
+    if constexpr (CK > 0) return load_sym_masked<R, NU, PAT::Rr>(rc.Rm.p + s * rc.Rm.sb, rc.Rm.sr, rc.Rm.sc);
+    else return 0;
+  }();
+  auto request_ckpt = [&](int c) {                       // issue the loads of checkpoint c (S at the END of chunk c)
+    const R* src = rc.Ls + (long)c * NS * rc.ldb + s;
+    LQG_UNROLL for (int e = 0; e < NS; ++e) Snx[e] = src[e * rc.ldb];
+  };
+  auto refill = [&](int t0) {                            // gains of steps t0 .. t0 + CK - 1 from the requested checkpoint
+    if constexpr (CK > 0) {
+      R Sr[NB * NB];
+      {
+        int e = 0;
+        LQG_UNROLL for (int i = 0; i < NB; ++i)
+          LQG_UNROLL for (int j = i; j < NB; ++j) { Sr[i * NB + j] = Snx[e]; Sr[j * NB + i] = Snx[e]; ++e; }
+      }
+      if (t0 + CK < a.T) request_ckpt(t0 / CK + 1);      // next chunk's checkpoint: a whole chunk of work hides it
+      LQG_UNROLL for (int j = CK - 1; j >= 0; --j)
+        if (t0 + j < a.T) riccati_step_sp<R, NB, NU>(Sr, Aa, Ba, rQ, rR, rc.eps, Lbuf[j]);
+    }
+  };
   auto innovate = [&](int n, int row, bool score) {        // trial n, data row `row`
 #if LQG_SP_PREFETCH
     (void)row;
@@ -215,7 +296,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
 
   // The first step is peeled (templated lambda): it alone initialises Sigma := G_0 G_0^T and skips the score of x_0;
   // inside one loop the compiler turns those two `t == 0` tests into ~30 v_cndmask per step.
-  auto step = [&]<bool FIRST>(int t) {
+  auto step = [&]<bool FIRST, int J>(int t) {
     // ---- Kalman step                                                   kf.py:10-14
     const auto AP = mul(Aa, Pm);
     const auto Pp = mul_nt_sym_add(AP, Aa, VVa);
@@ -225,14 +306,16 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
     assign_state(Pm, sym_sub_mul(Pp, K, FP));                            // P = Pp - K F Pp
     // ---- control gain L_t
     Mat<R, NU, NB> L;
+    if constexpr (CK > 0) {
+      LQG_UNROLL for (int e = 0; e < NU * NB; ++e) L.v[e] = Lbuf[J][e];
+    } else {
 #if LQG_SP_PREFETCH
-    LQG_UNROLL for (int e = 0; e < NU * NB; ++e) L.v[e] = Lnx[e];
+      LQG_UNROLL for (int e = 0; e < NU * NB; ++e) L.v[e] = Lnx[e];
 #else
-    {
       const R* src = a.Ls + (long)t * (NU * NB) * a.ldb + s;
       LQG_UNROLL for (int e = 0; e < NU * NB; ++e) L.v[e] = src[e * a.ldb];
-    }
 #endif
+    }
     // ---- joint dynamics                                                system.py:167-187
     const auto BK = add(Ba, mul(K, DB));
     const auto Fj = block2x2(Ad, mul(Bd, L), mul(K, FAd), add(sub(Aa, mul(K, FAa)), mul(BK, L)));
@@ -281,9 +364,11 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
 #if LQG_SP_PREFETCH
     {   // requests for step t+1 (row t+1 of x always exists; the last step re-reads its own gain row), issued BEFORE the
         // Sigma update below so that ~100 FMAs stand between the loads and the loop back-edge
-      const int tn = (t + 1 < a.T) ? t + 1 : t;
-      const R* src = a.Ls + (long)tn * (NU * NB) * a.ldb + s;
-      LQG_UNROLL for (int e = 0; e < NU * NB; ++e) Lnx[e] = src[e * a.ldb];
+      if constexpr (CK == 0) {
+        const int tn = (t + 1 < a.T) ? t + 1 : t;
+        const R* src = a.Ls + (long)tn * (NU * NB) * a.ldb + s;
+        LQG_UNROLL for (int e = 0; e < NU * NB; ++e) Lnx[e] = src[e * a.ldb];
+      }
       if (FUSED) {
         LQG_UNROLL for (int k = 0; k < NT; ++k) {
           const R* xr = xp + k * a.x.sn + (long)(t + 1) * a.x.st;
@@ -294,8 +379,21 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
 #endif
     to_dense(mul_nt_sym_add(mul(F2, C), F2, GG), Sg);
   };
-  step.template operator()<true>(0);
-  for (int t = 1; t < a.T; ++t) step.template operator()<false>(t);
+  if constexpr (CK == 0) {
+    step.template operator()<true, 0>(0);
+    for (int t = 1; t < a.T; ++t) step.template operator()<false, 0>(t);
+  } else {
+    request_ckpt(0);
+    auto chunk = [&]<int... J>(int t0, std::integer_sequence<int, J...>) {
+      ((t0 + J < a.T ? ((J == 0 && t0 == 0) ? step.template operator()<true, J>(0)
+                                             : step.template operator()<false, J>(t0 + J))
+                     : (void)0), ...);
+    };
+    for (int t0 = 0; t0 < a.T; t0 += CK) {
+      refill(t0);
+      chunk(t0, std::make_integer_sequence<int, CKN>{});
+    }
+  }
   condition();
   if (FUSED) {
     LQG_UNROLL for (int n = 0; n < NT; ++n) {

@@ -62,7 +62,11 @@ inline Workspace carve(const lqg_problem* p, bool need_ops) {
   const size_t esz = p->dtype == LQG_F64 ? 8 : 4;
   w.ldb = round_up(p->n_sys, 64);
   w.ls_off = 0;
-  w.ls_bytes = (size_t)p->T * p->dims.u * p->dims.b * (size_t)w.ldb * esz;
+  // gain scratch: L_t per step, or (structure-specialised libraries with checkpointed gains, chunk >= 4) the packed
+  // cost-to-go S every chunk — whichever is larger, so that every library agrees on the layout of the workspace
+  const size_t per_step = (size_t)p->T * p->dims.u * p->dims.b;
+  const size_t ckpt = ((size_t)p->T / 4 + 1) * (size_t)(p->dims.b * (p->dims.b + 1) / 2);
+  w.ls_bytes = (per_step > ckpt ? per_step : ckpt) * (size_t)w.ldb * esz;
   w.ops_off = (w.ls_bytes + 255) / 256 * 256;
   w.ops_bytes = need_ops ? (size_t)p->n_sys * (size_t)(p->T + 1) * ops_reals(p->dims) * esz : 0;
   w.total = w.ops_off + (w.ops_bytes + 255) / 256 * 256;

@@ -16,6 +16,8 @@ namespace host {
 template <typename R, typename PAT, int NX, int NB, int NU, int NY, int ND>
 int run_sp(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll_sn, void* workspace, size_t workspace_bytes,
            hipStream_t st) {
+  constexpr int CK = lqg::sp_chunk<R, NB, NU>();      // checkpointed gains (lqg_kernels_sp.hpp)
+  static_assert(CK == 0 || CK >= 4, "carve() sizes the checkpoint stream for chunks of at least 4 steps");
   const bool fused = p->n_trials <= 2;
   const Workspace w = carve(p, !fused);
   if (!workspace || workspace_bytes < w.total) return LQG_ERR_WORKSPACE;
@@ -35,7 +37,7 @@ int run_sp(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll_sn, v
     lqg::RiccatiArgs<R> k{dv<R>(a.Q), dv<R>(a.q), dv<R>(a.Qf), dv<R>(a.qf), dv<R>(a.P), dv<R>(a.R), dv<R>(a.r),
                           dv<R>(a.A), dv<R>(a.B), dv<R>(none), dv<R>(none), dv<R>(none), Ls, w.ldb,
                           (long)p->n_sys, p->T, (R)p->eps};
-    hipLaunchKernelGGL((lqg::k_riccati_sp<R, NB, NU, PAT>), grid, block, 0, st, k);
+    hipLaunchKernelGGL((lqg::k_riccati_sp<R, NB, NU, PAT, CK>), grid, block, 0, st, k);
   }
   mark(1);
   {
@@ -45,8 +47,12 @@ int run_sp(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll_sn, v
                           dt<R>(no_traj), dv<R>(none), (long)p->n_sys, p->T,
                           p->dims.nva, p->dims.nwa, p->dims.nvd, p->dims.nwd};
     // DENSE_P: an explicit Sigma0 may be dense, so the Kalman covariance cannot carry the structural mask derived from V V'
-#define LQG_SP_FWD(NTR_, DP_) \
-  hipLaunchKernelGGL((lqg::k_forward_sp<R, NX, NB, NU, NY, ND, PAT, NTR_, DP_>), grid, block, 0, st, k, ll_sn)
+    const lqg::RiccatiArgs<R> rc{dv<R>(a.Q), dv<R>(a.q), dv<R>(a.Qf), dv<R>(a.qf), dv<R>(a.P), dv<R>(a.R), dv<R>(a.r),
+                                 dv<R>(a.A), dv<R>(a.B), dv<R>(none), dv<R>(none), dv<R>(none), Ls, w.ldb,
+                                 (long)p->n_sys, p->T, (R)p->eps};
+#define LQG_SP_FWD(NTR_, DP_)                                                                                      \
+  hipLaunchKernelGGL((lqg::k_forward_sp<R, NX, NB, NU, NY, ND, PAT, NTR_, DP_, CK>), grid, block, 0, st,           \
+                     k, ll_sn, rc)
     const bool dense_p = p->Sigma0.ptr != nullptr;
     if (p->n_trials == 1) { if (dense_p) LQG_SP_FWD(1, true); else LQG_SP_FWD(1, false); }
     else if (p->n_trials == 2) { if (dense_p) LQG_SP_FWD(2, true); else LQG_SP_FWD(2, false); }

@@ -166,9 +166,11 @@ def identical_groups(system, d, parts, Sigma0=None):
     key = (type(system), tuple(sorted(zs.items())), d) if zs is not None else None
     if key is not None and key in _ZOO_GROUPS:
         return _ZOO_GROUPS[key]
+    from lqg_amd import specialize
     cache = system.__dict__.setdefault("_lqg_groups", {})
-    if d in cache:
-        return cache[d]
+    d_key = (d, specialize.spec_versions(system))
+    if d_key in cache:
+        return cache[d_key]
     groups = []
     for i, (sub, cols, _) in enumerate(parts):
         for g in groups:
@@ -178,31 +180,45 @@ def identical_groups(system, d, parts, Sigma0=None):
                 break
         else:
             groups.append([i])
-    cache[d] = groups
+    cache[d_key] = groups
     if key is not None:
         _ZOO_GROUPS[key] = groups
     return groups
 
 
-def plan(system, d, Sigma0=None):
+def plan(system, d, Sigma0=None, for_grad=False):
     """Decoupling plan of a System for data with d observed dims: list of (sub_system, data columns, belief dims)
-    or None.  Cached on the instance (per d); the model zoo uses the class-level probe pattern."""
+    or None.  The component structure is cached on the instance — keyed by d, the sparsity pattern of Sigma0 (which
+    enters the interaction graph) and the in-place version counters of the spec tensors; the model zoo uses the
+    class-level probe pattern.
+
+    for_grad=True (lqg_amd.grad, differentiable evaluation): (i) fields that require grad count as structurally FULL
+    unless the structure is a property of a zoo constructor — a leaf matrix that merely holds zeros right now must not
+    be split, its off-block derivatives are not zero; (ii) the sub-spec gathers are rebuilt on every call so that they
+    live on the caller's current autograd graph (a cached gather made under no_grad, or one whose graph a previous
+    backward() freed, would silently drop or break the gradient)."""
     from lqg_amd import specialize
     cache = system.__dict__.setdefault("_lqg_decouple", {})
-    key = (d, Sigma0 is not None)
-    if key in cache:
-        return cache[key]
-    dims, masks, _ = specialize.system_pattern(system, d)
     extra = None
     if Sigma0 is not None:
-        extra = specialize._any_nz(Sigma0) | specialize._any_nz(Sigma0).T
-    comps = components_from_masks(dims, masks, extra_bb=extra)
-    result = None
-    if comps is not None:
-        first = specialize._first
-        nz = specialize._any_nz
-        # noise-factor column masks come from the instance (cheap) — only used to pick columns, never to drop values
-        result = split_system(system, comps, nz(first(system.actor.V)), nz(first(system.actor.W)),
-                              nz(first(system.dynamics.V)), nz(first(system.dynamics.W)))
-    cache[key] = result
+        nz = specialize._any_nz(Sigma0)
+        if for_grad and Sigma0.requires_grad:
+            nz = np.ones_like(nz)
+        extra = nz | nz.T
+    key = (d, None if extra is None else np.packbits(extra).tobytes(), bool(for_grad), specialize.spec_versions(system))
+    if key not in cache:
+        dims, masks, _ = specialize.system_pattern(system, d, grad_full=for_grad)
+        cache[key] = dict(comps=components_from_masks(dims, masks, extra_bb=extra), parts=None)
+    entry = cache[key]
+    if entry["comps"] is None:
+        return None
+    if entry["parts"] is not None:
+        return entry["parts"]
+    first = specialize._first
+    nz = specialize._any_nz
+    # noise-factor column masks come from the instance (cheap) — only used to pick columns, never to drop values
+    result = split_system(system, entry["comps"], nz(first(system.actor.V)), nz(first(system.actor.W)),
+                          nz(first(system.dynamics.V)), nz(first(system.dynamics.W)))
+    if not for_grad:
+        entry["parts"] = result
     return result

@@ -181,7 +181,7 @@ def _one(system, x, Sigma0):
 def log_likelihood(system, x, Sigma0=None):
     """Differentiable log-likelihood: x[n,T+1,d] (or [B,n,T+1,d]) -> [n] (or [B,n])."""
     d = x.shape[-1]
-    parts = system.decoupled(d, Sigma0)
+    parts = system.decoupled(d, Sigma0, for_grad=True)
     if parts is None:
         return _one(system, x, Sigma0)
     # Identical axes of a ZOO model are one system observed on several data columns: one sweep with the axes as trials.

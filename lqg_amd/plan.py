@@ -7,7 +7,7 @@ import os
 
 import torch
 
-from lqg_amd import _abi, _hip, _hipev
+from lqg_amd import _abi, _hip, _hipev, specialize
 
 
 # Above this much operator-stream workspace a multi-trial evaluation is run as one fused single-trial sweep per
@@ -76,6 +76,7 @@ class LogLikelihoodPlan:
                                   ws=torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=ln.device),
                                   entry=sp or lib.lqg_log_likelihood, generic=lib.lqg_log_likelihood,
                                   specialised=sp is not None, n=n,
+                                  pattern_key=(specialize.system_pattern(sub, len(cols))[2] if sp is not None else None),
                                   loop_trials=loop_trials, is_b=is_b, group=(self.merged[ip] if self.merged else 1),
                                   dims=(sub.xdim, sub.bdim, sub.udim, sub.ydim, len(cols))))
         self.lib = lib

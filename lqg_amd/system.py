@@ -201,14 +201,15 @@ class System:
         from lqg_amd.plan import LogLikelihoodPlan
         return LogLikelihoodPlan(self, x, Sigma0=Sigma0).run()
 
-    def decoupled(self, d, Sigma0=None):
+    def decoupled(self, d, Sigma0=None, for_grad=False):
         """Independent components of this system for data with d observed dims ([(sub_system, data columns, belief
-        dims)], lqg_amd/decouple.py), or None when it does not decouple (or LQG_NO_DECOUPLE=1)."""
+        dims)], lqg_amd/decouple.py), or None when it does not decouple (or LQG_NO_DECOUPLE=1).  for_grad: the
+        differentiable evaluation's variant (decouple.plan)."""
         import os
         if os.environ.get("LQG_NO_DECOUPLE") == "1":
             return None
         from lqg_amd import _abi, decouple
-        parts = decouple.plan(self, d, Sigma0)
+        parts = decouple.plan(self, d, Sigma0, for_grad=for_grad)
         if parts is None:
             return None
         # every component must be solvable by a generic library too (several trials, moments, ...)

@@ -63,7 +63,9 @@ class NoiseRecorder:
         jax.random.normal = self._orig
 
 
-def run_case(name, system, n, d, seed, Sigma0=None, x0=None):
+def run_case(name, system, n, d, seed, Sigma0=None, x0=None, sigma_copies=None):
+    """sigma_copies: keep only that many of the n per-trial Sigma stacks (they are identical: Sigma does not depend on
+    the data) — for the large cases, to keep the fixture small."""
     T = system.T
     with NoiseRecorder() as rec:
         sx, sxh, sy, su = system.simulate(random.PRNGKey(seed), n=n, x0=x0, Sigma0=Sigma0, return_all=True)
@@ -78,8 +80,10 @@ def run_case(name, system, n, d, seed, Sigma0=None, x0=None):
         mu, Sig = system.conditional_moments(x[i], Sigma0=Sigma0)
         mus.append(mu), Sigs.append(Sig)
     ll = system.log_likelihood(x, Sigma0=Sigma0)
+    for S_ in Sigs[1:]:
+        assert np.array_equal(np.asarray(S_), np.asarray(Sigs[0]))        # Sigma is data-independent
     out = {"x": x, "L": gains.L, "l": gains.l, "H": gains.H, "K": K,
-           "mu": np.stack(mus), "Sigma": np.stack(Sigs), "ll": ll,
+           "mu": np.stack(mus), "Sigma": np.stack(Sigs[:sigma_copies]), "ll": ll,
            "sim_eps": eps, "sim_eta": eta, "sim_x": sx, "sim_xhat": sxh, "sim_y": sy, "sim_u": su}
     if Sigma0 is not None:
         out["Sigma0"] = np.array(Sigma0)
@@ -196,7 +200,7 @@ def main():
     # headline dims (x=4, b=6, u=2, y=4, d=4)
     run_case("subjective2d_T60", SubjectiveActor(dim=2, T=60, action_cost=0.5, sigma_cursor=3.0,
                                                  subj_noise=1.3, subj_vel_noise=0.7), n=3, d=4, seed=16)
-    run_case("subjective2d_T500", SubjectiveActor(dim=2, T=500), n=1, d=4, seed=21)
+    run_case("subjective2d_T500", SubjectiveActor(dim=2, T=500), n=3, d=4, seed=21, sigma_copies=1)
     # BASELINE config 2 dims (x=b=4, u=1, y=3); partial (d=2) and full (d=4) observation of the data
     run_case("pointmass_d2_T50", PointMassBoundedActor(T=50, action_variability=0.5), n=2, d=2, seed=17)
     run_case("pointmass_d4_T50", PointMassBoundedActor(T=50, action_variability=0.5), n=2, d=4, seed=17)
@@ -214,6 +218,13 @@ def main():
                                                                    action_cost=0.05), delay=2), n=2, d=2, seed=23)
     run_case("delay1_subjective1d_T30", TemporalDelayModel(SubjectiveActor(dim=1, T=30, action_cost=0.5), delay=1),
              n=2, d=2, seed=24)
+    # the reference's DelayedSubjectiveActor (lqg/tracking/delay.py:44-51): SubjectiveActor with that class's default
+    # parameters + a delay of 12 steps -> x=26, b=39, m=65.  The class fixes T=1000 through SubjectiveActor's default;
+    # the same constructor lines at a short horizon keep the fixture small.
+    run_case("delay12_subjective1d_T30",
+             TemporalDelayModel(SubjectiveActor(process_noise=1., action_cost=0.5, action_variability=0.5, subj_noise=1.,
+                                                subj_vel_noise=10., sigma_target=6., sigma_cursor=3., dt=1. / 60, T=30),
+                                delay=12), n=2, d=2, seed=25, sigma_copies=1)
     tracking_io_case()
 
 

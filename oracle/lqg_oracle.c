@@ -35,7 +35,7 @@
 
 #include "../include/lqg_hip.h"
 
-#define MAXB 16
+#define MAXB 40
 #define MAXB2 (MAXB * MAXB)
 #define MAXM (2 * MAXB)
 #define MAXM2 (MAXM * MAXM)

@@ -92,12 +92,18 @@ def test_dims_supported_lists_the_baseline_configs(lib):
     assert lib.lqg_dims_supported(_abi.F32, C.byref(dm)) == 0
 
 
-def test_workspace_size_formula(lib):
+def test_workspace_size_formula(lib, monkeypatch):
     from lqg_amd import _hip
     import lqg_amd
     m = lqg_amd.SubjectiveActor(dim=2, T=500, sigma_target=torch.linspace(1, 2, 100), device="cpu")
     ln = _hip.Launch(m.actor, m.dynamics, d=4, n_trials=1)
+    monkeypatch.setenv("LQG_COOP", "1")          # cooperative strategy: always through the operator stream
+    assert lib.lqg_strategy(C.byref(ln.p)) == _abi.STRATEGY_COOP
+    coop = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
+    monkeypatch.setenv("LQG_COOP", "0")          # lane strategy
+    assert lib.lqg_strategy(C.byref(ln.p)) == _abi.STRATEGY_LANE
     fused = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
+    assert coop == fused + (100 * 501 * 136 * 4 + 255) // 256 * 256      # + operator stream; the working set is in LDS
     assert fused == 500 * 2 * 6 * 128 * 4                               # gain scratch [T][u*b][B padded to 64]
     ln2 = _hip.Launch(m.actor, m.dynamics, d=4, n_trials=16)
     split = lib.lqg_workspace_bytes(C.byref(ln2.p), _abi.OP_LOG_LIKELIHOOD)

@@ -117,12 +117,16 @@ def test_loadmat_flattens_structs(tmp_path):
     assert m["cfg"]["rate"] == 60.0 and np.array_equal(m["cfg"]["inner"]["k"], np.arange(3))
 
 
-def test_out_of_range_shapes_are_rejected_before_any_compile():
-    """The delay-12 model (x=26, b=39) must raise at once — never start an hours-long on-demand hipcc build."""
+def test_out_of_range_shapes_go_to_the_cooperative_kernels_never_to_a_compile():
+    """The delay-12 model (x=26, b=39) is beyond the register-resident lane kernels: it must be routed to the
+    run-time-dims cooperative kernels of the MAIN library at once — never start an hours-long on-demand hipcc build."""
     from lqg_amd import _abi, _hip
     big = DelayedSubjectiveActor(T=20, device="cpu")
     ln = _hip.Launch(big.actor, big.dynamics, d=2, n_trials=1)
-    with pytest.raises(_abi.LqgHipError, match="outside the dims"):
-        _abi.library_for(ln.dims)
-    assert not _abi.shape_available(26, 39, 1, 2, 2) and not _abi.shape_in_range(11, 4, 1, 2, 2)
+    assert (ln.dims["x"], ln.dims["b"], ln.dims["u"], ln.dims["y"]) == (26, 39, 1, 2)
+    assert _abi.library_for(ln.dims, n_sys=1 << 20) is _abi.load()       # whatever the batch: no lane kernels possible
+    assert _abi.load().lqg_strategy(ln.p) == _abi.STRATEGY_COOP
+    assert _abi.shape_available(26, 39, 1, 2, 2) and not _abi.shape_in_range(11, 4, 1, 2, 2)
     assert _abi.shape_in_range(10, 10, 2, 4, 4) and _abi.shape_in_range(6, 6, 1, 2, 2)
+    with pytest.raises(_abi.LqgHipError, match="outside the dims"):      # u = 7: beyond both kernel families
+        _abi.library_for(dict(x=30, b=30, u=7, y=2, d=2))
