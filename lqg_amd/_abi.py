@@ -162,7 +162,12 @@ def library_for(dims, family=FAM_FORWARD, n_sys=None):
             return aux
     from lqg_amd import build
     key0 = (dims["x"], dims["b"], dims["u"], dims["y"], dims["d"] if 1 <= dims["d"] <= dims["x"] else min(dims["x"], 2))
-    coop_ok = family in (FAM_FORWARD, FAM_RICCATI, FAM_KALMAN) and lib.lqg_coop_supported(C.byref(dm))
+    dc = dict(dims)                                 # fields the family ignores must not disqualify the shape
+    if family == FAM_RICCATI:
+        dc.update(y=1, d=1)
+    elif family == FAM_KALMAN:
+        dc.update(u=1, d=1)
+    coop_ok = family in (FAM_FORWARD, FAM_RICCATI, FAM_KALMAN) and lib.lqg_coop_supported(C.byref(_dims_struct(dc)))
     can_jit = shape_in_range(*key0) and os.path.exists(build.HIPCC) and os.environ.get("LQG_JIT", "1") != "0"
     big = n_sys is not None and n_sys >= JIT_MIN_SYSTEMS
     names = "xbuyd"

@@ -54,6 +54,14 @@ def jobs(lists=None, extra_defs=()):
                 defs = [f"-DLQG_INST_{fam}={','.join(map(str, t))}", f"-DLQG_INST_{dt}"] + extra_defs
                 if fam == "ADJOINT":
                     js.append((base + ".o", "lqg_adjoint_inst.hip", defs))
+                    continue
+                if fam in ("FORWARD", "RICCATI"):   # fixed-dims cooperative kernels of the same shapes (lqg_coop.hpp)
+                    cf_ = "COOPF" if fam == "FORWARD" else "COOPR"
+                    if fam == "RICCATI" or t[0] + t[1] <= 11:      # WAVES mode: at most two elements per lane (m*m <= 128)
+                        js.append((f"{cf_.lower()}_{'_'.join(map(str, t))}_{dt.lower()}.o", "lqg_coop_inst.hip",
+                                   [f"-DLQG_INST_{cf_}={','.join(map(str, t))}", f"-DLQG_INST_{dt}"] + extra_defs))
+                if fam == "ADJOINT":
+                    pass
                 elif fam == "FORWARD":        # the 8 k_forward variants of a (dims, dtype) are split over four units
                     js += [(f"{base}_v{v}.o", "lqg_inst.hip", defs + [f"-DLQG_INST_VARIANT={v}"]) for v in range(4)]
                 else:

@@ -155,10 +155,13 @@ bool has_forward(const lqg_dims& d) {
 
 // ---- strategy: lane-per-system kernels (register-resident, instantiated per shape) or the cooperative
 // workgroup-per-system kernels (lqg_coop.hpp: run-time dims, LDS-staged).  LQG_COOP=1 forces the cooperative path
-// wherever it is defined, LQG_COOP=0 restricts it to shapes without a lane instantiation; default: shapes without an
-// instantiation, and few systems of a large enough joint dimension (a lane would walk the recursion alone).
+// wherever it is defined, LQG_COOP=0 restricts it to shapes without a lane instantiation (the default).  Measured
+// (profiles/r02_b_configs24_*.jsonl, one system, T=500 / 1000): the cooperative forward sweep beats the single-lane one
+// 1.5x at m=8 (0.84 vs 1.26 ms) but its Riccati sweep is 2x slower (0.31 vs 0.14 ms) and at m=10 with two merged
+// components it loses overall — so LQG_COOP_MAX_SYS (systems per call up to which a shape WITH lane kernels takes the
+// cooperative path) defaults to 0; build with -DLQG_COOP_MAX_SYS=512 or set LQG_COOP=1 to turn it on.
 #ifndef LQG_COOP_MAX_SYS
-#define LQG_COOP_MAX_SYS 512
+#define LQG_COOP_MAX_SYS 0
 #endif
 #ifndef LQG_COOP_MIN_M
 #define LQG_COOP_MIN_M 8
@@ -354,7 +357,7 @@ int lqg_riccati_backward(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view 
   if (p->n_sys == 0) return 0;
   bool found = false;
   hipError_t e = hipSuccess;
-  const bool can_coop = coop_supported(p->dims) && coop_fits_lds(p, false, true);
+  const bool can_coop = p->dims.u <= 6 && coop_fits_lds(p, false, true);     // (y, d play no part in lqr.backward)
   if (!(coop_mode() == 1 && can_coop))
     e = p->dtype == LQG_F64 ? dispatch_riccati<double>(p, L, l, H, nullptr, 0, (hipStream_t)stream, &found)
                             : dispatch_riccati<float>(p, L, l, H, nullptr, 0, (hipStream_t)stream, &found);
@@ -376,7 +379,7 @@ int lqg_kalman_forward(const lqg_problem* p, lqg_view K, void* stream) {
   if (p->n_sys == 0) return 0;
   bool found = false;
   hipError_t e = hipSuccess;
-  const bool can_coop = coop_supported(p->dims) && coop_fits_lds(p, true, false);
+  const bool can_coop = p->dims.y <= 6 && coop_fits_lds(p, true, false);     // (u, d play no part in kf.forward)
   if (!(coop_mode() == 1 && can_coop))
     e = p->dtype == LQG_F64 ? dispatch_kalman<double>(p, K, (hipStream_t)stream, &found)
                             : dispatch_kalman<float>(p, K, (hipStream_t)stream, &found);

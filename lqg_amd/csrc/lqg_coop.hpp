@@ -18,12 +18,14 @@
 // Cholesky-based inverses), so results agree with the lane kernels to rounding.  Reference parity:
 // lqg/control/lqr.py:16-42, lqg/belief/kf.py:6-21, lqg/system.py:142-248.
 #pragma once
+#include <type_traits>
+
 #include "lqg_kernels.hpp"
 
 namespace lqg {
 namespace coop {
 
-constexpr int kMaxSmall = 6;    // u, y, d <= 6: their u x u / y x y / d x d factorizations run in registers
+constexpr int kMaxSmall = 4;    // u, y, d <= 4: their u x u / y x y / d x d factorizations run in registers
 
 template <typename R>
 struct Args {
@@ -41,23 +43,51 @@ struct Args {
   R eps;
 };
 
-// (row, col) of this thread's first element of an r x c result; later elements (r*c > BLOCK) by division
-template <int BLOCK>
+// The lanes that share one product: lane `ln` of STRIDE (a whole workgroup, or — WAVES mode — one wave of it).
+// (row, col) of this lane's first element of an r x c result; later elements (r*c > STRIDE) by division.
+template <int STRIDE>
 struct Shape {
-  int rows, cols, n, i0, j0;
-  LQG_DEV Shape(int r, int c) : rows(r), cols(c), n(r * c) {
-    i0 = (int)threadIdx.x / (c > 0 ? c : 1);
-    j0 = (int)threadIdx.x - i0 * c;
+  int rows, cols, n, ln, i0, j0;
+  LQG_DEV Shape(int lane, int r, int c) : rows(r), cols(c), n(r * c), ln(lane) {
+    i0 = lane / (c > 0 ? c : 1);
+    j0 = lane - i0 * c;
   }
   template <typename F>
   LQG_DEV void each(F f) const {
-    if ((int)threadIdx.x < n) f(i0, j0);
-    for (int e = (int)threadIdx.x + BLOCK; e < n; e += BLOCK) {
-      const int i = e / cols;
-      f(i, e - i * cols);
-    }
+    if (ln < n) f(i0, j0);
+    if (n > STRIDE)
+      for (int e = ln + STRIDE; e < n; e += STRIDE) {
+        const int i = e / cols;
+        f(i, e - i * cols);
+      }
   }
 };
+
+// acc + sum_{k<K} a[k sa] b[k sb], terms added in order of k.  The operands of FOUR terms are fetched before their
+// multiply-adds, so a block's loads are in flight together (one LDS round trip per block instead of one per term);
+// the tail block clamps its indices and masks its terms instead of branching.
+template <typename R>
+LQG_DEV R dot4(const R* __restrict__ a, int sa, const R* __restrict__ b, int sb, int K, R acc) {
+  int k = 0;
+  for (; k + 4 <= K; k += 4) {
+    const R a0 = a[k * sa], a1 = a[(k + 1) * sa], a2 = a[(k + 2) * sa], a3 = a[(k + 3) * sa];
+    const R b0 = b[k * sb], b1 = b[(k + 1) * sb], b2 = b[(k + 2) * sb], b3 = b[(k + 3) * sb];
+    acc += a0 * b0;
+    acc += a1 * b1;
+    acc += a2 * b2;
+    acc += a3 * b3;
+  }
+  const int r = K - k;
+  if (r > 0) {
+    const int k1 = r > 1 ? k + 1 : k, k2 = r > 2 ? k + 2 : k;
+    const R a0 = a[k * sa], a1 = a[k1 * sa], a2 = a[k2 * sa];
+    const R b0 = b[k * sb], b1 = b[k1 * sb], b2 = b[k2 * sb];
+    acc += a0 * b0;
+    acc += (r > 1) ? a1 * b1 : R(0);
+    acc += (r > 2) ? a2 * b2 : R(0);
+  }
+  return acc;
+}
 
 template <int BLOCK>
 LQG_DEV void stage_end() {
@@ -65,20 +95,20 @@ LQG_DEV void stage_end() {
 }
 
 // ---- strided global -> arena loads (cooperative) ---------------------------------------------------------------------
-template <int BLOCK, typename R>
-LQG_DEV void ld_mat(const Shape<BLOCK>& sh, const DView<R>& v, long s, int t, R* dst) {
+template <int STRIDE, typename R>
+LQG_DEV void ld_mat(const Shape<STRIDE>& sh, const DView<R>& v, long s, int t, R* dst) {
   const R* p = v.p + s * v.sb + (long)t * v.st;
   sh.each([&](int i, int j) { dst[i * sh.cols + j] = p[i * v.sr + j * v.sc]; });
 }
-template <int BLOCK, typename R>
-LQG_DEV void ld_sym(const Shape<BLOCK>& sh, const DView<R>& v, long s, int t, R* dst) {   // symmetric part
+template <int STRIDE, typename R>
+LQG_DEV void ld_sym(const Shape<STRIDE>& sh, const DView<R>& v, long s, int t, R* dst) {   // symmetric part
   const R* p = v.p + s * v.sb + (long)t * v.st;
   sh.each([&](int i, int j) {
     dst[i * sh.cols + j] = (i == j) ? p[i * v.sr + i * v.sc] : R(0.5) * (p[i * v.sr + j * v.sc] + p[j * v.sr + i * v.sc]);
   });
 }
-template <int BLOCK, typename R>
-LQG_DEV void ld_gram(const Shape<BLOCK>& sh, const DView<R>& v, long s, int t, int nv, R* dst) {   // V V^T
+template <int STRIDE, typename R>
+LQG_DEV void ld_gram(const Shape<STRIDE>& sh, const DView<R>& v, long s, int t, int nv, R* dst) {   // V V^T
   const R* p = v.p + s * v.sb + (long)t * v.st;
   sh.each([&](int i, int j) {
     const int lo = i < j ? i : j, hi = i < j ? j : i;       // (min, max): both mirror entries get the same bits
@@ -87,16 +117,34 @@ LQG_DEV void ld_gram(const Shape<BLOCK>& sh, const DView<R>& v, long s, int t, i
     dst[i * sh.cols + j] = acc;
   });
 }
-template <int BLOCK, typename R>
-LQG_DEV void ld_vec(const DView<R>& v, long s, int t, int n, R* dst) {
-  for (int i = threadIdx.x; i < n; i += BLOCK) dst[i] = v.p ? v.p[s * v.sb + (long)t * v.st + i * v.sr] : R(0);
+template <int STRIDE, typename R>
+LQG_DEV void ld_vec(int ln, const DView<R>& v, long s, int t, int n, R* dst) {
+  for (int i = ln; i < n; i += STRIDE) dst[i] = v.p ? v.p[s * v.sb + (long)t * v.st + i * v.sr] : R(0);
 }
 
-// ---- small symmetric positive-definite factorizations in registers (every thread redundantly, N = run-time n) ---------
-// Hi = (H + max(0, eps - lambda_min(H)) I)^-1, Ht returned too (lqr.py:27-31)
+// ---- small symmetric positive-definite factorizations in registers --------------------------------------------------
+// u, y, d <= kMaxSmall.  The extent is a COMPILE-TIME constant inside each case of dispatch_small and the factors are
+// handed to the other lanes through LDS (lane 0 stores them with constant indices): a register array must never be
+// indexed at run time — it would live in scratch, i.e. in global memory, thousands of cycles per step (measured: the
+// first version of this file ran 7 k cycles per Riccati step that way; even chains of selects are turned into one).
+// C > 0: the extent is a template constant of the kernel (per-shape instantiation) — no switch
+template <int C, typename F>
+LQG_DEV void dispatch_small(int n, F f) {
+  if constexpr (C > 0) {
+    f(std::integral_constant<int, C>{});
+    return;
+  }
+  switch (n) {
+    case 1: f(std::integral_constant<int, 1>{}); break;
+    case 2: f(std::integral_constant<int, 2>{}); break;
+    case 3: f(std::integral_constant<int, 3>{}); break;
+    default: f(std::integral_constant<int, 4>{}); break;
+  }
+}
+// Hi = (H + max(0, eps - lambda_min(H)) I)^-1 and the regularised Ht (lqr.py:27-31); floor_ = false: plain inverse
 template <typename R, int N>
-LQG_DEV void small_reg_inverse(const R* Hs, R eps, bool floor_, R (&Hi)[kMaxSmall * kMaxSmall], R (&Ht_)[kMaxSmall * kMaxSmall]) {
-  R H[N * N], Ht[N * N], Lc[N * N], dinv[N], Li[N * N], Hv[N * N];
+LQG_DEV void spd_inverse_reg(const R* Hs, R eps, bool floor_, R (&Hi)[N * N], R (&Ht)[N * N]) {
+  R H[N * N], Lc[N * N], dinv[N], Li[N * N];
   LQG_UNROLL for (int i = 0; i < N * N; ++i) H[i] = Hs[i];
   LQG_UNROLL for (int i = 0; i < N * N; ++i) Ht[i] = H[i];
   if (floor_) {
@@ -106,25 +154,12 @@ LQG_DEV void small_reg_inverse(const R* Hs, R eps, bool floor_, R (&Hi)[kMaxSmal
   }
   chol_lower<R, N>(Ht, Lc, dinv);
   tri_inverse_lower<R, N>(Lc, dinv, Li);
-  spd_inverse_from_tri<R, N>(Li, Hv);
-  LQG_UNROLL for (int i = 0; i < N; ++i)
-    LQG_UNROLL for (int j = 0; j < N; ++j) { Hi[i * kMaxSmall + j] = Hv[i * N + j]; Ht_[i * kMaxSmall + j] = Ht[i * N + j]; }
+  spd_inverse_from_tri<R, N>(Li, Hi);
 }
-template <typename R>
-LQG_DEV void reg_inverse(int n, const R* Hs, R eps, bool floor_, R (&Hi)[kMaxSmall * kMaxSmall], R (&Ht)[kMaxSmall * kMaxSmall]) {
-  switch (n) {
-    case 1: small_reg_inverse<R, 1>(Hs, eps, floor_, Hi, Ht); break;
-    case 2: small_reg_inverse<R, 2>(Hs, eps, floor_, Hi, Ht); break;
-    case 3: small_reg_inverse<R, 3>(Hs, eps, floor_, Hi, Ht); break;
-    case 4: small_reg_inverse<R, 4>(Hs, eps, floor_, Hi, Ht); break;
-    case 5: small_reg_inverse<R, 5>(Hs, eps, floor_, Hi, Ht); break;
-    default: small_reg_inverse<R, 6>(Hs, eps, floor_, Hi, Ht); break;
-  }
-}
-// Li = chol(S_oo)^-1 (lower), half log-determinant; S_oo = leading n x n block of a matrix with leading dimension ld
+// Li = chol(S_oo)^-1 (lower), half log-determinant; S_oo = leading N x N block of a matrix with leading dimension ld
 template <typename R, int N>
-LQG_DEV void small_reg_chol(const R* Sg, int ld, R (&Li_)[kMaxSmall * kMaxSmall], R& hl) {
-  R A[N * N], Lc[N * N], dinv[N], Li[N * N];
+LQG_DEV void chol_inverse_reg(const R* Sg, int ld, R (&Li)[N * N], R& hl) {
+  R A[N * N], Lc[N * N], dinv[N];
   LQG_UNROLL for (int i = 0; i < N; ++i)
     LQG_UNROLL for (int j = 0; j < N; ++j) A[i * N + j] = Sg[i * ld + j];
   chol_lower<R, N>(A, Lc, dinv);
@@ -132,175 +167,160 @@ LQG_DEV void small_reg_chol(const R* Sg, int ld, R (&Li_)[kMaxSmall * kMaxSmall]
   R pd = dinv[0];
   LQG_UNROLL for (int i = 1; i < N; ++i) pd *= dinv[i];
   hl = -log_<R>(pd);
-  LQG_UNROLL for (int i = 0; i < N; ++i)
-    LQG_UNROLL for (int j = 0; j < N; ++j) Li_[i * kMaxSmall + j] = Li[i * N + j];
 }
-template <typename R>
-LQG_DEV void reg_chol(int n, const R* Sg, int ld, R (&Li)[kMaxSmall * kMaxSmall], R& hl) {
-  switch (n) {
-    case 1: small_reg_chol<R, 1>(Sg, ld, Li, hl); break;
-    case 2: small_reg_chol<R, 2>(Sg, ld, Li, hl); break;
-    case 3: small_reg_chol<R, 3>(Sg, ld, Li, hl); break;
-    case 4: small_reg_chol<R, 4>(Sg, ld, Li, hl); break;
-    case 5: small_reg_chol<R, 5>(Sg, ld, Li, hl); break;
-    default: small_reg_chol<R, 6>(Sg, ld, Li, hl); break;
-  }
-}
+
 // reals of the arena each kernel carves (host and device agree through these)
 inline __host__ __device__ long riccati_arena_reals(int b, int u) {
-  return 4L * b * b + 6L * b * u + 2L * u * u + 4L * b + 5L * u + 16;
+  return 4L * b * b + 6L * b * u + 4L * u * u + 4L * b + 5L * u + 16;
 }
-inline __host__ __device__ long kalman_arena_reals(int b, int y) { return 5L * b * b + 3L * y * b + 2L * y * y + 16; }
+inline __host__ __device__ long kalman_arena_reals(int b, int y) { return 5L * b * b + 3L * y * b + 3L * y * y + 16; }
 inline __host__ __device__ long forward_arena_reals(int x, int b, int u, int y, int d) {
   const long m = x + b, o = d, rr = m - d;
-  return /*Aa VVa P AP Pp KFAa*/ 6L * b * b + /*Ba BK*/ 2L * b * u + /*Fa FAa FP*/ 3L * y * b + /*WWa Gk N3 WWd*/ 4L * y * y +
+  return /*Aa VVa P AP Pp KFAa*/ 6L * b * b + /*Ba BK*/ 2L * b * u + /*Fa FAa FP*/ 3L * y * b + /*WWa Gk Gis N3 WWd*/ 5L * y * y + /*Lis*/ 1L * d * d +
          /*Ad N1*/ 2L * x * x + /*Bd*/ 1L * x * u + /*FAd N2 Fd*/ 3L * y * x + /*DB*/ 1L * y * u + /*K KN3*/ 2L * b * y +
          /*L*/ 1L * u * b + /*KFAd BdL KN2*/ 3L * b * x + /*Fj GG Sg*/ 3L * m * m + /*U2*/ rr * o + /*C*/ rr * rr + /*T1*/ m * rr + 16;
 }
 
 // ======================================================================================================================
 // Riccati backward (lqr.py:16-42): carries S[b,b], s[b]; emits L_t (scratch + optional L, l, H outputs)
-template <typename R, int BLOCK, bool GLOBAL>
+// CB, CU > 0: dimensions fixed at compile time (one instantiation per shape of lqg_dims.def): every index computation,
+// loop bound and LDS address folds to a constant and the inner products unroll — ~5x fewer instructions per stage than
+// the run-time-dims instantiation (CB = CU = 0), which stays the path for every other shape.
+template <typename R, int BLOCK, bool GLOBAL, bool WAVES, int CB = 0, int CU = 0>
 __global__ void __launch_bounds__(BLOCK) k_coop_riccati(const Args<R> a) {
   extern __shared__ double lqg_coop_smem[];
   const long s = blockIdx.x;
+  // WAVES: the independent products of a stage go to DIFFERENT waves (SIMDs) of the workgroup — within one wave they
+  // would only queue behind each other in its instruction stream — and each product is spread over that wave's 64 lanes;
+  // otherwise (large matrices) every product is spread over the whole workgroup.
+  constexpr int STRIDE = WAVES ? 64 : BLOCK;
+  constexpr int NW = BLOCK / 64;
+  const int wv = WAVES ? (int)(threadIdx.x >> 6) : 0;
+  const int ln = WAVES ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+  auto on = [&](int w) { return !WAVES || wv == (w % NW); };
   R* ar = GLOBAL ? a.arena + s * a.arena_reals : reinterpret_cast<R*>(lqg_coop_smem);
-  const int b = a.b, u = a.u;
+  const int b = CB ? CB : a.b, u = CU ? CU : a.u;
   const bool affine = a.aq.p || a.aqf.p || a.aP.p || a.ar.p;
   auto take = [&](long n) { R* p = ar; ar += n; return p; };
   R *S = take(b * b), *A = take(b * b), *Q = take(b * b), *SA = take(b * b);
   R *Bm = take(b * u), *SB = take(b * u), *P = take(b * u), *G = take(b * u), *Lm = take(b * u), *W1 = take(b * u);
-  R *Rm = take(u * u), *H = take(u * u);
+  R *Rm = take(u * u), *H = take(u * u), *His = take(u * u), *Hts = take(u * u);
   R *sv = take(b), *sn = take(b), *q = take(b), *gv = take(u), *lv = take(u), *Hl = take(u), *r = take(u);
-  const Shape<BLOCK> bb(b, b), bu(b, u), ub(u, b), uu(u, u);
+  const Shape<STRIDE> bb(ln, b, b), bu(ln, b, u), ub(ln, u, b), uu(ln, u, u);
 
   auto load_step = [&](int t) {
-    ld_mat(bb, a.aA, s, t, A);
-    ld_mat(bu, a.aB, s, t, Bm);
-    ld_sym(bb, a.aQ, s, t, Q);
-    ld_sym(uu, a.aR, s, t, Rm);
-    if (affine) {
+    if (on(0)) ld_mat(bb, a.aA, s, t, A);
+    if (on(1)) ld_mat(bu, a.aB, s, t, Bm);
+    if (on(2)) ld_sym(bb, a.aQ, s, t, Q);
+    if (on(3)) ld_sym(uu, a.aR, s, t, Rm);
+    if (affine && on(3)) {
       if (a.aP.p) ld_mat(ub, a.aP, s, t, P);
       else ub.each([&](int i, int j) { P[i * b + j] = R(0); });
-      ld_vec<BLOCK>(a.aq, s, t, b, q);
-      ld_vec<BLOCK>(a.ar, s, t, u, r);
+      ld_vec<STRIDE>(ln, a.aq, s, t, b, q);
+      ld_vec<STRIDE>(ln, a.ar, s, t, u, r);
     }
   };
-  ld_sym(bb, a.aQf, s, 0, S);                               // carry init (Qf, qf)  lqr.py:38
-  if (affine) ld_vec<BLOCK>(a.aqf, s, 0, b, sv);
+  if (on(0)) ld_sym(bb, a.aQf, s, 0, S);                    // carry init (Qf, qf)  lqr.py:38
+  if (affine && on(1)) ld_vec<STRIDE>(ln, a.aqf, s, 0, b, sv);
   if (a.ti) load_step(0);
   stage_end<BLOCK>();
 
   for (int t = a.T - 1; t >= 0; --t) {                      // reverse=True  lqr.py:40
     if (!a.ti) { load_step(t); stage_end<BLOCK>(); }
     // ---- R1: SA = S A, SB = S B
-    bb.each([&](int i, int j) {
+    if (on(0)) bb.each([&](int i, int j) {
       R acc = R(0);
-      for (int k = 0; k < b; ++k) acc += S[i * b + k] * A[k * b + j];
+      acc = dot4(S + i * b, 1, A + j, b, b, acc);
       SA[i * b + j] = acc;
     });
-    bu.each([&](int i, int j) {
+    if (on(1)) bu.each([&](int i, int j) {
       R acc = R(0);
-      for (int k = 0; k < b; ++k) acc += S[i * b + k] * Bm[k * u + j];
+      acc = dot4(S + i * b, 1, Bm + j, u, b, acc);
       SB[i * u + j] = acc;
     });
     stage_end<BLOCK>();
     // ---- R2: H = R + B'SB (symmetric), G = P + B'SA, g = r + B's                     lqr.py:22-24
-    uu.each([&](int i, int j) {
+    if (on(0)) uu.each([&](int i, int j) {
       const int lo = i < j ? i : j, hi = i < j ? j : i;
       R acc = Rm[lo * u + hi];
-      for (int k = 0; k < b; ++k) acc += Bm[k * u + lo] * SB[k * u + hi];
+      acc = dot4(Bm + lo, u, SB + hi, u, b, acc);
       H[i * u + j] = acc;
     });
-    ub.each([&](int i, int j) {
+    if (on(1)) ub.each([&](int i, int j) {
       R acc = affine ? P[i * b + j] : R(0);
-      for (int k = 0; k < b; ++k) acc += Bm[k * u + i] * SA[k * b + j];
+      acc = dot4(Bm + i, u, SA + j, b, b, acc);
       G[i * b + j] = acc;
     });
-    if (affine)
-      for (int i = threadIdx.x; i < u; i += BLOCK) {
+    if (affine && on(2))
+      for (int i = ln; i < u; i += STRIDE) {
         R acc = r[i];
-        for (int k = 0; k < b; ++k) acc += Bm[k * u + i] * sv[k];
+        acc = dot4(Bm + i, u, sv, 1, b, acc);
         gv[i] = acc;
       }
     stage_end<BLOCK>();
-    // ---- R3: Ht^-1 in registers; L = -Ht^-1 G, W1 = H L + G (each thread recomputes its column of L)   lqr.py:27-33
-    {
-      const bool busy = (int)threadIdx.x < (u * b > u * u ? u * b : u * u) || BLOCK < u * b;
-      if (busy) {
-        R Hi[kMaxSmall * kMaxSmall], Ht[kMaxSmall * kMaxSmall];
-        reg_inverse<R>(u, H, a.eps, true, Hi, Ht);
-        ub.each([&](int i, int j) {
-          R Lcol[kMaxSmall];
-          LQG_UNROLL for (int k = 0; k < kMaxSmall; ++k) {
-            R acc = R(0);
-            if (k < u) {
-              LQG_UNROLL for (int l2 = 0; l2 < kMaxSmall; ++l2)
-                if (l2 < u) acc -= Hi[k * kMaxSmall + l2] * G[l2 * b + j];
-            }
-            Lcol[k] = acc;
-          }
-          R lij = Lcol[0], w = G[i * b + j];
-          LQG_UNROLL for (int k = 1; k < kMaxSmall; ++k) lij = (i == k) ? Lcol[k] : lij;
-          LQG_UNROLL for (int k = 0; k < kMaxSmall; ++k)
-            if (k < u) w += H[i * u + k] * Lcol[k];
-          Lm[i * b + j] = lij;
-          W1[i * b + j] = w;
-          if (a.Ls) a.Ls[(s * a.T + t) * (long)(u * b) + i * b + j] = lij;
-          if (a.L.p) const_cast<R*>(a.L.p)[s * a.L.sb + (long)t * a.L.st + i * a.L.sr + j * a.L.sc] = lij;
-        });
-        if (a.H.p)
-          uu.each([&](int i, int j) {
-            R v = Ht[0];
-            LQG_UNROLL for (int k = 0; k < kMaxSmall; ++k)
-              LQG_UNROLL for (int c = 0; c < kMaxSmall; ++c) v = (i == k && j == c) ? Ht[k * kMaxSmall + c] : v;
-            const_cast<R*>(a.H.p)[s * a.H.sb + (long)t * a.H.st + i * a.H.sr + j * a.H.sc] = v;   // regularised Ht  lqr.py:36
-          });
-        if (affine && threadIdx.x == 0) {                     // l = -Ht^-1 g, Hl = H l + g (u <= 6: one thread)
-          R lvr[kMaxSmall];
-          LQG_UNROLL for (int i = 0; i < kMaxSmall; ++i) {
-            R acc = R(0);
-            if (i < u) {
-              LQG_UNROLL for (int k = 0; k < kMaxSmall; ++k)
-                if (k < u) acc -= Hi[i * kMaxSmall + k] * gv[k];
-            }
-            lvr[i] = acc;
-          }
-          for (int i = 0; i < u; ++i) {
-            R acc = gv[i];
-            LQG_UNROLL for (int k = 0; k < kMaxSmall; ++k)
-              if (k < u) acc += H[i * u + k] * lvr[k];
-            Hl[i] = acc;
-          }
-          LQG_UNROLL for (int i = 0; i < kMaxSmall; ++i)
-            if (i < u) lv[i] = lvr[i];
-        }
+    // ---- R3a: Ht^-1 (registers, compile-time extent) -> LDS                                          lqr.py:27-31
+    if (on(0)) dispatch_small<CU>(u, [&](auto nu_) {
+      constexpr int NU = decltype(nu_)::value;
+      R Hi[NU * NU], Ht[NU * NU];
+      spd_inverse_reg<R, NU>(H, a.eps, true, Hi, Ht);
+      if (ln == 0) {
+        LQG_UNROLL for (int e = 0; e < NU * NU; ++e) { His[e] = Hi[e]; Hts[e] = Ht[e]; }
       }
-      if (a.l.p && !affine)
-        for (int i = threadIdx.x; i < u; i += BLOCK) const_cast<R*>(a.l.p)[s * a.l.sb + (long)t * a.l.st + i * a.l.sr] = R(0);
+    });
+    stage_end<BLOCK>();
+    // ---- R3b: L = -Ht^-1 G, W1 = H L + G (each thread recomputes its column of L)                     lqr.py:30-33
+    if (on(0)) ub.each([&](int i, int j) {
+      R lij = R(0), w = G[i * b + j];
+      for (int k = 0; k < u; ++k) {
+        const R lkj = -dot4(His + k * u, 1, G + j, b, u, R(0));
+        lij = (k == i) ? lkj : lij;
+        w += H[i * u + k] * lkj;
+      }
+      Lm[i * b + j] = lij;
+      W1[i * b + j] = w;
+      if (a.Ls) a.Ls[(s * a.T + t) * (long)(u * b) + i * b + j] = lij;
+      if (a.L.p) const_cast<R*>(a.L.p)[s * a.L.sb + (long)t * a.L.st + i * a.L.sr + j * a.L.sc] = lij;
+    });
+    if (a.H.p && on(1))                                          // regularised Ht  lqr.py:36
+      uu.each([&](int i, int j) { const_cast<R*>(a.H.p)[s * a.H.sb + (long)t * a.H.st + i * a.H.sr + j * a.H.sc] = Hts[i * u + j]; });
+    if (affine && on(2)) {
+      for (int i = ln; i < u; i += STRIDE) {             // l = -Ht^-1 g, Hl = H l + g
+        R hl_ = gv[i], li = R(0);
+        for (int k = 0; k < u; ++k) {
+          const R lk = -dot4(His + k * u, 1, gv, 1, u, R(0));
+          li = (k == i) ? lk : li;
+          hl_ += H[i * u + k] * lk;
+        }
+        lv[i] = li;
+        Hl[i] = hl_;
+      }
+    } else if (!affine && a.l.p && on(2)) {
+      for (int i = ln; i < u; i += STRIDE) const_cast<R*>(a.l.p)[s * a.l.sb + (long)t * a.l.st + i * a.l.sr] = R(0);
     }
     stage_end<BLOCK>();
     // ---- R4: S = Q + A'SA + L'(HL + G) + G'L (symmetric); s = q + A's + G'l + L'(Hl + g)            lqr.py:33-34
-    bb.each([&](int i, int j) {
+    if (on(0)) bb.each([&](int i, int j) {
       const int lo = i < j ? i : j, hi = i < j ? j : i;
       R acc = Q[lo * b + hi];
-      for (int k = 0; k < b; ++k) acc += A[k * b + lo] * SA[k * b + hi];
-      for (int k = 0; k < u; ++k) acc += Lm[k * b + lo] * W1[k * b + hi] + G[k * b + lo] * Lm[k * b + hi];
+      acc = dot4(A + lo, b, SA + hi, b, b, acc);
+      acc = dot4(Lm + lo, b, W1 + hi, b, u, acc);
+      acc = dot4(G + lo, b, Lm + hi, b, u, acc);
       S[i * b + j] = acc;
     });
-    if (affine) {
-      for (int i = threadIdx.x; i < b; i += BLOCK) {
+    if (affine && on(1)) {
+      for (int i = ln; i < b; i += STRIDE) {
         R acc = q[i];
-        for (int k = 0; k < b; ++k) acc += A[k * b + i] * sv[k];
-        for (int k = 0; k < u; ++k) acc += G[k * b + i] * lv[k] + Lm[k * b + i] * Hl[k];
+        acc = dot4(A + i, b, sv, 1, b, acc);
+        acc = dot4(G + i, b, lv, 1, u, acc);
+        acc = dot4(Lm + i, b, Hl, 1, u, acc);
         sn[i] = acc;
       }
       if (a.l.p)
-        for (int i = threadIdx.x; i < u; i += BLOCK) const_cast<R*>(a.l.p)[s * a.l.sb + (long)t * a.l.st + i * a.l.sr] = lv[i];
+        for (int i = ln; i < u; i += STRIDE) const_cast<R*>(a.l.p)[s * a.l.sb + (long)t * a.l.st + i * a.l.sr] = lv[i];
     }
     stage_end<BLOCK>();
-    if (affine) {
-      for (int i = threadIdx.x; i < b; i += BLOCK) sv[i] = sn[i];
+    if (affine && on(1)) {
+      for (int i = ln; i < b; i += STRIDE) sv[i] = sn[i];
       // (sv is next read in R2 of the following step, after two more barriers)
     }
   }
@@ -309,16 +329,25 @@ __global__ void __launch_bounds__(BLOCK) k_coop_riccati(const Args<R> a) {
 // ======================================================================================================================
 // Forward sweep: Kalman recursion (kf.py:6-21), joint system (system.py:167-207), Schur-form moment recursion
 // (system.py:209-235), trial operators per step.  Kalman step t+1 is pipelined under the joint / Sigma stages of step t.
-template <typename R, int BLOCK, bool GLOBAL>
+template <typename R, int BLOCK, bool GLOBAL, bool WAVES, int CX = 0, int CB = 0, int CU = 0, int CY = 0, int CD = 0>
 __global__ void __launch_bounds__(BLOCK) k_coop_forward(const Args<R> a) {
   extern __shared__ double lqg_coop_smem[];
   const long s = blockIdx.x;
+  // WAVES: the independent products of a stage go to DIFFERENT waves (SIMDs) of the workgroup — within one wave they
+  // would only queue behind each other in its instruction stream — and each product is spread over that wave's 64 lanes;
+  // otherwise (large matrices) every product is spread over the whole workgroup.
+  constexpr int STRIDE = WAVES ? 64 : BLOCK;
+  constexpr int NW = BLOCK / 64;
+  const int wv = WAVES ? (int)(threadIdx.x >> 6) : 0;
+  const int ln = WAVES ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+  auto on = [&](int w) { return !WAVES || wv == (w % NW); };
   R* ar = GLOBAL ? a.arena + s * a.arena_reals : reinterpret_cast<R*>(lqg_coop_smem);
-  const int x = a.x, b = a.b, u = a.u, y = a.y, o = a.d, m = a.x + a.b, rr = m - a.d;
+  const int x = CX ? CX : a.x, b = CB ? CB : a.b, u = CU ? CU : a.u, y = CY ? CY : a.y, o = CD ? CD : a.d, m = x + b,
+            rr = m - o;
   auto take = [&](long n) { R* p = ar; ar += n; return p; };
   // (the arrays of the Kalman recursion come first: a gains-only call, kf.forward, needs kalman_arena_reals only)
   R *Aa = take(b * b), *VVa = take(b * b), *P = take(b * b), *AP = take(b * b), *Pp = take(b * b);
-  R *Fa = take(y * b), *FP = take(y * b), *WWa = take(y * y), *Gk = take(y * y), *K = take(b * y);
+  R *Fa = take(y * b), *FP = take(y * b), *WWa = take(y * y), *Gk = take(y * y), *Gis = take(y * y), *K = take(b * y);
   R *KFAa = take(b * b), *Ba = take(b * u), *BK = take(b * u), *FAa = take(y * b);
   R *N3 = take(y * y), *WWd = take(y * y);
   R *Ad = take(x * x), *N1 = take(x * x), *Bd = take(x * u);
@@ -326,110 +355,104 @@ __global__ void __launch_bounds__(BLOCK) k_coop_forward(const Args<R> a) {
   R *KN3 = take(b * y), *Lm = take(u * b);
   R *KFAd = take(b * x), *BdL = take(x * b), *KN2 = take(b * x);
   R *Fj = take(m * m), *GG = take(m * m), *Sg = take(m * m), *U2 = take(rr * o), *C = take(rr * rr), *T1 = take(m * rr);
-  const Shape<BLOCK> bb(b, b), bu(b, u), yb(y, b), yy(y, y), xx(x, x), xu(x, u), yx(y, x), yu(y, u), by(b, y), bx(b, x),
-      xb(x, b), mm_(m, m), ro(rr, o), rrs(rr, rr), mr(m, rr);
+  R* Lis = take(o * o);
+  const Shape<STRIDE> bb(ln, b, b), bu(ln, b, u), yb(ln, y, b), yy(ln, y, y), xx(ln, x, x), xu(ln, x, u), yx(ln, y, x),
+      yu(ln, y, u), by(ln, b, y), bx(ln, b, x), xb(ln, x, b), mm_(ln, m, m), ro(ln, rr, o), rrs(ln, rr, rr), mr(ln, m, rr);
   const bool joint = a.ops || a.Sig.p;                      // false: only the Kalman gains are wanted (kf.forward)
   const R kLogNorm = R(0.5 * 1.8378770664093453) * (R)o;
 
   auto load_consts = [&](int t) {                            // stage L1: direct loads and Gram matrices
-    ld_mat(bb, a.aA, s, t, Aa);
-    ld_mat(yb, a.aF, s, t, Fa);
-    ld_gram(bb, a.aV, s, t, a.nva, VVa);
-    ld_gram(yy, a.aW, s, t, a.nwa, WWa);
+    if (on(0)) ld_mat(bb, a.aA, s, t, Aa);
+    if (on(1)) ld_mat(yb, a.aF, s, t, Fa);
+    if (on(2)) ld_gram(bb, a.aV, s, t, a.nva, VVa);
+    if (on(3)) ld_gram(yy, a.aW, s, t, a.nwa, WWa);
     if (joint) {
-      ld_mat(bu, a.aB, s, t, Ba);
-      ld_mat(xx, a.dA, s, t, Ad);
-      ld_mat(xu, a.dB, s, t, Bd);
-      ld_mat(yx, a.dF, s, t, Fd);
-      ld_gram(xx, a.dV, s, t, a.nvd, N1);
-      ld_gram(yy, a.dW, s, t, a.nwd, WWd);
+      if (on(0)) ld_mat(bu, a.aB, s, t, Ba);
+      if (on(1)) { ld_mat(xx, a.dA, s, t, Ad); ld_mat(xu, a.dB, s, t, Bd); }
+      if (on(2)) ld_mat(yx, a.dF, s, t, Fd);
+      if (on(3)) { ld_gram(xx, a.dV, s, t, a.nvd, N1); ld_gram(yy, a.dW, s, t, a.nwd, WWd); }
     }
   };
   auto hoist1 = [&]() {                                      // stage L2: Fa Aa, Fd Ad, Fd Bd - Fa Ba, Fd Vd Vd'
     if (!joint) return;
-    yb.each([&](int i, int j) {
+    if (on(0)) yb.each([&](int i, int j) {
       R acc = R(0);
-      for (int k = 0; k < b; ++k) acc += Fa[i * b + k] * Aa[k * b + j];
+      acc = dot4(Fa + i * b, 1, Aa + j, b, b, acc);
       FAa[i * b + j] = acc;
     });
-    yx.each([&](int i, int j) {
+    if (on(1)) yx.each([&](int i, int j) {
       R acc = R(0), acc2 = R(0);
-      for (int k = 0; k < x; ++k) { acc += Fd[i * x + k] * Ad[k * x + j]; acc2 += Fd[i * x + k] * N1[k * x + j]; }
+      acc = dot4(Fd + i * x, 1, Ad + j, x, x, acc);
+      acc2 = dot4(Fd + i * x, 1, N1 + j, x, x, acc2);
       FAd[i * x + j] = acc;
       N2[i * x + j] = acc2;
     });
-    yu.each([&](int i, int j) {
+    if (on(2)) yu.each([&](int i, int j) {
       R f1 = R(0), f2 = R(0);
-      for (int k = 0; k < x; ++k) f1 += Fd[i * x + k] * Bd[k * u + j];
-      for (int k = 0; k < b; ++k) f2 += Fa[i * b + k] * Ba[k * u + j];
+      f1 = dot4(Fd + i * x, 1, Bd + j, u, x, f1);
+      f2 = dot4(Fa + i * b, 1, Ba + j, u, b, f2);
       DB[i * u + j] = f1 - f2;                               // system.py:177-180
     });
   };
   auto hoist2 = [&]() {                                      // stage L3: N3 = Fd Vd Vd' Fd' + Wd Wd'
     if (!joint) return;
-    yy.each([&](int i, int j) {
+    if (on(0)) yy.each([&](int i, int j) {
       const int lo = i < j ? i : j, hi = i < j ? j : i;
       R acc = WWd[lo * y + hi];
-      for (int k = 0; k < x; ++k) acc += N2[lo * x + k] * Fd[hi * x + k];
+      acc = dot4(N2 + lo * x, 1, Fd + hi * x, 1, x, acc);
       N3[i * y + j] = acc;
     });
   };
   // ---- Kalman stages (kf.py:10-14); each is followed by a stage_end by the caller
   auto kal1 = [&]() {                                        // AP = A P
-    bb.each([&](int i, int j) {
+    if (on(3)) bb.each([&](int i, int j) {
       R acc = R(0);
-      for (int k = 0; k < b; ++k) acc += Aa[i * b + k] * P[k * b + j];
+      acc = dot4(Aa + i * b, 1, P + j, b, b, acc);
       AP[i * b + j] = acc;
     });
   };
   auto kal2 = [&]() {                                        // Pp = AP A' + V V'
-    bb.each([&](int i, int j) {
+    if (on(3)) bb.each([&](int i, int j) {
       const int lo = i < j ? i : j, hi = i < j ? j : i;
       R acc = VVa[lo * b + hi];
-      for (int k = 0; k < b; ++k) acc += AP[lo * b + k] * Aa[hi * b + k];
+      acc = dot4(AP + lo * b, 1, Aa + hi * b, 1, b, acc);
       Pp[i * b + j] = acc;
     });
   };
   auto kal3 = [&]() {                                        // FP = F Pp
-    yb.each([&](int i, int j) {
+    if (on(3)) yb.each([&](int i, int j) {
       R acc = R(0);
-      for (int k = 0; k < b; ++k) acc += Fa[i * b + k] * Pp[k * b + j];
+      acc = dot4(Fa + i * b, 1, Pp + j, b, b, acc);
       FP[i * b + j] = acc;
     });
   };
   auto kal4 = [&]() {                                        // Gk = FP F' + W W'
-    yy.each([&](int i, int j) {
+    if (on(3)) yy.each([&](int i, int j) {
       const int lo = i < j ? i : j, hi = i < j ? j : i;
       R acc = WWa[lo * y + hi];
-      for (int k = 0; k < b; ++k) acc += FP[lo * b + k] * Fa[hi * b + k];
+      acc = dot4(FP + lo * b, 1, Fa + hi * b, 1, b, acc);
       Gk[i * y + j] = acc;
     });
   };
+  auto kalF = [&]() {                                        // Gk^-1 (registers, compile-time extent) -> LDS
+    if (on(3)) dispatch_small<CY>(y, [&](auto ny_) {
+      constexpr int NY = decltype(ny_)::value;
+      R Gi[NY * NY], unused[NY * NY];
+      spd_inverse_reg<R, NY>(Gk, R(0), false, Gi, unused);
+      if (ln == 0) {
+        LQG_UNROLL for (int e = 0; e < NY * NY; ++e) Gis[e] = Gi[e];
+      }
+    });
+  };
   auto kal5 = [&](int t) {                                   // K = (F Pp)' Gk^-1 ; P = Pp - K F Pp (row of K per thread)
-    R Gi[kMaxSmall * kMaxSmall], unused[kMaxSmall * kMaxSmall];
-    reg_inverse<R>(y, Gk, R(0), false, Gi, unused);
-    bb.each([&](int i, int j) {
+    if (on(3)) bb.each([&](int i, int j) {
       const int lo = i < j ? i : j, hi = i < j ? j : i;
       R acc = Pp[lo * b + hi];
-      LQG_UNROLL for (int k = 0; k < kMaxSmall; ++k) {
-        if (k < y) {
-          R kik = R(0);                                      // K[lo, k]
-          LQG_UNROLL for (int l2 = 0; l2 < kMaxSmall; ++l2)
-            if (l2 < y) kik += FP[l2 * b + lo] * Gi[l2 * kMaxSmall + k];
-          acc -= kik * FP[k * b + hi];
-        }
-      }
+      for (int k = 0; k < y; ++k) acc -= dot4(FP + lo, b, Gis + k, y, y, R(0)) * FP[k * b + hi];   // K[lo, k] (F Pp)[k, hi]
       P[i * b + j] = acc;
     });
-    by.each([&](int i, int j) {
-      R kij = R(0);
-      LQG_UNROLL for (int l2 = 0; l2 < kMaxSmall; ++l2) {
-        if (l2 < y) {
-          R g = Gi[l2 * kMaxSmall];
-          LQG_UNROLL for (int c = 1; c < kMaxSmall; ++c) g = (j == c) ? Gi[l2 * kMaxSmall + c] : g;
-          kij += FP[l2 * b + i] * g;
-        }
-      }
+    if (on(2)) by.each([&](int i, int j) {
+      const R kij = dot4(FP + i, b, Gis + j, y, y, R(0));
       K[i * y + j] = kij;
       if (a.K.p) const_cast<R*>(a.K.p)[s * a.K.sb + (long)t * a.K.st + i * a.K.sr + j * a.K.sc] = kij;
     });
@@ -437,37 +460,39 @@ __global__ void __launch_bounds__(BLOCK) k_coop_forward(const Args<R> a) {
   // ---- joint-system stages
   auto joint1 = [&](int t) {                                 // products that only need K_t, L_t and constants
     const R* Lg = a.Ls + (s * a.T + t) * (long)(u * b);
-    bu.each([&](int i, int j) {                              // BK = Ba + K DB
+    if (on(0)) bu.each([&](int i, int j) {                   // BK = Ba + K DB
       R acc = Ba[i * u + j];
-      for (int k = 0; k < y; ++k) acc += K[i * y + k] * DB[k * u + j];
+      acc = dot4(K + i * y, 1, DB + j, u, y, acc);
       BK[i * u + j] = acc;
     });
-    bx.each([&](int i, int j) {                              // K FAd, K N2
+    if (on(1)) bx.each([&](int i, int j) {                   // K FAd, K N2
       R a1 = R(0), a2 = R(0);
-      for (int k = 0; k < y; ++k) { a1 += K[i * y + k] * FAd[k * x + j]; a2 += K[i * y + k] * N2[k * x + j]; }
+      a1 = dot4(K + i * y, 1, FAd + j, x, y, a1);
+      a2 = dot4(K + i * y, 1, N2 + j, x, y, a2);
       KFAd[i * x + j] = a1;
       KN2[i * x + j] = a2;
     });
-    bb.each([&](int i, int j) {                              // K FAa
+    if (on(0)) bb.each([&](int i, int j) {                   // K FAa
       R acc = R(0);
-      for (int k = 0; k < y; ++k) acc += K[i * y + k] * FAa[k * b + j];
+      acc = dot4(K + i * y, 1, FAa + j, b, y, acc);
       KFAa[i * b + j] = acc;
     });
-    xb.each([&](int i, int j) {                              // Bd L
+    if (on(2)) xb.each([&](int i, int j) {                   // Bd L
       R acc = R(0);
-      for (int k = 0; k < u; ++k) acc += Bd[i * u + k] * Lg[k * b + j];
+      acc = dot4(Bd + i * u, 1, Lg + j, b, u, acc);
       BdL[i * b + j] = acc;
     });
-    by.each([&](int i, int j) {                              // K N3
+    if (on(1)) by.each([&](int i, int j) {                   // K N3
       R acc = R(0);
-      for (int k = 0; k < y; ++k) acc += K[i * y + k] * N3[k * y + j];
+      acc = dot4(K + i * y, 1, N3 + j, y, y, acc);
       KN3[i * y + j] = acc;
     });
-    for (int e = threadIdx.x; e < u * b; e += BLOCK) Lm[e] = Lg[e];
+    if (on(2))
+      for (int e = ln; e < u * b; e += STRIDE) Lm[e] = Lg[e];
   };
   auto joint2 = [&](bool first) {                            // Fj, GG (system.py:167-207); first: Sigma := GG
-    mm_.each([&](int i, int j) {
-      R f, g;
+    if (on(0)) mm_.each([&](int i, int j) {
+      R f;
       if (i < x) {
         f = (j < x) ? Ad[i * x + j] : BdL[i * b + (j - x)];
       } else {
@@ -477,163 +502,154 @@ __global__ void __launch_bounds__(BLOCK) k_coop_forward(const Args<R> a) {
         } else {
           const int jb = j - x;
           R acc = Aa[ib * b + jb] - KFAa[ib * b + jb];
-          for (int k = 0; k < u; ++k) acc += BK[ib * u + k] * Lm[k * b + jb];
+          acc = dot4(BK + ib * u, 1, Lm + jb, b, u, acc);
           f = acc;
         }
       }
+      Fj[i * m + j] = f;
+    });
+    if (on(1)) mm_.each([&](int i, int j) {
+      R g;
       const int lo = i < j ? i : j, hi = i < j ? j : i;
       if (hi < x) g = N1[lo * x + hi];
       else if (lo < x) g = KN2[(hi - x) * x + lo];
-      else {
-        R acc = R(0);
-        for (int k = 0; k < y; ++k) acc += KN3[(lo - x) * y + k] * K[(hi - x) * y + k];
-        g = acc;
-      }
-      Fj[i * m + j] = f;
+      else g = dot4(KN3 + (lo - x) * y, 1, K + (hi - x) * y, 1, y, R(0));
       GG[i * m + j] = g;
       if (first) Sg[i * m + j] = g;                          // Sigma0 := G[0] G[0]'  system.py:212
     });
   };
   // ---- conditioning on the observed block of Sg
-  auto cond1 = [&](int t, bool emit_f) {                     // Li, hl in registers; U2 = S_ro Li'; operator stream
-    R Li[kMaxSmall * kMaxSmall], hl;
-    reg_chol<R>(o, Sg, m, Li, hl);
-    ro.each([&](int p, int j) {
-      R acc = R(0);
-      LQG_UNROLL for (int k = 0; k < kMaxSmall; ++k) {
-        if (k < o) {
-          R l = Li[k];                                       // Li[j, k], run-time row j
-          LQG_UNROLL for (int r2 = 1; r2 < kMaxSmall; ++r2) l = (j == r2) ? Li[r2 * kMaxSmall + k] : l;
-          acc += (k <= j) ? Sg[(o + p) * m + k] * l : R(0);
+  auto condF = [&](int t) {                                  // Li = chol(S_oo)^-1, half log-det -> LDS + operator stream
+    if (on(2)) dispatch_small<CD>(o, [&](auto no_) {
+      constexpr int NO = decltype(no_)::value;
+      R Li[NO * NO], hl;
+      chol_inverse_reg<R, NO>(Sg, m, Li, hl);
+      if (ln == 0) {
+        LQG_UNROLL for (int e = 0; e < NO * NO; ++e) Lis[e] = Li[e];
+        if (a.ops) {
+          R* op = a.ops + (s * (a.T + 1) + t) * (long)a.nops + m * m + rr * o;
+          int e = 0;
+          LQG_UNROLL for (int i = 0; i < NO; ++i)
+            LQG_UNROLL for (int j = 0; j <= i; ++j) op[e++] = Li[i * NO + j];
+          op[e] = hl + kLogNorm;
         }
       }
-      U2[p * o + j] = acc;
-      if (a.ops) a.ops[(s * (a.T + 1) + t) * (long)a.nops + m * m + p * o + j] = acc;
     });
-    if (a.ops && threadIdx.x == 0) {
-      R* op = a.ops + (s * (a.T + 1) + t) * (long)a.nops + m * m + rr * o;
-      int e = 0;
-      LQG_UNROLL for (int i = 0; i < kMaxSmall; ++i)
-        LQG_UNROLL for (int j = 0; j <= i; ++j)
-          if (i < o) op[e++] = Li[i * kMaxSmall + j];
-      op[e] = hl + kLogNorm;
-    }
-    (void)emit_f;
+  };
+  auto cond1 = [&](int t) {                                  // U2 = S_ro Li'
+    if (on(2)) ro.each([&](int p, int j) {
+      const R v = dot4(Sg + (o + p) * m, 1, Lis + j * o, 1, j + 1, R(0));
+      U2[p * o + j] = v;
+      if (a.ops) a.ops[(s * (a.T + 1) + t) * (long)a.nops + m * m + p * o + j] = v;
+    });
   };
   auto cond2 = [&]() {                                       // C = S_rr - U2 U2'
-    rrs.each([&](int p, int q2) {
+    if (on(0)) rrs.each([&](int p, int q2) {
       const int lo = p < q2 ? p : q2, hi = p < q2 ? q2 : p;
       R acc = Sg[(o + lo) * m + o + hi];
-      for (int j = 0; j < o; ++j) acc -= U2[lo * o + j] * U2[hi * o + j];
+      acc = -dot4(U2 + lo * o, 1, U2 + hi * o, 1, o, -acc);
       C[p * rr + q2] = acc;
     });
   };
   auto sig1 = [&](int t) {                                   // T1 = Fj[:, o:] C ; emit Fj - [[I_o,0],[0,0]]
-    mr.each([&](int i, int q2) {
+    if (on(0)) mr.each([&](int i, int q2) {
       R acc = R(0);
-      for (int p = 0; p < rr; ++p) acc += Fj[i * m + o + p] * C[p * rr + q2];
+      acc = dot4(Fj + i * m + o, 1, C + q2, rr, rr, acc);
       T1[i * rr + q2] = acc;
     });
-    if (a.ops) {
+    if (a.ops && on(1)) {
       R* op = a.ops + (s * (a.T + 1) + t) * (long)a.nops;
       mm_.each([&](int i, int j) { op[i * m + j] = (i < o && i == j) ? Fj[i * m + j] - R(1) : Fj[i * m + j]; });
     }
   };
   auto sig2 = [&](int t) {                                   // Sigma' = T1 Fj[:, o:]' + GG          system.py:223-230
-    mm_.each([&](int i, int j) {
+    if (on(0)) mm_.each([&](int i, int j) {
       const int lo = i < j ? i : j, hi = i < j ? j : i;
       R acc = GG[lo * m + hi];
-      for (int q2 = 0; q2 < rr; ++q2) acc += T1[lo * rr + q2] * Fj[hi * m + o + q2];
+      acc = dot4(T1 + lo * rr, 1, Fj + hi * m + o, 1, rr, acc);
       Sg[i * m + j] = acc;
       if (a.Sig.p) const_cast<R*>(a.Sig.p)[s * a.Sig.sb + (long)t * a.Sig.st + i * a.Sig.sr + j * a.Sig.sc] = acc;
     });
   };
 
   // ---- prologue: P0, constants, Kalman step 0
-  if (a.Sigma0.p) ld_sym(bb, a.Sigma0, s, 0, P);
-  else ld_gram(bb, a.aV, s, 0, a.nva, P);                    // V[0] V[0]'  system.py:79,160
+  auto kalman_step = [&](int t) {                            // the six Kalman stages, unpipelined
+    kal1();
+    stage_end<BLOCK>();
+    kal2();
+    stage_end<BLOCK>();
+    kal3();
+    stage_end<BLOCK>();
+    kal4();
+    stage_end<BLOCK>();
+    kalF();
+    stage_end<BLOCK>();
+    kal5(t);
+    stage_end<BLOCK>();
+  };
+  if (on(3)) {
+    if (a.Sigma0.p) ld_sym(bb, a.Sigma0, s, 0, P);
+    else ld_gram(bb, a.aV, s, 0, a.nva, P);                  // V[0] V[0]'  system.py:79,160
+  }
   load_consts(0);
   stage_end<BLOCK>();
   hoist1();
   stage_end<BLOCK>();
   hoist2();
-  kal1();
-  stage_end<BLOCK>();
-  kal2();
-  stage_end<BLOCK>();
-  kal3();
-  stage_end<BLOCK>();
-  kal4();
-  stage_end<BLOCK>();
-  kal5(0);
-  stage_end<BLOCK>();
+  kalman_step(0);
 
   for (int t = 0; t < a.T; ++t) {
     const bool more = t + 1 < a.T;
-    if (!a.ti) {
-      // time-varying specs: K_{t+1} needs the constants of step t+1 while the joint system of step t needs those of
-      // step t — no pipelining: joint stages first, then reload, then the Kalman step
+    if (!a.ti || t == 0) {
+      // step 0 (Sigma is only initialised inside it) and time-varying specs (K_{t+1} needs the constants of step t+1
+      // while the joint system of step t needs those of step t) run unpipelined: joint stages, then the Kalman step
       if (joint) {
         joint1(t);
-        if (t > 0) cond1(t, true);
+        if (t > 0) condF(t);
         stage_end<BLOCK>();
         joint2(t == 0);
-        if (t > 0) cond2();
+        if (t > 0) cond1(t);
         stage_end<BLOCK>();
-        if (t == 0) { cond1(0, true); stage_end<BLOCK>(); cond2(); stage_end<BLOCK>(); }
+        if (t == 0) { condF(0); stage_end<BLOCK>(); cond1(0); stage_end<BLOCK>(); }
+        cond2();
+        stage_end<BLOCK>();
         sig1(t);
         stage_end<BLOCK>();
         sig2(t);
         stage_end<BLOCK>();
       }
       if (more) {
-        load_consts(t + 1);
-        stage_end<BLOCK>();
-        hoist1();
-        stage_end<BLOCK>();
-        hoist2();
-        kal1();
-        stage_end<BLOCK>();
-        kal2();
-        stage_end<BLOCK>();
-        kal3();
-        stage_end<BLOCK>();
-        kal4();
-        stage_end<BLOCK>();
-        kal5(t + 1);
-        stage_end<BLOCK>();
+        if (!a.ti) {
+          load_consts(t + 1);
+          stage_end<BLOCK>();
+          hoist1();
+          stage_end<BLOCK>();
+          hoist2();
+        }
+        kalman_step(t + 1);
       }
       continue;
     }
-    // ---- time-invariant: five stages per step
-    if (joint) { joint1(t); if (t > 0) cond1(t, true); }     // A
+    // ---- time-invariant, t > 0: six stages per step, Kalman step t+1 under the joint / Sigma stages of step t
+    if (joint) { joint1(t); condF(t); }                      // A
     if (more) kal1();
     stage_end<BLOCK>();
-    if (joint) { joint2(t == 0); if (t > 0) cond2(); }       // B
+    if (joint) { joint2(false); cond1(t); }                  // B   (K_t is dead after this stage)
     if (more) kal2();
     stage_end<BLOCK>();
-    if (joint && t == 0) { cond1(0, true); stage_end<BLOCK>(); cond2(); stage_end<BLOCK>(); }
-    if (joint) sig1(t);                                      // C
+    if (joint) cond2();                                      // C
     if (more) kal3();
     stage_end<BLOCK>();
-    if (joint) sig2(t);                                      // D
+    if (joint) sig1(t);                                      // D
     if (more) kal4();
     stage_end<BLOCK>();
-    if (more) { kal5(t + 1); stage_end<BLOCK>(); }           // E   (K_t is dead after stage B)
+    if (joint) sig2(t);                                      // E
+    if (more) kalF();
+    stage_end<BLOCK>();
+    if (more) { kal5(t + 1); stage_end<BLOCK>(); }           // F
   }
   // ---- last row: only the density operators of x_T
-  if (joint && a.ops) {
-    R Li[kMaxSmall * kMaxSmall], hl;
-    reg_chol<R>(o, Sg, m, Li, hl);
-    if (threadIdx.x == 0) {
-      R* op = a.ops + (s * (a.T + 1) + a.T) * (long)a.nops + m * m + rr * o;
-      int e = 0;
-      LQG_UNROLL for (int i = 0; i < kMaxSmall; ++i)
-        LQG_UNROLL for (int j = 0; j <= i; ++j)
-          if (i < o) op[e++] = Li[i * kMaxSmall + j];
-      op[e] = hl + kLogNorm;
-    }
-  }
+  if (joint && a.ops) condF(a.T);
 }
 
 // ======================================================================================================================

@@ -1,9 +1,16 @@
 // lqg_coop_inst.hip — the cooperative kernels of lqg_coop.hpp and their launch wrappers: ONE translation unit for every
 // model shape (dimensions are run-time arguments), both dtypes, LDS and global-arena variants, 64- and 256-lane
 // workgroups.
+// With -DLQG_INST_COOPF="x,b,u,y,d" / -DLQG_INST_COOPR="b,u" (+ -DLQG_INST_F32 / _F64) this file instead compiles ONE
+// fixed-dims instantiation of the forward / Riccati kernel (lqg_amd/build.py: one translation unit per shape of
+// lqg_dims.def, built in parallel); the base unit dispatches to them and keeps the run-time-dims kernels for the rest.
 #include "lqg_coop.hpp"
 #include "lqg_coop_launch.hpp"
 #include "lqg_launch.hpp"
+#ifndef LQG_DIMS_DEF
+#define LQG_DIMS_DEF "lqg_dims.def"
+#endif
+#include LQG_DIMS_DEF
 
 namespace lqg {
 namespace host {
@@ -18,8 +25,9 @@ inline long fwd_reals(const lqg_problem* p, bool kalman_only) {
   return kalman_only ? coop::kalman_arena_reals(p->dims.b, p->dims.y)
                      : coop::forward_arena_reals(p->dims.x, p->dims.b, p->dims.u, p->dims.y, p->dims.d);
 }
-// one wave per system while a step's largest product has at most two elements per lane, else four waves
-inline int block_for(int elems) { return elems <= 128 ? 64 : 256; }
+// WAVES mode (the independent products of a stage on different waves, each spread over one wave's lanes) while a step's
+// largest product has at most two elements per lane; larger systems spread every product over the whole workgroup
+inline bool waves_for(int elems) { return elems <= 128; }
 
 template <typename K>
 hipError_t raise_lds(K kernel, size_t bytes) {
@@ -45,6 +53,64 @@ coop::Args<R> make_args(const lqg_problem* p) {
   return k;
 }
 }  // namespace
+
+}  // namespace host
+}  // namespace lqg
+
+namespace lqg {
+namespace host {
+// fixed-dims launchers (LDS arena, WAVES mode): defined by the per-shape translation units
+template <typename R, int CX, int CB, int CU, int CY, int CD>
+hipError_t coop_forward_fixed(const coop::Args<R>& k, size_t lds, hipStream_t st) {
+  auto kern = coop::k_coop_forward<R, 256, false, true, CX, CB, CU, CY, CD>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)k.n_sys), dim3(256), lds, st, k);
+  return hipGetLastError();
+}
+template <typename R, int CB, int CU>
+hipError_t coop_riccati_fixed(const coop::Args<R>& k, size_t lds, hipStream_t st) {
+  auto kern = coop::k_coop_riccati<R, 256, false, true, CB, CU>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)k.n_sys), dim3(256), lds, st, k);
+  return hipGetLastError();
+}
+#if defined(LQG_INST_COOPF)
+#ifdef LQG_INST_F32
+template hipError_t coop_forward_fixed<float, LQG_INST_COOPF>(const coop::Args<float>&, size_t, hipStream_t);
+#endif
+#ifdef LQG_INST_F64
+template hipError_t coop_forward_fixed<double, LQG_INST_COOPF>(const coop::Args<double>&, size_t, hipStream_t);
+#endif
+#elif defined(LQG_INST_COOPR)
+#ifdef LQG_INST_F32
+template hipError_t coop_riccati_fixed<float, LQG_INST_COOPR>(const coop::Args<float>&, size_t, hipStream_t);
+#endif
+#ifdef LQG_INST_F64
+template hipError_t coop_riccati_fixed<double, LQG_INST_COOPR>(const coop::Args<double>&, size_t, hipStream_t);
+#endif
+#endif
+}  // namespace host
+}  // namespace lqg
+
+#if !defined(LQG_INST_COOPF) && !defined(LQG_INST_COOPR)
+namespace lqg {
+namespace host {
+#define X(X_, B_, U_, Y_, D_)                                                                                      \
+  extern template hipError_t coop_forward_fixed<float, X_, B_, U_, Y_, D_>(const coop::Args<float>&, size_t, hipStream_t); \
+  extern template hipError_t coop_forward_fixed<double, X_, B_, U_, Y_, D_>(const coop::Args<double>&, size_t, hipStream_t);
+LQG_FORWARD_DIMS(X)
+#undef X
+#define X(B_, U_)                                                                                              \
+  extern template hipError_t coop_riccati_fixed<float, B_, U_>(const coop::Args<float>&, size_t, hipStream_t);  \
+  extern template hipError_t coop_riccati_fixed<double, B_, U_>(const coop::Args<double>&, size_t, hipStream_t);
+LQG_RICCATI_DIMS(X)
+#undef X
 
 bool coop_supported(const lqg_dims& d) {
   return d.x >= 1 && d.b >= 1 && d.u >= 1 && d.y >= 1 && d.u <= coop::kMaxSmall && d.y <= coop::kMaxSmall &&
@@ -76,15 +142,21 @@ hipError_t coop_riccati(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view H
   k.arena = static_cast<R*>(arena);
   k.arena_reals = reals;
   const dim3 grid((unsigned)p->n_sys);
-  const int block = block_for(p->dims.b * p->dims.b);
-#define LQG_GO(B_, G_)                                                                     \
-  {                                                                                         \
-    auto kern = coop::k_coop_riccati<R, B_, G_>;                                            \
-    if (!(G_)) { hipError_t e = raise_lds(kern, lds); if (e != hipSuccess) return e; }      \
-    hipLaunchKernelGGL(kern, grid, dim3(B_), (G_) ? 0 : lds, st, k);                        \
+  const bool waves = waves_for(p->dims.b * p->dims.b);
+  if (waves && !global && k.ti) {             // a fixed-dims instantiation of this shape (time-invariant specs)
+#define X(B_, U_) \
+  if (p->dims.b == B_ && p->dims.u == U_) return coop_riccati_fixed<R, B_, U_>(k, lds, st);
+    LQG_RICCATI_DIMS(X)
+#undef X
   }
-  if (block == 64) { if (global) LQG_GO(64, true) else LQG_GO(64, false) }
-  else { if (global) LQG_GO(256, true) else LQG_GO(256, false) }
+#define LQG_GO(G_, W_)                                                                     \
+  {                                                                                         \
+    auto kern = coop::k_coop_riccati<R, 256, G_, W_>;                                       \
+    if (!(G_)) { hipError_t e = raise_lds(kern, lds); if (e != hipSuccess) return e; }      \
+    hipLaunchKernelGGL(kern, grid, dim3(256), (G_) ? 0 : lds, st, k);                       \
+  }
+  if (waves) { if (global) LQG_GO(true, true) else LQG_GO(false, true) }
+  else { if (global) LQG_GO(true, false) else LQG_GO(false, false) }
 #undef LQG_GO
   return hipGetLastError();
 }
@@ -106,15 +178,25 @@ hipError_t coop_forward(const lqg_problem* p, const void* Ls, void* ops, lqg_vie
   k.arena_reals = reals;
   const dim3 grid((unsigned)p->n_sys);
   const int m = p->dims.x + p->dims.b;
-  const int block = block_for(kalman_only ? p->dims.b * p->dims.b : m * m);
-#define LQG_GO(B_, G_)                                                                     \
-  {                                                                                         \
-    auto kern = coop::k_coop_forward<R, B_, G_>;                                            \
-    if (!(G_)) { hipError_t e = raise_lds(kern, lds); if (e != hipSuccess) return e; }      \
-    hipLaunchKernelGGL(kern, grid, dim3(B_), (G_) ? 0 : lds, st, k);                        \
+  const bool waves = waves_for(kalman_only ? p->dims.b * p->dims.b : m * m);
+  if (waves && !global && k.ti && !kalman_only) {
+    const lqg_dims& d = p->dims;
+#define X(X_, B_, U_, Y_, D_)                                                  \
+  if constexpr ((X_ + B_) * (X_ + B_) <= 128) {                                 \
+    if (d.x == X_ && d.b == B_ && d.u == U_ && d.y == Y_ && d.d == D_)         \
+      return coop_forward_fixed<R, X_, B_, U_, Y_, D_>(k, lds, st);             \
   }
-  if (block == 64) { if (global) LQG_GO(64, true) else LQG_GO(64, false) }
-  else { if (global) LQG_GO(256, true) else LQG_GO(256, false) }
+    LQG_FORWARD_DIMS(X)
+#undef X
+  }
+#define LQG_GO(G_, W_)                                                                     \
+  {                                                                                         \
+    auto kern = coop::k_coop_forward<R, 256, G_, W_>;                                       \
+    if (!(G_)) { hipError_t e = raise_lds(kern, lds); if (e != hipSuccess) return e; }      \
+    hipLaunchKernelGGL(kern, grid, dim3(256), (G_) ? 0 : lds, st, k);                       \
+  }
+  if (waves) { if (global) LQG_GO(true, true) else LQG_GO(false, true) }
+  else { if (global) LQG_GO(true, false) else LQG_GO(false, false) }
 #undef LQG_GO
   return hipGetLastError();
 }
@@ -145,3 +227,4 @@ template hipError_t coop_trial<double>(const lqg_problem*, const void*, lqg_traj
 
 }  // namespace host
 }  // namespace lqg
+#endif  // base translation unit

@@ -100,7 +100,7 @@ def test_workspace_size_formula(lib, monkeypatch):
     monkeypatch.setenv("LQG_COOP", "1")          # cooperative strategy: always through the operator stream
     assert lib.lqg_strategy(C.byref(ln.p)) == _abi.STRATEGY_COOP
     coop = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
-    monkeypatch.setenv("LQG_COOP", "0")          # lane strategy
+    monkeypatch.setenv("LQG_COOP", "0")          # lane strategy (also the default for shapes with lane kernels)
     assert lib.lqg_strategy(C.byref(ln.p)) == _abi.STRATEGY_LANE
     fused = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
     assert coop == fused + (100 * 501 * 136 * 4 + 255) // 256 * 256      # + operator stream; the working set is in LDS
