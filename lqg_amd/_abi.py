@@ -168,6 +168,8 @@ def library_for(dims, family=FAM_FORWARD, n_sys=None):
     elif family == FAM_KALMAN:
         dc.update(u=1, d=1)
     coop_ok = family in (FAM_FORWARD, FAM_RICCATI, FAM_KALMAN) and lib.lqg_coop_supported(C.byref(_dims_struct(dc)))
+    if family == FAM_SIMULATE:
+        coop_ok = True                              # k_coop_simulate: any (x, b, u, y)
     can_jit = shape_in_range(*key0) and os.path.exists(build.HIPCC) and os.environ.get("LQG_JIT", "1") != "0"
     big = n_sys is not None and n_sys >= JIT_MIN_SYSTEMS
     names = "xbuyd"

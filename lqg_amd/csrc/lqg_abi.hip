@@ -492,7 +492,10 @@ int lqg_simulate(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view K, lqg_t
                                                  (hipStream_t)stream, &found)
                      : dispatch_simulate<float>(p, L, l, K, eps, eta, x0, xhat0, xs, xhat, ys, us,
                                                 (hipStream_t)stream, &found);
-  if (!found) return unsupported(p, who);
+  if (!found)                   // no (x, b, u, y) instantiation: the run-time-dims kernel (per-thread state in LDS)
+    e = p->dtype == LQG_F64
+            ? coop_simulate<double>(p, L, l, K, eps, eta, x0, xhat0, xs, xhat, ys, us, (hipStream_t)stream)
+            : coop_simulate<float>(p, L, l, K, eps, eta, x0, xhat0, xs, xhat, ys, us, (hipStream_t)stream);
   return done(e, who);
 }
 

@@ -718,5 +718,87 @@ __global__ void __launch_bounds__(BLOCK) k_coop_trial(const R* __restrict__ ops_
   if (a.ll && live) a.ll[sys * a.ll_sb + n * a.ll_sn] = (R)acc;
 }
 
+// ======================================================================================================================
+// Run-time-dims twin of k_simulate (System.simulate's per-trial scan, lqg/system.py:106-128): one (system, trial) per
+// thread, the two state vectors and the per-step temporaries in LDS columns [element][thread]; gains and spec matrices
+// are read straight from global memory (every thread of a system reads the same address: broadcast).  For shapes
+// without an instantiated k_simulate<x,b,u,y> (e.g. the delay-12 model, x=26 b=39).
+template <typename R, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_coop_simulate(const SimArgs<R> a, const int nx, const int nb, const int nu,
+                                                         const int ny) {
+  extern __shared__ double lqg_coop_smem[];
+  R* sm = reinterpret_cast<R*>(lqg_coop_smem);
+  const int tid = threadIdx.x;
+  long gid = blockIdx.x * (long)BLOCK + tid;
+  const bool live = gid < a.n_sys * a.n_trials;
+  gid = live ? gid : a.n_sys * a.n_trials - 1;
+  const long s = gid / a.n_trials, n = gid % a.n_trials;
+  R *x = sm, *xn = x + nx * BLOCK, *xh = xn + nx * BLOCK, *xp = xh + nb * BLOCK, *uu = xp + nb * BLOCK,
+    *yy = uu + nu * BLOCK;
+#define AT(arr, i) arr[(i) * BLOCK + tid]
+  for (int i = 0; i < nx; ++i) AT(x, i) = a.x0.p ? a.x0.p[s * a.x0.sb + i * a.x0.sr] : R(0);
+  for (int i = 0; i < nb; ++i) AT(xh, i) = a.xh0.p ? a.xh0.p[s * a.xh0.sb + i * a.xh0.sr] : R(0);
+  auto out = [&](const DTraj<R>& v, int t) { return const_cast<R*>(v.p) + s * v.sb + n * v.sn + (long)t * v.st; };
+  if (live) {
+    R* d0 = out(a.xs, 0);
+    for (int i = 0; i < nx; ++i) d0[i * a.xs.sd] = AT(x, i);
+    if (a.xh.p) { R* d1 = out(a.xh, 0); for (int i = 0; i < nb; ++i) d1[i * a.xh.sd] = AT(xh, i); }
+  }
+  auto M = [&](const DView<R>& v, int t, int i, int j) { return v.p[s * v.sb + (long)t * v.st + i * v.sr + j * v.sc]; };
+  for (int t = 0; t < a.T; ++t) {
+    for (int i = 0; i < nu; ++i) {                           // u = L xhat + l     system.py:110
+      R v = a.l.p ? a.l.p[s * a.l.sb + (long)t * a.l.st + i * a.l.sr] : R(0);
+      for (int k = 0; k < nb; ++k) v += M(a.L, t, i, k) * AT(xh, k);
+      AT(uu, i) = v;
+    }
+    const R* ep = a.eps.p + s * a.eps.sb + n * a.eps.sn + (long)t * a.eps.st;
+    const R* et = a.eta.p + s * a.eta.sb + n * a.eta.sn + (long)t * a.eta.st;
+    for (int i = 0; i < nx; ++i) {                           // x = A x + B u + V eps   system.py:113-117
+      R v = R(0);
+      for (int k = 0; k < nx; ++k) v += M(a.dA, t, i, k) * AT(x, k);
+      for (int k = 0; k < nu; ++k) v += M(a.dB, t, i, k) * AT(uu, k);
+      AT(xn, i) = v;
+    }
+    for (int k = 0; k < a.nvd; ++k) {
+      const R e = ep[k * a.eps.sd];
+      for (int i = 0; i < nx; ++i) AT(xn, i) += M(a.dV, t, i, k) * e;
+    }
+    for (int i = 0; i < nx; ++i) AT(x, i) = AT(xn, i);
+    for (int i = 0; i < ny; ++i) {                           // y = F x + W eta          system.py:120
+      R v = R(0);
+      for (int k = 0; k < nx; ++k) v += M(a.dF, t, i, k) * AT(x, k);
+      AT(yy, i) = v;
+    }
+    for (int k = 0; k < a.nwd; ++k) {
+      const R e = et[k * a.eta.sd];
+      for (int i = 0; i < ny; ++i) AT(yy, i) += M(a.dW, t, i, k) * e;
+    }
+    for (int i = 0; i < nb; ++i) {                           // x_pred = A xhat + B u     system.py:123
+      R v = R(0);
+      for (int k = 0; k < nb; ++k) v += M(a.aA, t, i, k) * AT(xh, k);
+      for (int k = 0; k < nu; ++k) v += M(a.aB, t, i, k) * AT(uu, k);
+      AT(xp, i) = v;
+    }
+    if (live && a.ys.p) { R* d2 = out(a.ys, t); for (int i = 0; i < ny; ++i) d2[i * a.ys.sd] = AT(yy, i); }
+    for (int i = 0; i < ny; ++i) {                           // innovation y - F x_pred (kept in yy)
+      R v = AT(yy, i);
+      for (int k = 0; k < nb; ++k) v -= M(a.aF, t, i, k) * AT(xp, k);
+      AT(yy, i) = v;
+    }
+    for (int i = 0; i < nb; ++i) {                           // xhat = x_pred + K (y - F x_pred)  system.py:124
+      R v = AT(xp, i);
+      for (int k = 0; k < ny; ++k) v += M(a.K, t, i, k) * AT(yy, k);
+      AT(xh, i) = v;
+    }
+    if (live) {
+      R* d0 = out(a.xs, t + 1);
+      for (int i = 0; i < nx; ++i) d0[i * a.xs.sd] = AT(x, i);
+      if (a.xh.p) { R* d1 = out(a.xh, t + 1); for (int i = 0; i < nb; ++i) d1[i * a.xh.sd] = AT(xh, i); }
+      if (a.us.p) { R* d3 = out(a.us, t); for (int i = 0; i < nu; ++i) d3[i * a.us.sd] = AT(uu, i); }
+    }
+  }
+#undef AT
+}
+
 }  // namespace coop
 }  // namespace lqg

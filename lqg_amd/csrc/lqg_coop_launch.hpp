@@ -26,5 +26,10 @@ template <typename R>
 hipError_t coop_trial(const lqg_problem* p, const void* ops, lqg_traj x, lqg_traj mu, void* ll, long ll_sb, long ll_sn,
                       hipStream_t st);
 
+// run-time-dims twin of launch_simulate (any x, b, u, y whose per-thread state fits LDS)
+template <typename R>
+hipError_t coop_simulate(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view K, lqg_traj eps, lqg_traj eta, lqg_view x0,
+                         lqg_view xhat0, lqg_traj xs, lqg_traj xhat, lqg_traj ys, lqg_traj us, hipStream_t st);
+
 }  // namespace host
 }  // namespace lqg

@@ -7,9 +7,10 @@ independent 1-D models built with block_diag and then permuted (lqg/tracking/bas
 lqg/tracking/subjective.py:18-44), so this halves... in fact quarters their arithmetic.
 
 The components are found from DATA (which entries of A, B, F, V V^T, W W^T, Q, R, Sigma0 are non-zero for any
-candidate), with the class-level probe of lqg_amd/specialize.py for the model zoo.  One documented deviation: the
-eigenvalue floor of lqr.backward (lqg/control/lqr.py:27-28) is applied per component instead of to the joint H;
-the two differ only when the floor is ACTIVE (lambda_min(H) < 1e-8), which no proper cost matrix triggers.
+candidate), with the class-level probe of lqg_amd/specialize.py for the model zoo.  The eigenvalue floor of
+lqr.backward (lqg/control/lqr.py:27-28) acts on the JOINT H: when it is active it couples the components, so a system
+is only decoupled when the floor is provably inactive (floor_provably_inactive: lambda_min(R) >= eps, Q, Qf >= 0);
+otherwise the joint problem is solved, exactly as the reference does.
 """
 import numpy as np
 import torch
@@ -184,6 +185,41 @@ def identical_groups(system, d, parts, Sigma0=None):
     if key is not None:
         _ZOO_GROUPS[key] = groups
     return groups
+
+
+def floor_provably_inactive(system, eps=1e-8):
+    """True when the eigenvalue floor of lqr.backward (lqg/control/lqr.py:27-28: Ht = H + max(0, eps - lambda_min(H)) I)
+    can never be active, for any system and step.  H = R + B'SB >= R whenever S >= 0, and S stays >= 0 when Q and Qf
+    are, so  lambda_min(R) >= eps, Q >= 0, Qf >= 0  suffice.  Only then is block decoupling EXACT: an active floor
+    shifts every diagonal entry of the joint H by the same amount, i.e. it couples the components through the smallest
+    eigenvalue among them.  Decided with Gershgorin bounds (elementwise, no factorisation) and, where those are
+    inconclusive, the exact eigenvalues; one host synchronisation, cached on the instance per spec version."""
+    from lqg_amd import specialize
+    cache = system.__dict__.setdefault("_lqg_floor", {})
+    key = (float(eps), specialize.spec_versions(system))
+    if key in cache:
+        return cache[key]
+    a = system.actor
+    first = specialize._first
+
+    def lower_bound(M):                                  # Gershgorin: every eigenvalue >= min_i (M_ii - sum_{j != i} |M_ij|)
+        M = 0.5 * (M + M.transpose(-1, -2)).detach().double()
+        diag = torch.diagonal(M, dim1=-2, dim2=-1)
+        off = M.abs().sum(-1) - diag.abs()
+        return M, (diag - off).min()
+
+    Rs, r_lb = lower_bound(first(a.R))
+    Qs, q_lb = lower_bound(first(a.Q))
+    Qfs, qf_lb = lower_bound(a.Qf)
+    tol = -1e-12
+    checks = torch.stack([r_lb - eps, q_lb - tol, qf_lb - tol])
+    ok = bool((checks >= 0).all())                       # the one synchronisation
+    if not ok:
+        r_ok = bool(r_lb >= eps) or bool(torch.linalg.eigvalsh(Rs).min() >= eps)
+        q_ok = r_ok and (bool(q_lb >= tol) or bool(torch.linalg.eigvalsh(Qs).min() >= tol * max(1.0, float(Qs.abs().max()))))
+        ok = q_ok and (bool(qf_lb >= tol) or bool(torch.linalg.eigvalsh(Qfs).min() >= tol * max(1.0, float(Qfs.abs().max()))))
+    cache[key] = ok
+    return ok
 
 
 def plan(system, d, Sigma0=None, for_grad=False):

@@ -65,7 +65,7 @@ class Sweep:
     def __init__(self, actor, dynamics, x, Sigma0=None, eps=1e-8):
         d = x.shape[-1]
         ln = _hip.Launch(actor, dynamics, d=d, n_trials=x.shape[-3], Sigma0=Sigma0, eps=eps)
-        self.lib = ln.require_gpu()
+        self.lib = ln.require_gpu(_abi.FAM_ADJOINT)     # lane kernels only: an unlisted shape is compiled on first use
         if not self.lib.lqg_grad_supported(ln.p.dtype, C.byref(ln.p.dims)):
             raise _abi.LqgHipError(f"no adjoint kernels for model shape {tuple(ln.dims[k] for k in 'xbuyd')}: add it to "
                                    "LQG_ADJOINT_DIMS in lqg_amd/csrc/lqg_dims.def and rebuild (there is no CPU path)")

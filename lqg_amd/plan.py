@@ -25,7 +25,7 @@ class LogLikelihoodPlan:
         self.system = system
         d = x.shape[-1]
         lib = _abi.load()
-        parts = system.decoupled(d, Sigma0) or [(system, list(range(d)), None)]
+        parts = system.decoupled(d, Sigma0, eps=eps) or [(system, list(range(d)), None)]
         # merge=True: decoupled components with bit-identical specs are ONE system observed on different data columns
         # (every dim=2 zoo model): the per-system sweeps run once and the components become trials of that system
         self.merged = []

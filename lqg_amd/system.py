@@ -201,7 +201,7 @@ class System:
         from lqg_amd.plan import LogLikelihoodPlan
         return LogLikelihoodPlan(self, x, Sigma0=Sigma0).run()
 
-    def decoupled(self, d, Sigma0=None, for_grad=False):
+    def decoupled(self, d, Sigma0=None, for_grad=False, eps=1e-8):
         """Independent components of this system for data with d observed dims ([(sub_system, data columns, belief
         dims)], lqg_amd/decouple.py), or None when it does not decouple (or LQG_NO_DECOUPLE=1).  for_grad: the
         differentiable evaluation's variant (decouple.plan)."""
@@ -212,6 +212,8 @@ class System:
         parts = decouple.plan(self, d, Sigma0, for_grad=for_grad)
         if parts is None:
             return None
+        if not decouple.floor_provably_inactive(self, eps):
+            return None      # an active eigenvalue floor (lqr.py:27-28) couples the components: solve the joint problem
         # every component must be solvable by a generic library too (several trials, moments, ...)
         try:
             ok = all(_abi.shape_available(sub.xdim, sub.bdim, sub.udim, sub.ydim, len(cols)) for sub, cols, _ in parts)

@@ -100,13 +100,21 @@ def test_edge_cases_of_the_boundary():
 
 
 
-def test_unlisted_model_shape_compiles_on_demand(oracle_lib, monkeypatch):
-    """A hand-built model whose shape (x=b=3, u=2, y=2) is not in lqg_dims.def: lqg_amd compiles an auxiliary library
-    for it on first use (lqg_amd.build.build_dims_library) — every entry point works and matches the oracle; without
-    a compiler it fails loudly instead of falling back."""
+@pytest.mark.parametrize("big_batch", [False, True], ids=["cooperative", "compiled"])
+def test_unlisted_model_shape(oracle_lib, monkeypatch, big_batch):
+    """A hand-built model whose shape (x=b=3, u=2, y=2) is not in lqg_dims.def.  A small batch runs on the run-time-dims
+    cooperative kernels of the main library — nothing is compiled; from JIT_MIN_SYSTEMS systems per call lqg_amd compiles
+    an auxiliary lane-kernel library for the shape on first use (lqg_amd.build.build_dims_library; forced here by
+    lowering the threshold).  Every entry point works and matches the oracle either way; what has neither kernels nor
+    a compiler fails loudly instead of falling back."""
     from lqg_amd import _abi, build
     from lqg_amd.belief import kf
     from lqg_amd.control import lqr
+    if big_batch:
+        if not __import__("os").path.exists(build.HIPCC):
+            pytest.skip("no hipcc on this box")
+        monkeypatch.setattr(_abi, "JIT_MIN_SYSTEMS", 1)
+    before = set(_abi._dims_libs)
     rng = np.random.default_rng(11)
     A = np.eye(3) + 0.05 * rng.standard_normal((3, 3))
     B = 0.1 * rng.standard_normal((3, 2))
@@ -135,7 +143,9 @@ def test_unlisted_model_shape_compiles_on_demand(oracle_lib, monkeypatch):
     mu, Sig = m.conditional_moments(x[0])
     mu_r, Sig_r = oracle_lib.conditional_moments(spec, spec, xn[:1])
     assert np.abs(np_(mu) - mu_r[0]).max() < 1e-10 and np.abs(np_(Sig) - Sig_r).max() < 1e-10
-    # no compiler and an unknown shape: loud failure, never a fallback
+    assert (set(_abi._dims_libs) != before) == big_batch                  # compiled only in the big-batch mode
+    # the gradient sweep has lane kernels only: an unknown shape without a compiler fails loudly, never a fallback
     monkeypatch.setattr(build, "HIPCC", "/nonexistent/hipcc")
     with pytest.raises(_abi.LqgHipError, match="no hipcc"):
-        _abi.library_for(dict(x=3, b=4, u=1, y=2, d=3))
+        _abi.library_for(dict(x=3, b=4, u=1, y=2, d=3), family=_abi.FAM_ADJOINT)
+    assert _abi.library_for(dict(x=3, b=4, u=1, y=2, d=3)) is _abi.load()  # the likelihood itself needs no compiler

@@ -113,7 +113,7 @@ def test_gpu_kalman_gain_converges_to_dare():
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 1e-5)], ids=["f64", "f32"])
 def test_temporal_delay_model_on_the_hip_path(oracle_lib, dtype, tol):
     """lqg/tracking/delay.py: a delayed BoundedActor (shape compiled on first use) — likelihood over a candidate
-    axis against the fp64 oracle, and the delay-12 model of the reference rejected loudly (no CPU fallback)."""
+    axis against the fp64 oracle, and the delay-12 model of the reference on the cooperative kernels."""
     from lqg_amd.tracking.delay import DelayedSubjectiveActor, TemporalDelayModel
     sig = torch.tensor([4.0, 8.0, 16.0], dtype=dtype, device="cuda")
     m = TemporalDelayModel(lqg_amd.BoundedActor(T=80, sigma_target=sig, action_cost=0.1, device="cuda", dtype=dtype), delay=2)
@@ -127,9 +127,15 @@ def test_temporal_delay_model_on_the_hip_path(oracle_lib, dtype, tol):
         dyn = {f: getattr(ref_m.dynamics, f).numpy().copy() for f in O.FIELDS}
         ref = oracle_lib.log_likelihood(act, dyn, x.double().cpu().numpy())
         assert np.abs(np_(ll[c]) - ref).max() < tol * np.abs(ref).max()
+    # the delay-12 model of the reference (x=26, b=39): beyond the lane kernels, served by the cooperative run-time-dims
+    # kernels (simulate included) — against the fp64 oracle
     big = DelayedSubjectiveActor(T=20, device="cuda", dtype=dtype)
-    with pytest.raises(RuntimeError, match="outside the dims"):
-        big.log_likelihood(torch.zeros(1, 21, 2, device="cuda", dtype=dtype))
+    xb = big.simulate(7, n=3)[..., :2].contiguous()
+    ref_b = DelayedSubjectiveActor(T=20, device="cpu", dtype=torch.float64)
+    act = {f: getattr(ref_b.actor, f).numpy().copy() for f in O.FIELDS}
+    dyn = {f: getattr(ref_b.dynamics, f).numpy().copy() for f in O.FIELDS}
+    ref = oracle_lib.log_likelihood(act, dyn, xb.double().cpu().numpy())
+    assert np.abs(np_(big.log_likelihood(xb)) - ref).max() < tol * np.abs(ref).max()
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 2e-6)], ids=["f64", "f32"])
