@@ -1,18 +1,25 @@
-"""lqg/infer/utils.py: `infer` (NUTS / NeuTra through NumPyro) is out of scope (NumPyro drivers) — the
-gradient it needs exists (lqg_amd/grad.py: `model.log_likelihood(x)` is differentiable by torch.autograd through the HIP
-adjoint sweep), NumPyro's samplers do not; it raises instead of silently doing something else.  `sample_from_prior` is
-provided."""
+"""lqg/infer/utils.py: `infer` — posterior sampling with NUTS over the priors of lqg/infer/prior.py (the reference runs
+NumPyro's NUTS on `lifted_model`, utils.py:14-41) — and `sample_from_prior`.  NumPyro is not part of this build: the
+sampler is lqg_amd/infer/mcmc.py (NUTS with dual averaging; all chains' gradient evaluations batched on the candidate
+axis of the HIP likelihood).  method="neutra" (a BNAF normalising flow trained by SVI, utils.py:20-31) is not provided."""
 from lqg_amd.infer import prior
 from lqg_amd.infer.models import get_model_params
 
 
-def infer(x, num_samples, num_warmup, model=None, method="nuts", **kwargs):
+def infer(x, num_samples, num_warmup, model=None, process_noise=1., dt=1. / 60, method="nuts", progress_bar=True,
+          num_chains=1, seed=0, grad_method="fd", **fixed):
+    """lqg/infer/utils.py:14-41.  x[n, T, d] (T rows = T-1 steps, as lqg_model); returns an object with
+    get_samples(group_by_chain=False) / print_summary() / get_extra_fields() like numpyro's MCMC."""
     if method not in ("nuts", "neutra"):
         raise ValueError("Please specify a valid inference method (nuts, neutra).")      # lqg/infer/utils.py:33-34
-    raise NotImplementedError(
-        "lqg_amd has no MCMC driver (NumPyro is not part of this build).  d log p / d theta is available — "
-        "lqg_amd.infer.value_and_grad or torch.autograd through model.log_likelihood — for an external sampler; "
-        "lqg_amd.infer.max_likelihood and candidate_search are the built-in drivers.")
+    if method == "neutra":
+        raise NotImplementedError("method='neutra' (NumPyro AutoBNAFNormal + NeuTraReparam) is not part of lqg_amd; "
+                                  "method='nuts' samples the same posterior")
+    from lqg_amd.infer.mcmc import infer_nuts
+    from lqg_amd.tracking import BoundedActor
+    del progress_bar
+    return infer_nuts(x, num_samples, num_warmup, BoundedActor if model is None else model, process_noise=process_noise,
+                      dt=dt, num_chains=num_chains, seed=seed, grad_method=grad_method, **fixed)
 
 
 def sample_from_prior(model_type, seed, prior_dict=prior.default_prior, n=None):

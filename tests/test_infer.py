@@ -21,8 +21,35 @@ def test_get_model_params_matches_reference_reflection():
 def test_infer_rejects_unknown_method_like_the_reference():
     with pytest.raises(ValueError, match="valid inference method"):      # lqg/infer/utils.py:33-34
         infer(None, 10, 10, method="hmc")
-    with pytest.raises(NotImplementedError):
-        infer(None, 10, 10, method="nuts")
+    with pytest.raises(NotImplementedError, match="neutra"):
+        infer(None, 10, 10, method="neutra")
+
+
+def test_nuts_driver_samples_a_known_gaussian():
+    """The sampler itself (lqg_amd/infer/mcmc.py), with the log-density injected: four chains driven in lock step —
+    one batched evaluation per round — recover mean and covariance of a correlated Gaussian."""
+    from lqg_amd.infer import mcmc
+    A = torch.tensor([[1.0, 0.6, 0.0], [0.6, 2.0, 0.3], [0.0, 0.3, 0.5]], dtype=torch.float64)
+    Pm, mu = torch.linalg.inv(A), torch.tensor([0.5, -1.0, 2.0], dtype=torch.float64)
+    rounds = []
+
+    def pot(Z):
+        rounds.append(Z.shape[0])
+        dlt = Z - mu
+        return -0.5 * torch.einsum("ci,ij,cj->c", dlt, Pm, dlt), -(dlt @ Pm)
+
+    res = mcmc.run_chains(pot, [torch.zeros(3, dtype=torch.float64) for _ in range(4)], 200, 800, seed=1)
+    S = torch.cat([r["samples"] for r in res])
+    assert S.shape == (3200, 3) and max(rounds) == 4                    # all four chains in one evaluation
+    assert float((S.mean(0) - mu).abs().max()) < 0.12
+    assert float((torch.cov(S.T) - A).abs().max()) < 0.25
+    for r in res:
+        acc = sum(r["accept"]) / len(r["accept"])
+        assert 0.6 < acc < 0.98 and r["divergences"] == 0
+    names = ["a", "b", "c"]
+    out = mcmc.MCMCResult(names, res)
+    assert out.get_samples()["a"].shape == (3200,) and out.get_samples(group_by_chain=True)["b"].shape == (4, 800)
+    assert all(abs(v["r_hat"] - 1) < 0.1 for v in out.summary().values())
 
 
 def test_prior_helpers():
@@ -87,3 +114,72 @@ def test_value_and_grad_matches_oracle_finite_differences(oracle_lib):
     ref_grad = (oracle_obj(28.0 + h) - oracle_obj(28.0 - h)) / (2 * h)
     assert abs(val / oracle_obj(28.0) - 1) < 1e-11
     assert abs(grad["sigma_target"] / ref_grad - 1) < 1e-5
+
+
+@pytest.mark.gpu
+def test_infer_nuts_posterior_covers_the_truth():
+    """infer(x, num_samples, num_warmup, model, ...) as lqg/infer/utils.py:14-41: NUTS over the default priors; two
+    parameters inferred, two fixed; chains batched on the candidate axis; both gradient methods."""
+    true = dict(sigma_target=15.0, action_variability=0.5, action_cost=0.2, sigma_cursor=2.0)
+    m = lqg_amd.BoundedActor(T=250, device="cuda", dtype=torch.float64, **true)
+    x = m.simulate(4, n=30)
+    post = infer(x, 120, 100, model=lqg_amd.BoundedActor, num_chains=2, seed=3, action_variability=0.5, sigma_cursor=2.0)
+    s = post.summary()
+    assert set(s) == {"sigma_target", "action_cost"}
+    for k in s:
+        assert abs(s[k]["mean"] - true[k]) < 4 * s[k]["std"] + 0.05 * true[k], (k, s[k])
+        assert s[k]["std"] < 0.5 * true[k] and (s[k]["r_hat"] < 1.3)
+    assert post.get_samples()["sigma_target"].shape == (240,)
+    short = infer(x, 20, 20, model=lqg_amd.BoundedActor, num_chains=1, seed=3, grad_method="adjoint",
+                  action_variability=0.5, sigma_cursor=2.0)
+    assert torch.isfinite(short.get_samples()["action_cost"]).all()
+
+
+@pytest.mark.gpu
+def test_shared_params_objective_on_conditions_x_trials_data(oracle_lib):
+    """(Nc, N, T, d) data of lqg/io.py's loader (the committed fixture: 4 conditions x 3 trials x 268 rows x 2):
+    shared_params_lqg_model's likelihood (lqg/infer/models.py:67-130, T-1 convention of :32) — per-condition
+    sigma_target, everything else shared — against per-condition System.log_likelihood calls and the C oracle; a
+    candidate axis on a shared parameter; gradients through torch.autograd against finite differences."""
+    import os
+    from conftest import GOLDEN_DIR
+    from lqg_amd.infer import common_objective, shared_params_objective, split_params
+    import bench_configs
+    data = np.load(os.path.join(GOLDEN_DIR, "io", "tracking_small.npz"))["data_default"]        # [4, 3, 268, 2]
+    x = torch.as_tensor(data, dtype=torch.float64, device="cuda")
+    Nc, N, T, d = x.shape
+    shared = ["action_variability", "action_cost", "sigma_cursor"]
+    assert split_params(lqg_amd.BoundedActor, shared) == (["action_variability", "sigma_cursor", "action_cost"], ["sigma_target"])
+    sig = torch.tensor([8.0, 11.0, 15.0, 22.0], dtype=torch.float64, device="cuda")
+    pars = dict(sigma_target=sig, action_variability=0.6, action_cost=0.4, sigma_cursor=3.0)
+    table = shared_params_objective(x, lqg_amd.BoundedActor, pars, shared_params=shared, per_condition=True)
+    total = shared_params_objective(x, lqg_amd.BoundedActor, pars, shared_params=shared)
+    assert table.shape == (Nc,) and table.dtype == torch.float64 and abs(float(table.sum() / total) - 1) < 1e-14
+    assert abs(float(common_objective(x, lqg_amd.BoundedActor, pars) / total) - 1) < 1e-14    # common_lqg_model: same split
+    for k in range(Nc):
+        mk = lqg_amd.BoundedActor(T=T - 1, sigma_target=float(sig[k]), action_variability=0.6, action_cost=0.4,
+                                  sigma_cursor=3.0, device="cuda", dtype=torch.float64)
+        assert abs(float(mk.log_likelihood(x[k]).sum() / table[k]) - 1) < 1e-12
+        ref = oracle_lib.log_likelihood(bench_configs.host_spec(mk.actor), bench_configs.host_spec(mk.dynamics), data[k])
+        assert abs(float(ref.sum()) / float(table[k]) - 1) < 1e-10
+    # candidates of a shared parameter, and of the per-condition one
+    costs = torch.tensor([0.1, 0.4, 1.5], dtype=torch.float64, device="cuda")
+    obj = shared_params_objective(x, lqg_amd.BoundedActor, {**pars, "action_cost": costs}, shared_params=shared)
+    assert obj.shape == (3,) and abs(float(obj[1] / total) - 1) < 1e-12 and float(obj[0]) != float(obj[2])
+    sig2 = torch.stack([sig, sig * 1.3])
+    obj2 = shared_params_objective(x, lqg_amd.BoundedActor, {**pars, "sigma_target": sig2}, shared_params=shared)
+    assert obj2.shape == (2,) and abs(float(obj2[0] / total) - 1) < 1e-12
+    # reverse-mode gradient w.r.t. a shared and the per-condition parameter
+    sg = sig.clone().requires_grad_(True)
+    ac = torch.tensor(0.4, dtype=torch.float64, device="cuda", requires_grad=True)
+    val = shared_params_objective(x, lqg_amd.BoundedActor, {**pars, "sigma_target": sg, "action_cost": ac}, shared_params=shared)
+    val.backward()
+    h = 1e-5
+    f = lambda s_, a_: float(shared_params_objective(x, lqg_amd.BoundedActor, {**pars, "sigma_target": s_, "action_cost": a_},
+                                                     shared_params=shared))
+    fd_a = (f(sig, 0.4 + h) - f(sig, 0.4 - h)) / (2 * h)
+    assert abs(float(ac.grad) / fd_a - 1) < 1e-5
+    e2 = torch.zeros_like(sig)
+    e2[2] = h
+    fd_s = (f(sig + e2, 0.4) - f(sig - e2, 0.4)) / (2 * h)
+    assert abs(float(sg.grad[2]) / fd_s - 1) < 1e-5
