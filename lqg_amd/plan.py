@@ -14,6 +14,11 @@ from lqg_amd import _abi, _hip, _hipev, specialize
 # trial instead (N x the per-system work, no [system][step][operator] stream): e.g. 2^18 systems x 2 trials at
 # n=6, T=500 would need 71 GB of stream for 2 trials' worth of work.
 OPS_WORKSPACE_LIMIT = 16 << 30
+# Up to this many (system, trial) pairs a multi-trial evaluation is run as ONE fused sweep per PAIR (the system part is
+# recomputed per trial — the lanes are idle anyway — and the per-trial sweep over the operator stream, a third
+# latency-bound 500-step kernel, disappears): one parameter vector (or the 2P+1 finite-difference candidates) x tens of
+# trials, the inner loop of lqg/infer/mle.py:17-23 and of NUTS.  LQG_FUSE_TRIALS_MAX=0 disables.
+FUSE_TRIALS_MAX = int(os.environ.get("LQG_FUSE_TRIALS_MAX", "2048"))
 
 
 class LogLikelihoodPlan:
@@ -54,11 +59,17 @@ class LogLikelihoodPlan:
                 xs = merged_x[ip]                # [(B,) G*n, T+1, d_c]: the group's components as trials
             S0 = Sigma0 if (Sigma0 is None or bs is None) else Sigma0[..., bs, :][..., :, bs]
             n = xs.shape[-3]
+            n_sys0 = sub.n_systems or 1
+            sub0 = sub                           # (keeps the zoo class: its sparsity pattern is cached per class)
+            fuse_pairs = 2 < n and n_sys0 * n <= FUSE_TRIALS_MAX and _time_invariant(sub)
+            if fuse_pairs:                       # (system, trial) pairs as n_sys0 * n one-trial systems
+                sub, xs, S0 = _pairs_as_systems(sub, xs, S0, n_sys0, n)
+                n_pairs, n = n, 1
             ln = _hip.Launch(sub.actor, sub.dynamics, d=len(cols), n_trials=n, Sigma0=S0, eps=eps)
             lib = ln.require_gpu()               # liblqg_hip.so, or the auxiliary library of an unlisted shape
             xb, is_b = _hip._prep_x(ln, xs)
             nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
-            sp = _hip.specialised_entry(ln, sub, len(cols))
+            sp = _hip.specialised_entry(ln, sub0, len(cols))
             if sp is not None and n == 2:        # the specialised library sweeps two trials in-lane: no operator stream
                 ln.p.n_trials = 1
                 nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
@@ -72,11 +83,16 @@ class LogLikelihoodPlan:
                 ev = [_hipev.Event() for _ in range(4)]
                 for i in range(4):
                     ln.p.phase_events[i] = ev[i].h
-            self.work.append(dict(ln=ln, x=xb, traj=ln.traj(xb, is_b), ll=ln.empty(n), nbytes=nbytes, ev=ev,
+            ll_buf = ln.empty(n)
+            ll_sb = n if ln.batched else 0
+            if fuse_pairs:                       # [n_sys0 * n_pairs, 1] -> the caller's [(n_sys0,) n_pairs] view of it
+                ll_buf = ll_buf.view(n_sys0, n_pairs) if sub0.n_systems is not None else ll_buf.view(n_pairs)
+                n, ll_sb = n_pairs, 1
+            self.work.append(dict(ln=ln, x=xb, traj=ln.traj(xb, is_b), ll=ll_buf, ll_sb=ll_sb, nbytes=nbytes, ev=ev,
                                   ws=torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=ln.device),
                                   entry=sp or lib.lqg_log_likelihood, generic=lib.lqg_log_likelihood,
-                                  specialised=sp is not None, n=n,
-                                  pattern_key=(specialize.system_pattern(sub, len(cols))[2] if sp is not None else None),
+                                  specialised=sp is not None, n=n, fused_pairs=fuse_pairs,
+                                  pattern_key=(specialize.system_pattern(sub0, len(cols))[2] if sp is not None else None),
                                   loop_trials=loop_trials, is_b=is_b, group=(self.merged[ip] if self.merged else 1),
                                   dims=(sub.xdim, sub.bdim, sub.udim, sub.ydim, len(cols))))
         self.lib = lib
@@ -129,7 +145,7 @@ class LogLikelihoodPlan:
                 stream = self.side[i - 1] if (i > 0 and self.side) else main
                 if stream is not main:
                     stream.wait_event(self._fork)      # inputs produced on the caller's stream are ready
-                ll_sb = wk["n"] if ln.batched else 0
+                ll_sb = wk["ll_sb"]
                 trials = range(wk["n"]) if wk["loop_trials"] else (None,)
                 for tr in trials:
                     traj, llp = wk["traj"], wk["ll"].data_ptr()
@@ -179,6 +195,55 @@ class LogLikelihoodPlan:
         for wk in self.work:                       # components may run on different streams
             wk["ev"][3].synchronize()
         return tuple(sum(wk["ev"][i].elapsed_ms(wk["ev"][i + 1]) for wk in self.work) for i in range(3))
+
+
+def _time_invariant(sub):
+    for spec in (sub.actor, sub.dynamics):
+        for f in ("A", "B", "F", "V", "W", "Q", "R"):
+            t = getattr(spec, f)
+            if t.shape[-3] > 1 and t.stride(-3) != 0:
+                return False
+    return True
+
+
+def _pairs_as_systems(sub, xs, S0, B, n):
+    """System of B * n one-trial systems: pair (s, k) = system s of `sub` with trial k of `xs` (system-major order).
+    Spec fields with a system axis are repeated n times (a few kB), shared fields stay shared (system stride 0)."""
+    from lqg_amd.spec import LQGSpec
+    from lqg_amd.system import System
+    from lqg_amd.utils import mark_zero
+    batched = sub.n_systems is not None
+
+    def rep_spec(spec):
+        out = {}
+        for f in LQGSpec._fields:
+            t = getattr(spec, f)
+            zero = getattr(t, "_lqg_zero", False)
+            notime = f in ("Qf", "qf")
+            nd = (1 if f in ("q", "qf", "r") else 2) + (0 if notime else 1)
+            has_b = t.dim() == nd + 1
+            if not notime:
+                tax = -(2 if f in ("q", "r") else 3)
+                T = t.shape[tax]
+                base = t.select(tax, 0)
+                base = base.repeat_interleave(n, dim=0) if has_b else base.unsqueeze(0).expand(B * n, *base.shape)
+                t2 = base.unsqueeze(tax).expand(*base.shape[:base.dim() + tax + 1], T, *base.shape[base.dim() + tax + 1:])
+            else:
+                t2 = t.repeat_interleave(n, dim=0) if has_b else t.unsqueeze(0).expand(B * n, *t.shape)
+            out[f] = mark_zero(t2) if zero else t2
+        return LQGSpec(**out)
+
+    a = rep_spec(sub.actor)
+    d = a if sub.actor is sub.dynamics else rep_spec(sub.dynamics)
+    if xs.dim() == 3:
+        xe = xs.unsqueeze(0).expand(B, *xs.shape)
+    else:
+        xe = xs.expand(B, *xs.shape[1:])
+    xe = xe.reshape(B * n, 1, *xs.shape[-2:])
+    if S0 is not None and S0.dim() == 3:
+        S0 = S0.repeat_interleave(n, dim=0)
+    del batched
+    return System(actor=a, dynamics=d), xe, S0
 
 
 def _trial_stack(x, cols_list):

@@ -100,3 +100,18 @@ def test_trial_and_candidate_sharding_world2(tmp_path, oracle_lib):
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     r0, r1 = np.load(tmp_path / "r0.npy"), np.load(tmp_path / "r1.npy")
     assert np.array_equal(r0, r1)            # identical on every rank after the all-reduce
+
+
+def test_bench_gpus_n_starts_n_ranks_itself():
+    """`python bench.py --gpus 2` run bare must start two ranks as child processes (round-1 finding: it ran one rank and
+    printed n_gpus 1).  Here there is no GPU: both children must fail loudly (no CPU fallback), each naming its rank
+    environment, and the parent must relay the failure — which also shows the parent never touched the GPU itself."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    out = r.stdout + r.stderr
+    assert out.count("bench.py needs an MI355X") >= 2 or "local_rank: 1" in out or "rank      : 1" in out, out[-2000:]

@@ -279,10 +279,39 @@ def test_per_trial_fallback_when_the_operator_stream_would_be_huge(monkeypatch):
     x = torch.cat([workload.simulate_one_trial_each(sys_, seed=s) for s in (1, 2, 3)], dim=1)     # [300, 3, 61, 4]
     ref = sys_.log_likelihood(x).clone()
     monkeypatch.setattr(plan_mod, "OPS_WORKSPACE_LIMIT", 1024)
+    monkeypatch.setattr(plan_mod, "FUSE_TRIALS_MAX", 0)              # (1800 pairs would otherwise run as fused pairs)
     p = plan_mod.LogLikelihoodPlan(sys_, x)
     assert all(wk["loop_trials"] for wk in p.work)
     got = p.run()
     assert got.shape == (300, 3) and float((got / ref - 1).abs().max()) < 1e-12
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 2e-6)], ids=["f64", "f32"])
+def test_small_problems_run_as_fused_system_trial_pairs(monkeypatch, dtype, tol):
+    """Few systems x tens of trials (one parameter vector or its 2P+1 finite-difference neighbours: the inner loop of
+    lqg/infer/mle.py:17-23): the plan turns every (system, trial) pair into a one-trial system of the fused sweep — no
+    operator stream, no k_trial pass.  Same numbers as the split path; shared and per-system data; a merged dim=2 model."""
+    import lqg_amd
+    from lqg_amd import plan as plan_mod
+    sig = torch.linspace(5.0, 30.0, 9, dtype=dtype, device="cuda")
+    for m, d in ((lqg_amd.BoundedActor(T=120, sigma_target=sig, device="cuda", dtype=dtype), 2),
+                 (lqg_amd.BoundedActor(T=120, sigma_target=12.0, device="cuda", dtype=dtype), 2),
+                 (lqg_amd.SubjectiveActor(dim=2, T=80, sigma_target=sig, device="cuda", dtype=dtype), 4)):
+        one = lqg_amd.BoundedActor(T=120, device="cuda", dtype=dtype) if d == 2 else \
+            lqg_amd.SubjectiveActor(dim=2, T=80, device="cuda", dtype=dtype)
+        x = one.simulate(2, n=50)[..., :d].contiguous()
+        p = plan_mod.LogLikelihoodPlan(m, x)
+        assert all(wk["fused_pairs"] for wk in p.work)
+        got = p.run().clone()
+        monkeypatch.setattr(plan_mod, "FUSE_TRIALS_MAX", 0)
+        q = plan_mod.LogLikelihoodPlan(m, x)
+        assert not any(wk["fused_pairs"] for wk in q.work)
+        ref = q.run().clone()
+        monkeypatch.undo()
+        assert got.shape == ref.shape and float((got.double() / ref.double() - 1).abs().max()) < tol
+        if m.n_systems is not None:                         # per-system data [B, n, T+1, d]
+            xb = x.unsqueeze(0).expand(m.n_systems, *x.shape).contiguous()
+            assert float((m.log_likelihood(xb).double() / ref.double() - 1).abs().max()) < tol
 
 
 def test_joint_m20_kernels_still_agree_with_the_decoupled_path(monkeypatch):
