@@ -310,15 +310,20 @@ struct FwdStep {
   // conditioning on x_t and propagation                                              system.py:219-230
   // The observed rows of the conditional mean / covariance are x_t and 0 exactly, so only the unobserved block is
   // formed, through Wm = S_ro S_oo^-1 (no Soo - Soo Soo^-1 Soo cancellation: the point-mass model has cond(S_oo) ~ 1e8).
+  // DEVIATION FORM (as the forward kernels): the observed entries of `mu` hold dO = mu_o - x_{t-1}, the
+  // predicted mean relative to the PREVIOUS data row (xprev), so that the innovation is (x_t - x_{t-1}) - dO — the data
+  // difference is exact in floating point and nothing large is cancelled; mu1's observed entries come out relative to
+  // x_t.  Derivatives are unaffected (d mu_o / d dO = 1): only the evaluation of r changes.  Without it the fp32
+  // gradients of the fully observed point-mass model (cond(S_oo) ~ 5e8) were useless.
   template <bool FULL>
-  LQG_DEV void moments(const R (&Sig)[M * M], const R (&mu)[M], const R (&xt)[ND]) {
+  LQG_DEV void moments(const R (&Sig)[M * M], const R (&mu)[M], const R (&xt)[ND], const R (&xprev)[ND]) {
     R Soo[ND * ND], Sro[RR * ND], Srr[RR * RR];
     get_block<R, M, ND, ND>(Sig, 0, 0, Soo);
     get_block<R, M, RR, ND>(Sig, ND, 0, Sro);
     get_block<R, M, RR, RR>(Sig, ND, ND, Srr);
     get_block<R, M, M, RR>(F, 0, ND, Fr);
     spd_inverse<R, ND>(Soo, N);
-    LQG_UNROLL for (int k = 0; k < ND; ++k) r[k] = xt[k] - mu[k];
+    LQG_UNROLL for (int k = 0; k < ND; ++k) r[k] = (xt[k] - xprev[k]) - mu[k];
     LQG_UNROLL for (int k = 0; k < ND; ++k) {
       R acc = R(0);
       LQG_UNROLL for (int j = 0; j < ND; ++j) acc += N[k * ND + j] * r[j];
@@ -339,8 +344,8 @@ struct FwdStep {
     mm_acc<R, M, RR, RR>(Fr, Crr, FCr);
     LQG_UNROLL for (int k = 0; k < M; ++k) {
       R acc = R(0);
-      LQG_UNROLL for (int j = 0; j < M; ++j) acc += F[k * M + j] * c[j];
-      mu1[k] = acc;
+      LQG_UNROLL for (int j = 0; j < M; ++j) acc += ((k < ND && k == j) ? F[k * M + j] - R(1) : F[k * M + j]) * c[j];
+      mu1[k] = acc;                                   // observed rows: relative to x_t
     }
     if (FULL) {
       copy<R, M * M>(GG, Sig1);
@@ -370,9 +375,10 @@ __global__ void __launch_bounds__(LQG_BLOCK, 1) k_adj_forward(const AdjArgs<R> a
   if (a.Sigma0.p) load_sym<R, NB>(a.Sigma0.p + s * a.Sigma0.sb, a.Sigma0.sr, a.Sigma0.sc, P);
   else copy<R, NB * NB>(sp.VVa, P);
   const R* xp = a.x.p + s * a.x.sb + n * a.x.sn;
-  zero<R, M>(mu);
+  R xprev[ND];
+  zero<R, M>(mu);                                                    // mu0 = [x[0], 0...] (system.py:211): dO = 0
   LQG_UNROLL for (int k = 0; k < ND; ++k) xt[k] = xp[k * a.x.sd];
-  LQG_UNROLL for (int k = 0; k < ND; ++k) mu[k] = xt[k];             // system.py:211
+  LQG_UNROLL for (int k = 0; k < ND; ++k) xprev[k] = xt[k];
   double ll = 0.0;
   FwdStep<R, NX, NB, NU, NY, ND> f;
   for (int t = 0; t < a.T; ++t) {
@@ -384,16 +390,17 @@ __global__ void __launch_bounds__(LQG_BLOCK, 1) k_adj_forward(const AdjArgs<R> a
     store_tri<R, NB>(w + Lay::P_OFF * a.ld, a.ld, P);
     store_tri<R, M>(w + Lay::SIG_OFF * a.ld, a.ld, Sig);
     store_flat<R, M>(w + Lay::MU_OFF * a.ld, a.ld, mu);
-    f.template moments<true>(Sig, mu, xt);
+    f.template moments<true>(Sig, mu, xt, xprev);
     f.kalman_update(P);
     copy<R, M * M>(f.Sig1, Sig);
     copy<R, M>(f.mu1, mu);
+    LQG_UNROLL for (int k = 0; k < ND; ++k) xprev[k] = xt[k];
     LQG_UNROLL for (int k = 0; k < ND; ++k) xt[k] = xp[(long)(t + 1) * a.x.st + k * a.x.sd];
     R Soo[ND * ND], Ni[ND * ND], e[ND];
     get_block<R, M, ND, ND>(Sig, 0, 0, Soo);
     R nhl = spd_inverse<R, ND>(Soo, Ni);                             // -0.5 log det
     R q = R(0);
-    LQG_UNROLL for (int k = 0; k < ND; ++k) e[k] = xt[k] - mu[k];
+    LQG_UNROLL for (int k = 0; k < ND; ++k) e[k] = (xt[k] - xprev[k]) - mu[k];
     LQG_UNROLL for (int p = 0; p < ND; ++p)
       LQG_UNROLL for (int k = 0; k < ND; ++k) q += e[p] * Ni[p * ND + k] * e[k];
     ll += (double)(nhl - R(0.5) * q) - 0.5 * ND * 1.8378770664093453;  // system.py:244-248
@@ -445,10 +452,12 @@ __global__ void __launch_bounds__(LQG_BLOCK, 1) k_adj_reverse(const AdjArgs<R> a
     load_tri<R, NB>(w + Lay::P_OFF * a.ld, a.ld, P0);
     load_tri<R, M>(w + Lay::SIG_OFF * a.ld, a.ld, Sig);
     load_flat<R, M>(w + Lay::MU_OFF * a.ld, a.ld, mu);
+    R xm1[ND];
     LQG_UNROLL for (int k = 0; k < ND; ++k) xt[k] = xp[(long)t * a.x.st + k * a.x.sd];
     LQG_UNROLL for (int k = 0; k < ND; ++k) x1[k] = xp[(long)(t + 1) * a.x.st + k * a.x.sd];
+    LQG_UNROLL for (int k = 0; k < ND; ++k) xm1[k] = xp[(long)(t > 0 ? t - 1 : 0) * a.x.st + k * a.x.sd];
     f.system(sp, P0, L);
-    f.template moments<false>(Sig, mu, xt);
+    f.template moments<false>(Sig, mu, xt, xm1);
     // ---- log-density of x[t+1]                                                     system.py:244-248
     {
       R Soo[ND * ND], Ni[ND * ND], wv[ND];
@@ -456,7 +465,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, 1) k_adj_reverse(const AdjArgs<R> a
       spd_inverse<R, ND>(Soo, Ni);
       LQG_UNROLL for (int p = 0; p < ND; ++p) {
         R acc = R(0);
-        LQG_UNROLL for (int k = 0; k < ND; ++k) acc += Ni[p * ND + k] * (x1[k] - f.mu1[k]);
+        LQG_UNROLL for (int k = 0; k < ND; ++k) acc += Ni[p * ND + k] * ((x1[k] - xt[k]) - f.mu1[k]);
         wv[p] = acc;
       }
       LQG_UNROLL for (int p = 0; p < ND; ++p) mub[p] += g * wv[p];
