@@ -159,6 +159,37 @@ constexpr Mask<NB, NB> kalman_state_mask() {
   return P;
 }
 
+// Structural mask of the per-step trial operator  Fj - [[I_o, 0], [0, 0]]  that k_forward_sp<NTR = 0> writes to the
+// operator stream: the mask algebra of the joint system (system.py:167-187) on the pattern's masks, the loop-carried
+// Kalman mask included.  k_forward_sp static_asserts that it equals the mask of the matrix it really builds.  The diagonal
+// of the observed block is F_ii - 1: structurally zero where the dynamics' A has a unit diagonal (PAT::AdmI = mask of Ad - I).
+template <int N>
+constexpr Mask<N, N> mask_sym(const Mask<N, N>& a) { return mask_or(a, mask_t(a)); }
+
+template <typename PAT, int NX, int NB, int NU, int NY, bool DENSE_P>
+constexpr Mask<NX + NB, NX + NB> joint_dynamics_mask() {
+  const auto P = kalman_state_mask<PAT, NB, NY, DENSE_P>();
+  const auto AP = mask_mul(PAT::Aa, P);
+  const auto Pp = mask_or(mask_sym(mask_mul(AP, mask_t(PAT::Aa))), PAT::VVa);
+  const auto FP = mask_mul(PAT::Fa, Pp);
+  const auto G = mask_or(mask_sym(mask_mul(FP, mask_t(PAT::Fa))), PAT::WWa);
+  const auto Gi = mask_is_diag(G) ? G : mask_full<NY, NY>();
+  const auto K = mask_mul(mask_t(FP), Gi);
+  const auto FAa = mask_and(mask_mul(PAT::Fa, PAT::Aa), PAT::FAa);
+  const auto FAd = mask_and(mask_mul(PAT::Fd, PAT::Ad), PAT::FAd);
+  const auto DB = mask_and(mask_or(mask_mul(PAT::Fd, PAT::Bd), mask_mul(PAT::Fa, PAT::Ba)), PAT::DB);
+  const auto BK = mask_or(PAT::Ba, mask_mul(K, DB));
+  const auto Lf = mask_full<NU, NB>();
+  return mask_block(PAT::Ad, mask_mul(PAT::Bd, Lf), mask_mul(K, FAd),
+                    mask_or(mask_or(PAT::Aa, mask_mul(K, FAa)), mask_mul(BK, Lf)));
+}
+template <typename PAT, int NX, int NB, int NU, int NY, int ND, bool DENSE_P>
+constexpr Mask<NX + NB, NX + NB> trial_operator_mask() {
+  auto m = joint_dynamics_mask<PAT, NX, NB, NU, NY, DENSE_P>();
+  for (int i = 0; i < ND; ++i) m.b[i * (NX + NB) + i] = PAT::AdmI(i, i);
+  return m;
+}
+
 // NTR >= 1 (fused): the NTR trials of each system are swept in-lane (1: the headline; 2: two identical decoupled
 // components solved as ONE system with two trials, lqg_amd/plan.py); NTR == 0: the per-step trial operators are written
 // to the operator stream for k_trial (many trials per system), exactly as k_forward does.  ll_sn: trial stride of ll.
@@ -319,6 +350,8 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
     // ---- joint dynamics                                                system.py:167-187
     const auto BK = add(Ba, mul(K, DB));
     const auto Fj = block2x2(Ad, mul(Bd, L), mul(K, FAd), add(sub(Aa, mul(K, FAa)), mul(BK, L)));
+    static_assert(mask_eq(decltype(Fj)::mask, joint_dynamics_mask<PAT, NX, NB, NU, NY, DENSE_P>()),
+                  "joint_dynamics_mask() must mirror the mask algebra of the joint system built here");
     // ---- joint noise covariance                                        system.py:190-207
     const auto KN2 = mul(K, N2);
     const auto GG = block2x2(N1, transpose(KN2), KN2, mul_nt_sym_add(mul(K, N3), K, Mat<R, NB, NB, mask_none<NB, NB>()>{}));
@@ -409,6 +442,119 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
   }
 }
 
+// ---------------------------------------------------------------- per-trial sweep with the operator's structure
+// k_trial (lqg_kernels.hpp) with the structural zeros of the operator Fj - [[I_o,0],[0,0]] (FM) resolved at compile time:
+// the mean update is ~half of a trial-step's instructions and the tracking models' operators are 40-60 % dense (unit
+// diagonal of A, a single control row, selection-shaped K Fd Ad).  Same operator stream, same arithmetic order for the
+// terms that remain; rows without any term make their deviation a compile-time zero.  (Compile-time recursion instead
+// of `if` inside unrolled loops: see dev_matvec_row in lqg_sparse.hpp.)
+template <bool PF, int NPF, int IDX, typename R>
+LQG_DEV R trial_op_at(const R (&opc)[NPF], const R* __restrict__ op) {
+  if constexpr (PF) return opc[IDX];
+  else return op[IDX];
+}
+template <typename R, int M, int ND, Mask<M, M> FM, bool PF, int NPF, int I, int J>
+LQG_DEV void trial_mean_term(const R (&opc)[NPF], const R* __restrict__ op, const R (&cv)[M], R& v) {
+  if constexpr (J < M) {
+    if constexpr (FM.b[I * M + J]) v += trial_op_at<PF, NPF, TrialOps<M, ND>::F_OFF + I * M + J, R>(opc, op) * cv[J];
+    trial_mean_term<R, M, ND, FM, PF, NPF, I, J + 1>(opc, op, cv, v);
+  }
+}
+template <typename R, int M, int ND, Mask<M, M> FM, bool PF, int NPF, int I>
+LQG_DEV void trial_mean_rows(const R (&opc)[NPF], const R* __restrict__ op, const R (&cv)[M], R (&mn)[M]) {
+  if constexpr (I < M) {
+    R v = R(0);
+    trial_mean_term<R, M, ND, FM, PF, NPF, I, 0>(opc, op, cv, v);
+    mn[I] = v;
+    trial_mean_rows<R, M, ND, FM, PF, NPF, I + 1>(opc, op, cv, mn);
+  }
+}
+
+template <typename R, int M, int ND, int TPL, Mask<M, M> FM>
+__global__ void __launch_bounds__(LQG_BLOCK) k_trial_sp(const R* __restrict__ ops_all, const TrialArgs<R> a) {
+  constexpr int O = ND, RR = M - ND;
+  constexpr int kAccChunk = 8;
+  using Ops = TrialOps<M, ND>;
+  const long sys = blockIdx.y;
+  const long n0 = (long)blockIdx.x * (LQG_BLOCK * TPL) + threadIdx.x;
+  const R* __restrict__ op = ops_all + sys * (long)(a.T + 1) * Ops::N;
+  const R* xr[TPL];
+  bool live[TPL];
+  R xprev[TPL][O], dO[TPL][O], muR[TPL][RR];
+  double acc[TPL];
+  R part[TPL];
+  LQG_UNROLL for (int k = 0; k < TPL; ++k) {
+    long n = n0 + (long)k * LQG_BLOCK;
+    live[k] = n < a.n_trials;
+    n = live[k] ? n : (a.n_trials - 1);
+    xr[k] = a.x.p + sys * a.x.sb + n * a.x.sn;
+    LQG_UNROLL for (int i = 0; i < O; ++i) { xprev[k][i] = xr[k][i * a.x.sd]; dO[k][i] = R(0); }
+    LQG_UNROLL for (int i = 0; i < RR; ++i) muR[k][i] = R(0);
+    acc[k] = 0.0;
+    part[k] = R(0);
+  }
+  R xq[TPL][O];                                           // data rows one step ahead
+  LQG_UNROLL for (int k = 0; k < TPL; ++k)
+    LQG_UNROLL for (int i = 0; i < O; ++i) xq[k][i] = xprev[k][i];
+  constexpr bool PF = LQG_TRIAL_OPS_PREFETCH && (Ops::N * (int)(sizeof(R) / 4) <= 32);
+  constexpr int NPF = PF ? Ops::N : 1;
+  R opn[NPF], opc[NPF];
+  if (PF) {
+    LQG_UNROLL for (int i = 0; i < NPF; ++i) opn[i] = op[i];
+  } else {
+    opc[0] = R(0);
+  }
+  for (int t = 0; t <= a.T; ++t) {
+    if (PF) {
+      LQG_UNROLL for (int i = 0; i < NPF; ++i) opc[i] = opn[i];
+      const R* __restrict__ nx = op + ((t < a.T) ? Ops::N : 0);
+      LQG_UNROLL for (int i = 0; i < NPF; ++i) opn[i] = nx[i];
+    }
+#define LQG_OP(i_) (PF ? opc[PF ? (i_) : 0] : op[i_])
+    R Li[O * (O + 1) / 2];
+    LQG_UNROLL for (int i = 0; i < O * (O + 1) / 2; ++i) Li[i] = LQG_OP(Ops::L_OFF + i);
+    const R hlc = LQG_OP(Ops::H_OFF);
+    const bool flush = ((t & (kAccChunk - 1)) == 0) || t == a.T;
+    LQG_UNROLL for (int k = 0; k < TPL; ++k) {
+      R cv[M], w[O];                                      // cv = [x_t ; c]
+      LQG_UNROLL for (int i = 0; i < O; ++i) cv[i] = xq[k][i];
+      {
+        const long row = (t + 1 < a.T) ? (long)(t + 1) : (long)a.T;
+        LQG_UNROLL for (int i = 0; i < O; ++i) xq[k][i] = xr[k][row * a.x.st + i * a.x.sd];
+      }
+      R zz = R(0);
+      {
+        int e = 0;
+        LQG_UNROLL for (int i = 0; i < O; ++i) {
+          R v = R(0);
+          LQG_UNROLL for (int j = 0; j <= i; ++j) v += Li[e++] * ((cv[j] - xprev[k][j]) - dO[k][j]);
+          w[i] = v;
+          zz += v * v;
+        }
+      }
+      if (t > 0) part[k] += R(0.5) * zz + hlc;
+      if (flush) { acc[k] -= (double)part[k]; part[k] = R(0); }
+      if (t < a.T) {
+        LQG_UNROLL for (int p = 0; p < RR; ++p) {
+          R v = muR[k][p];
+          LQG_UNROLL for (int j = 0; j < O; ++j) v += LQG_OP(Ops::U_OFF + p * O + j) * w[j];
+          cv[O + p] = v;
+        }
+        R mn[M];
+        trial_mean_rows<R, M, ND, FM, PF, NPF, 0>(opc, op, cv, mn);
+        LQG_UNROLL for (int i = 0; i < O; ++i) { dO[k][i] = mn[i]; xprev[k][i] = cv[i]; }
+        LQG_UNROLL for (int p = 0; p < RR; ++p) muR[k][p] = mn[O + p];
+      }
+    }
+    op += Ops::N;
+#undef LQG_OP
+  }
+  if (a.ll) {
+    LQG_UNROLL for (int k = 0; k < TPL; ++k)
+      if (live[k]) a.ll[sys * a.ll_sb + (n0 + (long)k * LQG_BLOCK) * a.ll_sn] = (R)acc[k];
+  }
+}
+
 // dense pattern (every constant may be non-zero everywhere): the specialised kernels reduce to the generic ones
 template <int NX, int NB, int NU, int NY>
 struct DensePattern {
@@ -420,6 +566,7 @@ struct DensePattern {
   static constexpr auto Q = mask_full<NB, NB>();
   static constexpr auto Rr = mask_full<NU, NU>();
   static constexpr auto Ad = mask_full<NX, NX>();
+  static constexpr auto AdmI = mask_full<NX, NX>();
   static constexpr auto Bd = mask_full<NX, NU>();
   static constexpr auto Fd = mask_full<NY, NX>();
   static constexpr auto N1 = mask_full<NX, NX>();

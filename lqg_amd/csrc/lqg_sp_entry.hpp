@@ -61,8 +61,23 @@ int run_sp(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll_sn, v
   }
   mark(2);
   if (!fused) {   // several trials per system: the generic per-trial sweep over the operator stream
-    hipError_t e = launch_trial<R, NX + NB, ND>(p, ops, x, no_traj, ll, ll_sb, ll_sn, st);
-    if (e != hipSuccess) return (int)e;
+    // the per-trial sweep with the operator's structural zeros compiled out (k_trial_sp); trials-per-lane rule of
+    // launch_trial (lqg_launch.hpp)
+    lqg::TrialArgs<R> tk{dt<R>(x), dt<R>(no_traj), static_cast<R*>(ll), ll_sb, ll_sn, (long)p->n_trials, p->T};
+    const long lanes4 = (long)p->n_sys * ((p->n_trials + 4 * LQG_BLOCK - 1) / (4 * LQG_BLOCK)) * LQG_BLOCK;
+    const bool wide = lanes4 >= 2L * 1024 * 64;
+    const long per_block = (long)LQG_BLOCK * (wide ? LQG_TRIALS_PER_LANE : 1);
+    const dim3 tgrid((unsigned)((p->n_trials + per_block - 1) / per_block), (unsigned)p->n_sys);
+    const R* o = static_cast<const R*>(ops);
+    if (p->Sigma0.ptr != nullptr) {
+      constexpr auto FM = lqg::trial_operator_mask<PAT, NX, NB, NU, NY, ND, true>();
+      if (wide) hipLaunchKernelGGL((lqg::k_trial_sp<R, NX + NB, ND, LQG_TRIALS_PER_LANE, FM>), tgrid, block, 0, st, o, tk);
+      else hipLaunchKernelGGL((lqg::k_trial_sp<R, NX + NB, ND, 1, FM>), tgrid, block, 0, st, o, tk);
+    } else {
+      constexpr auto FM = lqg::trial_operator_mask<PAT, NX, NB, NU, NY, ND, false>();
+      if (wide) hipLaunchKernelGGL((lqg::k_trial_sp<R, NX + NB, ND, LQG_TRIALS_PER_LANE, FM>), tgrid, block, 0, st, o, tk);
+      else hipLaunchKernelGGL((lqg::k_trial_sp<R, NX + NB, ND, 1, FM>), tgrid, block, 0, st, o, tk);
+    }
   }
   mark(3);
   const hipError_t e = hipGetLastError();

@@ -71,7 +71,8 @@ def test_lqg_likelihood():
 
 
 def test_numpyro_distribution():
-    """infer_test.py:29-51: the distribution adapter samples and scores; `infer` (NumPyro NUTS) is the documented gap."""
+    """infer_test.py:29-51: the distribution adapter samples and scores, then a 10 + 10-sample NUTS run over the data
+    (`infer(x, num_samples=10, num_warmup=10, model=BoundedActor)`, the reference's last three lines)."""
     T = 500
     model = BoundedActor(T=T, device="cuda")
     adapter = model.to_numpyro()
@@ -80,5 +81,7 @@ def test_numpyro_distribution():
     assert x.shape == (10, T + 1, 2)
     assert adapter.log_prob(x) is not None and adapter.log_prob(x).shape == (10,)
     assert adapter.sample(2).shape == (T + 1, 2)
-    with pytest.raises(NotImplementedError):
-        lqg.infer.infer(x, num_samples=10, num_warmup=10, model=BoundedActor)
+    mcmc = lqg.infer.infer(x, num_samples=10, num_warmup=10, model=BoundedActor)
+    samples = mcmc.get_samples()
+    assert set(samples) == {"action_variability", "sigma_target", "sigma_cursor", "action_cost"}
+    assert all(v.shape == (10,) and torch.isfinite(v).all() and (v > 0).all() for v in samples.values())
