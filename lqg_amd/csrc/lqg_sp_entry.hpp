@@ -13,10 +13,32 @@
 namespace lqg {
 namespace host {
 
+// Checkpointed gains trade HBM traffic (and, per step, one dependent gain load) for VALU work in the forward kernel: a win
+// for batches (2^20 systems: +5 %; 4096 systems of a small model, config 3: forward sweep 0.55 -> 0.32 ms — the per-step
+// gain load's latency disappears), a loss when ONE wave walks a large model alone (every extra instruction is latency:
+// config 2, m = 8, forward sweep 0.95 -> 1.26 ms).  Below this many systems the gains stream through HBM as in round 1.
+#ifndef LQG_SP_CHUNK_MIN_SYS
+#define LQG_SP_CHUNK_MIN_SYS 1024
+#endif
+
+template <typename R, typename PAT, int NX, int NB, int NU, int NY, int ND, int CK>
+int run_sp_ck(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll_sn, void* workspace, size_t workspace_bytes,
+              hipStream_t st);
+
 template <typename R, typename PAT, int NX, int NB, int NU, int NY, int ND>
 int run_sp(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll_sn, void* workspace, size_t workspace_bytes,
            hipStream_t st) {
   constexpr int CK = lqg::sp_chunk<R, NB, NU>();      // checkpointed gains (lqg_kernels_sp.hpp)
+  if constexpr (CK > 0) {
+    if (p->n_sys >= LQG_SP_CHUNK_MIN_SYS)
+      return run_sp_ck<R, PAT, NX, NB, NU, NY, ND, CK>(p, x, ll, ll_sb, ll_sn, workspace, workspace_bytes, st);
+  }
+  return run_sp_ck<R, PAT, NX, NB, NU, NY, ND, 0>(p, x, ll, ll_sb, ll_sn, workspace, workspace_bytes, st);
+}
+
+template <typename R, typename PAT, int NX, int NB, int NU, int NY, int ND, int CK>
+int run_sp_ck(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll_sn, void* workspace, size_t workspace_bytes,
+              hipStream_t st) {
   static_assert(CK == 0 || CK >= 4, "carve() sizes the checkpoint stream for chunks of at least 4 steps");
   const bool fused = p->n_trials <= 2;
   const Workspace w = carve(p, !fused);
