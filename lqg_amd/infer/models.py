@@ -49,7 +49,7 @@ def split_params(model_type, shared_params=None, **fixed_params):
 
 
 def shared_params_objective(x, model_type, params, shared_params=None, process_noise=1.0, dt=1.0 / 60, dim=1, group=None,
-                            per_condition=False, **fixed_params):
+                            per_condition=False, _log_likelihood=None, **fixed_params):
     """sum_k sum_n log p(x[k, n] | theta_shared, theta_k) — the likelihood part of shared_params_lqg_model's potential.
 
     x[Nc, N, T, d]: conditions x trials x rows x observed dims (this rank's shard of the trial axis when `group` is an
@@ -95,6 +95,8 @@ def shared_params_objective(x, model_type, params, shared_params=None, process_n
     if "dim" in inspect.signature(model_type.__init__).parameters:
         ctor["dim"] = dim
 
+    loglik = _log_likelihood or (lambda model, data: model.log_likelihood(data))   # (CPU tests inject the oracle here)
+
     def trial_sum(ll):                                    # [B, N] -> fp64 [B]
         if ll.requires_grad or not ll.is_cuda:
             return ll.double().sum(-1)
@@ -104,7 +106,7 @@ def shared_params_objective(x, model_type, params, shared_params=None, process_n
         kw = dict(base)
         for name, v in conv.items():
             kw[name] = v.expand(Nc) if name in shared else v
-        table = trial_sum(model_type(**ctor, **kw).log_likelihood(x))                       # [Nc]
+        table = trial_sum(loglik(model_type(**ctor, **kw), x))                              # [Nc]
     else:                                                 # candidates on the system axis, one launch per condition
         cols = []
         for k in range(Nc):
@@ -114,7 +116,7 @@ def shared_params_objective(x, model_type, params, shared_params=None, process_n
                     kw[name] = v if v.dim() == 1 else v.expand(C)
                 else:
                     kw[name] = v[:, k] if v.dim() == 2 else v[k].expand(C)
-            cols.append(trial_sum(model_type(**ctor, **kw).log_likelihood(x[k])))           # [C]
+            cols.append(trial_sum(loglik(model_type(**ctor, **kw), x[k])))                  # [C]
         table = torch.stack(cols, dim=-1)                                                   # [C, Nc]
     table = _all_reduce_autograd(table, group) if table.requires_grad else ld.all_reduce_sum(table, group=group)
     return table if per_condition else table.sum(-1)

@@ -80,6 +80,41 @@ def _worker(rank, world, port, out_dir):
     res = minimize(lambda p: ((mine8 - p["m"]) ** 2).sum() + 0.0 * p["s"], dict(m=torch.zeros((), dtype=torch.float64),
                    s=torch.ones((), dtype=torch.float64)), method="L-BFGS-B", group=dist.group.WORLD)
     assert abs(float(res.x["m"]) - float(data.mean())) < 1e-6 and abs(res.fun - float(((data - data.mean()) ** 2).sum())) < 1e-8
+    # the (Nc, N, T, d) shared-parameter objective (lqg/infer/models.py:67-130) with the TRIAL axis split over the ranks:
+    # every rank scores its shard of each condition's trials (the C oracle injected as the likelihood, CPU models), the
+    # [C, Nc] table of partial sums is all-reduced once and equals the single-process value
+    import lqg_amd
+    from lqg_amd.infer import shared_params_objective
+    rng = np.random.default_rng(3)
+    xc = torch.from_numpy(np.cumsum(rng.standard_normal((2, 5, 41, 2)), axis=2))          # 2 conditions x 5 trials
+
+    def oracle_ll(model, data):
+        from lqg_amd import workload
+        B_ = model.n_systems
+
+        def f(spec):                       # every field with the system axis (the zoo shares what does not depend on a parameter)
+            out = {}
+            for k in lqg_amd.LQGSpec._fields:
+                t = getattr(spec, k)
+                if B_ is not None and t.dim() < workload._batched_ndim(k):
+                    t = t.expand(B_, *t.shape)
+                out[k] = np.ascontiguousarray(t.double().numpy())
+            return out
+        a_, d_ = f(model.actor), f(model.dynamics)
+        dn = data.numpy()
+        if dn.shape[-3] == 0:
+            return torch.zeros(a_["A"].shape[:-3] + (0,), dtype=torch.float64)
+        if a_["A"].ndim == 4 and dn.ndim == 3:
+            dn = np.broadcast_to(dn, (a_["A"].shape[0],) + dn.shape)
+        return torch.from_numpy(np.asarray(OC.log_likelihood(a_, d_, np.ascontiguousarray(dn))))
+
+    pars = dict(sigma_target=torch.tensor([6.0, 12.0], dtype=torch.float64), action_cost=torch.tensor([0.1, 0.5, 2.0], dtype=torch.float64))
+    kw = dict(shared_params=["action_cost", "action_variability", "sigma_cursor"], per_condition=True, _log_likelihood=oracle_ll)
+    lo5, hi5 = ld.shard_bounds(5, rank, world)
+    part = shared_params_objective(xc[:, lo5:hi5], lqg_amd.BoundedActor, pars, group=dist.group.WORLD, **kw)
+    # (with a process group initialised every evaluation is all-reduced over it: all data on both ranks counts twice)
+    whole = shared_params_objective(xc, lqg_amd.BoundedActor, pars, **kw) / world
+    assert part.shape == (3, 2) and torch.allclose(part, whole, rtol=1e-12), (part, whole)
     np.save(os.path.join(out_dir, f"r{rank}.npy"), total.numpy())
     dist.destroy_process_group()
 
