@@ -390,6 +390,35 @@ def config3(torch, dist, args, dev, rank, world):
     }
 
 
+def extra_legs(torch, args, dev):
+    """Secondary legs, outside the headline's timed region (same workload generator, same timing protocol): the other
+    dtype of the headline, and the generic dense joint n=6 kernels (no specialisation, no decoupling) in both dtypes."""
+    extra = {}
+    other = "f64" if args.dtype == "f32" else "f32"
+    torch.cuda.empty_cache()
+    leg = headline_leg(torch, None, args, dev, 0, 1, other, args.log2_batch, min(args.steps, 10), 2)
+    extra[f"headline_{other}"] = {k: leg[k] for k in ("value", "unit", "ms_per_step", "dtype", "parity", "roofline")}
+    extra[f"headline_{other}"]["path"] = leg["config"]["path"]
+    torch.cuda.empty_cache()
+    for dn in ("f32", "f64"):
+        leg = headline_leg(torch, None, args, dev, 0, 1, dn, 17, min(args.steps, 5), 1,
+                           env={"LQG_NO_SPECIALIZE": "1", "LQG_NO_DECOUPLE": "1"})
+        r = leg["roofline"]
+        # dense joint n=6 (m=10) kernel: VALU-bound; executed-instruction figures come from the ISA of
+        # k_forward<R,4,6,2,4,4,TI,FUSED> (profiles/README.md), the algorithmic flop rate from SURVEY 8(d)
+        fl_rate = r["algorithmic_flops_per_solve"] * leg["value"] / 1e12
+        extra[f"dense_generic_{dn}"] = {
+            "value": leg["value"], "unit": leg["unit"], "ms_per_step": leg["ms_per_step"], "dtype": dn,
+            "solves_per_gpu": 1 << 17, "path": leg["config"]["path"], "parity": leg.get("parity"),
+            "env": "LQG_NO_SPECIALIZE=1 LQG_NO_DECOUPLE=1",
+            "roofline": {"bound": "valu", "achieved": fl_rate, "unit": "TFLOP/s (algorithmic, SURVEY 8d)",
+                         "peak": PEAK_FP32_TFLOPS if dn == "f32" else PEAK_FP64_TFLOPS,
+                         "frac": fl_rate / (PEAK_FP32_TFLOPS if dn == "f32" else PEAK_FP64_TFLOPS),
+                         "kernel_ms": r["kernel_ms"], "riccati_kernel_ms": r["riccati_kernel_ms"]}}
+        torch.cuda.empty_cache()
+    return extra
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -420,31 +449,10 @@ def main():
         out = headline_leg(torch, dist, args, dev, rank, world, args.dtype, args.log2_batch, args.steps, args.warmup,
                            cpu=(world == 1 and not args.no_cpu_baseline))
         if world == 1 and not args.no_extra and out is not None:
-            # secondary legs, outside the headline's timed region (same workload generator, same timing protocol)
-            extra = {}
-            other = "f64" if args.dtype == "f32" else "f32"
-            torch.cuda.empty_cache()
-            leg = headline_leg(torch, None, args, dev, 0, 1, other, args.log2_batch, min(args.steps, 10), 2)
-            extra[f"headline_{other}"] = {k: leg[k] for k in ("value", "unit", "ms_per_step", "dtype", "parity", "roofline")}
-            extra[f"headline_{other}"]["path"] = leg["config"]["path"]
-            torch.cuda.empty_cache()
-            for dn in ("f32", "f64"):
-                leg = headline_leg(torch, None, args, dev, 0, 1, dn, 17, min(args.steps, 5), 1,
-                                   env={"LQG_NO_SPECIALIZE": "1", "LQG_NO_DECOUPLE": "1"})
-                r = leg["roofline"]
-                # dense joint n=6 (m=10) kernel: VALU-bound; executed-instruction figures come from the ISA of
-                # k_forward<R,4,6,2,4,4,TI,FUSED> (profiles/README.md), the algorithmic flop rate from SURVEY 8(d)
-                fl_rate = r["algorithmic_flops_per_solve"] * leg["value"] / 1e12
-                extra[f"dense_generic_{dn}"] = {
-                    "value": leg["value"], "unit": leg["unit"], "ms_per_step": leg["ms_per_step"], "dtype": dn,
-                    "solves_per_gpu": 1 << 17, "path": leg["config"]["path"], "parity": leg.get("parity"),
-                    "env": "LQG_NO_SPECIALIZE=1 LQG_NO_DECOUPLE=1",
-                    "roofline": {"bound": "valu", "achieved": fl_rate, "unit": "TFLOP/s (algorithmic, SURVEY 8d)",
-                                 "peak": PEAK_FP32_TFLOPS if dn == "f32" else PEAK_FP64_TFLOPS,
-                                 "frac": fl_rate / (PEAK_FP32_TFLOPS if dn == "f32" else PEAK_FP64_TFLOPS),
-                                 "kernel_ms": r["kernel_ms"], "riccati_kernel_ms": r["riccati_kernel_ms"]}}
-                torch.cuda.empty_cache()
-            out["extra"] = extra
+            try:
+                out["extra"] = extra_legs(torch, args, dev)
+            except Exception as e:          # the secondary legs must never cost the headline line
+                out["extra"] = {"error": repr(e)}
     if rank == 0 and out is not None:
         print(json.dumps(out), flush=True)
     if dist is not None:
