@@ -153,6 +153,21 @@ int lqg_conditional_moments(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_v
 int lqg_log_likelihood(const lqg_problem* p, lqg_traj x, void* ll, int64_t ll_sb, int64_t ll_sn,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* TIME-PARALLEL twins of the two entry points above (lqg_amd/csrc/lqg_scan.hpp): the Riccati recursion of lqr.py:16-42, the
+ * Kalman recursion of kf.py:6-21 and the moment recursion of system.py:209-235 are evaluated as ASSOCIATIVE SCANS over the
+ * time axis — log2(T) dependent combines of (A, C, J) window elements, one wave per window, instead of T dependent steps
+ * — then the same per-trial sweep.  For few systems with many steps (one parameter vector x many trials).  Same
+ * arguments, same results to rounding (fp64 arithmetic inside, whatever the problem dtype).  Preconditions the CALLER
+ * guarantees: the eigenvalue floor of lqr.py:27-28 is inactive (lambda_min(R) >= eps, Q, Qf >= 0 suffice); checked here:
+ * no affine cost terms (q, qf, P, r NULL), u, y, d <= 4, y <= b, x + b <= 24, T >= 2 (lqg_scan_supported).
+ * Workspace: lqg_scan_workspace_bytes(p). */
+int lqg_scan_supported(const lqg_problem* p);
+size_t lqg_scan_workspace_bytes(const lqg_problem* p);
+int lqg_log_likelihood_scan(const lqg_problem* p, lqg_traj x, void* ll, int64_t ll_sb, int64_t ll_sn,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int lqg_conditional_moments_scan(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_view Sigma,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
 /* Structure-specialised twin (NOT in liblqg_hip.so): libraries generated per sparsity pattern by
  * lqg_amd/specialize.py (lqg_amd/csrc/pat/pat_<hash>.so, kernels in csrc/lqg_kernels_sp.hpp) export
  *     int lqg_log_likelihood_sp(<exactly the argument list of lqg_log_likelihood>);

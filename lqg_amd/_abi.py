@@ -87,6 +87,14 @@ def _bind(path):
     lib.lqg_kernel_supported.argtypes, lib.lqg_kernel_supported.restype = [C.c_int32, C.POINTER(Dims)], C.c_int
     lib.lqg_coop_supported.argtypes, lib.lqg_coop_supported.restype = [C.POINTER(Dims)], C.c_int
     lib.lqg_strategy.argtypes, lib.lqg_strategy.restype = [C.POINTER(Problem)], C.c_int
+    if hasattr(lib, "lqg_log_likelihood_scan"):
+        lib.lqg_scan_supported.argtypes, lib.lqg_scan_supported.restype = [C.POINTER(Problem)], C.c_int
+        lib.lqg_scan_workspace_bytes.argtypes, lib.lqg_scan_workspace_bytes.restype = [C.POINTER(Problem)], C.c_size_t
+        lib.lqg_log_likelihood_scan.argtypes = [C.POINTER(Problem), Traj, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                                C.c_size_t, C.c_void_p]
+        lib.lqg_log_likelihood_scan.restype = C.c_int
+        lib.lqg_conditional_moments_scan.argtypes = [C.POINTER(Problem), Traj, Traj, View, C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.lqg_conditional_moments_scan.restype = C.c_int
     lib.lqg_workspace_bytes.argtypes, lib.lqg_workspace_bytes.restype = [C.POINTER(Problem), C.c_int32], C.c_size_t
     lib.lqg_sum_trials.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                    C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]

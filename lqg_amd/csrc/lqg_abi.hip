@@ -300,6 +300,31 @@ int run_coop(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_view Sigma, void
   return done(e, who);
 }
 
+// Time-parallel system sweeps (lqg_scan.hpp), then the per-trial sweep over the operator stream they leave.
+template <typename R>
+int run_scan_path(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_view Sigma, void* ll, long ll_sb, long ll_sn,
+                  void* workspace, size_t workspace_bytes, hipStream_t st, const char* who) {
+  const size_t need = scan_workspace_bytes(p);
+  if (!workspace || workspace_bytes < need)
+    return fail(LQG_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B", who, workspace_bytes, need);
+  auto mark = [&](int i) {
+    if (p->phase_events[i]) (void)hipEventRecord(static_cast<hipEvent_t>(p->phase_events[i]), st);
+  };
+  mark(0);
+  mark(1);                                  // (no separate Riccati phase: the three scans are reported as "forward")
+  void* ops = nullptr;
+  hipError_t e = scan_system_sweeps<R>(p, Sigma, workspace, &ops, st);
+  if (e != hipSuccess) return done(e, who);
+  mark(2);
+  if (p->n_trials > 0 && (ll || mu.ptr)) {
+    bool found;
+    e = dispatch_trial<R>(p, ops, x, mu, ll, ll_sb, ll_sn, st, &found);
+    if (!found) e = coop_trial<R>(p, ops, x, mu, ll, ll_sb, ll_sn, st);
+  }
+  mark(3);
+  return done(e, who);
+}
+
 }  // namespace
 
 extern "C" {
@@ -307,6 +332,38 @@ extern "C" {
 int lqg_abi_version(void) { return LQG_ABI_VERSION; }
 const char* lqg_last_error(void) { return g_err; }
 const char* lqg_target_arch(void) { return "gfx950"; }
+
+int lqg_scan_supported(const lqg_problem* p) { return p && check_problem(p, "lqg_scan_supported") == 0 && scan_supported(p) ? 1 : 0; }
+size_t lqg_scan_workspace_bytes(const lqg_problem* p) { return p ? scan_workspace_bytes(p) : 0; }
+
+int lqg_log_likelihood_scan(const lqg_problem* p, lqg_traj x, void* ll, int64_t ll_sb, int64_t ll_sn, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  static const char* who = "lqg_log_likelihood_scan";
+  if (int rc = check_full(p, who)) return rc;
+  if (!scan_supported(p)) return fail(LQG_ERR_DIMS, "%s: needs u, y, d <= 4, x + b <= 24, no affine cost terms, T >= 2", who);
+  if (p->n_sys == 0 || p->n_trials == 0) return 0;
+  if (!x.ptr) return fail(LQG_ERR_NULL, "%s: x.ptr is NULL", who);
+  if (!ll) return fail(LQG_ERR_NULL, "%s: ll is NULL", who);
+  const lqg_traj no_mu{nullptr, 0, 0, 0, 0};
+  const lqg_view no_sig{nullptr, 0, 0, 0, 0};
+  return p->dtype == LQG_F64 ? run_scan_path<double>(p, x, no_mu, no_sig, ll, ll_sb, ll_sn, workspace, workspace_bytes,
+                                                     (hipStream_t)stream, who)
+                             : run_scan_path<float>(p, x, no_mu, no_sig, ll, ll_sb, ll_sn, workspace, workspace_bytes,
+                                                    (hipStream_t)stream, who);
+}
+
+int lqg_conditional_moments_scan(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_view Sigma, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  static const char* who = "lqg_conditional_moments_scan";
+  if (int rc = check_full(p, who)) return rc;
+  if (!scan_supported(p)) return fail(LQG_ERR_DIMS, "%s: needs u, y, d <= 4, x + b <= 24, no affine cost terms, T >= 2", who);
+  if (!x.ptr) return fail(LQG_ERR_NULL, "%s: x.ptr is NULL", who);
+  if (p->n_sys == 0) return 0;
+  return p->dtype == LQG_F64 ? run_scan_path<double>(p, x, mu, Sigma, nullptr, 0, 0, workspace, workspace_bytes,
+                                                     (hipStream_t)stream, who)
+                             : run_scan_path<float>(p, x, mu, Sigma, nullptr, 0, 0, workspace, workspace_bytes,
+                                                    (hipStream_t)stream, who);
+}
 
 int lqg_coop_supported(const lqg_dims* dims) { return dims && coop_supported(*dims) ? 1 : 0; }
 int lqg_strategy(const lqg_problem* p) { return p && use_coop(p) ? LQG_STRATEGY_COOP : LQG_STRATEGY_LANE; }

@@ -31,5 +31,13 @@ template <typename R>
 hipError_t coop_simulate(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view K, lqg_traj eps, lqg_traj eta, lqg_view x0,
                          lqg_view xhat0, lqg_traj xs, lqg_traj xhat, lqg_traj ys, lqg_traj us, hipStream_t st);
 
+// ---- time-parallel system sweeps (lqg_scan.hpp / lqg_scan_inst.hip)
+// dims and problem class the scan path serves (u, y, d <= 4, x + b <= 24, no affine cost terms); the caller additionally
+// guarantees that the eigenvalue floor of lqr.py:27-28 is inactive
+bool scan_supported(const lqg_problem* p);
+size_t scan_workspace_bytes(const lqg_problem* p);
+template <typename R>
+hipError_t scan_system_sweeps(const lqg_problem* p, lqg_view Sig, void* workspace, void** ops_out, hipStream_t st);
+
 }  // namespace host
 }  // namespace lqg

@@ -1,0 +1,495 @@
+// lqg_scan.hpp — TIME-PARALLEL system sweeps: the three recursions of the path as associative scans.
+//
+// The Riccati recursion (lqr.py:16-42), the Kalman covariance recursion (kf.py:6-21) and the moment recursion
+// (system.py:209-235) are T dependent steps each: with ONE system (one parameter vector x many trials — the inner loop
+// of NUTS / Adam, BASELINE configs 2 and 4) no mapping of a step onto lanes removes that chain (lane-per-system: T x
+// ~1000 scalar instructions; workgroup-per-system, lqg_coop.hpp: T x ~6 LDS stages).  All three are linear-fractional
+// (Riccati-type) maps, and those compose associatively: an element (A, C, J) of n x n matrices stands for a WINDOW of
+// steps, and two adjacent windows combine as (Sarkka & Garcia-Fernandez 2021, Temporal parallelization of Bayesian
+// smoothers / of dynamic programming and LQ control)
+//     M   = I + C1 J2
+//     A   = A2 M^-1 A1
+//     C   = A2 M^-1 C1 A2' + C2
+//     J   = A1' J2 M^-1 A1 + J1
+// so the state after EVERY step follows from a prefix scan: log2(T) dependent combines instead of T dependent steps,
+// and the T windows of a level are independent — one wave each, spread over the whole chip.
+//   Riccati : elements (A_t, B_t R_t^-1 B_t', Q_t), closed by (0, 0, Qf); the SUFFIX products' J are the costs-to-go S_t.
+//   Kalman  : elements ((I - K H) A_t, (I - K H) V V', A_t' H' S^-1 H A_t) with S = H V V' H' + W W', K = V V' H' S^-1,
+//             H = F_t; the first element carries the prior; the PREFIX products' C are the filtered covariances P_t|t.
+//   moments : the same Kalman construction on the joint (state, belief) system F_j[t], G_j[t] G_j[t]' with the first d
+//             components observed exactly (H = [I_d 0], no observation noise); the prefix products' C are the
+//             conditional covariances, from which Sigma_t = F_j C F_j' + G_j G_j'.
+// Everything between the scans is independent per step and runs as one wave per (system, step): gains L_t from S_{t+1},
+// K_t from P_{t-1|t-1}, the joint system, and finally the per-step trial operators (the same stream k_trial reads).
+// Arithmetic is fp64 whatever the problem dtype (there are few systems: the cost is irrelevant, and the fp32 operator
+// stream gets fp64-accurate operators); scripts/scan_prototype.py and tests/test_gpu_scan.py pin it: the scans reproduce
+// the sequential fp64 recursions to 1e-15 .. 1e-11 on every model of the zoo.
+// Preconditions (checked by the caller, lqg_amd/plan.py): no affine cost terms (q, r, P, qf: the likelihood ignores l,
+// but P enters G), eigenvalue floor provably inactive (lqr.py:27-28 is not a linear-fractional map when active), u, y,
+// d <= 4.  Time-varying specs are fine (elements are per step).
+#pragma once
+#include "lqg_coop.hpp"
+
+namespace lqg {
+namespace scan {
+
+using D = double;
+constexpr int kWave = 64;
+
+template <typename F>
+LQG_DEV void each(int n, F f) {
+  for (int e = threadIdx.x; e < n; e += kWave) f(e);
+}
+LQG_DEV void wsync() { __syncthreads(); }   // one wave per workgroup: a fence, no barrier instruction
+
+// C[i*ldc + j] = init(i, j) + sum_k A(i,k) B(k,j),  A(i,k) = a[i*ars + k*acs], B(k,j) = b[k*brs + j*bcs]
+template <typename Init>
+LQG_DEV void mm(D* c, int ldc, int M, int N, int K, const D* a, int ars, int acs, const D* b, int brs, int bcs, Init init) {
+  each(M * N, [&](int e) {
+    const int i = e / N, j = e - i * N;
+    c[i * ldc + j] = coop::dot4<D>(a + i * ars, acs, b + j * bcs, brs, K, init(i, j));
+  });
+}
+LQG_DEV D zero_init(int, int) { return 0.0; }
+
+// symmetric result of a product that is symmetric in exact arithmetic: average of the two mirror entries
+template <typename Init>
+LQG_DEV void mm_sym(D* c, int n, int K, const D* a, int ars, int acs, const D* b, int brs, int bcs, Init init) {
+  each(n * n, [&](int e) {
+    const int i = e / n, j = e - i * n;
+    const D v1 = coop::dot4<D>(a + i * ars, acs, b + j * bcs, brs, K, init(i, j));
+    const D v2 = coop::dot4<D>(a + j * ars, acs, b + i * bcs, brs, K, init(j, i));
+    c[i * n + j] = 0.5 * (v1 + v2);
+  });
+}
+
+// In-place Gauss-Jordan with partial pivoting on the n x w matrix Wm (leading n x n block -> identity, the other columns
+// -> M^-1 [rest]); fac: n doubles of scratch.
+LQG_DEV void gauss_jordan(D* Wm, int n, int w, D* fac) {
+  for (int c = 0; c < n; ++c) {
+    // pivot: row of the largest |W[r][c]|, r >= c (wave reduction)
+    D best = -1.0;
+    int brow = c;
+    for (int r = c + (int)threadIdx.x; r < n; r += kWave) {
+      const D v = fabs(Wm[r * w + c]);
+      if (v > best) { best = v; brow = r; }
+    }
+    LQG_UNROLL for (int off = 32; off >= 1; off >>= 1) {
+      const D ob = __shfl_xor(best, off);
+      const int orow = __shfl_xor(brow, off);
+      if (ob > best || (ob == best && orow < brow)) { best = ob; brow = orow; }
+    }
+    if (brow != c) each(w, [&](int e) { const D t = Wm[c * w + e]; Wm[c * w + e] = Wm[brow * w + e]; Wm[brow * w + e] = t; });
+    wsync();
+    const D pinv = 1.0 / Wm[c * w + c];
+    each(n, [&](int i) { fac[i] = (i == c) ? 0.0 : Wm[i * w + c]; });
+    wsync();
+    each(w, [&](int e) { Wm[c * w + e] *= pinv; });
+    wsync();
+    each(n * w, [&](int e) {
+      const int i = e / w, j = e - i * w;
+      if (i != c) Wm[i * w + j] -= fac[i] * Wm[c * w + j];
+    });
+    wsync();
+  }
+}
+
+// ---------------------------------------------------------------- one level of the scan
+// Elements live in global memory as [system][index][A | C | J] (3 n^2 doubles).  Level d of Hillis-Steele:
+//   prefix (left = 0): out[k] = in[k-d] (x) in[k]      suffix stored in reversed order (left = 1): out[k] = in[k] (x) in[k-d]
+__global__ void __launch_bounds__(kWave) k_scan_level(const D* __restrict__ in, D* __restrict__ out, int n, int len, int d,
+                                                      int left) {
+  extern __shared__ double lqg_coop_smem[];
+  D* sm = lqg_coop_smem;
+  const int k = blockIdx.x;
+  const long sys = blockIdx.y;
+  const int nn = n * n;
+  const long es = 3L * nn;
+  const D* ek = in + (sys * len + k) * es;
+  D* eo = out + (sys * len + k) * es;
+  if (k < d) {
+    each(3 * nn, [&](int e) { eo[e] = ek[e]; });
+    return;
+  }
+  const D* ep = in + (sys * len + k - d) * es;
+  const D* e1 = left ? ek : ep;        // the window that comes FIRST in time
+  const D* e2 = left ? ep : ek;
+  D *A1 = sm, *C1 = A1 + nn, *J1 = C1 + nn, *A2 = J1 + nn, *C2 = A2 + nn, *J2 = C2 + nn, *Wm = J2 + nn, *T1 = Wm + 3 * nn,
+    *fac = T1 + nn;
+  each(3 * nn, [&](int e) { A1[e] = e1[e]; A2[e] = e2[e]; });     // (A, C, J are contiguous in both)
+  wsync();
+  const int w = 3 * n;
+  // Wm = [ I + C1 J2 | A1 | C1 ]
+  each(nn, [&](int e) {
+    const int i = e / n, j = e - i * n;
+    Wm[i * w + j] = coop::dot4<D>(C1 + i * n, 1, J2 + j, n, n, (i == j) ? 1.0 : 0.0);
+    Wm[i * w + n + j] = A1[e];
+    Wm[i * w + 2 * n + j] = C1[e];
+  });
+  wsync();
+  gauss_jordan(Wm, n, w, fac);                                      // -> [ I | X1 = M^-1 A1 | X2 = M^-1 C1 ]
+  // A = A2 X1 ; T1 = A2 X2
+  mm(eo, n, n, n, n, A2, n, 1, Wm + n, w, 1, zero_init);
+  mm(T1, n, n, n, n, A2, n, 1, Wm + 2 * n, w, 1, zero_init);
+  // U = J2 X1 (into the first block of Wm, free now)
+  wsync();
+  mm(Wm, w, n, n, n, J2, n, 1, Wm + n, w, 1, zero_init);
+  wsync();
+  // C = T1 A2' + C2 (symmetrised) ; J = A1' U + J1 (symmetrised)
+  mm_sym(eo + nn, n, n, T1, n, 1, A2, 1, n, [&](int i, int j) { return C2[i * n + j]; });
+  mm_sym(eo + 2 * nn, n, n, A1, 1, n, Wm, w, 1, [&](int i, int j) { return J1[i * n + j]; });
+}
+
+// ---------------------------------------------------------------- per-step kernels
+template <typename R>
+struct Args {
+  DView<R> aQ, aQf, aR, aA, aB, aF, aV, aW;
+  DView<R> dA, dB, dF, dV, dW;
+  DView<R> Sigma0;
+  DView<R> Sig;            // optional output Sigma[B,T,m,m]
+  D* elems;                // scan input buffer [n_sys][len][3 n^2]
+  const D* res;            // scan result buffer
+  D* Lbuf;                 // [n_sys][T][u*b]
+  D* Kbuf;                 // [n_sys][T][b*y]
+  D* FG;                   // [n_sys][T][2 m^2]   Fj | GG
+  R* ops;                  // [n_sys][T+1][nops]  (problem dtype)
+  long n_sys;
+  int T, x, b, u, y, d, nva, nwa, nvd, nwd, nops;
+  D eps;
+};
+
+template <typename R>
+LQG_DEV void ld(const DView<R>& v, long s, int t, int rows, int cols, D* dst) {
+  const R* p = v.p + s * v.sb + (long)t * v.st;
+  each(rows * cols, [&](int e) { const int i = e / cols, j = e - i * cols; dst[e] = (D)p[i * v.sr + j * v.sc]; });
+}
+template <typename R>
+LQG_DEV void ld_sym(const DView<R>& v, long s, int t, int n, D* dst) {
+  const R* p = v.p + s * v.sb + (long)t * v.st;
+  each(n * n, [&](int e) {
+    const int i = e / n, j = e - i * n;
+    dst[e] = (i == j) ? (D)p[i * v.sr + i * v.sc] : 0.5 * ((D)p[i * v.sr + j * v.sc] + (D)p[j * v.sr + i * v.sc]);
+  });
+}
+template <typename R>
+LQG_DEV void ld_gram(const DView<R>& v, long s, int t, int n, int nv, D* dst) {
+  const R* p = v.p + s * v.sb + (long)t * v.st;
+  each(n * n, [&](int e) {
+    const int i = e / n, j = e - i * n;
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    D acc = 0.0;
+    for (int k = 0; k < nv; ++k) acc += (D)p[lo * v.sr + k * v.sc] * (D)p[hi * v.sr + k * v.sc];
+    dst[e] = acc;
+  });
+}
+// inverse of a small SPD matrix (n <= 4) held in LDS -> LDS (lane 0 writes; every lane computes)
+LQG_DEV void small_inverse(const D* src, int n, D* dst, D eps, bool floor_) {
+  coop::dispatch_small<0>(n, [&](auto nc) {
+    constexpr int N = decltype(nc)::value;
+    D Hi[N * N], Ht[N * N];
+    coop::spd_inverse_reg<D, N>(src, eps, floor_, Hi, Ht);
+    if (threadIdx.x == 0) {
+      LQG_UNROLL for (int e = 0; e < N * N; ++e) dst[e] = Hi[e];
+    }
+  });
+  wsync();
+}
+
+// Riccati elements, reversed index j: j = 0 terminal (0, 0, Qf); j >= 1 <-> step t = T - j: (A_t, B R^-1 B', Q_t)
+template <typename R>
+__global__ void __launch_bounds__(kWave) k_scan_build_riccati(const Args<R> a) {
+  extern __shared__ double lqg_coop_smem[];
+  D* sm = lqg_coop_smem;
+  const int j = blockIdx.x, b = a.b, u = a.u, nn = b * b;
+  const long s = blockIdx.y;
+  D* e = a.elems + (s * (a.T + 1) + j) * 3L * nn;
+  if (j == 0) {
+    each(2 * nn, [&](int i) { e[i] = 0.0; });
+    ld_sym(a.aQf, s, 0, b, e + 2 * nn);
+    return;
+  }
+  const int t = a.T - j;
+  D *Bm = sm, *Rm = Bm + b * u, *Ri = Rm + u * u, *BR = Ri + u * u;
+  ld(a.aB, s, t, b, u, Bm);
+  ld_sym(a.aR, s, t, u, Rm);
+  ld(a.aA, s, t, b, b, e);
+  ld_sym(a.aQ, s, t, b, e + 2 * nn);
+  wsync();
+  small_inverse(Rm, u, Ri, 0.0, false);
+  mm(BR, u, b, u, u, Bm, u, 1, Ri, u, 1, zero_init);                 // B R^-1
+  wsync();
+  mm_sym(e + nn, b, u, BR, u, 1, Bm, 1, u, zero_init);               // (B R^-1) B'
+}
+
+// L_t = -Ht^-1 G from S_{t+1} (J of the suffix product at reversed index T - 1 - t)          lqr.py:22-31
+template <typename R>
+__global__ void __launch_bounds__(kWave) k_scan_gains(const Args<R> a) {
+  extern __shared__ double lqg_coop_smem[];
+  D* sm = lqg_coop_smem;
+  const int t = blockIdx.x, b = a.b, u = a.u, nn = b * b;
+  const long s = blockIdx.y;
+  const D* S = a.res + (s * (a.T + 1) + (a.T - 1 - t)) * 3L * nn + 2 * nn;
+  D *A = sm, *Bm = A + nn, *Rm = Bm + b * u, *SA = Rm + u * u, *SB = SA + nn, *H = SB + b * u, *G = H + u * u, *Hi = G + u * b;
+  ld(a.aA, s, t, b, b, A);
+  ld(a.aB, s, t, b, u, Bm);
+  ld_sym(a.aR, s, t, u, Rm);
+  wsync();
+  mm(SA, b, b, b, b, S, b, 1, A, b, 1, zero_init);
+  mm(SB, u, b, u, b, S, b, 1, Bm, u, 1, zero_init);
+  wsync();
+  mm_sym(H, u, b, Bm, 1, u, SB, u, 1, [&](int i, int j) { return Rm[i * u + j]; });     // H = R + B'SB
+  mm(G, b, u, b, b, Bm, 1, u, SA, b, 1, zero_init);                                      // G = B'SA
+  wsync();
+  small_inverse(H, u, Hi, a.eps, true);                                                  // (H + floor)^-1
+  D* L = a.Lbuf + (s * a.T + t) * (long)(u * b);
+  mm(L, b, u, b, u, Hi, u, 1, G, b, 1, zero_init);
+  wsync();
+  each(u * b, [&](int e) { L[e] = -L[e]; });
+}
+
+// Kalman elements, index t = 0 .. T-1 (the filtered covariance after step t)                  kf.py:10-14
+template <typename R>
+__global__ void __launch_bounds__(kWave) k_scan_build_kalman(const Args<R> a) {
+  extern __shared__ double lqg_coop_smem[];
+  D* sm = lqg_coop_smem;
+  const int t = blockIdx.x, b = a.b, y = a.y, nn = b * b;
+  const long s = blockIdx.y;
+  D* e = a.elems + (s * a.T + t) * 3L * nn;
+  D *A = sm, *F = A + nn, *VV = F + y * b, *WW = VV + nn, *Pp = WW + y * y, *FP = Pp + nn, *Sm = FP + y * b, *Si = Sm + y * y,
+    *K = Si + y * y, *T1 = K + b * y, *IKF = T1 + nn;
+  ld(a.aA, s, t, b, b, A);
+  ld(a.aF, s, t, y, b, F);
+  ld_gram(a.aV, s, t, b, a.nva, VV);
+  ld_gram(a.aW, s, t, y, a.nwa, WW);
+  if (t == 0) {                                   // prior P0 -> predicted Pp = A P0 A' + V V'
+    if (a.Sigma0.p) ld_sym(a.Sigma0, s, 0, b, T1);
+    else ld_gram(a.aV, s, 0, b, a.nva, T1);
+    wsync();
+    mm(IKF, b, b, b, b, A, b, 1, T1, b, 1, zero_init);
+    wsync();
+    mm_sym(Pp, b, b, IKF, b, 1, A, 1, b, [&](int i, int j) { return VV[i * b + j]; });
+  } else {
+    wsync();
+    each(nn, [&](int i) { Pp[i] = VV[i]; });      // one step from a point: "prior" covariance = process noise
+  }
+  wsync();
+  mm(FP, b, y, b, b, F, b, 1, Pp, b, 1, zero_init);                                       // F Pp
+  wsync();
+  mm_sym(Sm, y, b, FP, b, 1, F, 1, b, [&](int i, int j) { return WW[i * y + j]; });       // S = F Pp F' + W W'
+  wsync();
+  small_inverse(Sm, y, Si, 0.0, false);
+  mm(K, y, b, y, y, FP, 1, b, Si, y, 1, zero_init);                                        // K = (F Pp)' S^-1
+  wsync();
+  each(nn, [&](int i2) {                                                                   // I - K F
+    const int i = i2 / b, j = i2 - i * b;
+    IKF[i2] = coop::dot4<D>(K + i * y, 1, F + j, b, y, 0.0);
+    IKF[i2] = ((i == j) ? 1.0 : 0.0) - IKF[i2];
+  });
+  wsync();
+  mm_sym(e + nn, b, b, IKF, b, 1, Pp, b, 1, zero_init);                                    // C = (I - K F) Pp
+  if (t == 0) {
+    each(nn, [&](int i) { e[i] = 0.0; e[2 * nn + i] = 0.0; });
+  } else {
+    mm(e, b, b, b, b, IKF, b, 1, A, b, 1, zero_init);                                      // A = (I - K F) A_t
+    mm(T1, b, y, b, y, Si, y, 1, F, b, 1, zero_init);                                      // S^-1 F            [y, b]
+    mm(FP, b, y, b, b, F, b, 1, A, b, 1, zero_init);                                       // F A_t             [y, b] (FP reused)
+    wsync();
+    mm(Pp, b, y, b, b, T1, b, 1, A, b, 1, zero_init);                                      // S^-1 F A_t        [y, b] (Pp reused)
+    wsync();
+    mm_sym(e + 2 * nn, b, y, FP, 1, b, Pp, b, 1, zero_init);                               // J = (F A)' S^-1 (F A)
+  }
+}
+
+// K_t from the filtered covariance of the previous step                                      kf.py:10-12
+template <typename R>
+__global__ void __launch_bounds__(kWave) k_scan_kgain(const Args<R> a) {
+  extern __shared__ double lqg_coop_smem[];
+  D* sm = lqg_coop_smem;
+  const int t = blockIdx.x, b = a.b, y = a.y, nn = b * b;
+  const long s = blockIdx.y;
+  D *A = sm, *F = A + nn, *VV = F + y * b, *WW = VV + nn, *P0 = WW + y * y, *AP = P0 + nn, *Pp = AP + nn, *FP = Pp + nn,
+    *Sm = FP + y * b, *Si = Sm + y * y;
+  ld(a.aA, s, t, b, b, A);
+  ld(a.aF, s, t, y, b, F);
+  ld_gram(a.aV, s, t, b, a.nva, VV);
+  ld_gram(a.aW, s, t, y, a.nwa, WW);
+  if (t == 0) {
+    if (a.Sigma0.p) ld_sym(a.Sigma0, s, 0, b, P0);
+    else ld_gram(a.aV, s, 0, b, a.nva, P0);
+  } else {
+    const D* C = a.res + (s * a.T + t - 1) * 3L * nn + nn;
+    each(nn, [&](int i) { P0[i] = C[i]; });
+  }
+  wsync();
+  mm(AP, b, b, b, b, A, b, 1, P0, b, 1, zero_init);
+  wsync();
+  mm_sym(Pp, b, b, AP, b, 1, A, 1, b, [&](int i, int j) { return VV[i * b + j]; });
+  wsync();
+  mm(FP, b, y, b, b, F, b, 1, Pp, b, 1, zero_init);
+  wsync();
+  mm_sym(Sm, y, b, FP, b, 1, F, 1, b, [&](int i, int j) { return WW[i * y + j]; });
+  wsync();
+  small_inverse(Sm, y, Si, 0.0, false);
+  D* K = a.Kbuf + (s * a.T + t) * (long)(b * y);
+  mm(K, y, b, y, y, FP, 1, b, Si, y, 1, zero_init);
+}
+
+// joint system of step t into LDS: Fj[m,m], GG[m,m]                                          system.py:167-207
+template <typename R>
+LQG_DEV void joint_step(const Args<R>& a, long s, int t, D* sm, D* Fj, D* GG) {
+  const int x = a.x, b = a.b, u = a.u, y = a.y, m = x + b;
+  const D* L = a.Lbuf + (s * a.T + t) * (long)(u * b);
+  const D* K = a.Kbuf + (s * a.T + t) * (long)(b * y);
+  D *Aa = sm, *Ba = Aa + b * b, *Fa = Ba + b * u, *Ad = Fa + y * b, *Bd = Ad + x * x, *Fd = Bd + x * u, *N1 = Fd + y * x,
+    *WWd = N1 + x * x, *FAa = WWd + y * y, *FAd = FAa + y * b, *DB = FAd + y * x, *N2 = DB + y * u, *N3 = N2 + y * x,
+    *BK = N3 + y * y, *KN2 = BK + b * u, *KN3 = KN2 + b * x;
+  ld(a.aA, s, t, b, b, Aa);
+  ld(a.aB, s, t, b, u, Ba);
+  ld(a.aF, s, t, y, b, Fa);
+  ld(a.dA, s, t, x, x, Ad);
+  ld(a.dB, s, t, x, u, Bd);
+  ld(a.dF, s, t, y, x, Fd);
+  ld_gram(a.dV, s, t, x, a.nvd, N1);
+  ld_gram(a.dW, s, t, y, a.nwd, WWd);
+  wsync();
+  mm(FAa, b, y, b, b, Fa, b, 1, Aa, b, 1, zero_init);
+  mm(FAd, x, y, x, x, Fd, x, 1, Ad, x, 1, zero_init);
+  mm(N2, x, y, x, x, Fd, x, 1, N1, x, 1, zero_init);
+  each(y * u, [&](int e) {
+    const int i = e / u, j = e - i * u;
+    DB[e] = coop::dot4<D>(Fd + i * x, 1, Bd + j, u, x, 0.0) - coop::dot4<D>(Fa + i * b, 1, Ba + j, u, b, 0.0);
+  });
+  wsync();
+  mm_sym(N3, y, x, N2, x, 1, Fd, 1, x, [&](int i, int j) { return WWd[i * y + j]; });
+  mm(BK, u, b, u, y, K, y, 1, DB, u, 1, [&](int i, int j) { return Ba[i * u + j]; });
+  mm(KN2, x, b, x, y, K, y, 1, N2, x, 1, zero_init);
+  wsync();
+  mm(KN3, y, b, y, y, K, y, 1, N3, y, 1, zero_init);
+  wsync();
+  each(m * m, [&](int e) {
+    const int i = e / m, j = e - i * m;
+    D f;
+    if (i < x) {
+      f = (j < x) ? Ad[i * x + j] : coop::dot4<D>(Bd + i * u, 1, L + (j - x), b, u, 0.0);
+    } else {
+      const int ib = i - x;
+      if (j < x) {
+        f = coop::dot4<D>(K + ib * y, 1, FAd + j, x, y, 0.0);
+      } else {
+        const int jb = j - x;
+        D acc = Aa[ib * b + jb] - coop::dot4<D>(K + ib * y, 1, FAa + jb, b, y, 0.0);
+        f = coop::dot4<D>(BK + ib * u, 1, L + jb, b, u, acc);
+      }
+    }
+    Fj[e] = f;
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    D g;
+    if (hi < x) g = N1[lo * x + hi];
+    else if (lo < x) g = KN2[(hi - x) * x + lo];
+    else g = 0.5 * (coop::dot4<D>(KN3 + (lo - x) * y, 1, K + (hi - x) * y, 1, y, 0.0) +
+                    coop::dot4<D>(KN3 + (hi - x) * y, 1, K + (lo - x) * y, 1, y, 0.0));
+    GG[e] = g;
+  });
+  wsync();
+}
+inline __host__ __device__ long joint_scratch(int x, int b, int u, int y) {
+  return (long)b * b + 2L * b * u + 2L * y * b + 2L * x * x + x * u + 3L * y * x + 3L * y * y + y * u + b * x + b * y;
+}
+
+// moment-recursion elements (index k = 0 .. T-1: the conditional covariance after conditioning on x_k); block k also
+// stores the joint system of step k-1.  Grid: T + 1 blocks (block T only stores the joint system of step T-1).
+template <typename R>
+__global__ void __launch_bounds__(kWave) k_scan_build_sigma(const Args<R> a) {
+  extern __shared__ double lqg_coop_smem[];
+  D* sm = lqg_coop_smem;
+  const int k = blockIdx.x, m = a.x + a.b, o = a.d, mm2 = m * m;
+  const long s = blockIdx.y;
+  D *Fj = sm, *GG = Fj + mm2, *Qi = GG + mm2, *Kk = Qi + o * o, *IKH = Kk + m * o, *scratch = IKH + mm2;
+  const int st = (k == 0) ? 0 : k - 1;
+  joint_step(a, s, st, scratch, Fj, GG);
+  if (k >= 1) {
+    D* fg = a.FG + (s * a.T + st) * 2L * mm2;
+    each(mm2, [&](int e) { fg[e] = Fj[e]; fg[mm2 + e] = GG[e]; });
+  }
+  if (k >= a.T) return;
+  D* e = a.elems + (s * a.T + k) * 3L * mm2;
+  // Q_oo^-1, K = Q[:, :o] Q_oo^-1, I - K H (H = [I_o 0])
+  each(o * o, [&](int i2) { const int i = i2 / o, j = i2 - i * o; IKH[i2] = GG[i * m + j]; });   // (IKH as temp for Q_oo)
+  wsync();
+  small_inverse(IKH, o, Qi, 0.0, false);
+  mm(Kk, o, m, o, o, GG, m, 1, Qi, o, 1, zero_init);
+  wsync();
+  each(mm2, [&](int i2) {
+    const int i = i2 / m, j = i2 - i * m;
+    IKH[i2] = ((i == j) ? 1.0 : 0.0) - ((j < o) ? Kk[i * o + j] : 0.0);
+  });
+  wsync();
+  mm_sym(e + mm2, m, m, IKH, m, 1, GG, m, 1, zero_init);            // C = (I - K H) Q   (k = 0: Q = Sigma_0 = GG_0)
+  if (k == 0) {
+    each(mm2, [&](int i) { e[i] = 0.0; e[2 * mm2 + i] = 0.0; });
+  } else {
+    mm(e, m, m, m, m, IKH, m, 1, Fj, m, 1, zero_init);              // A = (I - K H) F
+    // J = F[:o, :]' Q_oo^-1 F[:o, :]
+    D* T1 = Kk;                                                      // [o, m] temp (Kk is dead after IKH)
+    wsync();
+    mm(T1, m, o, m, o, Qi, o, 1, Fj, m, 1, zero_init);
+    wsync();
+    mm_sym(e + 2 * mm2, m, o, Fj, 1, m, T1, m, 1, zero_init);
+  }
+}
+
+// trial operators of step t (t = 0 .. T) from the predictive covariance Sigma_t                system.py:219-230, 244-248
+template <typename R>
+__global__ void __launch_bounds__(kWave) k_scan_ops(const Args<R> a) {
+  extern __shared__ double lqg_coop_smem[];
+  D* sm = lqg_coop_smem;
+  const int t = blockIdx.x, m = a.x + a.b, o = a.d, rr = m - o, mm2 = m * m;
+  const long s = blockIdx.y;
+  D *Sg = sm, *T1 = Sg + mm2, *Lis = T1 + mm2, *hls = Lis + o * o;
+  if (t == 0) {
+    const D* fg = a.FG + (s * a.T) * 2L * mm2;
+    each(mm2, [&](int e) { Sg[e] = fg[mm2 + e]; });                  // Sigma_0 = G_0 G_0'   system.py:212
+  } else {
+    const D* fg = a.FG + (s * a.T + t - 1) * 2L * mm2;
+    const D* C = a.res + (s * a.T + t - 1) * 3L * mm2 + mm2;
+    mm(T1, m, m, m, m, fg, m, 1, C, m, 1, zero_init);               // F C
+    wsync();
+    mm_sym(Sg, m, m, T1, m, 1, fg, 1, m, [&](int i, int j) { return fg[mm2 + i * m + j]; });   // F C F' + GG
+    if (a.Sig.p) {
+      wsync();
+      R* out = const_cast<R*>(a.Sig.p) + s * a.Sig.sb + (long)(t - 1) * a.Sig.st;
+      each(mm2, [&](int e) { const int i = e / m, j = e - i * m; out[i * a.Sig.sr + j * a.Sig.sc] = (R)Sg[e]; });
+    }
+  }
+  wsync();
+  const D kLogNorm = 0.5 * 1.8378770664093453 * (D)o;
+  R* op = a.ops + (s * (a.T + 1) + t) * (long)a.nops;
+  coop::dispatch_small<0>(o, [&](auto no_) {
+    constexpr int NO = decltype(no_)::value;
+    D Li[NO * NO], hl;
+    coop::chol_inverse_reg<D, NO>(Sg, m, Li, hl);
+    if (threadIdx.x == 0) {
+      LQG_UNROLL for (int e = 0; e < NO * NO; ++e) Lis[e] = Li[e];
+      int e = 0;
+      LQG_UNROLL for (int i = 0; i < NO; ++i)
+        LQG_UNROLL for (int j = 0; j <= i; ++j) op[m * m + rr * o + (e++)] = (R)Li[i * NO + j];
+      op[m * m + rr * o + e] = (R)(hl + kLogNorm);
+      hls[0] = hl;
+    }
+  });
+  wsync();
+  if (t < a.T) {
+    each(rr * o, [&](int e) {                                        // U2 = S_ro Li'
+      const int p = e / o, j = e - p * o;
+      op[m * m + e] = (R)coop::dot4<D>(Sg + (o + p) * m, 1, Lis + j * o, 1, j + 1, 0.0);
+    });
+    const D* fg = a.FG + (s * a.T + t) * 2L * mm2;
+    each(mm2, [&](int e) {
+      const int i = e / m, j = e - i * m;
+      op[e] = (R)((i < o && i == j) ? fg[e] - 1.0 : fg[e]);
+    });
+  }
+}
+
+}  // namespace scan
+}  // namespace lqg

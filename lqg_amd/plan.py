@@ -19,6 +19,41 @@ OPS_WORKSPACE_LIMIT = 16 << 30
 # latency-bound 500-step kernel, disappears): one parameter vector (or the 2P+1 finite-difference candidates) x tens of
 # trials, the inner loop of lqg/infer/mle.py:17-23 and of NUTS.  LQG_FUSE_TRIALS_MAX=0 disables.
 FUSE_TRIALS_MAX = int(os.environ.get("LQG_FUSE_TRIALS_MAX", "2048"))
+# TIME-PARALLEL system sweeps (csrc/lqg_scan.hpp: Riccati, Kalman and moment recursions as associative scans, log2(T)
+# dependent combines instead of T dependent steps): chosen for at most this many systems per call with at least this
+# many steps — where the sequential sweeps are one lone wave walking the recursion.  LQG_SCAN=0 never, LQG_SCAN=1 wherever
+# the path is defined (no affine terms, floor provably inactive, u, y, d <= 4).
+SCAN_MAX_SYSTEMS = int(os.environ.get("LQG_SCAN_MAX_SYSTEMS", "8"))
+SCAN_MIN_STEPS = int(os.environ.get("LQG_SCAN_MIN_STEPS", "96"))
+# The scan elements hold (F' Sigma_oo^-1 F)-type terms, so an ill-conditioned observed block costs the scans more digits
+# than the sequential recursion: scripts/scan_cond.py, point mass with all four states observed, scan against sequential
+# fp64 — cond((V V')[:d, :d]) <= 5.6e6: 1e-11; 5.6e8 (golden pointmass_d4_T50): 2e-6.  Above this condition number of the
+# observed process-noise block the default rule keeps the sequential sweeps.
+SCAN_MAX_COND = float(os.environ.get("LQG_SCAN_MAX_COND", "1e7"))
+
+
+def _observed_noise_cond(sub, d):
+    """Largest condition number of (V V')[:d, :d] of the dynamics over systems and steps (one tiny host sync; the plan is
+    built once per dataset)."""
+    V = sub.dynamics.V.detach().double()
+    ev = torch.linalg.eigvalsh((V @ V.transpose(-1, -2))[..., :d, :d])
+    lo, hi = ev[..., 0].clamp_min(0.0), ev[..., -1]
+    return float((hi / lo.clamp_min(1e-300)).max())
+
+
+def scan_eligible(lib, ln, sub, eps):
+    """True when the time-parallel sweeps may serve this launch (include/lqg_hip.h: lqg_log_likelihood_scan)."""
+    mode = os.environ.get("LQG_SCAN", "")
+    if mode == "0" or not hasattr(lib, "lqg_log_likelihood_scan"):
+        return False
+    if mode != "1" and not (ln.B <= SCAN_MAX_SYSTEMS and ln.T >= SCAN_MIN_STEPS):
+        return False
+    if not lib.lqg_scan_supported(C.byref(ln.p)):
+        return False
+    from lqg_amd import decouple
+    if not decouple.floor_provably_inactive(sub, eps):
+        return False
+    return mode == "1" or _observed_noise_cond(sub, ln.dims["d"]) <= SCAN_MAX_COND
 
 
 class LogLikelihoodPlan:
@@ -61,7 +96,9 @@ class LogLikelihoodPlan:
             n = xs.shape[-3]
             n_sys0 = sub.n_systems or 1
             sub0 = sub                           # (keeps the zoo class: its sparsity pattern is cached per class)
-            fuse_pairs = 2 < n and n_sys0 * n <= FUSE_TRIALS_MAX and _time_invariant(sub)
+            use_scan = scan_eligible(_abi.load(), _hip.Launch(sub.actor, sub.dynamics, d=len(cols), n_trials=n, Sigma0=S0,
+                                                               eps=eps), sub, eps) if sub.actor.A.is_cuda else False
+            fuse_pairs = (not use_scan) and 2 < n and n_sys0 * n <= FUSE_TRIALS_MAX and _time_invariant(sub)
             if fuse_pairs:                       # (system, trial) pairs as n_sys0 * n one-trial systems
                 sub, xs, S0 = _pairs_as_systems(sub, xs, S0, n_sys0, n)
                 n_pairs, n = n, 1
@@ -69,12 +106,16 @@ class LogLikelihoodPlan:
             lib = ln.require_gpu()               # liblqg_hip.so, or the auxiliary library of an unlisted shape
             xb, is_b = _hip._prep_x(ln, xs)
             nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
-            sp = _hip.specialised_entry(ln, sub0, len(cols))
+            sp = None if use_scan else _hip.specialised_entry(ln, sub0, len(cols))
+            if use_scan:
+                use_scan = lib is _abi.load()            # (an auxiliary lane-kernel library has no scan entry)
+            if use_scan:
+                nbytes = lib.lqg_scan_workspace_bytes(C.byref(ln.p))
             if sp is not None and n == 2:        # the specialised library sweeps two trials in-lane: no operator stream
                 ln.p.n_trials = 1
                 nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
                 ln.p.n_trials = 2
-            loop_trials = n > 1 and nbytes > OPS_WORKSPACE_LIMIT
+            loop_trials = (not use_scan) and n > 1 and nbytes > OPS_WORKSPACE_LIMIT
             if loop_trials:                      # one fused sweep per trial: the problem describes ONE trial
                 ln.p.n_trials = 1
                 nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
@@ -90,7 +131,8 @@ class LogLikelihoodPlan:
                 n, ll_sb = n_pairs, 1
             self.work.append(dict(ln=ln, x=xb, traj=ln.traj(xb, is_b), ll=ll_buf, ll_sb=ll_sb, nbytes=nbytes, ev=ev,
                                   ws=torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=ln.device),
-                                  entry=sp or lib.lqg_log_likelihood, generic=lib.lqg_log_likelihood,
+                                  entry=(lib.lqg_log_likelihood_scan if use_scan else (sp or lib.lqg_log_likelihood)),
+                                  generic=lib.lqg_log_likelihood, scan=use_scan,
                                   specialised=sp is not None, n=n, fused_pairs=fuse_pairs,
                                   pattern_key=(specialize.system_pattern(sub0, len(cols))[2] if sp is not None else None),
                                   loop_trials=loop_trials, is_b=is_b, group=(self.merged[ip] if self.merged else 1),
@@ -121,6 +163,13 @@ class LogLikelihoodPlan:
         w = self.work
         in_lane = w[0]["n"] == 1 or (w[0]["n"] == 2 and w[0]["specialised"])
         tail = ")" if in_lane else " + k_trial)"
+        if all(k.get("scan") for k in w):
+            kind = "time-parallel scans (Riccati, Kalman, moment recursion: k_scan_level x log2 T) + k_trial"
+            if len(w) > 1:
+                kind += f", {len(w)} decoupled components of dims (x,b,u,y,d)={w[0]['dims']}"
+            if self.merged and max(self.merged) > 1:
+                kind += f"; {max(self.merged)} identical components as trials of one system"
+            return kind
         kind = ("structure-specialised (k_riccati_sp + k_forward_sp" if all(k["specialised"] for k in w) else
                 "generic dense (k_riccati + k_forward") + tail
         if len(w) > 1:

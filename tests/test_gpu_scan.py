@@ -1,0 +1,102 @@
+"""-m gpu: the TIME-PARALLEL system sweeps (lqg_amd/csrc/lqg_scan.hpp: Riccati, Kalman and moment recursions as associative
+scans over the time axis) against the golden vectors of the reference's own source and against the sequential kernels.
+
+LQG_SCAN=1 selects the scan path wherever it is defined (no affine cost terms, eigenvalue floor provably inactive,
+u, y, d <= 4); by default it serves few systems with many steps.  The scans run in fp64 whatever the problem dtype, so the
+fp32 tolerances are those of the fp32 per-trial sweep alone."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names, load_golden, relerr
+from gpu_common import np_, system_from_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float64: dict(ll=1e-10, mat=1e-9), torch.float32: dict(ll=1e-6, mat=2e-5)}
+AFFINE = {"timevarying_T30"}                    # q, r, P, qf non-zero: not a scan case (falls back to the sequential kernels)
+BIG = {"delay12_subjective1d_T30"}              # x + b = 65 > 24
+ILL = {"pointmass_d4_T50"}
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("name", [n for n in golden_names() if n not in AFFINE | BIG])
+def test_scan_sweeps_match_golden(name, dtype, monkeypatch):
+    from lqg_amd import _hip
+    from lqg_amd.plan import LogLikelihoodPlan
+    monkeypatch.setenv("LQG_SCAN", "1")
+    monkeypatch.setenv("LQG_NO_DECOUPLE", "1")           # the joint problem, as the reference solves it
+    g, actor, dyn = load_golden(name)
+    tol = dict(TOL[dtype])
+    if name in ILL:
+        if dtype == torch.float32:
+            pytest.skip("fp32 per-trial sweep cannot carry cond(Sigma_oo) ~ 1e12 (see test_gpu_parity)")
+        tol = dict(ll=5e-6, mat=1e-6)      # cond 5.6e8 of the observed noise block costs the scans ~4 digits more than the sequential
+                                            # recursion; the default rule keeps such systems off the scan (plan.SCAN_MAX_COND)
+    sys_ = system_from_golden(actor, dyn, dtype)
+    S0 = torch.as_tensor(g["Sigma0"], dtype=dtype, device="cuda") if "Sigma0" in g else None
+    x = torch.as_tensor(g["x"], dtype=dtype, device="cuda")
+    plan = LogLikelihoodPlan(sys_, x, Sigma0=S0)
+    assert all(wk["scan"] for wk in plan.work), plan.description
+    ll = plan.run().clone()
+    assert np.abs(np_(ll) / g["ll"] - 1).max() < tol["ll"]
+    ll1 = LogLikelihoodPlan(sys_, x[:1], Sigma0=S0).run().clone()
+    assert np.abs(np_(ll1) / g["ll"][:1] - 1).max() < tol["ll"]
+    mu, Sig = _hip.conditional_moments(sys_.actor, sys_.dynamics, x, Sigma0=S0)
+    assert relerr(np_(mu), g["mu"]) < tol["mat"] and relerr(np_(Sig), g["Sigma"][0]) < tol["mat"]
+
+
+@pytest.mark.parametrize("model", ["pointmass", "hand2d", "bounded_candidates", "subjective2d"])
+def test_scan_and_sequential_sweeps_agree_at_full_horizon(model, monkeypatch):
+    """T = 500 / 1000, the shapes of BASELINE configs 2 and 4 and a handful of candidates: scan vs sequential, fp64 1e-10;
+    for an fp32 problem the scan path (fp64 operators) is at least as close to fp64 as the sequential fp32 sweeps."""
+    import lqg_amd
+    from lqg_amd.plan import LogLikelihoodPlan
+    dev = torch.device("cuda")
+    if model == "pointmass":
+        m = lqg_amd.PointMassBoundedActor(T=500, action_variability=0.5, device=dev, dtype=torch.float64)
+        d, n = 2, 512
+    elif model == "hand2d":
+        import os, sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench_configs import hand2d_system
+        m = hand2d_system(1000, dev, torch.float64)
+        d, n = 4, 256
+    elif model == "bounded_candidates":
+        sig = torch.tensor([4.0, 9.0, 15.0, 30.0], dtype=torch.float64, device=dev)
+        m = lqg_amd.BoundedActor(T=700, sigma_target=sig, action_cost=0.2, device=dev, dtype=torch.float64)
+        d, n = 2, 64
+    else:
+        m = lqg_amd.SubjectiveActor(dim=2, T=300, device=dev, dtype=torch.float64)
+        d, n = 4, 128
+    with torch.no_grad():
+        x = m.simulate(4, n=n)[..., :d].contiguous()
+    monkeypatch.setenv("LQG_SCAN", "0")
+    ref = m.log_likelihood(x).clone()
+    ref32 = m.to(torch.float32).log_likelihood(x.float()).clone()
+    monkeypatch.setenv("LQG_SCAN", "1")
+    p = LogLikelihoodPlan(m, x)
+    assert all(wk["scan"] for wk in p.work)
+    got = p.run().clone()
+    assert got.shape == ref.shape and float((got / ref - 1).abs().max()) < 1e-10
+    got32 = LogLikelihoodPlan(m.to(torch.float32), x.float()).run().clone()
+    e_scan = float((got32.double() / ref - 1).abs().max())
+    e_seq = float((ref32.double() / ref - 1).abs().max())
+    assert e_scan < max(2e-6, 1.5 * e_seq), (e_scan, e_seq)
+
+
+def test_scan_is_the_default_for_one_long_system_and_not_for_batches():
+    import lqg_amd
+    from lqg_amd.plan import LogLikelihoodPlan
+    m = lqg_amd.PointMassBoundedActor(T=500, device="cuda", dtype=torch.float32)
+    x = m.simulate(1, n=300)[..., :2].contiguous()
+    assert all(wk["scan"] for wk in LogLikelihoodPlan(m, x).work)
+    short = lqg_amd.PointMassBoundedActor(T=40, device="cuda", dtype=torch.float32)
+    assert not any(wk["scan"] for wk in LogLikelihoodPlan(short, short.simulate(1, n=300)[..., :2].contiguous()).work)
+    sig = torch.linspace(3.0, 30.0, 64, device="cuda")
+    many = lqg_amd.BoundedActor(T=500, sigma_target=sig, device="cuda")
+    assert not any(wk["scan"] for wk in LogLikelihoodPlan(many, many.simulate(1, n=4)[0]).work)
+    # an ill-conditioned observed block (all four point-mass states observed, cond((V V')[:4, :4]) = 5.6e8) stays on the
+    # sequential sweeps by default (plan.SCAN_MAX_COND)
+    ill = lqg_amd.PointMassBoundedActor(T=500, action_variability=0.5, device="cuda", dtype=torch.float64)
+    assert not any(wk["scan"] for wk in LogLikelihoodPlan(ill, ill.simulate(1, n=8).contiguous()).work)
