@@ -168,6 +168,16 @@ int lqg_log_likelihood_scan(const lqg_problem* p, lqg_traj x, void* ll, int64_t 
 int lqg_conditional_moments_scan(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_view Sigma,
                                  void* workspace, size_t workspace_bytes, void* stream);
 
+/* The per-trial sweep of a structure-specialised library (csrc/lqg_sp_entry.hpp: `lqg_trial_sweep_sp`, the operator's
+ * structural zeros compiled out) over an operator stream produced elsewhere.  `ops` points at the stream
+ * [n_sys][T+1][ops_reals]; the scratch of the time-chunked sweep follows it (csrc/lqg_trial_chunk.hpp). */
+typedef int (*lqg_trial_sweep_fn)(const lqg_problem* p, lqg_traj x, void* ll, int64_t ll_sb, int64_t ll_sn,
+                                  const void* ops, void* stream);
+/* lqg_log_likelihood_scan with the per-trial sweep delegated to `trial_sweep` (NULL: the library's own kernels; a
+ * non-zero return of the delegate also falls back to them). */
+int lqg_log_likelihood_scan_with(const lqg_problem* p, lqg_traj x, void* ll, int64_t ll_sb, int64_t ll_sn,
+                                 void* workspace, size_t workspace_bytes, void* stream, lqg_trial_sweep_fn trial_sweep);
+
 /* Structure-specialised twin (NOT in liblqg_hip.so): libraries generated per sparsity pattern by
  * lqg_amd/specialize.py (lqg_amd/csrc/pat/pat_<hash>.so, kernels in csrc/lqg_kernels_sp.hpp) export
  *     int lqg_log_likelihood_sp(<exactly the argument list of lqg_log_likelihood>);

@@ -199,14 +199,20 @@ def solve_materialised(actor, dynamics, x, Sigma0=None, eps=1e-8, out=None):
 
 
 def specialised_entry(ln, system, d):
-    """The structure-specialised `lqg_log_likelihood_sp` for this launch, or None (lqg_amd/specialize.py).
+    """The structure-specialised `lqg_log_likelihood_sp` for this launch, or None (lqg_amd/specialize.py)."""
+    lib = specialised_library(ln, system, d)
+    return None if lib is None else lib.lqg_log_likelihood_sp
+
+
+def specialised_library(ln, system, d, check_strategy=True):
+    """The structure-specialised library for this launch, or None (lqg_amd/specialize.py).
 
     Eligible: every spec field time-invariant, no affine cost terms.  LQG_NO_SPECIALIZE=1 forces the generic dense
     library (A/B measurements, tests)."""
     import os
     if system is None or os.environ.get("LQG_NO_SPECIALIZE") == "1" or ln.p.n_trials < 1:
         return None
-    if _abi.load().lqg_strategy(C.byref(ln.p)) == _abi.STRATEGY_COOP:
+    if check_strategy and _abi.load().lqg_strategy(C.byref(ln.p)) == _abi.STRATEGY_COOP:
         return None             # few systems of a large joint dimension: the cooperative kernels of the main library
     p = ln.p
     for spec, fields in ((p.actor, ("Q", "R", "A", "B", "V", "F", "W")), (p.dynamics, ("A", "B", "V", "F", "W"))):
@@ -217,8 +223,7 @@ def specialised_entry(ln, system, d):
         return None
     from lqg_amd import specialize
     dims, masks, key = specialize.system_pattern(system, d)
-    lib = specialize.load_pattern(key, dims, masks)
-    return None if lib is None else lib.lqg_log_likelihood_sp
+    return specialize.load_pattern(key, dims, masks)
 
 
 def sum_trials(ll):

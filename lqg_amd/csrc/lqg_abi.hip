@@ -303,7 +303,8 @@ int run_coop(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_view Sigma, void
 // Time-parallel system sweeps (lqg_scan.hpp), then the per-trial sweep over the operator stream they leave.
 template <typename R>
 int run_scan_path(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_view Sigma, void* ll, long ll_sb, long ll_sn,
-                  void* workspace, size_t workspace_bytes, hipStream_t st, const char* who) {
+                  void* workspace, size_t workspace_bytes, hipStream_t st, const char* who,
+                  lqg_trial_sweep_fn trial_sweep = nullptr) {
   const size_t need = scan_workspace_bytes(p);
   if (!workspace || workspace_bytes < need)
     return fail(LQG_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B", who, workspace_bytes, need);
@@ -317,9 +318,13 @@ int run_scan_path(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_view Sigma,
   if (e != hipSuccess) return done(e, who);
   mark(2);
   if (p->n_trials > 0 && (ll || mu.ptr)) {
-    bool found;
-    e = dispatch_trial<R>(p, ops, x, mu, ll, ll_sb, ll_sn, st, &found);
-    if (!found) e = coop_trial<R>(p, ops, x, mu, ll, ll_sb, ll_sn, st);
+    // (a structure-specialised library's sweep when the caller brought one and it accepts the problem)
+    const bool delegated = trial_sweep && ll && !mu.ptr && trial_sweep(p, x, ll, ll_sb, ll_sn, ops, st) == 0;
+    if (!delegated) {
+      bool found;
+      e = dispatch_trial<R>(p, ops, x, mu, ll, ll_sb, ll_sn, st, &found);
+      if (!found) e = coop_trial<R>(p, ops, x, mu, ll, ll_sb, ll_sn, st);
+    }
   }
   mark(3);
   return done(e, who);
@@ -338,6 +343,11 @@ size_t lqg_scan_workspace_bytes(const lqg_problem* p) { return p ? scan_workspac
 
 int lqg_log_likelihood_scan(const lqg_problem* p, lqg_traj x, void* ll, int64_t ll_sb, int64_t ll_sn, void* workspace,
                             size_t workspace_bytes, void* stream) {
+  return lqg_log_likelihood_scan_with(p, x, ll, ll_sb, ll_sn, workspace, workspace_bytes, stream, nullptr);
+}
+
+int lqg_log_likelihood_scan_with(const lqg_problem* p, lqg_traj x, void* ll, int64_t ll_sb, int64_t ll_sn, void* workspace,
+                                 size_t workspace_bytes, void* stream, lqg_trial_sweep_fn trial_sweep) {
   static const char* who = "lqg_log_likelihood_scan";
   if (int rc = check_full(p, who)) return rc;
   if (!scan_supported(p)) return fail(LQG_ERR_DIMS, "%s: needs u, y, d <= 4, x + b <= 24, no affine cost terms, T >= 2", who);
@@ -347,9 +357,9 @@ int lqg_log_likelihood_scan(const lqg_problem* p, lqg_traj x, void* ll, int64_t 
   const lqg_traj no_mu{nullptr, 0, 0, 0, 0};
   const lqg_view no_sig{nullptr, 0, 0, 0, 0};
   return p->dtype == LQG_F64 ? run_scan_path<double>(p, x, no_mu, no_sig, ll, ll_sb, ll_sn, workspace, workspace_bytes,
-                                                     (hipStream_t)stream, who)
+                                                     (hipStream_t)stream, who, trial_sweep)
                              : run_scan_path<float>(p, x, no_mu, no_sig, ll, ll_sb, ll_sn, workspace, workspace_bytes,
-                                                    (hipStream_t)stream, who);
+                                                    (hipStream_t)stream, who, trial_sweep);
 }
 
 int lqg_conditional_moments_scan(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_view Sigma, void* workspace,

@@ -448,6 +448,12 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
 // diagonal of A, a single control row, selection-shaped K Fd Ad).  Same operator stream, same arithmetic order for the
 // terms that remain; rows without any term make their deviation a compile-time zero.  (Compile-time recursion instead
 // of `if` inside unrolled loops: see dev_matvec_row in lqg_sparse.hpp.)
+// compile-time mask as the operator-structure policy of the time-chunked sweep (lqg_trial_chunk.hpp)
+template <int M, Mask<M, M> FM>
+struct MaskPolicy {
+  static constexpr bool at(int i, int j) { return FM.b[i * M + j]; }
+};
+
 template <bool PF, int NPF, int IDX, typename R>
 LQG_DEV R trial_op_at(const R (&opc)[NPF], const R* __restrict__ op) {
   if constexpr (PF) return opc[IDX];

@@ -6,6 +6,7 @@
 
 #include "../../include/lqg_hip.h"
 #include "lqg_kernels.hpp"
+#include "lqg_trial_chunk.hpp"
 
 namespace lqg {
 namespace host {
@@ -69,7 +70,8 @@ inline Workspace carve(const lqg_problem* p, bool need_ops) {
   w.ls_bytes = (per_step > ckpt ? per_step : ckpt) * (size_t)w.ldb * esz;
   w.ops_off = (w.ls_bytes + 255) / 256 * 256;
   w.ops_bytes = need_ops ? (size_t)p->n_sys * (size_t)(p->T + 1) * ops_reals(p->dims) * esz : 0;
-  w.total = w.ops_off + (w.ops_bytes + 255) / 256 * 256;
+  // (+ the scratch of the time-chunked per-trial sweep, lqg_trial_chunk.hpp: by convention it FOLLOWS the operator stream)
+  w.total = w.ops_off + (w.ops_bytes + 255) / 256 * 256 + (need_ops ? trial_chunk_scratch(p).total : 0);
   return w;
 }
 
@@ -136,6 +138,12 @@ hipError_t launch_forward(const lqg_problem* p, const void* Ls, long ldb, bool f
 template <typename R, int M, int ND>
 hipError_t launch_trial(const lqg_problem* p, const void* ops, lqg_traj x, lqg_traj mu, void* ll, long ll_sb,
                         long ll_sn, hipStream_t st) {
+  if (!mu.ptr && ll && trial_chunks(p) > 1) {      // few trials, long horizon: the sweep split along time
+    const size_t esz = p->dtype == LQG_F64 ? 8 : 4;
+    const size_t ops_bytes = (size_t)p->n_sys * (size_t)(p->T + 1) * ops_reals(p->dims) * esz;
+    void* scratch = static_cast<char*>(const_cast<void*>(ops)) + (ops_bytes + 255) / 256 * 256;
+    return launch_trial_chunked<R, M, ND, lqg::FullMask>(p, ops, x, ll, ll_sb, ll_sn, scratch, st);
+  }
   lqg::TrialArgs<R> k{dt<R>(x), dt<R>(mu), static_cast<R*>(ll), ll_sb, ll_sn, (long)p->n_trials, p->T};
   // Trials per lane: a few trials per lane amortise the per-step operator (scalar) loads when there are trials to spare
   // (2 measured best with the pipelined data loads: 2 / 4 / 8 -> 2.20 / 2.31 / 2.57 ms on config 5); with fewer than ~2

@@ -63,82 +63,116 @@ LQG_DEV void mm_sym(D* c, int n, int K, const D* a, int ars, int acs, const D* b
   });
 }
 
-// In-place Gauss-Jordan with partial pivoting on the n x w matrix Wm (leading n x n block -> identity, the other columns
-// -> M^-1 [rest]); fac: n doubles of scratch.
-LQG_DEV void gauss_jordan(D* Wm, int n, int w, D* fac) {
-  for (int c = 0; c < n; ++c) {
-    // pivot: row of the largest |W[r][c]|, r >= c (wave reduction)
-    D best = -1.0;
-    int brow = c;
-    for (int r = c + (int)threadIdx.x; r < n; r += kWave) {
-      const D v = fabs(Wm[r * w + c]);
-      if (v > best) { best = v; brow = r; }
-    }
-    LQG_UNROLL for (int off = 32; off >= 1; off >>= 1) {
-      const D ob = __shfl_xor(best, off);
-      const int orow = __shfl_xor(brow, off);
-      if (ob > best || (ob == best && orow < brow)) { best = ob; brow = orow; }
-    }
-    if (brow != c) each(w, [&](int e) { const D t = Wm[c * w + e]; Wm[c * w + e] = Wm[brow * w + e]; Wm[brow * w + e] = t; });
-    wsync();
-    const D pinv = 1.0 / Wm[c * w + c];
-    each(n, [&](int i) { fac[i] = (i == c) ? 0.0 : Wm[i * w + c]; });
-    wsync();
-    each(w, [&](int e) { Wm[c * w + e] *= pinv; });
-    wsync();
-    each(n * w, [&](int e) {
-      const int i = e / w, j = e - i * w;
-      if (i != c) Wm[i * w + j] -= fac[i] * Wm[c * w + j];
-    });
-    wsync();
-  }
-}
-
 // ---------------------------------------------------------------- one level of the scan
 // Elements live in global memory as [system][index][A | C | J] (3 n^2 doubles).  Level d of Hillis-Steele:
 //   prefix (left = 0): out[k] = in[k-d] (x) in[k]      suffix stored in reversed order (left = 1): out[k] = in[k] (x) in[k-d]
-__global__ void __launch_bounds__(kWave) k_scan_level(const D* __restrict__ in, D* __restrict__ out, int n, int len, int d,
-                                                      int left) {
+// One launch serves up to two independent scans of the same n (the Riccati and the Kalman scan run side by side).
+struct Seg {
+  const D* in;
+  D* out;
+  int len, d, left;
+};
+
+template <int NT, typename F>
+LQG_DEV void each_t(int n, F f) {
+  for (int e = threadIdx.x; e < n; e += NT) f(e);
+}
+template <int N>
+LQG_DEV D dotn(const D* a, int as, const D* b, int bs, D acc) {
+  LQG_UNROLL for (int k = 0; k < N; ++k) acc = fma(a[k * as], b[k * bs], acc);
+  return acc;
+}
+
+// Everything about the window size is a compile-time constant (N): index arithmetic is multiply-shift, the loops unroll
+// and the loads of a dot product are in flight together.  The linear solve M^-1 [A1 | C1] is Gauss-Jordan with partial
+// pivoting where EVERY lane finds the pivot itself from N broadcast LDS reads (no cross-lane reduction) and the step
+// reads the old matrix from one LDS buffer and writes the new one to another: one fence per column.
+template <int N, int NT>
+__global__ void __launch_bounds__(NT) k_scan_level(const Seg s0, const Seg s1) {
+  constexpr int NN = N * N, W = 3 * N;
   extern __shared__ double lqg_coop_smem[];
   D* sm = lqg_coop_smem;
-  const int k = blockIdx.x;
+  int k = blockIdx.x;
+  const bool second = k >= s0.len;
+  if (second) k -= s0.len;
+  const D* in = second ? s1.in : s0.in;
+  D* out = second ? s1.out : s0.out;
+  const int len = second ? s1.len : s0.len, d = second ? s1.d : s0.d, left = second ? s1.left : s0.left;
   const long sys = blockIdx.y;
-  const int nn = n * n;
-  const long es = 3L * nn;
+  constexpr long es = 3L * NN;
   const D* ek = in + (sys * len + k) * es;
   D* eo = out + (sys * len + k) * es;
   if (k < d) {
-    each(3 * nn, [&](int e) { eo[e] = ek[e]; });
+    each_t<NT>(3 * NN, [&](int e) { eo[e] = ek[e]; });
     return;
   }
   const D* ep = in + (sys * len + k - d) * es;
   const D* e1 = left ? ek : ep;        // the window that comes FIRST in time
   const D* e2 = left ? ep : ek;
-  D *A1 = sm, *C1 = A1 + nn, *J1 = C1 + nn, *A2 = J1 + nn, *C2 = A2 + nn, *J2 = C2 + nn, *Wm = J2 + nn, *T1 = Wm + 3 * nn,
-    *fac = T1 + nn;
-  each(3 * nn, [&](int e) { A1[e] = e1[e]; A2[e] = e2[e]; });     // (A, C, J are contiguous in both)
-  wsync();
-  const int w = 3 * n;
-  // Wm = [ I + C1 J2 | A1 | C1 ]
-  each(nn, [&](int e) {
-    const int i = e / n, j = e - i * n;
-    Wm[i * w + j] = coop::dot4<D>(C1 + i * n, 1, J2 + j, n, n, (i == j) ? 1.0 : 0.0);
-    Wm[i * w + n + j] = A1[e];
-    Wm[i * w + 2 * n + j] = C1[e];
+  D *A1 = sm, *C1 = A1 + NN, *J1 = C1 + NN, *A2 = J1 + NN, *C2 = A2 + NN, *J2 = C2 + NN, *Wa = J2 + NN, *Wb = Wa + 3 * NN,
+    *T1 = Wb + 3 * NN, *U = T1 + NN;
+  each_t<NT>(3 * NN, [&](int e) { A1[e] = e1[e]; A2[e] = e2[e]; });     // (A, C, J are contiguous in both)
+  __syncthreads();
+  // Wa = [ I + C1 J2 | A1 | C1 ]
+  each_t<NT>(NN, [&](int e) {
+    const int i = e / N, j = e - i * N;
+    Wa[i * W + j] = dotn<N>(C1 + i * N, 1, J2 + j, N, (i == j) ? 1.0 : 0.0);
+    Wa[i * W + N + j] = A1[e];
+    Wa[i * W + 2 * N + j] = C1[e];
   });
-  wsync();
-  gauss_jordan(Wm, n, w, fac);                                      // -> [ I | X1 = M^-1 A1 | X2 = M^-1 C1 ]
-  // A = A2 X1 ; T1 = A2 X2
-  mm(eo, n, n, n, n, A2, n, 1, Wm + n, w, 1, zero_init);
-  mm(T1, n, n, n, n, A2, n, 1, Wm + 2 * n, w, 1, zero_init);
-  // U = J2 X1 (into the first block of Wm, free now)
-  wsync();
-  mm(Wm, w, n, n, n, J2, n, 1, Wm + n, w, 1, zero_init);
-  wsync();
-  // C = T1 A2' + C2 (symmetrised) ; J = A1' U + J1 (symmetrised)
-  mm_sym(eo + nn, n, n, T1, n, 1, A2, 1, n, [&](int i, int j) { return C2[i * n + j]; });
-  mm_sym(eo + 2 * nn, n, n, A1, 1, n, Wm, w, 1, [&](int i, int j) { return J1[i * n + j]; });
+  __syncthreads();
+  D *src = Wa, *dst = Wb;
+  LQG_UNROLL for (int c = 0; c < N; ++c) {
+    D best = fabs(src[c * W + c]);
+    int p = c;
+    LQG_UNROLL for (int r = c + 1; r < N; ++r) {
+      const D v = fabs(src[r * W + c]);
+      if (v > best) { best = v; p = r; }
+    }
+    const D pinv = 1.0 / src[p * W + c];
+    // rows c and p change places; columns <= c are never read again
+    constexpr int PER = (N * W + NT - 1) / NT;
+    LQG_UNROLL for (int q = 0; q < PER; ++q) {
+      const int e = (int)threadIdx.x + q * NT;
+      const int i = e / W, j = e - i * W;
+      if (e < N * W && j > c) {
+        const D piv = src[p * W + j] * pinv;
+        if (i == c) {
+          dst[e] = piv;
+        } else {
+          const int row = (i == p) ? c : i;
+          dst[e] = fma(-src[row * W + c], piv, src[row * W + j]);
+        }
+      }
+    }
+    __syncthreads();
+    D* t = src; src = dst; dst = t;
+  }
+  const D* X = src;                                                  // [ . | X1 = M^-1 A1 | X2 = M^-1 C1 ]
+  // A = A2 X1 ; T1 = A2 X2 ; U = J2 X1
+  each_t<NT>(3 * NN, [&](int e) {
+    const int blk = e / NN, r = e - blk * NN, i = r / N, j = r - i * N;
+    if (blk == 0) eo[r] = dotn<N>(A2 + i * N, 1, X + N + j, W, 0.0);
+    else if (blk == 1) T1[r] = dotn<N>(A2 + i * N, 1, X + 2 * N + j, W, 0.0);
+    else U[r] = dotn<N>(J2 + i * N, 1, X + N + j, W, 0.0);
+  });
+  __syncthreads();
+  // C = T1 A2' + C2 ; J = A1' U + J1 (both symmetric in exact arithmetic: the mirror entries are averaged)
+  each_t<NT>(2 * NN, [&](int e) {
+    const int blk = e / NN, r = e - blk * NN, i = r / N, j = r - i * N;
+    if (blk == 0) {
+      const D v1 = dotn<N>(T1 + i * N, 1, A2 + j * N, 1, C2[i * N + j]);
+      const D v2 = dotn<N>(T1 + j * N, 1, A2 + i * N, 1, C2[j * N + i]);
+      eo[NN + r] = 0.5 * (v1 + v2);
+    } else {
+      const D v1 = dotn<N>(A1 + i, N, U + j, N, J1[i * N + j]);
+      const D v2 = dotn<N>(A1 + j, N, U + i, N, J1[j * N + i]);
+      eo[2 * NN + r] = 0.5 * (v1 + v2);
+    }
+  });
 }
+constexpr int scan_level_threads(int n) { return n <= 8 ? 64 : 256; }
+inline size_t scan_level_lds(int n) { return (size_t)(14 * n * n + 8) * sizeof(D); }
 
 // ---------------------------------------------------------------- per-step kernels
 template <typename R>
@@ -149,6 +183,8 @@ struct Args {
   DView<R> Sig;            // optional output Sigma[B,T,m,m]
   D* elems;                // scan input buffer [n_sys][len][3 n^2]
   const D* res;            // scan result buffer
+  D* elems2;               // the Kalman scan's buffers (it runs side by side with the Riccati scan)
+  const D* res2;
   D* Lbuf;                 // [n_sys][T][u*b]
   D* Kbuf;                 // [n_sys][T][b*y]
   D* FG;                   // [n_sys][T][2 m^2]   Fj | GG
@@ -197,11 +233,8 @@ LQG_DEV void small_inverse(const D* src, int n, D* dst, D eps, bool floor_) {
 
 // Riccati elements, reversed index j: j = 0 terminal (0, 0, Qf); j >= 1 <-> step t = T - j: (A_t, B R^-1 B', Q_t)
 template <typename R>
-__global__ void __launch_bounds__(kWave) k_scan_build_riccati(const Args<R> a) {
-  extern __shared__ double lqg_coop_smem[];
-  D* sm = lqg_coop_smem;
-  const int j = blockIdx.x, b = a.b, u = a.u, nn = b * b;
-  const long s = blockIdx.y;
+LQG_DEV void build_riccati(const Args<R>& a, D* sm, int j, long s) {
+  const int b = a.b, u = a.u, nn = b * b;
   D* e = a.elems + (s * (a.T + 1) + j) * 3L * nn;
   if (j == 0) {
     each(2 * nn, [&](int i) { e[i] = 0.0; });
@@ -223,11 +256,8 @@ __global__ void __launch_bounds__(kWave) k_scan_build_riccati(const Args<R> a) {
 
 // L_t = -Ht^-1 G from S_{t+1} (J of the suffix product at reversed index T - 1 - t)          lqr.py:22-31
 template <typename R>
-__global__ void __launch_bounds__(kWave) k_scan_gains(const Args<R> a) {
-  extern __shared__ double lqg_coop_smem[];
-  D* sm = lqg_coop_smem;
-  const int t = blockIdx.x, b = a.b, u = a.u, nn = b * b;
-  const long s = blockIdx.y;
+LQG_DEV void gains_step(const Args<R>& a, D* sm, int t, long s) {
+  const int b = a.b, u = a.u, nn = b * b;
   const D* S = a.res + (s * (a.T + 1) + (a.T - 1 - t)) * 3L * nn + 2 * nn;
   D *A = sm, *Bm = A + nn, *Rm = Bm + b * u, *SA = Rm + u * u, *SB = SA + nn, *H = SB + b * u, *G = H + u * u, *Hi = G + u * b;
   ld(a.aA, s, t, b, b, A);
@@ -249,12 +279,9 @@ __global__ void __launch_bounds__(kWave) k_scan_gains(const Args<R> a) {
 
 // Kalman elements, index t = 0 .. T-1 (the filtered covariance after step t)                  kf.py:10-14
 template <typename R>
-__global__ void __launch_bounds__(kWave) k_scan_build_kalman(const Args<R> a) {
-  extern __shared__ double lqg_coop_smem[];
-  D* sm = lqg_coop_smem;
-  const int t = blockIdx.x, b = a.b, y = a.y, nn = b * b;
-  const long s = blockIdx.y;
-  D* e = a.elems + (s * a.T + t) * 3L * nn;
+LQG_DEV void build_kalman(const Args<R>& a, D* sm, int t, long s) {
+  const int b = a.b, y = a.y, nn = b * b;
+  D* e = a.elems2 + (s * a.T + t) * 3L * nn;
   D *A = sm, *F = A + nn, *VV = F + y * b, *WW = VV + nn, *Pp = WW + y * y, *FP = Pp + nn, *Sm = FP + y * b, *Si = Sm + y * y,
     *K = Si + y * y, *T1 = K + b * y, *IKF = T1 + nn;
   ld(a.aA, s, t, b, b, A);
@@ -302,11 +329,8 @@ __global__ void __launch_bounds__(kWave) k_scan_build_kalman(const Args<R> a) {
 
 // K_t from the filtered covariance of the previous step                                      kf.py:10-12
 template <typename R>
-__global__ void __launch_bounds__(kWave) k_scan_kgain(const Args<R> a) {
-  extern __shared__ double lqg_coop_smem[];
-  D* sm = lqg_coop_smem;
-  const int t = blockIdx.x, b = a.b, y = a.y, nn = b * b;
-  const long s = blockIdx.y;
+LQG_DEV void kgain_step(const Args<R>& a, D* sm, int t, long s) {
+  const int b = a.b, y = a.y, nn = b * b;
   D *A = sm, *F = A + nn, *VV = F + y * b, *WW = VV + nn, *P0 = WW + y * y, *AP = P0 + nn, *Pp = AP + nn, *FP = Pp + nn,
     *Sm = FP + y * b, *Si = Sm + y * y;
   ld(a.aA, s, t, b, b, A);
@@ -317,7 +341,7 @@ __global__ void __launch_bounds__(kWave) k_scan_kgain(const Args<R> a) {
     if (a.Sigma0.p) ld_sym(a.Sigma0, s, 0, b, P0);
     else ld_gram(a.aV, s, 0, b, a.nva, P0);
   } else {
-    const D* C = a.res + (s * a.T + t - 1) * 3L * nn + nn;
+    const D* C = a.res2 + (s * a.T + t - 1) * 3L * nn + nn;
     each(nn, [&](int i) { P0[i] = C[i]; });
   }
   wsync();
@@ -332,6 +356,24 @@ __global__ void __launch_bounds__(kWave) k_scan_kgain(const Args<R> a) {
   small_inverse(Sm, y, Si, 0.0, false);
   D* K = a.Kbuf + (s * a.T + t) * (long)(b * y);
   mm(K, y, b, y, y, FP, 1, b, Si, y, 1, zero_init);
+}
+
+// The Riccati and the Kalman recursion do not depend on each other: their elements are built by one launch (blocks
+// 0 .. T: Riccati, T+1 .. 2T: Kalman), their scans advance in the same launches (k_scan_level's two segments), and one
+// launch turns the results into the gains L_t (blocks 0 .. T-1) and K_t (T .. 2T-1).
+template <typename R>
+__global__ void __launch_bounds__(kWave) k_scan_build_rk(const Args<R> a) {
+  extern __shared__ double lqg_coop_smem[];
+  const int k = blockIdx.x;
+  if (k <= a.T) build_riccati(a, lqg_coop_smem, k, (long)blockIdx.y);
+  else build_kalman(a, lqg_coop_smem, k - (a.T + 1), (long)blockIdx.y);
+}
+template <typename R>
+__global__ void __launch_bounds__(kWave) k_scan_gains_rk(const Args<R> a) {
+  extern __shared__ double lqg_coop_smem[];
+  const int k = blockIdx.x;
+  if (k < a.T) gains_step(a, lqg_coop_smem, k, (long)blockIdx.y);
+  else kgain_step(a, lqg_coop_smem, k - a.T, (long)blockIdx.y);
 }
 
 // joint system of step t into LDS: Fj[m,m], GG[m,m]                                          system.py:167-207

@@ -14,7 +14,8 @@ using scan::D;
 
 struct ScanPlan {
   size_t elems_off, elems_bytes, l_off, k_off, fg_off, ops_off, total;
-  long elem_reals;        // doubles of ONE element buffer (largest of the three scans)
+  long rk_reals;          // doubles of ONE element buffer of the Riccati / Kalman scans (four of them: in/out each)
+  long sig_reals;         // doubles of ONE element buffer of the moment scan (two of them, reusing the same region)
 };
 
 inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
@@ -23,30 +24,50 @@ ScanPlan scan_plan(const lqg_problem* p) {
   const long B = p->n_sys, T = p->T, b = p->dims.b, u = p->dims.u, y = p->dims.y, m = p->dims.x + p->dims.b;
   const size_t esz = p->dtype == LQG_F64 ? 8 : 4;
   ScanPlan s{};
-  const long r1 = (T + 1) * 3 * b * b, r2 = T * 3 * m * m;
-  s.elem_reals = B * (r1 > r2 ? r1 : r2);
+  s.rk_reals = B * (T + 1) * 3 * b * b;
+  s.sig_reals = B * T * 3 * m * m;
+  const long reals = 4 * s.rk_reals > 2 * s.sig_reals ? 4 * s.rk_reals : 2 * s.sig_reals;
   s.elems_off = 0;
-  s.elems_bytes = al(2 * (size_t)s.elem_reals * sizeof(D));
+  s.elems_bytes = al((size_t)reals * sizeof(D));
   s.l_off = s.elems_off + s.elems_bytes;
   s.k_off = s.l_off + al((size_t)(B * T * u * b) * sizeof(D));
   s.fg_off = s.k_off + al((size_t)(B * T * b * y) * sizeof(D));
   s.ops_off = s.fg_off + al((size_t)(B * T * 2 * m * m) * sizeof(D));
-  s.total = s.ops_off + al((size_t)B * (size_t)(T + 1) * ops_reals(p->dims) * esz);
+  s.total = s.ops_off + al((size_t)B * (size_t)(T + 1) * ops_reals(p->dims) * esz) + trial_chunk_scratch(p).total;
   return s;
 }
 
-// Hillis-Steele over `len` elements of n x n triples starting in buffer 0; returns the buffer holding the result
-D* run_scan(D* buf0, D* buf1, int n, int len, long n_sys, int left, hipStream_t st) {
-  const size_t lds = (size_t)(10 * n * n + n + 8) * sizeof(D);
-  D *in = buf0, *out = buf1;
-  for (int d = 1; d < len; d *= 2) {
-    hipLaunchKernelGGL(scan::k_scan_level, dim3((unsigned)len, (unsigned)n_sys), dim3(scan::kWave), lds, st, in, out, n, len,
-                       d, left);
-    D* t = in;
-    in = out;
-    out = t;
+template <int N>
+void launch_level(const scan::Seg& s0, const scan::Seg& s1, long n_sys, hipStream_t st) {
+  constexpr int NT = scan::scan_level_threads(N);
+  hipLaunchKernelGGL((scan::k_scan_level<N, NT>), dim3((unsigned)(s0.len + s1.len), (unsigned)n_sys), dim3(NT),
+                     scan::scan_level_lds(N), st, s0, s1);
+}
+
+// Hillis-Steele over one or two independent sequences of n x n triples (segment i: len[i] elements starting in in[i],
+// ping-ponging with out[i]); on return res[i] is the buffer holding segment i's result.
+void run_scan(int n, int nseg, D* const in[2], D* const out[2], const int len[2], const int left[2], long n_sys,
+              const D* res[2], hipStream_t st) {
+  D* a[2] = {in[0], nseg > 1 ? in[1] : nullptr};
+  D* b[2] = {out[0], nseg > 1 ? out[1] : nullptr};
+  const int l1 = nseg > 1 ? len[1] : 0;
+  const int longest = len[0] > l1 ? len[0] : l1;
+  for (int d = 1; d < longest; d *= 2) {
+    const scan::Seg s0{a[0], b[0], len[0], d, left[0]};
+    const scan::Seg s1{a[1], b[1], l1, d, nseg > 1 ? left[1] : 0};
+    switch (n) {
+#define LQG_SCAN_CASE(N_) case N_: launch_level<N_>(s0, s1, n_sys, st); break;
+      LQG_SCAN_CASE(1) LQG_SCAN_CASE(2) LQG_SCAN_CASE(3) LQG_SCAN_CASE(4) LQG_SCAN_CASE(5) LQG_SCAN_CASE(6)
+      LQG_SCAN_CASE(7) LQG_SCAN_CASE(8) LQG_SCAN_CASE(9) LQG_SCAN_CASE(10) LQG_SCAN_CASE(11) LQG_SCAN_CASE(12)
+      LQG_SCAN_CASE(13) LQG_SCAN_CASE(14) LQG_SCAN_CASE(15) LQG_SCAN_CASE(16) LQG_SCAN_CASE(17) LQG_SCAN_CASE(18)
+      LQG_SCAN_CASE(19) LQG_SCAN_CASE(20) LQG_SCAN_CASE(21) LQG_SCAN_CASE(22) LQG_SCAN_CASE(23) LQG_SCAN_CASE(24)
+#undef LQG_SCAN_CASE
+      default: break;                 // (scan_supported: n <= 24)
+    }
+    for (int i = 0; i < 2; ++i) { D* t = a[i]; a[i] = b[i]; b[i] = t; }
   }
-  return in;
+  res[0] = a[0];
+  res[1] = a[1];
 }
 
 template <typename R>
@@ -82,8 +103,7 @@ template <typename R>
 hipError_t scan_system_sweeps(const lqg_problem* p, lqg_view Sig, void* workspace, void** ops_out, hipStream_t st) {
   const ScanPlan sp = scan_plan(p);
   char* base = static_cast<char*>(workspace);
-  D* buf0 = reinterpret_cast<D*>(base + sp.elems_off);
-  D* buf1 = buf0 + sp.elem_reals;
+  D* rk = reinterpret_cast<D*>(base + sp.elems_off);
   scan::Args<R> k = make_scan_args<R>(p);
   k.Sig = dv<R>(Sig);
   k.Lbuf = reinterpret_cast<D*>(base + sp.l_off);
@@ -95,29 +115,37 @@ hipError_t scan_system_sweeps(const lqg_problem* p, lqg_view Sig, void* workspac
   const unsigned B = (unsigned)p->n_sys;
   const dim3 blk(scan::kWave);
   const int mx = b > y ? b : y;
-  // ---- Riccati: suffix scan over T + 1 elements (reversed storage)
-  k.elems = buf0;
-  hipLaunchKernelGGL((scan::k_scan_build_riccati<R>), dim3(T + 1, B), blk, (size_t)(2 * b * u + 2 * u * u + 8) * sizeof(D), st, k);
-  k.res = run_scan(buf0, buf1, b, T + 1, p->n_sys, 1, st);
-  hipLaunchKernelGGL((scan::k_scan_gains<R>), dim3(T, B), blk,
-                     (size_t)(3 * b * b + 3 * b * u + 3 * u * u + 8) * sizeof(D), st, k);
-  // ---- Kalman: prefix scan over T elements
-  D* kin = (k.res == buf0) ? buf1 : buf0;       // (the Riccati result is dead after k_scan_gains: stream order)
-  D* kout = (kin == buf0) ? buf1 : buf0;
-  k.elems = kin;
-  hipLaunchKernelGGL((scan::k_scan_build_kalman<R>), dim3(T, B), blk, (size_t)(6 * mx * mx + 6 * mx * mx + 8) * sizeof(D), st, k);
-  k.res = run_scan(kin, kout, b, T, p->n_sys, 0, st);
-  hipLaunchKernelGGL((scan::k_scan_kgain<R>), dim3(T, B), blk, (size_t)(12 * mx * mx + 8) * sizeof(D), st, k);
+  // ---- Riccati (suffix scan over T + 1 elements, reversed storage) and Kalman (prefix scan over T elements) side by side
+  {
+    D* const in[2] = {rk, rk + 2 * sp.rk_reals};
+    D* const out[2] = {rk + sp.rk_reals, rk + 3 * sp.rk_reals};
+    const int len[2] = {T + 1, T}, left[2] = {1, 0};
+    const D* res[2];
+    k.elems = in[0];
+    k.elems2 = in[1];
+    const size_t lds_build = (size_t)(12 * mx * mx + 2 * b * u + 2 * u * u + 8) * sizeof(D);
+    hipLaunchKernelGGL((scan::k_scan_build_rk<R>), dim3(2 * T + 1, B), blk, lds_build, st, k);
+    run_scan(b, 2, in, out, len, left, p->n_sys, res, st);
+    k.res = res[0];
+    k.res2 = res[1];
+    const size_t lds_gain = (size_t)(12 * mx * mx + 3 * b * u + 3 * u * u + 8) * sizeof(D);
+    hipLaunchKernelGGL((scan::k_scan_gains_rk<R>), dim3(2 * T, B), blk, lds_gain, st, k);
+  }
   if (const char* dbg = getenv("LQG_SCAN_DEBUG_STOP")) {     // developer hook: leave the Kalman scan's buffers intact
-    if (dbg[0] == '1') { *ops_out = const_cast<D*>(k.res); return hipGetLastError(); }
+    if (dbg[0] == '1') { *ops_out = const_cast<D*>(k.res2); return hipGetLastError(); }
   }
   // ---- moment recursion: joint system per step, prefix scan over T elements of m x m, operators
-  D* sin = (k.res == buf0) ? buf1 : buf0;
-  D* sout = (sin == buf0) ? buf1 : buf0;
-  k.elems = sin;
-  const size_t lds_sig = (size_t)(3 * m * m + o * o + m * o + scan::joint_scratch(x, b, u, y) + 16) * sizeof(D);
-  hipLaunchKernelGGL((scan::k_scan_build_sigma<R>), dim3(T + 1, B), blk, lds_sig, st, k);
-  k.res = run_scan(sin, sout, m, T, p->n_sys, 0, st);
+  {
+    D* const in[2] = {rk, nullptr};
+    D* const out[2] = {rk + sp.sig_reals, nullptr};
+    const int len[2] = {T, 0}, left[2] = {0, 0};
+    const D* res[2];
+    k.elems = in[0];
+    const size_t lds_sig = (size_t)(3 * m * m + o * o + m * o + scan::joint_scratch(x, b, u, y) + 16) * sizeof(D);
+    hipLaunchKernelGGL((scan::k_scan_build_sigma<R>), dim3(T + 1, B), blk, lds_sig, st, k);
+    run_scan(m, 1, in, out, len, left, p->n_sys, res, st);
+    k.res = res[0];
+  }
   hipLaunchKernelGGL((scan::k_scan_ops<R>), dim3(T + 1, B), blk, (size_t)(2 * m * m + o * o + 8) * sizeof(D), st, k);
   return hipGetLastError();
 }

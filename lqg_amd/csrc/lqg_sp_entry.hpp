@@ -21,6 +21,40 @@ namespace host {
 #define LQG_SP_CHUNK_MIN_SYS 1024
 #endif
 
+// The per-trial sweep with the operator's structural zeros compiled out: k_trial_sp in one pass, or — few trials over a
+// long horizon — the time-chunked sweep (lqg_trial_chunk.hpp; its scratch follows the operator stream).  Trials-per-lane
+// rule of launch_trial (lqg_launch.hpp).
+template <typename R, typename PAT, int NX, int NB, int NU, int NY, int ND>
+hipError_t trial_sweep_sp(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll_sn, const void* ops, hipStream_t st) {
+  const lqg_traj no_traj{nullptr, 0, 0, 0, 0};
+  const dim3 block(LQG_BLOCK);
+  constexpr auto FM_dense = lqg::trial_operator_mask<PAT, NX, NB, NU, NY, ND, true>();
+  constexpr auto FM_noise = lqg::trial_operator_mask<PAT, NX, NB, NU, NY, ND, false>();
+  const bool dense_p = p->Sigma0.ptr != nullptr;
+  if (trial_chunks(p) > 1) {
+    const size_t esz = p->dtype == LQG_F64 ? 8 : 4;
+    const size_t ops_bytes = (size_t)p->n_sys * (size_t)(p->T + 1) * ops_reals(p->dims) * esz;
+    void* scratch = static_cast<char*>(const_cast<void*>(ops)) + (ops_bytes + 255) / 256 * 256;
+    if (dense_p)
+      return launch_trial_chunked<R, NX + NB, ND, lqg::MaskPolicy<NX + NB, FM_dense>>(p, ops, x, ll, ll_sb, ll_sn, scratch, st);
+    return launch_trial_chunked<R, NX + NB, ND, lqg::MaskPolicy<NX + NB, FM_noise>>(p, ops, x, ll, ll_sb, ll_sn, scratch, st);
+  }
+  lqg::TrialArgs<R> tk{dt<R>(x), dt<R>(no_traj), static_cast<R*>(ll), ll_sb, ll_sn, (long)p->n_trials, p->T};
+  const long lanes4 = (long)p->n_sys * ((p->n_trials + 4 * LQG_BLOCK - 1) / (4 * LQG_BLOCK)) * LQG_BLOCK;
+  const bool wide = lanes4 >= 2L * 1024 * 64;
+  const long per_block = (long)LQG_BLOCK * (wide ? LQG_TRIALS_PER_LANE : 1);
+  const dim3 tgrid((unsigned)((p->n_trials + per_block - 1) / per_block), (unsigned)p->n_sys);
+  const R* o = static_cast<const R*>(ops);
+  if (dense_p) {
+    if (wide) hipLaunchKernelGGL((lqg::k_trial_sp<R, NX + NB, ND, LQG_TRIALS_PER_LANE, FM_dense>), tgrid, block, 0, st, o, tk);
+    else hipLaunchKernelGGL((lqg::k_trial_sp<R, NX + NB, ND, 1, FM_dense>), tgrid, block, 0, st, o, tk);
+  } else {
+    if (wide) hipLaunchKernelGGL((lqg::k_trial_sp<R, NX + NB, ND, LQG_TRIALS_PER_LANE, FM_noise>), tgrid, block, 0, st, o, tk);
+    else hipLaunchKernelGGL((lqg::k_trial_sp<R, NX + NB, ND, 1, FM_noise>), tgrid, block, 0, st, o, tk);
+  }
+  return hipGetLastError();
+}
+
 template <typename R, typename PAT, int NX, int NB, int NU, int NY, int ND, int CK>
 int run_sp_ck(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll_sn, void* workspace, size_t workspace_bytes,
               hipStream_t st);
@@ -82,24 +116,9 @@ int run_sp_ck(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll_sn
 #undef LQG_SP_FWD
   }
   mark(2);
-  if (!fused) {   // several trials per system: the generic per-trial sweep over the operator stream
-    // the per-trial sweep with the operator's structural zeros compiled out (k_trial_sp); trials-per-lane rule of
-    // launch_trial (lqg_launch.hpp)
-    lqg::TrialArgs<R> tk{dt<R>(x), dt<R>(no_traj), static_cast<R*>(ll), ll_sb, ll_sn, (long)p->n_trials, p->T};
-    const long lanes4 = (long)p->n_sys * ((p->n_trials + 4 * LQG_BLOCK - 1) / (4 * LQG_BLOCK)) * LQG_BLOCK;
-    const bool wide = lanes4 >= 2L * 1024 * 64;
-    const long per_block = (long)LQG_BLOCK * (wide ? LQG_TRIALS_PER_LANE : 1);
-    const dim3 tgrid((unsigned)((p->n_trials + per_block - 1) / per_block), (unsigned)p->n_sys);
-    const R* o = static_cast<const R*>(ops);
-    if (p->Sigma0.ptr != nullptr) {
-      constexpr auto FM = lqg::trial_operator_mask<PAT, NX, NB, NU, NY, ND, true>();
-      if (wide) hipLaunchKernelGGL((lqg::k_trial_sp<R, NX + NB, ND, LQG_TRIALS_PER_LANE, FM>), tgrid, block, 0, st, o, tk);
-      else hipLaunchKernelGGL((lqg::k_trial_sp<R, NX + NB, ND, 1, FM>), tgrid, block, 0, st, o, tk);
-    } else {
-      constexpr auto FM = lqg::trial_operator_mask<PAT, NX, NB, NU, NY, ND, false>();
-      if (wide) hipLaunchKernelGGL((lqg::k_trial_sp<R, NX + NB, ND, LQG_TRIALS_PER_LANE, FM>), tgrid, block, 0, st, o, tk);
-      else hipLaunchKernelGGL((lqg::k_trial_sp<R, NX + NB, ND, 1, FM>), tgrid, block, 0, st, o, tk);
-    }
+  if (!fused) {   // several trials per system: the per-trial sweep over the operator stream
+    const hipError_t te = trial_sweep_sp<R, PAT, NX, NB, NU, NY, ND>(p, x, ll, ll_sb, ll_sn, ops, st);
+    if (te != hipSuccess) return (int)te;
   }
   mark(3);
   const hipError_t e = hipGetLastError();
@@ -122,6 +141,26 @@ int log_likelihood_sp(const lqg_problem* p, lqg_traj x, void* ll, int64_t ll_sb,
     return run_sp<float, PAT, NX, NB, NU, NY, ND>(p, x, ll, (long)ll_sb, (long)ll_sn, workspace, workspace_bytes,
                                                   (hipStream_t)stream);
   return LQG_ERR_ARG;
+}
+
+// lqg_trial_sweep_fn (include/lqg_hip.h): the sweep alone, over an operator stream some other library produced (the
+// time-parallel system sweeps of the main library).  Same refusals as log_likelihood_sp.
+template <typename PAT, int NX, int NB, int NU, int NY, int ND>
+int trial_sweep_entry(const lqg_problem* p, lqg_traj x, void* ll, int64_t ll_sb, int64_t ll_sn, const void* ops, void* stream) {
+  if (!p || !x.ptr || !ll || !ops) return LQG_ERR_NULL;
+  const lqg_dims& dm = p->dims;
+  if (dm.x != NX || dm.b != NB || dm.u != NU || dm.y != NY || dm.d != ND) return LQG_ERR_DIMS;
+  if (p->n_trials < 1 || p->T < 1) return LQG_ERR_ARG;
+  if (!forward_ti(p) || !actor_ti_riccati(p) || affine(p)) return LQG_ERR_ARG;
+  if (p->n_sys == 0) return 0;
+  hipError_t e;
+  if (p->dtype == LQG_F64)
+    e = trial_sweep_sp<double, PAT, NX, NB, NU, NY, ND>(p, x, ll, (long)ll_sb, (long)ll_sn, ops, (hipStream_t)stream);
+  else if (p->dtype == LQG_F32)
+    e = trial_sweep_sp<float, PAT, NX, NB, NU, NY, ND>(p, x, ll, (long)ll_sb, (long)ll_sn, ops, (hipStream_t)stream);
+  else
+    return LQG_ERR_ARG;
+  return e == hipSuccess ? 0 : (int)e;
 }
 
 }  // namespace host

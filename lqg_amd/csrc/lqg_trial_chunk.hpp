@@ -1,0 +1,286 @@
+// lqg_trial_chunk.hpp — the per-trial sweep (lqg/system.py:219-221 mean recursion + :244-248 log_prob) split along TIME.
+//
+// k_trial walks one trial per lane through all T steps.  With few trials (one parameter vector x tens..thousands of
+// trials: the inner loop of MLE / NUTS, BASELINE configs 2 and 4) that is one dependent chain of T steps on a handful of
+// waves — a latency-bound sweep on a nearly empty chip.  The recursion of the conditional mean is AFFINE in its state
+// s_t = (dO_t, muR_t) with operators that do not depend on the trial,
+//     s_{t+1} = Phi_t s_t + g_t(x_t, x_{t-1}),        Phi_t = Fm[:, O:] [ -U2 Li | I ],
+// so the horizon is cut into chunks that run side by side:
+//   1. k_trial_zs   one lane per (trial, chunk): the chunk's recursion from s = 0 (zero-state response z_c); one extra
+//                   block per (system, chunk) pushes the M unit vectors through the chunk with the data set to zero —
+//                   the chunk's transition matrix Phi_c, column by column.  No densities are evaluated.
+//   2. k_trial_fix  one lane per trial walks the chunk boundaries: s_{c+1} = Phi_c s_c + z_c  (n_chunks - 1 mat-vecs).
+//   3. k_trial_ll   one lane per (trial, chunk): the chunk again, now from its true start state, evaluating the
+//                   densities of its steps exactly as k_trial does; per-chunk partial sums in fp64.
+//   4. k_trial_sum  log-likelihood of a trial = sum of its chunks' partial sums, in chunk order (deterministic).
+// The dependent chain is 2 T / n_chunks + n_chunks steps instead of T, and the lanes in flight grow n_chunks-fold for
+// 1.6x the arithmetic.  Results differ from the one-pass sweep by rounding only (the start state of a chunk is
+// Phi_c s_c + z_c instead of the step-by-step value).
+// The structural zeros of the operator are a compile-time policy (FMP::at(i, j)): FullMask for the generic library,
+// the pattern's operator mask in a structure-specialised one.
+#pragma once
+#include <cmath>
+#include <cstdlib>
+
+#include "lqg_kernels.hpp"
+
+namespace lqg {
+
+struct FullMask {
+  static constexpr bool at(int, int) { return true; }
+};
+
+template <typename R>
+struct TrialChunkArgs {
+  DTraj<R> x;
+  long n_trials;
+  int T, n_chunks, chunk_len;
+  R* state;          // [sys][n_chunks-1][M][n_trials]: zero-state ends, then (k_trial_fix) start states of chunk c+1
+  R* phi;            // [sys][n_chunks-1][M][M]
+  double* part;      // [sys][n_chunks][n_trials]
+};
+
+template <typename R, int M, int ND, class FMP, int I, int J>
+LQG_DEV void tc_mean_term(const R* __restrict__ op, const R (&cv)[M], R& v) {
+  if constexpr (J < M) {
+    if constexpr (FMP::at(I, J)) v += op[TrialOps<M, ND>::F_OFF + I * M + J] * cv[J];
+    tc_mean_term<R, M, ND, FMP, I, J + 1>(op, cv, v);
+  }
+}
+template <typename R, int M, int ND, class FMP, int I>
+LQG_DEV void tc_mean_rows(const R* __restrict__ op, const R (&cv)[M], R (&mn)[M]) {
+  if constexpr (I < M) {
+    R v = R(0);
+    tc_mean_term<R, M, ND, FMP, I, 0>(op, cv, v);
+    mn[I] = v;
+    tc_mean_rows<R, M, ND, FMP, I + 1>(op, cv, mn);
+  }
+}
+
+// one step of the recursion: whitened innovation w (and its square zz), then — when `update` — the new state
+template <typename R, int M, int ND, class FMP>
+LQG_DEV R tc_step(const R* __restrict__ op, const R (&xt)[ND], R (&xprev)[ND], R (&dO)[ND], R (&muR)[M - ND], bool update) {
+  constexpr int O = ND, RR = M - ND;
+  using Ops = TrialOps<M, ND>;
+  R cv[M], w[O];
+  LQG_UNROLL for (int i = 0; i < O; ++i) cv[i] = xt[i];
+  R zz = R(0);
+  {
+    int e = 0;
+    LQG_UNROLL for (int i = 0; i < O; ++i) {
+      R v = R(0);
+      LQG_UNROLL for (int j = 0; j <= i; ++j) v += op[Ops::L_OFF + (e++)] * ((cv[j] - xprev[j]) - dO[j]);
+      w[i] = v;
+      zz += v * v;
+    }
+  }
+  if (update) {
+    LQG_UNROLL for (int p = 0; p < RR; ++p) {
+      R v = muR[p];
+      LQG_UNROLL for (int j = 0; j < O; ++j) v += op[Ops::U_OFF + p * O + j] * w[j];
+      cv[O + p] = v;
+    }
+    R mn[M];
+    tc_mean_rows<R, M, ND, FMP, 0>(op, cv, mn);
+    LQG_UNROLL for (int i = 0; i < O; ++i) { dO[i] = mn[i]; xprev[i] = cv[i]; }
+    LQG_UNROLL for (int p = 0; p < RR; ++p) muR[p] = mn[O + p];
+  }
+  return zz;
+}
+
+// grid: (trial blocks + 1, n_sys, n_chunks - 1); the last block in x carries the unit vectors
+template <typename R, int M, int ND, class FMP>
+__global__ void __launch_bounds__(LQG_BLOCK) k_trial_zs(const R* __restrict__ ops_all, const TrialChunkArgs<R> a) {
+  constexpr int O = ND, RR = M - ND;
+  using Ops = TrialOps<M, ND>;
+  const long sys = blockIdx.y;
+  const int c = blockIdx.z;
+  const bool hom = blockIdx.x == gridDim.x - 1;
+  const long n = hom ? (long)threadIdx.x : (long)blockIdx.x * LQG_BLOCK + threadIdx.x;
+  const bool live = n < (hom ? (long)M : a.n_trials);
+  const int t0 = c * a.chunk_len, t1 = t0 + a.chunk_len;               // (c <= n_chunks - 2: the chunk is complete)
+  const R* __restrict__ op = ops_all + (sys * (long)(a.T + 1) + t0) * Ops::N;
+  const R* xr = a.x.p + sys * a.x.sb + ((live && !hom) ? n : 0) * a.x.sn;
+  R xprev[O], dO[O], muR[RR], xq[O];
+  LQG_UNROLL for (int i = 0; i < O; ++i) {
+    xprev[i] = hom ? R(0) : xr[(long)(t0 > 0 ? t0 - 1 : 0) * a.x.st + i * a.x.sd];
+    xq[i] = hom ? R(0) : xr[(long)t0 * a.x.st + i * a.x.sd];
+    dO[i] = (hom && n == i) ? R(1) : R(0);
+  }
+  LQG_UNROLL for (int p = 0; p < RR; ++p) muR[p] = (hom && n == O + p) ? R(1) : R(0);
+  for (int t = t0; t < t1; ++t) {
+    R xt[O];
+    LQG_UNROLL for (int i = 0; i < O; ++i) xt[i] = xq[i];
+    const long row = (t + 1 < a.T) ? (long)(t + 1) : (long)a.T;          // data row one step ahead
+    LQG_UNROLL for (int i = 0; i < O; ++i) xq[i] = hom ? R(0) : xr[row * a.x.st + i * a.x.sd];
+    (void)tc_step<R, M, ND, FMP>(op, xt, xprev, dO, muR, true);
+    op += Ops::N;
+  }
+  if (!live) return;
+  const long slot = sys * (a.n_chunks - 1) + c;
+  if (hom) {
+    R* ph = a.phi + slot * (M * M) + n;
+    LQG_UNROLL for (int i = 0; i < O; ++i) ph[i * M] = dO[i];
+    LQG_UNROLL for (int p = 0; p < RR; ++p) ph[(O + p) * M] = muR[p];
+  } else {
+    R* sp = a.state + slot * M * a.n_trials + n;
+    LQG_UNROLL for (int i = 0; i < O; ++i) sp[i * a.n_trials] = dO[i];
+    LQG_UNROLL for (int p = 0; p < RR; ++p) sp[(O + p) * a.n_trials] = muR[p];
+  }
+}
+
+// grid: (trial blocks, n_sys).  Slot c of `state` holds the zero-state end of chunk c on entry and the start state of
+// chunk c + 1 on return (slot 0 is both: chunk 0 starts from zero).
+template <typename R, int M>
+__global__ void __launch_bounds__(LQG_BLOCK) k_trial_fix(const R* __restrict__ phi_all, R* state, long n_trials, int n_slots) {
+  const long sys = blockIdx.y;
+  const long n = (long)blockIdx.x * LQG_BLOCK + threadIdx.x;
+  if (n >= n_trials) return;
+  R* sp = state + sys * n_slots * M * n_trials + n;
+  const R* __restrict__ ph = phi_all + sys * n_slots * (M * M);
+  R s[M];
+  LQG_UNROLL for (int i = 0; i < M; ++i) s[i] = sp[i * n_trials];
+  for (int c = 1; c < n_slots; ++c) {
+    sp += M * n_trials;
+    ph += M * M;
+    R z[M];
+    LQG_UNROLL for (int i = 0; i < M; ++i) z[i] = sp[i * n_trials];
+    LQG_UNROLL for (int i = 0; i < M; ++i) {
+      R v = z[i];
+      LQG_UNROLL for (int j = 0; j < M; ++j) v += ph[i * M + j] * s[j];
+      z[i] = v;
+    }
+    LQG_UNROLL for (int i = 0; i < M; ++i) { s[i] = z[i]; sp[i * n_trials] = z[i]; }
+  }
+}
+
+// grid: (trial blocks, n_sys, n_chunks)
+template <typename R, int M, int ND, class FMP>
+__global__ void __launch_bounds__(LQG_BLOCK) k_trial_ll(const R* __restrict__ ops_all, const TrialChunkArgs<R> a) {
+  constexpr int O = ND, RR = M - ND;
+  constexpr int kAccChunk = 8;
+  using Ops = TrialOps<M, ND>;
+  const long sys = blockIdx.y;
+  const int c = blockIdx.z;
+  const long n = (long)blockIdx.x * LQG_BLOCK + threadIdx.x;
+  const bool live = n < a.n_trials;
+  const long nn = live ? n : a.n_trials - 1;
+  const int t0 = c * a.chunk_len;
+  const bool last = c == a.n_chunks - 1;
+  const int t1 = last ? a.T : t0 + a.chunk_len;
+  const R* __restrict__ op = ops_all + (sys * (long)(a.T + 1) + t0) * Ops::N;
+  const R* xr = a.x.p + sys * a.x.sb + nn * a.x.sn;
+  R xprev[O], dO[O], muR[RR], xq[O];
+  LQG_UNROLL for (int i = 0; i < O; ++i) {
+    xprev[i] = xr[(long)(t0 > 0 ? t0 - 1 : 0) * a.x.st + i * a.x.sd];
+    xq[i] = xr[(long)t0 * a.x.st + i * a.x.sd];
+  }
+  if (c == 0) {
+    LQG_UNROLL for (int i = 0; i < O; ++i) dO[i] = R(0);
+    LQG_UNROLL for (int p = 0; p < RR; ++p) muR[p] = R(0);
+  } else {
+    const R* sp = a.state + (sys * (a.n_chunks - 1) + (c - 1)) * M * a.n_trials + nn;
+    LQG_UNROLL for (int i = 0; i < O; ++i) dO[i] = sp[i * a.n_trials];
+    LQG_UNROLL for (int p = 0; p < RR; ++p) muR[p] = sp[(O + p) * a.n_trials];
+  }
+  double acc = 0.0;
+  R part = R(0);
+  const int tend = last ? t1 + 1 : t1;                                   // the last chunk also scores x_T
+  for (int t = t0; t < tend; ++t) {
+    R xt[O];
+    LQG_UNROLL for (int i = 0; i < O; ++i) xt[i] = xq[i];
+    const long row = (t + 1 < a.T) ? (long)(t + 1) : (long)a.T;
+    LQG_UNROLL for (int i = 0; i < O; ++i) xq[i] = xr[row * a.x.st + i * a.x.sd];
+    const R zz = tc_step<R, M, ND, FMP>(op, xt, xprev, dO, muR, t < a.T);
+    if (t > 0) part += R(0.5) * zz + op[Ops::H_OFF];
+    if (((t & (kAccChunk - 1)) == 0) || t + 1 == tend) { acc -= (double)part; part = R(0); }
+    op += Ops::N;
+  }
+  if (live) a.part[(sys * a.n_chunks + c) * a.n_trials + n] = acc;
+}
+
+template <typename R>
+__global__ void __launch_bounds__(LQG_BLOCK) k_trial_sum(const double* __restrict__ part, R* ll, long ll_sb, long ll_sn,
+                                                         long n_trials, int n_chunks) {
+  const long sys = blockIdx.y;
+  const long n = (long)blockIdx.x * LQG_BLOCK + threadIdx.x;
+  if (n >= n_trials) return;
+  const double* p = part + sys * n_chunks * n_trials + n;
+  double v = 0.0;
+  for (int c = 0; c < n_chunks; ++c) v += p[c * n_trials];
+  ll[sys * ll_sb + n * ll_sn] = (R)v;
+}
+
+namespace host {
+
+// Number of chunks the per-trial sweep of this problem is cut into (1: the one-pass k_trial).  LQG_TRIAL_CHUNKS=0/1
+// disables, =k forces k chunks (clamped to chunks of >= 4 steps); by default enough chunks to put LQG_TRIAL_CHUNK_WAVES
+// waves in flight (16 per SIMD; measured on configs 2 / 4, per-trial sweep in ms: one pass 0.62 / 1.82, 4096 waves
+// 0.33 / 1.04, 8192: 0.25 / 0.69, 16384: 0.25 / 0.65, 65536: 0.26 / 0.71), at most sqrt(2 T) chunks (the minimum of the
+// dependent chain 2 T / k + k).
+inline int trial_chunks(const lqg_problem* p) {
+  if (p->n_trials <= 2 || p->T < 16) return 1;
+  // (read per call: a test or a tuning script may change them between launches)
+  const char* e1 = getenv("LQG_TRIAL_CHUNKS");
+  const char* e2 = getenv("LQG_TRIAL_CHUNK_WAVES");
+  const int forced = e1 ? atoi(e1) : -1;
+  const long target = e2 ? atol(e2) : 16384L;
+  long nc;
+  if (forced >= 0) {
+    nc = forced;
+  } else {
+    const long waves = (long)p->n_sys * ((p->n_trials + LQG_BLOCK - 1) / LQG_BLOCK);
+    nc = (target + waves - 1) / waves;
+    const long cap = (long)std::sqrt(2.0 * (double)p->T);
+    if (nc > cap) nc = cap;
+  }
+  if (nc > p->T / 4) nc = p->T / 4;
+  if (nc < 2) return 1;
+  const int len = (int)((p->T + nc - 1) / nc);
+  return (p->T + len - 1) / len;                        // (every chunk non-empty)
+}
+inline int trial_chunk_len(const lqg_problem* p, int n_chunks) { return (p->T + n_chunks - 1) / n_chunks; }
+
+struct TrialChunkScratch {
+  size_t state_off, phi_off, part_off, total;
+};
+inline TrialChunkScratch trial_chunk_scratch(const lqg_problem* p) {
+  TrialChunkScratch s{};
+  const int nc = trial_chunks(p);
+  if (nc <= 1) return s;
+  const size_t esz = p->dtype == LQG_F64 ? 8 : 4;
+  const size_t m = (size_t)(p->dims.x + p->dims.b), B = (size_t)p->n_sys, N = (size_t)p->n_trials;
+  auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+  s.state_off = 0;
+  s.phi_off = al(B * (nc - 1) * m * N * esz);
+  s.part_off = s.phi_off + al(B * (nc - 1) * m * m * esz);
+  s.total = s.part_off + al(B * nc * N * sizeof(double));
+  return s;
+}
+
+// scratch: trial_chunk_scratch(p).total bytes (by convention it follows the operator stream in the workspace)
+template <typename R, int M, int ND, class FMP>
+hipError_t launch_trial_chunked(const lqg_problem* p, const void* ops, lqg_traj x, void* ll, long ll_sb, long ll_sn,
+                                void* scratch, hipStream_t st) {
+  const int nc = trial_chunks(p);
+  const TrialChunkScratch sc = trial_chunk_scratch(p);
+  char* base = static_cast<char*>(scratch);
+  lqg::TrialChunkArgs<R> k{lqg::DTraj<R>{static_cast<const R*>(x.ptr), (long)x.sb, (long)x.sn, (long)x.st, (long)x.sd},
+                           (long)p->n_trials, p->T, nc, trial_chunk_len(p, nc),
+                           reinterpret_cast<R*>(base + sc.state_off), reinterpret_cast<R*>(base + sc.phi_off),
+                           reinterpret_cast<double*>(base + sc.part_off)};
+  const unsigned tb = (unsigned)((p->n_trials + LQG_BLOCK - 1) / LQG_BLOCK), B = (unsigned)p->n_sys;
+  const dim3 block(LQG_BLOCK);
+  const R* o = static_cast<const R*>(ops);
+  hipLaunchKernelGGL((lqg::k_trial_zs<R, M, ND, FMP>), dim3(tb + 1, B, nc - 1), block, 0, st, o, k);
+  if (nc > 2)
+    hipLaunchKernelGGL((lqg::k_trial_fix<R, M>), dim3(tb, B), block, 0, st, static_cast<const R*>(k.phi), k.state,
+                       (long)p->n_trials, nc - 1);
+  hipLaunchKernelGGL((lqg::k_trial_ll<R, M, ND, FMP>), dim3(tb, B, nc), block, 0, st, o, k);
+  hipLaunchKernelGGL((lqg::k_trial_sum<R>), dim3(tb, B), block, 0, st, static_cast<const double*>(k.part),
+                     static_cast<R*>(ll), ll_sb, ll_sn, (long)p->n_trials, nc);
+  return hipGetLastError();
+}
+
+}  // namespace host
+}  // namespace lqg

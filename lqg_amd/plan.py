@@ -20,11 +20,14 @@ OPS_WORKSPACE_LIMIT = 16 << 30
 # trials, the inner loop of lqg/infer/mle.py:17-23 and of NUTS.  LQG_FUSE_TRIALS_MAX=0 disables.
 FUSE_TRIALS_MAX = int(os.environ.get("LQG_FUSE_TRIALS_MAX", "2048"))
 # TIME-PARALLEL system sweeps (csrc/lqg_scan.hpp: Riccati, Kalman and moment recursions as associative scans, log2(T)
-# dependent combines instead of T dependent steps): chosen for at most this many systems per call with at least this
-# many steps — where the sequential sweeps are one lone wave walking the recursion.  LQG_SCAN=0 never, LQG_SCAN=1 wherever
-# the path is defined (no affine terms, floor provably inactive, u, y, d <= 4).
-SCAN_MAX_SYSTEMS = int(os.environ.get("LQG_SCAN_MAX_SYSTEMS", "8"))
-SCAN_MIN_STEPS = int(os.environ.get("LQG_SCAN_MIN_STEPS", "96"))
+# dependent combines instead of T dependent steps), followed by the time-chunked per-trial sweep.  The sequential sweeps
+# cost T dependent steps whatever the number of systems (one lane each); the scans cost a fixed ~0.14 ms plus ~10 us
+# (m = 4) .. ~18 us (m = 8) per system, one wave per (system, step).  Measured crossover (scripts/small_batch.py, T = 500,
+# fp32): m = 4: ~8 systems (0.20 ms sequential), m = 8: ~40 systems (1.0 ms sequential) — so the default rule takes the
+# scans for at most 8 (m / 4)^2 systems (8 at m <= 4, capped at 64) with at least scan_min_steps(m) steps.
+# LQG_SCAN=0 never, LQG_SCAN=1 wherever the path is defined (no affine terms, floor provably inactive, u, y, d <= 4).
+SCAN_MAX_SYSTEMS = int(os.environ.get("LQG_SCAN_MAX_SYSTEMS", "0"))       # 0: the rule above
+SCAN_MIN_STEPS = int(os.environ.get("LQG_SCAN_MIN_STEPS", "0"))           # 0: the rule below
 # The scan elements hold (F' Sigma_oo^-1 F)-type terms, so an ill-conditioned observed block costs the scans more digits
 # than the sequential recursion: scripts/scan_cond.py, point mass with all four states observed, scan against sequential
 # fp64 — cond((V V')[:d, :d]) <= 5.6e6: 1e-11; 5.6e8 (golden pointmass_d4_T50): 2e-6.  Above this condition number of the
@@ -32,13 +35,31 @@ SCAN_MIN_STEPS = int(os.environ.get("LQG_SCAN_MIN_STEPS", "96"))
 SCAN_MAX_COND = float(os.environ.get("LQG_SCAN_MAX_COND", "1e7"))
 
 
+def scan_min_steps(m):
+    """Horizon from which the scans beat one lane walking the recursion: the sequential step costs ~0.4 us at m = 4 and
+    ~2 us at m = 8 (~m^2), the scans ~0.11-0.15 ms whatever T (config 1, m = 4, T = 100: 0.064 ms sequential, 0.11 ms
+    scans; m = 4, T = 500: 0.20 / 0.14; m = 8, T = 500: 1.0 / 0.21)."""
+    if SCAN_MIN_STEPS > 0:
+        return SCAN_MIN_STEPS
+    return int(max(64, 6000 / (m * m)))
+
+
+def scan_max_systems(m):
+    if SCAN_MAX_SYSTEMS > 0:
+        return SCAN_MAX_SYSTEMS
+    return int(min(64, max(8, 8 * (m / 4.0) ** 2)))
+
+
 def _observed_noise_cond(sub, d):
-    """Largest condition number of (V V')[:d, :d] of the dynamics over systems and steps (one tiny host sync; the plan is
-    built once per dataset)."""
-    V = sub.dynamics.V.detach().double()
-    ev = torch.linalg.eigvalsh((V @ V.transpose(-1, -2))[..., :d, :d])
-    lo, hi = ev[..., 0].clamp_min(0.0), ev[..., -1]
-    return float((hi / lo.clamp_min(1e-300)).max())
+    """Largest condition number of (V V')[:d, :d] of the dynamics over systems and steps.  One small device-to-host copy;
+    the eigenvalues are taken on the host (a batched eigvalsh of 2x2..4x4 blocks costs ~0.3 ms on the GPU, more than the
+    evaluation it guards)."""
+    import numpy as np
+    V = sub.dynamics.V.detach()[..., :d, :]
+    VV = (V @ V.transpose(-1, -2)).double().cpu().numpy()
+    ev = np.linalg.eigvalsh(VV)
+    lo, hi = np.maximum(ev[..., 0], 0.0), ev[..., -1]
+    return float(np.max(hi / np.maximum(lo, 1e-300)))
 
 
 def scan_eligible(lib, ln, sub, eps):
@@ -46,7 +67,7 @@ def scan_eligible(lib, ln, sub, eps):
     mode = os.environ.get("LQG_SCAN", "")
     if mode == "0" or not hasattr(lib, "lqg_log_likelihood_scan"):
         return False
-    if mode != "1" and not (ln.B <= SCAN_MAX_SYSTEMS and ln.T >= SCAN_MIN_STEPS):
+    if mode != "1" and not (ln.B <= scan_max_systems(ln.m) and ln.T >= scan_min_steps(ln.m)):
         return False
     if not lib.lqg_scan_supported(C.byref(ln.p)):
         return False
@@ -109,8 +130,15 @@ class LogLikelihoodPlan:
             sp = None if use_scan else _hip.specialised_entry(ln, sub0, len(cols))
             if use_scan:
                 use_scan = lib is _abi.load()            # (an auxiliary lane-kernel library has no scan entry)
+            scan_entry = None
             if use_scan:
                 nbytes = lib.lqg_scan_workspace_bytes(C.byref(ln.p))
+                # the per-trial sweep after the scans: the pattern library's (structural zeros of the operator compiled
+                # out) when the system has one, else the main library's dense sweep
+                spl = _hip.specialised_library(ln, sub0, len(cols), check_strategy=False) if n > 2 else None
+                fn = C.cast(spl.lqg_trial_sweep_sp, C.c_void_p) if spl is not None else C.c_void_p(None)
+                scan_entry = (lambda *a, _f=lib.lqg_log_likelihood_scan_with, _t=fn: _f(*a, _t))
+                scan_sp = spl is not None
             if sp is not None and n == 2:        # the specialised library sweeps two trials in-lane: no operator stream
                 ln.p.n_trials = 1
                 nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
@@ -131,7 +159,8 @@ class LogLikelihoodPlan:
                 n, ll_sb = n_pairs, 1
             self.work.append(dict(ln=ln, x=xb, traj=ln.traj(xb, is_b), ll=ll_buf, ll_sb=ll_sb, nbytes=nbytes, ev=ev,
                                   ws=torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=ln.device),
-                                  entry=(lib.lqg_log_likelihood_scan if use_scan else (sp or lib.lqg_log_likelihood)),
+                                  entry=(scan_entry if use_scan else (sp or lib.lqg_log_likelihood)),
+                                  scan_sp=bool(use_scan and scan_sp),
                                   generic=lib.lqg_log_likelihood, scan=use_scan,
                                   specialised=sp is not None, n=n, fused_pairs=fuse_pairs,
                                   pattern_key=(specialize.system_pattern(sub0, len(cols))[2] if sp is not None else None),
@@ -164,7 +193,8 @@ class LogLikelihoodPlan:
         in_lane = w[0]["n"] == 1 or (w[0]["n"] == 2 and w[0]["specialised"])
         tail = ")" if in_lane else " + k_trial)"
         if all(k.get("scan") for k in w):
-            kind = "time-parallel scans (Riccati, Kalman, moment recursion: k_scan_level x log2 T) + k_trial"
+            kind = ("time-parallel scans (Riccati, Kalman, moment recursion: k_scan_level x log2 T) + per-trial sweep ("
+                    + ("pattern library" if all(k.get("scan_sp") for k in w) else "dense") + ", time-chunked when few trials)")
             if len(w) > 1:
                 kind += f", {len(w)} decoupled components of dims (x,b,u,y,d)={w[0]['dims']}"
             if self.merged and max(self.merged) > 1:

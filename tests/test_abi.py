@@ -106,9 +106,16 @@ def test_workspace_size_formula(lib, monkeypatch):
     assert coop == fused + (100 * 501 * 136 * 4 + 255) // 256 * 256      # + operator stream; the working set is in LDS
     assert fused == 500 * 2 * 6 * 128 * 4                               # gain scratch [T][u*b][B padded to 64]
     ln2 = _hip.Launch(m.actor, m.dynamics, d=4, n_trials=16)
+    monkeypatch.setenv("LQG_TRIAL_CHUNKS", "0")  # the one-pass per-trial sweep
     split = lib.lqg_workspace_bytes(C.byref(ln2.p), _abi.OP_LOG_LIKELIHOOD)
     ops = (100 + 24 + 10 + 1 + 3) // 4 * 4
     assert ops == 136 and split == fused + (100 * 501 * ops * 4 + 255) // 256 * 256
+    # the time-chunked per-trial sweep (csrc/lqg_trial_chunk.hpp) adds, after the operator stream: start states
+    # [B][chunks-1][m][n], chunk transition matrices [B][chunks-1][m][m], fp64 partial sums [B][chunks][n]
+    monkeypatch.setenv("LQG_TRIAL_CHUNKS", "4")
+    al = lambda v: (v + 255) // 256 * 256
+    chunked = lib.lqg_workspace_bytes(C.byref(ln2.p), _abi.OP_LOG_LIKELIHOOD)
+    assert chunked == split + al(100 * 3 * 10 * 16 * 4) + al(100 * 3 * 10 * 10 * 4) + al(100 * 4 * 16 * 8)
 
 
 def test_no_cpu_fallback():
