@@ -416,6 +416,37 @@ def extra_legs(torch, args, dev):
                          "frac": fl_rate / (PEAK_FP32_TFLOPS if dn == "f32" else PEAK_FP64_TFLOPS),
                          "kernel_ms": r["kernel_ms"], "riccati_kernel_ms": r["riccati_kernel_ms"]}}
         torch.cuda.empty_cache()
+    # one system x many trials (BASELINE configs 2 and 4, the inner loop of MLE / NUTS): the time-parallel path (scans over
+    # the time axis + time-chunked per-trial sweep) against the sequential lane kernels, wall ms per evaluation
+    import bench_configs as bc
+    import lqg_amd
+    from lqg_amd import workload
+    for cfg in (2, 4):
+        if cfg == 2:
+            m = lqg_amd.PointMassBoundedActor(T=500, action_variability=0.5, device=dev, dtype=torch.float32)
+            x = workload.pack_trials(m.simulate(12, n=65536)[..., :2].contiguous())
+        else:
+            m = bc.hand2d_system(1000, dev, torch.float32)
+            x = workload.pack_trials(m.simulate(14, n=32768)[..., :4].contiguous())
+        leg = {"systems": 1, "trials": int(x.shape[-3]), "T": int(m.T), "dtype": "f32"}
+        for name, env in (("time_parallel", {}), ("sequential", {"LQG_SCAN": "0", "LQG_TRIAL_CHUNKS": "0"})):
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                ll, ph = bc.timed_loglik(m, x, 10)
+            finally:
+                for k, v in old.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+            leg[name] = {"wall_ms": ph["wall_ms"], "system_sweeps_ms": ph["riccati_ms"] + ph["forward_ms"],
+                         "per_trial_sweep_ms": ph["trial_ms"], "path": ph["path"],
+                         "max_rel_err_vs_fp64_oracle": bc.oracle_check(m, x, ll, n_samples=4)}
+        leg["speedup"] = leg["sequential"]["wall_ms"] / leg["time_parallel"]["wall_ms"]
+        extra[f"config{cfg}_one_system"] = leg
+        del x
+        torch.cuda.empty_cache()
     return extra
 
 

@@ -150,15 +150,13 @@ def conditional_moments(actor, dynamics, x, Sigma0=None, eps=1e-8, want_mu=True,
     x, xb = _prep_x(ln, x)
     mu = ln.empty(n, ln.T, ln.m) if want_mu else None
     Sig = ln.empty(ln.T, ln.m, ln.m) if want_sigma else None
-    import os
     use_scan = False
-    if os.environ.get("LQG_SCAN") == "1" and lib is _abi.load() and hasattr(lib, "lqg_conditional_moments_scan") \
-            and lib.lqg_scan_supported(C.byref(ln.p)):
-        from lqg_amd import decouple
+    if lib is _abi.load() and hasattr(lib, "lqg_conditional_moments_scan"):
+        from lqg_amd import plan as _plan          # (same rule as the log-likelihood: few systems, long horizon)
         from lqg_amd.system import System
-        use_scan = decouple.floor_provably_inactive(System(actor=actor, dynamics=dynamics), eps)
+        use_scan = _plan.scan_eligible(lib, ln, System(actor=actor, dynamics=dynamics), eps)
     with torch.cuda.device(ln.device):
-        if use_scan:                     # time-parallel system sweeps (csrc/lqg_scan.hpp), forced for tests / A-B
+        if use_scan:                     # time-parallel system sweeps (csrc/lqg_scan.hpp)
             nbytes = lib.lqg_scan_workspace_bytes(C.byref(ln.p))
             ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=ln.device)
             entry, what = lib.lqg_conditional_moments_scan, "lqg_conditional_moments_scan"

@@ -1,0 +1,36 @@
+#!/bin/bash
+# Everything the committed records under profiles/ come from, in one GPU-box call:
+#   bash scripts/final_records.sh <tag>
+# headline kernel trace + PMC passes (fp32, fp64), M2 (fp32), the default bench line with its extra legs, all five configs,
+# the gradient bench, the small-batch latency table and the kernel timeline of config 2.
+cd "$(dirname "$0")/.."
+TAG=$1
+mkdir -p gpurun_out
+bash scripts/profile_headline.sh ${TAG} f32 > /dev/null 2>&1
+bash scripts/profile_headline.sh ${TAG}64 f64 > /dev/null 2>&1
+bash scripts/profile_m2.sh ${TAG}m2 f32 17 > /dev/null 2>&1
+python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+python3 bench_configs.py > gpurun_out/${TAG}_configs.jsonl 2> gpurun_out/${TAG}_configs.err
+python3 bench_grad.py > gpurun_out/${TAG}_grad_f64.jsonl 2> gpurun_out/${TAG}_grad.err
+python3 scripts/small_batch.py 2> /dev/null | grep -v amdgpu > gpurun_out/${TAG}_small_batch_f32.txt
+python3 scripts/small_batch.py f64 2> /dev/null | grep -v amdgpu > gpurun_out/${TAG}_small_batch_f64.txt
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_cfg2 -o p -- python3 bench_configs.py --configs 2 > /dev/null 2>&1
+python3 - <<PY > gpurun_out/${TAG}_timeline_config2.txt
+import csv, glob
+f = glob.glob("gpurun_out/prof_${TAG}_cfg2/**/*kernel_trace.csv", recursive=True)[0]
+rows = [r for r in csv.DictReader(open(f)) if "scan" in r["Kernel_Name"] or "k_trial" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if "build_rk" in r["Kernel_Name"]][-1]
+seq = rows[idx:]
+t0 = int(seq[0]["Start_Timestamp"])
+busy = 0
+print("# one evaluation of config 2 (PointMassBoundedActor, T=500, 65536 trials, fp32): start us, duration us, kernel")
+for r in seq:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    busy += e - s
+    print("%8.1f %7.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, r["Kernel_Name"][:90]))
+print("# span us", (int(seq[-1]["End_Timestamp"]) - t0) / 1e3, "busy us", busy / 1e3)
+PY
+find gpurun_out/prof_${TAG}_cfg2 -type f ! -name "*stats*.csv" -delete
+tail -c 1500 gpurun_out/${TAG}_bench.json
