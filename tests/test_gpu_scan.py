@@ -100,3 +100,47 @@ def test_scan_is_the_default_for_one_long_system_and_not_for_batches():
     # sequential sweeps by default (plan.SCAN_MAX_COND)
     ill = lqg_amd.PointMassBoundedActor(T=500, action_variability=0.5, device="cuda", dtype=torch.float64)
     assert not any(wk["scan"] for wk in LogLikelihoodPlan(ill, ill.simulate(1, n=8).contiguous()).work)
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_time_parallel_path_on_random_dense_systems(oracle_lib, case, monkeypatch):
+    """Random dense systems (no structure), time-invariant and genuinely time-varying, partial observation, custom Sigma0,
+    horizons that do not divide into the chunks: scans + time-chunked per-trial sweep against the fp64 C oracle."""
+    import lqg_amd
+    from gpu_common import to_spec
+    from lqg_amd.plan import LogLikelihoodPlan
+    from test_gpu_random import SHAPES, random_system
+    rng = np.random.default_rng(7000 + case)
+    x, b, u, y = SHAPES[case % len(SHAPES)]
+    T = int(rng.integers(70, 260))
+    tv = bool(case & 1)
+    actor, dyn = random_system(rng, x, b, u, y, T, tv, affine=False)
+    for spec in (actor, dyn):            # open-loop stable: over 70-260 steps a spectral radius > 1 makes the problem itself
+        rho = max(np.abs(np.linalg.eigvals(spec["A"][t])).max() for t in range(0, T, 7))    # ill-conditioned (every path,
+        spec["A"] = spec["A"] * min(1.0, 0.97 / rho)                                         # sequential included, then
+    d = x if case % 3 else (2 if x == 4 else x)                                              # agrees with the oracle to 1e-3 only)
+    S0 = None
+    if case % 4 == 3:
+        M = rng.standard_normal((b, b))
+        S0 = M @ M.T / b + 0.3 * np.eye(b)
+    n = 5
+    X, _, _, _ = oracle_lib.simulate(actor, dyn, rng.standard_normal((n, T, x)), rng.standard_normal((n, T, y)), Sigma0=S0)
+    xs = X[..., :d]
+    ref_ll = oracle_lib.log_likelihood(actor, dyn, xs, S0)
+    ref_mu, ref_Sig = oracle_lib.conditional_moments(actor, dyn, xs, S0)
+    sys_ = lqg_amd.System(actor=to_spec(actor, torch.float64), dynamics=to_spec(dyn, torch.float64))
+    S0t = None if S0 is None else torch.as_tensor(S0, dtype=torch.float64, device="cuda")
+    xt = torch.as_tensor(xs, dtype=torch.float64, device="cuda")
+    monkeypatch.setenv("LQG_SCAN", "1")
+    monkeypatch.setenv("LQG_FUSE_TRIALS_MAX", "0")
+    for chunks in ("", "3", "11"):
+        if chunks:
+            monkeypatch.setenv("LQG_TRIAL_CHUNKS", chunks)
+        plan = LogLikelihoodPlan(sys_, xt, Sigma0=S0t)
+        assert all(wk["scan"] for wk in plan.work), plan.description
+        ll = np_(plan.run().clone())
+        assert np.abs(ll - ref_ll).max() < 1e-9 * np.abs(ref_ll).max(), (chunks, np.abs(ll - ref_ll).max())
+    from lqg_amd import _hip
+    mu, Sig = _hip.conditional_moments(sys_.actor, sys_.dynamics, xt, Sigma0=S0t)
+    assert np.abs(np_(mu) - ref_mu).max() < 1e-8 * max(1.0, np.abs(ref_mu).max())
+    assert np.abs(np_(Sig) - ref_Sig).max() < 1e-8 * max(1.0, np.abs(ref_Sig).max())
