@@ -7,14 +7,17 @@ import inspect
 _NOT_INFERRED = ("self", "dim", "dt", "T", "process_noise", "delay", "covar", "device", "dtype")
 
 
+_model_params_cache = {}
+
+
 def get_model_params(model_class):
-    """Constructor arguments that are model parameters, with their defaults (lqg/infer/models.py:9-17)."""
-    init_signature = inspect.signature(model_class.__init__)
-    parameters = {}
-    for name, param in init_signature.parameters.items():
-        if name not in _NOT_INFERRED:
-            parameters[param.name] = param.default
-    return parameters
+    """Constructor arguments that are model parameters, with their defaults (lqg/infer/models.py:9-17).
+    (Cached per class: the signature walk costs ~40 us, once per objective evaluation in an optimiser loop.)"""
+    if model_class not in _model_params_cache:
+        init_signature = inspect.signature(model_class.__init__)
+        _model_params_cache[model_class] = {name: param.default for name, param in init_signature.parameters.items()
+                                            if name not in _NOT_INFERRED}
+    return dict(_model_params_cache[model_class])
 
 
 def log_likelihood_objective(x, model_type, params, process_noise=1.0, dt=1.0 / 60, group=None, **fixed_params):

@@ -122,3 +122,40 @@ def test_pattern_extraction_of_the_model_zoo():
     # a parameter that happens to be zero must not narrow the cached class mask
     z = lqg_amd.SubjectiveActor(dim=2, T=3, subj_vel_noise=0.0, device="cpu")
     assert specialize.system_pattern(z, 4)[2] == key
+
+
+def test_time_parallel_rules():
+    """The host-side rules that pick the time-parallel path (lqg_amd/plan.py) and the chunk count of the per-trial sweep
+    (csrc/lqg_trial_chunk.hpp through lqg_workspace_bytes): monotone in the joint dimension, overridable by environment."""
+    from lqg_amd import plan
+    assert plan.scan_max_systems(4) == 8 and plan.scan_max_systems(8) == 32 and plan.scan_max_systems(20) == 64
+    assert plan.scan_min_steps(4) == 375 and plan.scan_min_steps(8) == 93 and plan.scan_min_steps(20) == 64
+    assert all(plan.scan_max_systems(m) <= plan.scan_max_systems(m + 1) for m in range(2, 30))
+    assert all(plan.scan_min_steps(m) >= plan.scan_min_steps(m + 1) for m in range(2, 30))
+
+
+def test_trial_chunk_scratch_grows_with_the_chunk_count(monkeypatch):
+    import ctypes as C
+    import torch
+    import lqg_amd
+    from lqg_amd import _abi, _hip
+    from lqg_amd import build
+    build.build(verbose=False)
+    lib = _abi.load()
+    m = lqg_amd.BoundedActor(T=400, device="cpu")
+    sizes = []
+    for chunks in ("0", "2", "8", "1000"):
+        monkeypatch.setenv("LQG_TRIAL_CHUNKS", chunks)
+        ln = _hip.Launch(m.actor, m.dynamics, d=2, n_trials=64)
+        sizes.append(lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD))
+    assert sizes[0] < sizes[1] < sizes[2] < sizes[3]
+    # forced counts are clamped to chunks of at least 4 steps: 1000 -> 100 chunks of 4
+    al = lambda v: (v + 255) // 256 * 256
+    assert sizes[3] - sizes[0] == al(99 * 4 * 64 * 4) + al(99 * 4 * 4 * 4) + al(100 * 64 * 8)
+    # one or two trials run in-lane (no operator stream, no chunking); a short horizon is never chunked
+    monkeypatch.delenv("LQG_TRIAL_CHUNKS")
+    short = lqg_amd.BoundedActor(T=12, device="cpu")
+    a = lib.lqg_workspace_bytes(C.byref(_hip.Launch(short.actor, short.dynamics, d=2, n_trials=64).p), _abi.OP_LOG_LIKELIHOOD)
+    monkeypatch.setenv("LQG_TRIAL_CHUNKS", "0")
+    b = lib.lqg_workspace_bytes(C.byref(_hip.Launch(short.actor, short.dynamics, d=2, n_trials=64).p), _abi.OP_LOG_LIKELIHOOD)
+    assert a == b

@@ -2,7 +2,8 @@
 `lqg_amd` — same test names, same models, same assertions — so that a maintainer switching `import lqg` to
 `import lqg_amd as lqg` sees their tests pass.  (The reference's tests assert shapes / finiteness / one metamorphic
 relation only; numeric parity is pinned elsewhere: tests/test_gpu_parity.py.)  Differences are the documented ones:
-an int seed where the reference passes a jax PRNGKey, and `infer` (NumPyro NUTS) raising NotImplementedError."""
+an int seed where the reference passes a jax PRNGKey; `infer` runs lqg_amd's own NUTS (lqg_amd/infer/mcmc.py) and returns an
+object with numpyro's `get_samples()` / `print_summary()`."""
 import pytest
 import torch
 
