@@ -214,22 +214,28 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial_sum(const double* __restric
 namespace host {
 
 // Number of chunks the per-trial sweep of this problem is cut into (1: the one-pass k_trial).  LQG_TRIAL_CHUNKS=0/1
-// disables, =k forces k chunks (clamped to chunks of >= 4 steps); by default enough chunks to put LQG_TRIAL_CHUNK_WAVES
-// waves in flight (16 per SIMD; measured on configs 2 / 4, per-trial sweep in ms: one pass 0.62 / 1.82, 4096 waves
-// 0.33 / 1.04, 8192: 0.25 / 0.69, 16384: 0.25 / 0.65, 65536: 0.26 / 0.71), at most sqrt(2 T) chunks (the minimum of the
-// dependent chain 2 T / k + k).
+// disables, =k forces k chunks (clamped to chunks of >= 4 steps).  By default the sweep is chunked only while the trials
+// alone leave the chip latency-bound — at most LQG_TRIAL_CHUNK_MAX_WAVES (2048) waves, two per SIMD — into enough chunks
+// to put LQG_TRIAL_CHUNK_WAVES (16384) waves in flight, at most sqrt(2 T) chunks (the minimum of the dependent chain
+// 2 T / k + k).  Measured, one system of m = 8, T = 500, fp32, per-trial sweep in ms, one pass / chunked
+// (scripts/chunk_regime.py): 2^10 trials 0.49 / 0.06, 2^14: 0.50 / 0.11, 2^16 (1024 waves): 0.52 / 0.23, 2^17: 0.55 / 0.44,
+// 2^18 (4096 waves): 0.63 / 0.81, 2^19: 0.93 / 1.5 — the two passes cost ~2x the arithmetic, which only pays while the
+// one-pass sweep is bound by the latency of its dependent steps and not by instruction issue.
 inline int trial_chunks(const lqg_problem* p) {
   if (p->n_trials <= 2 || p->T < 16) return 1;
   // (read per call: a test or a tuning script may change them between launches)
   const char* e1 = getenv("LQG_TRIAL_CHUNKS");
   const char* e2 = getenv("LQG_TRIAL_CHUNK_WAVES");
+  const char* e3 = getenv("LQG_TRIAL_CHUNK_MAX_WAVES");
   const int forced = e1 ? atoi(e1) : -1;
   const long target = e2 ? atol(e2) : 16384L;
+  const long max_waves = e3 ? atol(e3) : 2048L;
   long nc;
   if (forced >= 0) {
     nc = forced;
   } else {
     const long waves = (long)p->n_sys * ((p->n_trials + LQG_BLOCK - 1) / LQG_BLOCK);
+    if (waves > max_waves) return 1;
     nc = (target + waves - 1) / waves;
     const long cap = (long)std::sqrt(2.0 * (double)p->T);
     if (nc > cap) nc = cap;
