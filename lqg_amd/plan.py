@@ -45,6 +45,9 @@ def scan_min_steps(m):
 
 
 def scan_max_systems(m):
+    """(fp64 problems would tolerate twice as many on the GPU timeline — their sequential sweeps are ~1.5x slower, the scans
+    are fp64 either way — but for a throw-away plan the scan route's extra host checks eat the difference: one vector's
+    central differences, 9 systems x 50 trials at m = 4 in fp64: 1.01 ms fused pairs / 1.12 ms scans end to end.)"""
     if SCAN_MAX_SYSTEMS > 0:
         return SCAN_MAX_SYSTEMS
     return int(min(64, max(8, 8 * (m / 4.0) ** 2)))
@@ -55,7 +58,7 @@ def _observed_noise_cond(sub, d):
     the eigenvalues are taken on the host (a batched eigvalsh of 2x2..4x4 blocks costs ~0.3 ms on the GPU, more than the
     evaluation it guards)."""
     import numpy as np
-    V = sub.dynamics.V.detach()[..., :d, :]
+    V = specialize._first(sub.dynamics.V.detach())[..., :d, :]       # (one time slice when the spec is time-invariant)
     VV = (V @ V.transpose(-1, -2)).double().cpu().numpy()
     ev = np.linalg.eigvalsh(VV)
     lo, hi = np.maximum(ev[..., 0], 0.0), ev[..., -1]

@@ -23,4 +23,4 @@ for _ in range(200):
     value_and_grad(x, lqg_amd.BoundedActor, params, method="fd")
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(40)
+st.sort_stats("cumulative").print_stats(40)
