@@ -9,6 +9,11 @@ mkdir -p gpurun_out
 bash scripts/profile_headline.sh ${TAG} f32 > /dev/null 2>&1
 bash scripts/profile_headline.sh ${TAG}64 f64 > /dev/null 2>&1
 bash scripts/profile_m2.sh ${TAG}m2 f32 17 > /dev/null 2>&1
+# PMC record of THIS build first (bench.py reports `roofline.traffic` only from a record carrying the running build's hashes);
+# profiles/ does not travel back from the box, so the record is also left under gpurun_out/ to be copied into profiles/
+python3 scripts/make_pmc_record.py ${TAG} f32 20 > /dev/null 2>&1
+python3 scripts/make_pmc_record.py ${TAG}64 f64 20 > /dev/null 2>&1
+cp profiles/r02_pmc_traffic.json gpurun_out/${TAG}_pmc_traffic.json
 python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 python3 bench_configs.py > gpurun_out/${TAG}_configs.jsonl 2> gpurun_out/${TAG}_configs.err
 python3 bench_grad.py > gpurun_out/${TAG}_grad_f64.jsonl 2> gpurun_out/${TAG}_grad.err
@@ -21,10 +26,13 @@ import csv, glob
 f = glob.glob("gpurun_out/prof_${TAG}_cfg2/**/*kernel_trace.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if "scan" in r["Kernel_Name"] or "k_trial" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "build_rk" in r["Kernel_Name"]][-1]
-seq = rows[idx:]
+starts = [i for i, r in enumerate(rows) if "build_rk" in r["Kernel_Name"]] + [len(rows)]
+evals = [rows[a:b] for a, b in zip(starts[:-1], starts[1:])]
+span = lambda q: int(q[-1]["End_Timestamp"]) - int(q[0]["Start_Timestamp"])
+seq = min(evals, key=span)                      # (the evaluation the profiler disturbed least)
 t0 = int(seq[0]["Start_Timestamp"])
 busy = 0
+print("# %d evaluations traced, spans us: %s" % (len(evals), " ".join("%.0f" % (span(q) / 1e3) for q in evals)))
 print("# one evaluation of config 2 (PointMassBoundedActor, T=500, 65536 trials, fp32): start us, duration us, kernel")
 for r in seq:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
