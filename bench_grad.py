@@ -57,8 +57,19 @@ def eval_workload(args, dev):
     va, ga = gradient.value_and_grad(x, lqg_amd.BoundedActor, p0, method="adjoint")
     vf, gf = gradient.value_and_grad(x, lqg_amd.BoundedActor, p0, method="fd")
     err = max(abs(ga[k] - gf[k]) / max(1.0, abs(gf[k])) for k in p0)
-    for method in ("adjoint", "fd"):
-        sec = timed(lambda: gradient.value_and_grad(x, lqg_amd.BoundedActor, p0, method=method), args.steps, args.warmup)
+    import os
+    # "fd": the default — batched central differences, the whole evaluation replayed as one hipGraph
+    # (lqg_amd/infer/graphed.py); "fd_eager": the same arithmetic launched from Python (LQG_GRAPH=0)
+    for label in ("adjoint", "fd", "fd_eager"):
+        method = "fd" if label.startswith("fd") else label
+        if label == "fd_eager":
+            os.environ["LQG_GRAPH"] = "0"
+        # (a different parameter vector every call: nothing may be cached across evaluations)
+        it = iter(range(10 ** 9))
+        sec = timed(lambda: gradient.value_and_grad(x, lqg_amd.BoundedActor, dict(p0, sigma_target=20.0 + 1e-3 * next(it)),
+                                                    method=method), args.steps, args.warmup)
+        os.environ.pop("LQG_GRAPH", None)
+        method = label
         print(json.dumps({"metric": "value_and_grad_evals_per_s", "value": 1.0 / sec, "unit": "evals/s", "method": method,
                           "ms_per_eval": sec * 1e3, "dtype": "f64", "n_gpus": 1,
                           "config": {"workload": "BoundedActor T=500 x=b=2, 50 trials, 4 parameters, one parameter vector"},

@@ -203,6 +203,15 @@ int lqg_sum_trials(int32_t dtype, const void* ll, int64_t n_sys, int64_t n_trial
  * so that the result is bitwise reproducible run to run (no atomics) */
 size_t lqg_sum_trials_workspace_bytes(int64_t n_sys, int64_t n_trials);
 
+/* Model-zoo setup of lqg/tracking/point_mass.py:113-127 (`point_mass_dynamics_matrices`): per candidate i the zero-order-hold
+ * discretisation (A[i] 3x3, B[i] 3x1; :50-79), the Van Loan process-noise block (:82-110) made positive definite by
+ * eigenvalue clipping at psd_eps (:130-144) and its UPPER Cholesky factor V[i] 3x3 (:123).  fp64, contiguous [n] inputs,
+ * row-major outputs.  Replaces torch.linalg.matrix_exp / eigh / cholesky on 3x3..6x6 matrices (host-synchronising
+ * rocSOLVER calls) when no gradient is asked for. */
+int lqg_point_mass_setup(int64_t n, const double* damping, const double* mass, const double* tau,
+                         const double* action_variability, double dt, double psd_eps, double* A, double* B, double* V,
+                         void* stream);
+
 /* Replaces the per-trial scan of System.simulate [lqg/system.py:106-128] with the standard-normal
  * draws supplied by the caller (the reference draws them from jax.random, :102-105).
  * gains L[B,T,u,b], l[B,T,u] (l.ptr NULL = 0), K[B,T,b,y] as produced by the two calls above;

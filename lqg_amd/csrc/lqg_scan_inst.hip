@@ -1,7 +1,5 @@
 // lqg_scan_inst.hip — host side of the time-parallel system sweeps (lqg_scan.hpp): workspace accounting and the launch
 // sequence  elements -> log2(T) scan levels -> per-step finalisers  for the Riccati, Kalman and moment recursions.
-#include <cstdlib>
-
 #include "lqg_scan.hpp"
 #include "lqg_coop_launch.hpp"
 #include "lqg_launch.hpp"
@@ -130,9 +128,6 @@ hipError_t scan_system_sweeps(const lqg_problem* p, lqg_view Sig, void* workspac
     k.res2 = res[1];
     const size_t lds_gain = (size_t)(12 * mx * mx + 3 * b * u + 3 * u * u + 8) * sizeof(D);
     hipLaunchKernelGGL((scan::k_scan_gains_rk<R>), dim3(2 * T, B), blk, lds_gain, st, k);
-  }
-  if (const char* dbg = getenv("LQG_SCAN_DEBUG_STOP")) {     // developer hook: leave the Kalman scan's buffers intact
-    if (dbg[0] == '1') { *ops_out = const_cast<D*>(k.res2); return hipGetLastError(); }
   }
   // ---- moment recursion: joint system per step, prefix scan over T elements of m x m, operators
   {

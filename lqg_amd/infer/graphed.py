@@ -1,0 +1,168 @@
+"""One objective evaluation as ONE hipGraph.
+
+The inner loop of the reference's inference drivers (lqg/infer/mle.py:17-23, the NUTS transitions of
+lqg/infer/utils.py:18,37-39) evaluates  theta -> sum_n log p(x_n | theta)  (and its gradient) thousands of times on the SAME
+data with the SAME model class.  After round 2's time-parallel kernels one such evaluation is ~0.25 ms of GPU work under
+~0.75 ms of Python: ~30 small torch kernels that build the model matrices from the parameters, the host-side decisions of
+LogLikelihoodPlan, and ~35 kernel launches.  None of that depends on the parameter VALUES, so it is recorded once:
+
+    parameters (a static device tensor)  ->  model constructor  ->  C-ABI log-likelihood entry  ->  lqg_sum_trials
+                                                                                              ->  central differences
+
+is captured into a hipGraph (torch.cuda.CUDAGraph; the ctypes launches of liblqg_hip.so go to the capturing stream like any
+other kernel) and an evaluation becomes: copy the parameters in, replay, read the result.
+
+What makes the capture legal: the zoo constructors are sync-free and copy nothing from the host once their constants are
+cached (lqg_amd/tracking/_build.py); every decision that needs host values — which library, scan path or lane kernels, the
+pattern library — is taken in an EAGER warm-up evaluation of the same shapes and frozen.  What is not captured: a model
+whose constructor synchronises (PointMassBoundedActor: eigh / cholesky error checks), a model that decouples into several
+components (LogLikelihoodPlan merges them; here the joint problem would run), an initialised process group (the all-reduce
+stays outside).  `make()` returns None in those cases and the callers keep the eager path.  LQG_GRAPH=0 disables.
+"""
+import ctypes as C
+import os
+import warnings
+
+import torch
+
+from lqg_amd import _abi, _hip
+from lqg_amd.infer.models import get_model_params
+
+
+class GraphedLogLik:
+    """obj[c] = sum_n log p(x_n | theta[c]) for a FIXED number of parameter vectors, fixed data, fixed model class."""
+
+    def __init__(self, x, model_type, names, n_cand, fixed=None, process_noise=1.0, dt=1.0 / 60, eps=1e-8):
+        if not x.is_cuda:
+            raise _abi.LqgHipError("GraphedLogLik needs cuda data")
+        self.x = x.contiguous()
+        self.model_type, self.names, self.fixed = model_type, list(names), dict(fixed or {})
+        self.pn, self.dt, self.eps = process_noise, dt, eps
+        self.n, self.rows, self.d = self.x.shape
+        self.C, self.P = int(n_cand), len(self.names)
+        self.theta = torch.ones(self.C, self.P, dtype=self.x.dtype, device=self.x.device)      # static input
+        self.out = None                                                                        # static output, fp64 [C]
+        self.graph = None
+        self._keep = None
+
+    # ---- the captured region -------------------------------------------------------------------------------------
+    def _model(self, theta):
+        kw = dict(get_model_params(self.model_type))
+        kw.update(self.fixed)
+        kw.update({k: theta[:, i] for i, k in enumerate(self.names)})
+        return self.model_type(process_noise=self.pn, dt=self.dt, T=self.rows - 1, device=self.x.device,
+                               dtype=self.x.dtype, **kw)
+
+    def _decide(self, model):
+        """Eager, once: everything that needs host values."""
+        from lqg_amd import plan
+        if model.decoupled(self.d, None, eps=self.eps):
+            return False                     # several components: LogLikelihoodPlan's merged / stacked launches are the better path
+        ln = _hip.Launch(model.actor, model.dynamics, d=self.d, n_trials=self.n, eps=self.eps)
+        lib = ln.require_gpu()
+        main = _abi.load()
+        self.use_scan = lib is main and plan.scan_eligible(main, ln, model, self.eps)
+        spl = _hip.specialised_library(ln, model, self.d, check_strategy=not self.use_scan)
+        self.sp_lib = spl
+        return True
+
+    def _loglik(self, model):
+        ln = _hip.Launch(model.actor, model.dynamics, d=self.d, n_trials=self.n, eps=self.eps)
+        lib = ln.require_gpu()
+        ll = ln.empty(self.n)
+        traj = ln.traj(self.x, False)
+        ll_sb = self.n if ln.batched else 0
+        if self.use_scan:
+            nbytes = lib.lqg_scan_workspace_bytes(C.byref(ln.p))
+            fn = C.cast(self.sp_lib.lqg_trial_sweep_sp, C.c_void_p) if (self.sp_lib is not None and self.n > 2) else C.c_void_p(None)
+            entry = lambda *a: lib.lqg_log_likelihood_scan_with(*a, fn)
+        else:
+            sp = self.sp_lib.lqg_log_likelihood_sp if self.sp_lib is not None else None
+            if sp is not None and self.n == 2:            # (the specialised library sweeps two trials in-lane)
+                ln.p.n_trials = 1
+                nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
+                ln.p.n_trials = 2
+            else:
+                nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
+            entry = sp or lib.lqg_log_likelihood
+        ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=ln.device)
+        args = (C.byref(ln.p), traj, C.c_void_p(ll.data_ptr()), ll_sb, 1, C.c_void_p(ws.data_ptr()), nbytes, ln.stream())
+        rc = entry(*args)
+        if rc != 0 and not self.use_scan and entry is not lib.lqg_log_likelihood:
+            rc = lib.lqg_log_likelihood(*args)            # the specialised library refused (checked in the eager warm-up too)
+        _abi.check(rc, "lqg_log_likelihood (graphed)")
+        self._keep = (model, ln, ws, ll)
+        return _hip.sum_trials(ll)                        # fp64 [C]
+
+    def _forward(self):
+        return self._loglik(self._model(self.theta))
+
+    # ---- capture / replay ----------------------------------------------------------------------------------------
+    def capture(self):
+        dev = self.x.device
+        with torch.cuda.device(dev):
+            with torch.no_grad():
+                if not self._decide(self._model(self.theta)):
+                    return False
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):             # warm-up on a side stream (allocator, constant caches, library loads)
+                    for _ in range(2):
+                        self._forward()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.out = self._forward()
+                self.graph = g
+        return True
+
+    def __call__(self, theta):
+        """theta [C, P] (any device / float dtype) -> fp64 [C] on the device (valid until the next call)."""
+        self.theta.copy_(theta, non_blocking=True)
+        self.graph.replay()
+        return self.out
+
+
+class GraphedFiniteDifference(GraphedLogLik):
+    """z [C, P] (log-parameters) -> [C, 1 + P]: objective and its central-difference gradient w.r.t. z, in one graph
+    (the 2P+1 perturbed parameter vectors of every z are candidates of ONE launch)."""
+
+    def __init__(self, x, model_type, names, n_points, h=1e-4, **kw):
+        P = len(names)
+        super().__init__(x, model_type, names, n_points * (2 * P + 1), **kw)
+        self.K, self.h = int(n_points), float(h)
+        self.z = torch.zeros(self.K, P, dtype=torch.float64, device=x.device)                  # static input
+        self._eye = self.h * torch.eye(P, dtype=torch.float64, device=x.device)
+
+    def _forward(self):
+        K, P = self.K, self.P
+        z = self.z
+        Z = torch.cat([z[:, None, :], z[:, None, :] + self._eye, z[:, None, :] - self._eye], dim=1).reshape(K * (2 * P + 1), P)
+        f = self._loglik(self._model(torch.exp(Z).to(self.x.dtype))).reshape(K, 2 * P + 1)
+        return torch.cat([f[:, :1], (f[:, 1:P + 1] - f[:, P + 1:]) / (2 * self.h)], dim=1)
+
+    def __call__(self, z):
+        self.z.copy_(z, non_blocking=True)
+        self.graph.replay()
+        return self.out
+
+
+_warned = set()
+
+
+def make(cls, x, model_type, names, n, group=None, **kw):
+    """A captured evaluator, or None when this evaluation cannot be captured (the caller keeps its eager path)."""
+    if os.environ.get("LQG_GRAPH") == "0" or group is not None or not x.is_cuda:
+        return None
+    try:
+        ev = cls(x, model_type, names, n, **kw)
+        return ev if ev.capture() else None
+    except Exception as e:                       # a constructor that synchronises, an allocator / capture restriction, ...
+        torch.cuda.synchronize()
+        key = (getattr(model_type, "__name__", str(model_type)), type(e).__name__)
+        if key not in _warned:
+            _warned.add(key)
+            warnings.warn(f"lqg_amd: {key[0]} objective not captured into a hipGraph ({type(e).__name__}: {str(e)[:160]}); "
+                          "using the eager path")
+        return None

@@ -52,6 +52,20 @@ class Potential:
             return ll.sum(-1)
         return ld.all_reduce_sum(_hip.sum_trials(ll), group=self.group)
 
+    def _graphed(self, z, C):
+        """Captured finite-difference evaluator for up to the largest number of positions asked so far (fewer are padded);
+        None when the evaluation cannot be captured or a process group shards the trials."""
+        import os
+        if self.group is not None or not z.is_cuda or os.environ.get("LQG_GRAPH") == "0":
+            return None
+        cur = getattr(self, "_gev", None)
+        if cur is None or (cur is not False and cur.K < C):
+            from lqg_amd.infer import graphed
+            ev = graphed.make(graphed.GraphedFiniteDifference, self.x, self.model_type, self.names, C, h=self.h,
+                              fixed=self.fixed, process_noise=self.pn, dt=self.dt)
+            self._gev = ev if ev is not None else False
+        return self._gev or None
+
     def _extra(self, z):                                  # prior + Jacobian, [C]
         theta = torch.exp(z)
         out = z.sum(-1)
@@ -72,6 +86,12 @@ class Potential:
             val.sum().backward()
             both = ld.all_reduce_sum(torch.cat([val.detach()[:, None], zz.grad], dim=1), group=self.group)
             return both[:, 0] + ex.detach(), both[:, 1:] + ze.grad
+        ev = self._graphed(z, C)
+        if ev is not None:          # the 2P+1 perturbed vectors of every position, model construction, sweeps, differences:
+            zp = z if C == ev.K else torch.cat([z, z[:1].expand(ev.K - C, P)])     # one hipGraph replay (infer/graphed.py)
+            out = ev(zp)[:C]
+            self.evaluations += C * (2 * P + 1)
+            return out[:, 0] + ex.detach(), out[:, 1:] + ze.grad
         eye = self.h * torch.eye(P, dtype=torch.float64, device=z.device)
         Z = torch.cat([z[:, None, :], z[:, None, :] + eye, z[:, None, :] - eye], dim=1).reshape(C * (2 * P + 1), P)
         with torch.no_grad():

@@ -23,9 +23,29 @@ def resolve(device, dtype, *params):
     return device, dtype
 
 
+# Python scalars and constant matrices as device tensors, kept per (value, dtype, device): a host-to-device copy per
+# constant per constructor call costs ~10 us each, and is not allowed at all while a hipGraph is being captured
+# (lqg_amd/infer/graphed.py captures the whole constructor).  Entries are never handed out for writing: scalars are only
+# read inside the constructors, constant matrices are cloned.
+_CACHE_MAX = 512
+_scalar_cache, _const_cache = {}, {}
+
+
+def _scalar(v, dtype, device):
+    if isinstance(v, torch.Tensor):
+        return torch.as_tensor(v, dtype=dtype, device=device)
+    key = (float(v), dtype, str(device))
+    t = _scalar_cache.get(key)
+    if t is None:
+        if len(_scalar_cache) >= _CACHE_MAX:
+            _scalar_cache.clear()
+        t = _scalar_cache[key] = torch.as_tensor(float(v), dtype=dtype, device=device)
+    return t
+
+
 def params(device, dtype, *values):
     """Scalars / [B] tensors -> list of tensors broadcast to a common shape () or [B]."""
-    ts = [torch.as_tensor(v, dtype=dtype, device=device) for v in values]
+    ts = [_scalar(v, dtype, device) for v in values]
     shape = torch.broadcast_shapes(*[t.shape for t in ts])
     if len(shape) > 1:
         raise ValueError(f"model parameters must be scalars or 1-D candidate vectors, got shape {tuple(shape)}")
@@ -34,8 +54,24 @@ def params(device, dtype, *values):
 
 def const(rows, lead, device, dtype):
     """Constant matrix from nested lists, broadcast over the candidate axis (stride 0)."""
-    m = torch.tensor(rows, dtype=dtype, device=device)
+    key = (repr(rows), dtype, str(device))
+    master = _const_cache.get(key)
+    if master is None:
+        if len(_const_cache) >= _CACHE_MAX:
+            _const_cache.clear()
+        master = _const_cache[key] = torch.tensor(rows, dtype=dtype, device=device)
+    m = master.clone()
     return m.expand(*lead, *m.shape) if lead else m
+
+
+def take(t, idx, axis):
+    """t[..., idx, :] (axis = -2) or t[..., :, idx] (axis = -1) for a Python list of indices: index_select with a cached
+    device index tensor (indexing with the list itself builds the index on the host and copies it over on every call)."""
+    key = ("idx", tuple(idx), str(t.device))
+    i = _const_cache.get(key)
+    if i is None:
+        i = _const_cache[key] = torch.tensor(list(idx), dtype=torch.long, device=t.device)
+    return torch.index_select(t, axis, i)
 
 
 def diag(entries):

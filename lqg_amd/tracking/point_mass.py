@@ -37,9 +37,35 @@ def make_psd(M, eps=1e-6):
     return U @ torch.diag_embed(w.clamp(min=eps)) @ U.transpose(-1, -2)
 
 
+def _setup_on_gpu(damping, m, tau, action_variability, dt, eps=1e-6):
+    """The same matrices from ONE kernel (csrc/lqg_setup.hip, `lqg_point_mass_setup`): no rocSOLVER call, no host
+    synchronisation, capturable into a hipGraph.  No-grad route only."""
+    import ctypes as C
+    from lqg_amd import _abi
+    lib = _abi.load()
+    lead = damping.shape
+    n = max(1, damping.numel())
+    vec = lambda t: t.to(torch.float64).expand(lead).reshape(n).contiguous()
+    dmp, mm, ta, av = vec(damping), vec(m), vec(tau), vec(action_variability)
+    A = torch.empty(n, 3, 3, dtype=torch.float64, device=damping.device)
+    B = torch.empty(n, 3, 1, dtype=torch.float64, device=damping.device)
+    V = torch.empty(n, 3, 3, dtype=torch.float64, device=damping.device)
+    with torch.cuda.device(damping.device):
+        _abi.check(lib.lqg_point_mass_setup(n, dmp.data_ptr(), mm.data_ptr(), ta.data_ptr(), av.data_ptr(), float(dt), float(eps),
+                                            A.data_ptr(), B.data_ptr(), V.data_ptr(),
+                                            C.c_void_p(torch.cuda.current_stream(damping.device).cuda_stream)),
+                   "lqg_point_mass_setup")
+    shape = tuple(lead)
+    return A.reshape(shape + (3, 3)), B.reshape(shape + (3, 1)), V.reshape(shape + (3, 3))
+
+
 def point_mass_dynamics_matrices(damping, m, tau, action_variability, dt):
     """Continuous point mass + muscle filter, discretised                      point_mass.py:113-127
     (setup arithmetic is done in float64 on the host device of the parameters and cast by the caller)."""
+    import os
+    if damping.is_cuda and not any(t.requires_grad for t in (damping, m, tau, action_variability)) \
+            and isinstance(dt, float) and os.environ.get("LQG_SETUP_KERNEL") != "0":
+        return _setup_on_gpu(damping, m, tau, action_variability, dt)
     z, o = torch.zeros_like(damping), torch.ones_like(damping)
     A_c = torch.stack([torch.stack([z, o, z], -1), torch.stack([z, -damping / m, o / m], -1),
                        torch.stack([z, z, -o / tau], -1)], -2)

@@ -39,11 +39,11 @@ class SubjectiveActor(System):
         Q = bd.block_diag(*[c([[1., -1., 0.], [-1., 1., 0.], [0., 0., 0.]])] * dim)
         R = bd.diag([ac] * dim)
         dims = swap_dims(A.shape[-1], dim)                                      # subjective.py:38-44
-        A = A[..., dims, :][..., :, dims]
-        B = B[..., dims, :]
-        V = V[..., dims, :]
-        F = F[..., :, dims]
-        Q = Q[..., dims, :][..., :, dims]
+        A = bd.take(bd.take(A, dims, -2), dims, -1)
+        B = bd.take(B, dims, -2)
+        V = bd.take(V, dims, -2)
+        F = bd.take(F, dims, -1)
+        Q = bd.take(bd.take(Q, dims, -2), dims, -1)
         act = Actor(A=A, B=B, F=F, V=V, W=W, Q=Q, R=R, T=T)
         super().__init__(actor=act, dynamics=dyn)
         self._zoo_structure = dict(dim=dim)

@@ -144,3 +144,26 @@ def test_time_parallel_path_on_random_dense_systems(oracle_lib, case, monkeypatc
     mu, Sig = _hip.conditional_moments(sys_.actor, sys_.dynamics, xt, Sigma0=S0t)
     assert np.abs(np_(mu) - ref_mu).max() < 1e-8 * max(1.0, np.abs(ref_mu).max())
     assert np.abs(np_(Sig) - ref_Sig).max() < 1e-8 * max(1.0, np.abs(ref_Sig).max())
+
+
+def test_point_mass_setup_kernel_equals_the_torch_construction(monkeypatch):
+    """csrc/lqg_setup.hip (`lqg_point_mass_setup`: matrix exponentials, Van Loan block, eigenvalue clipping, upper Cholesky in
+    one kernel) against the torch.linalg construction of lqg_amd/tracking/point_mass.py (the reference's own sequence of
+    operations, point_mass.py:50-144) over a wide parameter range; and the no-grad / grad routes give the same model."""
+    import lqg_amd
+    g = torch.Generator(device="cpu").manual_seed(5)
+    B = 300
+    u = lambda lo, hi: torch.exp(torch.rand(B, generator=g, dtype=torch.float64) * (np.log(hi) - np.log(lo)) + np.log(lo)).cuda()
+    kw = dict(damping=u(0.02, 5.0), m=u(0.2, 5.0), tau=u(0.0015, 0.5), action_variability=u(1e-3, 2.0),
+              sigma_target=u(1.0, 30.0), sigma_cursor=u(0.5, 10.0), action_cost=u(1e-3, 1.0))
+    a = lqg_amd.PointMassBoundedActor(T=10, device="cuda", dtype=torch.float64, **kw)
+    monkeypatch.setenv("LQG_SETUP_KERNEL", "0")
+    b = lqg_amd.PointMassBoundedActor(T=10, device="cuda", dtype=torch.float64, **kw)
+    for f in ("A", "B", "V"):
+        x, y = getattr(a.actor, f)[:, 0], getattr(b.actor, f)[:, 0]
+        # (the Van Loan block passes through exp(+dt / tau) ~ 6e4 at tau = 0.0015: both routes carry ~1e-11 of cancellation)
+        scale = y.abs().amax((-1, -2), keepdim=True).clamp_min(1e-300)          # per candidate
+        assert float(((x - y).abs() / scale).max()) < 1e-10, f
+    # V V' is what the path consumes: relative agreement of the whole covariance
+    VVa, VVb = a.actor.V @ a.actor.V.transpose(-1, -2), b.actor.V @ b.actor.V.transpose(-1, -2)
+    assert float(((VVa - VVb).abs().amax((-1, -2)) / VVb.abs().amax((-1, -2))).max()) < 1e-10
