@@ -183,3 +183,54 @@ def test_shared_params_objective_on_conditions_x_trials_data(oracle_lib):
     e2[2] = h
     fd_s = (f(sig + e2, 0.4) - f(sig - e2, 0.4)) / (2 * h)
     assert abs(float(sg.grad[2]) / fd_s - 1) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,params", [
+    ("BoundedActor", dict(action_variability=0.5, sigma_target=6.0, sigma_cursor=3.0, action_cost=0.1)),
+    ("SubjectiveActor", dict(action_cost=0.2, action_variability=0.5, subj_noise=1.0, subj_vel_noise=0.5, sigma_target=6.0,
+                             sigma_cursor=3.0)),
+    ("PointMassBoundedActor", dict(action_variability=0.5, sigma_target=6.0, sigma_cursor=3.0, action_cost=0.1)),
+    ("RelativeObservationBoundedActor", dict(action_variability=0.5, sigma=4.0, action_cost=0.3))])
+def test_graphed_evaluation_equals_the_eager_one(model, params, monkeypatch):
+    """lqg_amd/infer/graphed.py: model construction + log-likelihood + central differences captured once as a hipGraph and
+    replayed with new parameters — same value and gradient as launching every piece from Python, for every replay."""
+    import lqg_amd
+    from lqg_amd.infer import graphed
+    from lqg_amd.infer.gradient import value_and_grad
+    cls = getattr(lqg_amd, model)
+    truth = cls(T=300, device="cuda", dtype=torch.float64)
+    with torch.no_grad():
+        x = truth.simulate(3, n=40)[..., :2].contiguous()
+    x = torch.cat([x, x[:, -1:]], dim=1)                      # lqg_model's convention: T rows = T - 1 steps
+    names = list(params)
+    ev = graphed.make(graphed.GraphedFiniteDifference, x, cls, names, 1, h=1e-4)
+    assert ev is not None, "this zoo model must be capturable"
+    for scale in (1.0, 1.3, 0.8):
+        p = {k: v * scale for k, v in params.items()}
+        monkeypatch.setenv("LQG_GRAPH", "0")
+        v0, g0 = value_and_grad(x, cls, p, method="fd")
+        monkeypatch.setenv("LQG_GRAPH", "1")
+        v1, g1 = value_and_grad(x, cls, p, method="fd")
+        assert abs(v1 / v0 - 1) < 1e-12
+        assert all(abs(g1[k] - g0[k]) < 1e-7 * max(abs(g0[k]), 1e-3 * max(abs(v) for v in g0.values())) for k in g0), (g0, g1)
+
+
+@pytest.mark.gpu
+def test_nuts_potential_uses_the_graph_and_agrees_with_eager(monkeypatch):
+    import lqg_amd
+    from lqg_amd.infer.mcmc import Potential
+    truth = lqg_amd.BoundedActor(T=200, device="cuda", dtype=torch.float64)
+    with torch.no_grad():
+        x = truth.simulate(5, n=30)
+    names = ["action_variability", "sigma_target", "sigma_cursor", "action_cost"]
+    z = torch.log(torch.tensor([[0.5, 6.0, 3.0, 0.1], [0.4, 8.0, 2.0, 0.2], [0.7, 5.0, 4.0, 0.05]], dtype=torch.float64, device="cuda"))
+    from lqg_amd.infer import prior
+    pot = Potential(x, lqg_amd.BoundedActor, names, {}, 1.0, 1.0 / 60, prior.default_prior)
+    lp, g = pot(z)
+    assert getattr(pot, "_gev", None) not in (None, False) and pot._gev.K == 3
+    lp2, g2 = pot(z[:2])                                       # fewer positions than captured: padded, same graph
+    assert torch.allclose(lp2, lp[:2], rtol=1e-13) and torch.allclose(g2, g[:2], rtol=1e-9, atol=1e-9)
+    monkeypatch.setenv("LQG_GRAPH", "0")
+    lp0, g0 = Potential(x, lqg_amd.BoundedActor, names, {}, 1.0, 1.0 / 60, prior.default_prior)(z)
+    assert torch.allclose(lp, lp0, rtol=1e-12) and torch.allclose(g, g0, rtol=1e-6, atol=1e-6)
