@@ -14,8 +14,10 @@ other kernel) and an evaluation becomes: copy the parameters in, replay, read th
 
 What makes the capture legal: the zoo constructors are sync-free and copy nothing from the host once their constants are
 cached (lqg_amd/tracking/_build.py); every decision that needs host values — which library, scan path or lane kernels, the
-pattern library — is taken in an EAGER warm-up evaluation of the same shapes and frozen.  What is not captured: a model
-whose constructor synchronises (PointMassBoundedActor: eigh / cholesky error checks), a model that decouples into several
+pattern library — is taken in an EAGER warm-up evaluation of the same shapes and frozen (the time-parallel scans are taken
+for up to twice the systems of the eager rule in fp64: their host-side checks are paid once here).  PointMassBoundedActor's
+discretisation runs as one kernel (csrc/lqg_setup.hip) instead of host-synchronising torch.linalg calls.  What is not
+captured: a user model whose constructor synchronises or copies from the host, a model that decouples into several
 components (LogLikelihoodPlan merges them; here the joint problem would run), an initialised process group (the all-reduce
 stays outside).  `make()` returns None in those cases and the callers keep the eager path.  LQG_GRAPH=0 disables.
 """
@@ -61,7 +63,8 @@ class GraphedLogLik:
         ln = _hip.Launch(model.actor, model.dynamics, d=self.d, n_trials=self.n, eps=self.eps)
         lib = ln.require_gpu()
         main = _abi.load()
-        self.use_scan = lib is main and plan.scan_eligible(main, ln, model, self.eps)
+        self.use_scan = lib is main and plan.scan_eligible(main, ln, model, self.eps,
+                                                           systems_scale=2 if self.x.dtype == torch.float64 else 1)
         spl = _hip.specialised_library(ln, model, self.d, check_strategy=not self.use_scan)
         self.sp_lib = spl
         return True

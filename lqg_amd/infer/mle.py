@@ -4,7 +4,8 @@ log-likelihood of positive-constrained parameters).
 The reference differentiates the likelihood with JAX reverse mode.  Two gradient methods are provided:
 method="fd" (default): CENTRAL FINITE DIFFERENCES in the unconstrained (log) space evaluated as ONE batched candidate
 sweep of 2P+1 systems through the fused HIP path — for ONE parameter vector this is the faster of the two on MI355X
-(all 2P+1 candidates x trials run in parallel: 1.6 ms per evaluation at T=500, 50 trials, P=4);
+(all 2P+1 candidates x trials run in parallel; the whole evaluation is one hipGraph replay, lqg_amd/infer/graphed.py:
+0.30 ms per evaluation at T=500, 50 trials, P=4, and the Adam loop never synchronises with the host);
 method="adjoint": the reverse-mode HIP sweep behind torch.autograd (lqg_amd/grad.py; 2.8 ms per evaluation on the same
 workload — one lane walks one trial's 500 steps four times — but exact, and P-independent / 3x cheaper per gradient when
 many parameter vectors are differentiated at once).  fp64 is used throughout.  `candidate_search` is the
@@ -35,9 +36,13 @@ def max_likelihood(x, model=BoundedActor, process_noise=1.0, dt=1.0 / 60, steps=
     m1, m2 = torch.zeros_like(z), torch.zeros_like(z)
     b1, b2, eps = 0.9, 0.999, 1e-8
     eye = torch.eye(P, dtype=torch.float64, device=x.device)
-    losses = torch.empty(steps, dtype=torch.float64)
+    losses = torch.empty(steps, dtype=torch.float64, device=x.device)     # (kept on the device: no synchronisation per step)
     if method not in ("fd", "adjoint"):
         raise ValueError(f"method must be 'fd' or 'adjoint', got {method!r}")
+    ev = None
+    if method == "fd":            # the whole evaluation as one hipGraph replay when it can be captured (infer/graphed.py)
+        from lqg_amd.infer.gradient import _graphed_fd
+        ev = _graphed_fd(x, model, names, fixed, process_noise, dt, fd_step, group)
     for it in range(steps):
         if method == "adjoint":
             from lqg_amd.infer.gradient import value_and_grad
@@ -45,6 +50,9 @@ def max_likelihood(x, model=BoundedActor, process_noise=1.0, dt=1.0 / 60, steps=
             val, g = value_and_grad(x, model, theta, process_noise=process_noise, dt=dt, group=group, **fixed)
             loss = torch.tensor(-val, dtype=torch.float64, device=x.device)
             grad = -torch.tensor([g[k] * theta[k] for k in names], dtype=torch.float64, device=x.device)   # d/d log
+        elif ev is not None:
+            out = ev(z[None])                                 # [1, 1 + P]: objective, d objective / d z
+            loss, grad = -out[0, 0].clone(), -out[0, 1:].clone()
         else:
             # one sweep over 2P+1 candidates: z, z + h e_i, z - h e_i
             Z = torch.cat([z[None], z[None] + fd_step * eye, z[None] - fd_step * eye])
@@ -56,5 +64,5 @@ def max_likelihood(x, model=BoundedActor, process_noise=1.0, dt=1.0 / 60, steps=
         m1 = b1 * m1 + (1 - b1) * grad
         m2 = b2 * m2 + (1 - b2) * grad * grad
         z = z - step_size * (m1 / (1 - b1 ** (it + 1))) / (torch.sqrt(m2 / (1 - b2 ** (it + 1))) + eps)
-    params = {k: float(torch.exp(z[i])) for i, k in enumerate(names)}
-    return params, losses
+    params = {k: float(v) for k, v in zip(names, torch.exp(z).cpu())}
+    return params, losses.cpu()
