@@ -131,10 +131,11 @@ class GraphedFiniteDifference(GraphedLogLik):
     """z [C, P] (log-parameters) -> [C, 1 + P]: objective and its central-difference gradient w.r.t. z, in one graph
     (the 2P+1 perturbed parameter vectors of every z are candidates of ONE launch)."""
 
-    def __init__(self, x, model_type, names, n_points, h=1e-4, **kw):
+    def __init__(self, x, model_type, names, n_points, h=1e-4, extra=None, **kw):
         P = len(names)
         super().__init__(x, model_type, names, n_points * (2 * P + 1), **kw)
         self.K, self.h = int(n_points), float(h)
+        self.extra = extra               # optional z [K, P] -> (value [K], gradient [K, P]) added to the result (prior terms)
         self.z = torch.zeros(self.K, P, dtype=torch.float64, device=x.device)                  # static input
         self._eye = self.h * torch.eye(P, dtype=torch.float64, device=x.device)
 
@@ -143,7 +144,11 @@ class GraphedFiniteDifference(GraphedLogLik):
         z = self.z
         Z = torch.cat([z[:, None, :], z[:, None, :] + self._eye, z[:, None, :] - self._eye], dim=1).reshape(K * (2 * P + 1), P)
         f = self._loglik(self._model(torch.exp(Z).to(self.x.dtype))).reshape(K, 2 * P + 1)
-        return torch.cat([f[:, :1], (f[:, 1:P + 1] - f[:, P + 1:]) / (2 * self.h)], dim=1)
+        out = torch.cat([f[:, :1], (f[:, 1:P + 1] - f[:, P + 1:]) / (2 * self.h)], dim=1)
+        if self.extra is not None:
+            ev, eg = self.extra(z)
+            out = out + torch.cat([ev[:, None], eg], dim=1)
+        return out
 
     def __call__(self, z):
         self.z.copy_(z, non_blocking=True)

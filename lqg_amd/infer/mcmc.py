@@ -62,7 +62,7 @@ class Potential:
         if cur is None or (cur is not False and cur.K < C):
             from lqg_amd.infer import graphed
             ev = graphed.make(graphed.GraphedFiniteDifference, self.x, self.model_type, self.names, C, h=self.h,
-                              fixed=self.fixed, process_noise=self.pn, dt=self.dt)
+                              fixed=self.fixed, process_noise=self.pn, dt=self.dt, extra=self.extra_and_grad)
             self._gev = ev if ev is not None else False
         return self._gev or None
 
@@ -73,30 +73,48 @@ class Potential:
             out = out + log_prior(k, theta[:, i], self.prior)
         return out
 
+    def extra_and_grad(self, z):
+        """_extra(z) and its gradient in closed form (z = log theta): lognormal(mu, s): -z - (z - mu)^2 / (2 s^2);
+        halfnormal(s): -exp(2 z) / (2 s^2); Jacobian: + z.  Pure elementwise torch ops (capturable in the hipGraph)."""
+        c = self.__dict__.get("_prior_consts")
+        if c is None or c[0].device != z.device:
+            ln = torch.tensor([1.0 if self.prior[k][0] == "lognormal" else 0.0 for k in self.names], dtype=torch.float64)
+            mu = torch.tensor([float(self.prior[k][1]) if self.prior[k][0] == "lognormal" else 0.0 for k in self.names], dtype=torch.float64)
+            i2 = torch.tensor([1.0 / float(self.prior[k][2 if self.prior[k][0] == "lognormal" else 1]) ** 2 for k in self.names],
+                              dtype=torch.float64)
+            for k in self.names:
+                if self.prior[k][0] not in ("lognormal", "halfnormal"):
+                    raise ValueError(f"unknown prior family {self.prior[k][0]!r} for {k}")
+            c = self._prior_consts = tuple(t.to(z.device) for t in (ln, mu, i2))
+        ln, mu, i2 = c
+        e2 = torch.exp(2.0 * z)
+        val = z + ln * (-z - 0.5 * (z - mu) ** 2 * i2) + (1.0 - ln) * (-0.5 * e2 * i2)
+        grad = 1.0 + ln * (-1.0 - (z - mu) * i2) + (1.0 - ln) * (-e2 * i2)
+        return val.sum(-1), grad
+
     def __call__(self, z):
         from lqg_amd import dist as ld
         z = z.to(torch.float64)
         C, P = z.shape
-        ze = z.clone().requires_grad_(True)               # prior + Jacobian: analytic, through a tiny autograd graph
-        ex = self._extra(ze)
-        ex.sum().backward()
+        if self.method == "fd":
+            ev = self._graphed(z, C)
+            if ev is not None:      # the 2P+1 perturbed vectors of every position, model construction, sweeps, differences,
+                zp = z if C == ev.K else torch.cat([z, z[:1].expand(ev.K - C, P)])     # prior: ONE hipGraph replay
+                out = ev(zp)[:C].clone()                                                 # (infer/graphed.py; the graph owns its output)
+                self.evaluations += C * (2 * P + 1)
+                return out[:, 0], out[:, 1:]
+        ex, eg = self.extra_and_grad(z)
         if self.method == "adjoint":
             zz = z.clone().requires_grad_(True)
             val = self._loglik(torch.exp(zz))             # this rank's trials
             val.sum().backward()
             both = ld.all_reduce_sum(torch.cat([val.detach()[:, None], zz.grad], dim=1), group=self.group)
-            return both[:, 0] + ex.detach(), both[:, 1:] + ze.grad
-        ev = self._graphed(z, C)
-        if ev is not None:          # the 2P+1 perturbed vectors of every position, model construction, sweeps, differences:
-            zp = z if C == ev.K else torch.cat([z, z[:1].expand(ev.K - C, P)])     # one hipGraph replay (infer/graphed.py)
-            out = ev(zp)[:C]
-            self.evaluations += C * (2 * P + 1)
-            return out[:, 0] + ex.detach(), out[:, 1:] + ze.grad
+            return both[:, 0] + ex, both[:, 1:] + eg
         eye = self.h * torch.eye(P, dtype=torch.float64, device=z.device)
         Z = torch.cat([z[:, None, :], z[:, None, :] + eye, z[:, None, :] - eye], dim=1).reshape(C * (2 * P + 1), P)
         with torch.no_grad():
             f = self._loglik(torch.exp(Z)).reshape(C, 2 * P + 1)
-        return f[:, 0] + ex.detach(), (f[:, 1:P + 1] - f[:, P + 1:]) / (2 * self.h) + ze.grad
+        return f[:, 0] + ex, (f[:, 1:P + 1] - f[:, P + 1:]) / (2 * self.h) + eg
 
 
 def _finite(v):

@@ -52,6 +52,22 @@ def test_nuts_driver_samples_a_known_gaussian():
     assert all(abs(v["r_hat"] - 1) < 0.1 for v in out.summary().values())
 
 
+def test_prior_and_jacobian_gradient_in_closed_form():
+    """Potential.extra_and_grad (elementwise, capturable) against autograd through Potential._extra."""
+    import lqg_amd
+    from lqg_amd.infer import prior
+    from lqg_amd.infer.mcmc import Potential
+    names = ["action_variability", "sigma_target", "sigma_cursor", "action_cost"]
+    pd = dict(prior.default_prior)
+    pd["action_cost"] = ("halfnormal", 0.7)
+    pot = Potential(torch.zeros(2, 5, 2), lqg_amd.BoundedActor, names, {}, 1.0, 1.0 / 60, pd)
+    z = torch.randn(6, 4, dtype=torch.float64, generator=torch.Generator().manual_seed(0)).requires_grad_(True)
+    ex = pot._extra(z)
+    ex.sum().backward()
+    val, grad = pot.extra_and_grad(z.detach())
+    assert torch.allclose(val, ex.detach(), rtol=1e-13, atol=1e-13) and torch.allclose(grad, z.grad, rtol=1e-12, atol=1e-13)
+
+
 def test_prior_helpers():
     p = sample_from_prior(lqg_amd.BoundedActor, seed=1)
     assert set(p) == {"action_cost", "sigma_target", "action_variability", "sigma_cursor"}
