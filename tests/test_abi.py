@@ -81,6 +81,12 @@ def test_argument_errors_do_not_launch(lib):
     assert b"actor.A" in lib.lqg_last_error()
 
 
+def test_setup_entry_checks_its_arguments_before_launching(lib):
+    assert lib.lqg_point_mass_setup(-1, None, None, None, None, 1.0 / 60, 1e-6, None, None, None, None) == -3
+    assert lib.lqg_point_mass_setup(4, None, None, None, None, 1.0 / 60, 1e-6, None, None, None, None) == -1
+    assert lib.lqg_point_mass_setup(0, None, None, None, None, 1.0 / 60, 1e-6, None, None, None, None) == 0
+
+
 def test_dims_supported_lists_the_baseline_configs(lib):
     ok = [(2, 2, 1, 2, 2), (2, 2, 1, 1, 2), (2, 3, 1, 2, 2), (4, 6, 2, 4, 4), (4, 4, 1, 3, 2), (4, 4, 1, 3, 4),
           (4, 4, 2, 4, 4), (10, 10, 2, 4, 4)]
