@@ -87,12 +87,18 @@ LQG_DEV D dotn(const D* a, int as, const D* b, int bs, D acc) {
 // and the loads of a dot product are in flight together.  The linear solve M^-1 [A1 | C1] is Gauss-Jordan with partial
 // pivoting where EVERY lane finds the pivot itself from N broadcast LDS reads (no cross-lane reduction) and the step
 // reads the old matrix from one LDS buffer and writes the new one to another: one fence per column.
-template <int N, int NT>
-__global__ void __launch_bounds__(NT) k_scan_level(const Seg s0, const Seg s1) {
+// EPB elements share one 256-thread workgroup, NT lanes each (sub-wave for small windows): one element per 64-lane workgroup
+// left 48 of 64 lanes idle at n = 4 and made a level of S systems S x T single-wave workgroups — 27 us per level at 32
+// systems against 4.7 us at one (the slope of ~10 us per system of scripts/small_batch.py).
+template <int N, int NT, int EPB>
+__global__ void __launch_bounds__(NT * EPB) k_scan_level(const Seg s0, const Seg s1) {
   constexpr int NN = N * N, W = 3 * N;
+  constexpr int LDS_PER = 14 * NN + 8;
   extern __shared__ double lqg_coop_smem[];
-  D* sm = lqg_coop_smem;
-  int k = blockIdx.x;
+  const int sub = (int)threadIdx.x / NT, tid = (int)threadIdx.x - sub * NT;
+  D* sm = lqg_coop_smem + sub * LDS_PER;
+  int k = (int)blockIdx.x * EPB + sub;
+  const bool valid = k < s0.len + s1.len;
   const bool second = k >= s0.len;
   if (second) k -= s0.len;
   const D* in = second ? s1.in : s0.in;
@@ -100,21 +106,22 @@ __global__ void __launch_bounds__(NT) k_scan_level(const Seg s0, const Seg s1) {
   const int len = second ? s1.len : s0.len, d = second ? s1.d : s0.d, left = second ? s1.left : s0.left;
   const long sys = blockIdx.y;
   constexpr long es = 3L * NN;
-  const D* ek = in + (sys * len + k) * es;
-  D* eo = out + (sys * len + k) * es;
-  if (k < d) {
-    each_t<NT>(3 * NN, [&](int e) { eo[e] = ek[e]; });
-    return;
-  }
-  const D* ep = in + (sys * len + k - d) * es;
+  const bool copy = valid && k < d, comb = valid && k >= d;
+  const D* ek = in + (sys * len + (valid ? k : 0)) * es;
+  D* eo = out + (sys * len + (valid ? k : 0)) * es;
+  auto each = [&](int n, auto f) {
+    for (int e = tid; e < n; e += NT) f(e);
+  };
+  if (copy) each(3 * NN, [&](int e) { eo[e] = ek[e]; });
+  const D* ep = in + (sys * len + (comb ? k - d : 0)) * es;
   const D* e1 = left ? ek : ep;        // the window that comes FIRST in time
   const D* e2 = left ? ep : ek;
   D *A1 = sm, *C1 = A1 + NN, *J1 = C1 + NN, *A2 = J1 + NN, *C2 = A2 + NN, *J2 = C2 + NN, *Wa = J2 + NN, *Wb = Wa + 3 * NN,
     *T1 = Wb + 3 * NN, *U = T1 + NN;
-  each_t<NT>(3 * NN, [&](int e) { A1[e] = e1[e]; A2[e] = e2[e]; });     // (A, C, J are contiguous in both)
+  if (comb) each(3 * NN, [&](int e) { A1[e] = e1[e]; A2[e] = e2[e]; });     // (A, C, J are contiguous in both)
   __syncthreads();
   // Wa = [ I + C1 J2 | A1 | C1 ]
-  each_t<NT>(NN, [&](int e) {
+  if (comb) each(NN, [&](int e) {
     const int i = e / N, j = e - i * N;
     Wa[i * W + j] = dotn<N>(C1 + i * N, 1, J2 + j, N, (i == j) ? 1.0 : 0.0);
     Wa[i * W + N + j] = A1[e];
@@ -123,25 +130,27 @@ __global__ void __launch_bounds__(NT) k_scan_level(const Seg s0, const Seg s1) {
   __syncthreads();
   D *src = Wa, *dst = Wb;
   LQG_UNROLL for (int c = 0; c < N; ++c) {
-    D best = fabs(src[c * W + c]);
-    int p = c;
-    LQG_UNROLL for (int r = c + 1; r < N; ++r) {
-      const D v = fabs(src[r * W + c]);
-      if (v > best) { best = v; p = r; }
-    }
-    const D pinv = 1.0 / src[p * W + c];
-    // rows c and p change places; columns <= c are never read again
-    constexpr int PER = (N * W + NT - 1) / NT;
-    LQG_UNROLL for (int q = 0; q < PER; ++q) {
-      const int e = (int)threadIdx.x + q * NT;
-      const int i = e / W, j = e - i * W;
-      if (e < N * W && j > c) {
-        const D piv = src[p * W + j] * pinv;
-        if (i == c) {
-          dst[e] = piv;
-        } else {
-          const int row = (i == p) ? c : i;
-          dst[e] = fma(-src[row * W + c], piv, src[row * W + j]);
+    if (comb) {
+      D best = fabs(src[c * W + c]);
+      int p = c;
+      LQG_UNROLL for (int r = c + 1; r < N; ++r) {
+        const D v = fabs(src[r * W + c]);
+        if (v > best) { best = v; p = r; }
+      }
+      const D pinv = 1.0 / src[p * W + c];
+      // rows c and p change places; columns <= c are never read again
+      constexpr int PER = (N * W + NT - 1) / NT;
+      LQG_UNROLL for (int q = 0; q < PER; ++q) {
+        const int e = tid + q * NT;
+        const int i = e / W, j = e - i * W;
+        if (e < N * W && j > c) {
+          const D piv = src[p * W + j] * pinv;
+          if (i == c) {
+            dst[e] = piv;
+          } else {
+            const int row = (i == p) ? c : i;
+            dst[e] = fma(-src[row * W + c], piv, src[row * W + j]);
+          }
         }
       }
     }
@@ -150,7 +159,7 @@ __global__ void __launch_bounds__(NT) k_scan_level(const Seg s0, const Seg s1) {
   }
   const D* X = src;                                                  // [ . | X1 = M^-1 A1 | X2 = M^-1 C1 ]
   // A = A2 X1 ; T1 = A2 X2 ; U = J2 X1
-  each_t<NT>(3 * NN, [&](int e) {
+  if (comb) each(3 * NN, [&](int e) {
     const int blk = e / NN, r = e - blk * NN, i = r / N, j = r - i * N;
     if (blk == 0) eo[r] = dotn<N>(A2 + i * N, 1, X + N + j, W, 0.0);
     else if (blk == 1) T1[r] = dotn<N>(A2 + i * N, 1, X + 2 * N + j, W, 0.0);
@@ -158,7 +167,7 @@ __global__ void __launch_bounds__(NT) k_scan_level(const Seg s0, const Seg s1) {
   });
   __syncthreads();
   // C = T1 A2' + C2 ; J = A1' U + J1 (both symmetric in exact arithmetic: the mirror entries are averaged)
-  each_t<NT>(2 * NN, [&](int e) {
+  if (comb) each(2 * NN, [&](int e) {
     const int blk = e / NN, r = e - blk * NN, i = r / N, j = r - i * N;
     if (blk == 0) {
       const D v1 = dotn<N>(T1 + i * N, 1, A2 + j * N, 1, C2[i * N + j]);
@@ -171,8 +180,15 @@ __global__ void __launch_bounds__(NT) k_scan_level(const Seg s0, const Seg s1) {
     }
   });
 }
-constexpr int scan_level_threads(int n) { return n <= 8 ? 64 : 256; }
-inline size_t scan_level_lds(int n) { return (size_t)(14 * n * n + 8) * sizeof(D); }
+// lanes per element: enough for ~3 entries of the n x 3n elimination matrix per lane (a 4 x 4 window keeps 16 lanes busy, not
+// 64: four of them share a wave); elements per 256-thread workgroup
+// (packed = true: many elements per level, throughput matters — 32 systems at n = 4: 27 -> ~9 us per level; packed = false:
+// few elements, the latency of one element matters — a full wave per element up to n = 8: 4.7 us against 5.5 us)
+constexpr int scan_level_threads(int n, bool packed) {
+  return n <= 8 ? (packed ? (n <= 4 ? 16 : n <= 6 ? 32 : 64) : 64) : n <= 12 ? 128 : 256;
+}
+constexpr int scan_level_epb(int n, bool packed) { return 256 / scan_level_threads(n, packed); }
+inline size_t scan_level_lds(int n, bool packed) { return (size_t)(14 * n * n + 8) * sizeof(D) * scan_level_epb(n, packed); }
 
 // ---------------------------------------------------------------- per-step kernels
 template <typename R>

@@ -35,11 +35,19 @@ ScanPlan scan_plan(const lqg_problem* p) {
   return s;
 }
 
+template <int N, bool PACKED>
+void launch_level_v(const scan::Seg& s0, const scan::Seg& s1, long n_sys, hipStream_t st) {
+  constexpr int NT = scan::scan_level_threads(N, PACKED), EPB = scan::scan_level_epb(N, PACKED);
+  hipLaunchKernelGGL((scan::k_scan_level<N, NT, EPB>), dim3((unsigned)((s0.len + s1.len + EPB - 1) / EPB), (unsigned)n_sys),
+                     dim3(NT * EPB), scan::scan_level_lds(N, PACKED), st, s0, s1);
+}
 template <int N>
 void launch_level(const scan::Seg& s0, const scan::Seg& s1, long n_sys, hipStream_t st) {
-  constexpr int NT = scan::scan_level_threads(N);
-  hipLaunchKernelGGL((scan::k_scan_level<N, NT>), dim3((unsigned)(s0.len + s1.len), (unsigned)n_sys), dim3(NT),
-                     scan::scan_level_lds(N), st, s0, s1);
+  // sub-wave packing of small windows once a level holds enough elements to be throughput-bound
+  if (scan::scan_level_threads(N, true) != scan::scan_level_threads(N, false) && n_sys * (long)(s0.len + s1.len) >= 8192)
+    launch_level_v<N, true>(s0, s1, n_sys, st);
+  else
+    launch_level_v<N, false>(s0, s1, n_sys, st);
 }
 
 // Hillis-Steele over one or two independent sequences of n x n triples (segment i: len[i] elements starting in in[i],
