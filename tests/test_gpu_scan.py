@@ -167,3 +167,28 @@ def test_point_mass_setup_kernel_equals_the_torch_construction(monkeypatch):
     # V V' is what the path consumes: relative agreement of the whole covariance
     VVa, VVb = a.actor.V @ a.actor.V.transpose(-1, -2), b.actor.V @ b.actor.V.transpose(-1, -2)
     assert float(((VVa - VVb).abs().amax((-1, -2)) / VVb.abs().amax((-1, -2))).max()) < 1e-10
+
+
+@pytest.mark.parametrize("model", ["bounded", "pointmass", "subjective1d"])
+def test_scan_levels_packed_sub_wave_for_many_candidates(model, monkeypatch):
+    """24 candidates x 500 steps: a level holds > 8192 elements, so the 2x2 .. 6x6 windows run several per wave
+    (lqg_scan_inst.hip launch_level): same result as the sequential sweeps."""
+    import lqg_amd
+    from lqg_amd.plan import LogLikelihoodPlan
+    dev = torch.device("cuda")
+    sig = torch.linspace(3.0, 30.0, 24, dtype=torch.float64, device=dev)
+    if model == "bounded":
+        m = lqg_amd.BoundedActor(T=500, sigma_target=sig, device=dev, dtype=torch.float64)
+    elif model == "pointmass":
+        m = lqg_amd.PointMassBoundedActor(T=500, sigma_target=sig, action_variability=0.5, device=dev, dtype=torch.float64)
+    else:
+        m = lqg_amd.SubjectiveActor(T=500, sigma_target=sig, device=dev, dtype=torch.float64)
+    with torch.no_grad():
+        x = m.simulate(2, n=12)[0][..., :2].contiguous()
+    monkeypatch.setenv("LQG_SCAN", "0")
+    ref = LogLikelihoodPlan(m, x).run().clone()
+    monkeypatch.setenv("LQG_SCAN", "1")
+    p = LogLikelihoodPlan(m, x)
+    assert all(wk["scan"] for wk in p.work)
+    got = p.run().clone()
+    assert got.shape == (24, 12) and float((got / ref - 1).abs().max()) < 1e-10
