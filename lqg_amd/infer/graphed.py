@@ -31,6 +31,60 @@ from lqg_amd import _abi, _hip
 from lqg_amd.infer.models import get_model_params
 
 
+# ---- parameters -> spec matrices as ONE affine map -------------------------------------------------------------------------
+# The constructors of the tracking models place their parameters (and fixed constants) into the spec matrices: every entry
+# is an affine function of the parameter vector (V = diag(process_noise, action_variability), W = diag(sigma_target,
+# sigma_cursor), R = action_cost dt, ...).  Inside the captured graph the ~30 small kernels of such a constructor are
+# replaced by one addmm: flat[C, F] = base[F] + theta[C, P] D[P, F], the fields being views of `flat`.  Nothing is assumed:
+# base and D are measured by probing the real constructor, and the map is used only if two further random probes reproduce
+# the constructor to 1e-12 (PointMassBoundedActor's Cholesky factor is not affine in action_variability: it keeps its
+# constructor, which is one kernel anyway).
+_TIME_FIELDS = {"Q": 3, "P": 3, "R": 3, "A": 3, "B": 3, "V": 3, "F": 3, "W": 3, "q": 2, "r": 2}    # ndim without candidates
+_FLAT_FIELDS = {"Qf": 2, "qf": 1}
+
+
+def _flatten_spec(spec, C):
+    """-> (layout [(field, shape without time / candidate axes, structural-zero tag)], flat [C, F]); None when a field
+    varies in time."""
+    layout, pieces = [], []
+    for f in spec._fields:
+        t = getattr(spec, f)
+        nd = _TIME_FIELDS.get(f, _FLAT_FIELDS.get(f))
+        has_c = t.dim() == nd + 1
+        if f in _TIME_FIELDS:
+            td = 1 if has_c else 0
+            if t.shape[td] > 1 and t.stride(td) != 0:
+                return None
+            t = t.select(td, 0)
+        if not has_c:
+            t = t.expand(C, *t.shape)
+        layout.append((f, tuple(t.shape[1:]), bool(getattr(getattr(spec, f), "_lqg_zero", False))))
+        pieces.append(t.reshape(C, -1))
+    return layout, torch.cat(pieces, dim=1)
+
+
+def _unflatten_spec(cls, layout, flat, T):
+    C, out, o = flat.shape[0], {}, 0
+    for f, shape, is_zero in layout:
+        n = 1
+        for s_ in shape:
+            n *= s_
+        t = flat[:, o:o + n].view(C, *shape)
+        o += n
+        t = t.unsqueeze(1).expand(C, T, *shape) if f in _TIME_FIELDS else t
+        if is_zero:                      # (the structural-zero tag of time_stack_spec: the ABI gets a NULL view)
+            t._lqg_zero = True
+        out[f] = t
+    return cls(**out)
+
+
+class _Specs:
+    """What the log-likelihood entry needs of a model: the two specs."""
+
+    def __init__(self, actor, dynamics):
+        self.actor, self.dynamics = actor, dynamics
+
+
 class GraphedLogLik:
     """obj[c] = sum_n log p(x_n | theta[c]) for a FIXED number of parameter vectors, fixed data, fixed model class."""
 
@@ -46,9 +100,43 @@ class GraphedLogLik:
         self.out = None                                                                        # static output, fp64 [C]
         self.graph = None
         self._keep = None
+        self._affine = None
 
     # ---- the captured region -------------------------------------------------------------------------------------
+    def _probe_affine(self):
+        """Measure base / D of the affine map parameters -> flattened specs on the real constructor (eager); None when the
+        constructor is not affine in the parameters or a field varies in time."""
+        P, dev, dt_ = self.P, self.x.device, self.x.dtype
+        g = torch.Generator().manual_seed(1234)
+        th0 = torch.exp(torch.rand(P, generator=g, dtype=torch.float64) * 2.0 - 1.0)
+        rows = [th0] + [th0 + 0.5 * th0[i] * torch.eye(P, dtype=torch.float64)[i] for i in range(P)]
+        rows += [torch.exp(torch.rand(P, generator=g, dtype=torch.float64) * 3.0 - 1.5) for _ in range(2)]
+        th = torch.stack(rows).to(device=dev, dtype=dt_)                              # [1 + P + 2, P]
+        m = self._construct(th)
+        fa, fd = _flatten_spec(m.actor, th.shape[0]), _flatten_spec(m.dynamics, th.shape[0])
+        if fa is None or fd is None:
+            return None
+        flat = torch.cat([fa[1], fd[1]], dim=1).to(torch.float64)
+        thd = th.to(torch.float64)
+        D = (flat[1:P + 1] - flat[:1]) / (thd[1:P + 1] - thd[:1]).diagonal()[:, None]   # [P, F]
+        base = flat[0] - thd[0] @ D
+        pred = base + thd[P + 1:] @ D
+        err = float((pred - flat[P + 1:]).abs().max() / (1.0 + flat[P + 1:].abs().max()))
+        if not err < 1e-12:
+            return None
+        return dict(layout_a=fa[0], layout_d=fd[0], n_a=fa[1].shape[1], base=base.to(dt_).contiguous(), D=D.to(dt_).contiguous(),
+                    actor_cls=type(m.actor), dyn_cls=type(m.dynamics))
+
     def _model(self, theta):
+        af = self._affine
+        if af is not None:                                   # one addmm; the fields are views of its result
+            flat = torch.addmm(af["base"].unsqueeze(0), theta, af["D"])
+            T = self.rows - 1
+            return _Specs(_unflatten_spec(af["actor_cls"], af["layout_a"], flat[:, :af["n_a"]], T),
+                          _unflatten_spec(af["dyn_cls"], af["layout_d"], flat[:, af["n_a"]:], T))
+        return self._construct(theta)
+
+    def _construct(self, theta):
         kw = dict(get_model_params(self.model_type))
         kw.update(self.fixed)
         kw.update({k: theta[:, i] for i, k in enumerate(self.names)})
@@ -67,6 +155,8 @@ class GraphedLogLik:
                                                            systems_scale=2 if self.x.dtype == torch.float64 else 1)
         spl = _hip.specialised_library(ln, model, self.d, check_strategy=not self.use_scan)
         self.sp_lib = spl
+        if os.environ.get("LQG_GRAPH_AFFINE") != "0":
+            self._affine = self._probe_affine()
         return True
 
     def _loglik(self, model):
@@ -105,7 +195,7 @@ class GraphedLogLik:
         dev = self.x.device
         with torch.cuda.device(dev):
             with torch.no_grad():
-                if not self._decide(self._model(self.theta)):
+                if not self._decide(self._construct(self.theta)):
                     return False
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
