@@ -222,6 +222,9 @@ def test_graphed_evaluation_equals_the_eager_one(model, params, monkeypatch):
     names = list(params)
     ev = graphed.make(graphed.GraphedFiniteDifference, x, cls, names, 1, h=1e-4)
     assert ev is not None, "this zoo model must be capturable"
+    # the tracking models' constructors are affine in their parameters (one addmm inside the graph, verified by probing);
+    # the point-mass Cholesky factor is not, and keeps its constructor
+    assert (ev._affine is not None) == (model != "PointMassBoundedActor")
     for scale in (1.0, 1.3, 0.8):
         p = {k: v * scale for k, v in params.items()}
         monkeypatch.setenv("LQG_GRAPH", "0")
