@@ -92,6 +92,22 @@ class Potential:
         grad = 1.0 + ln * (-1.0 - (z - mu) * i2) + (1.0 - ln) * (-e2 * i2)
         return val.sum(-1), grad
 
+    def host(self, z):
+        """z [C, P] on any device -> (logp [C], grad [C, P]) on the HOST with one device-to-host copy (what the chains'
+        coroutines consume)."""
+        z = z.to(device=self.x.device, dtype=torch.float64)
+        C, P = z.shape
+        if self.method == "fd":
+            ev = self._graphed(z, C)
+            if ev is not None:
+                zp = z if C == ev.K else torch.cat([z, z[:1].expand(ev.K - C, P)])
+                out = ev(zp)[:C].cpu()
+                self.evaluations += C * (2 * P + 1)
+                return out[:, 0], out[:, 1:]
+        lp, gr = self(z)
+        both = torch.cat([lp.detach()[:, None], gr.detach()], dim=1).cpu()
+        return both[:, 0], both[:, 1:]
+
     def __call__(self, z):
         from lqg_amd import dist as ld
         z = z.to(torch.float64)
@@ -239,9 +255,12 @@ def run_chains(potential, z0, num_warmup, num_samples, seed=0, max_depth=10, tar
     active = list(range(len(gens)))
     dev = getattr(potential, "x", torch.zeros(())).device
     while active:
-        Z = torch.stack([req[c] for c in active]).to(dev)
-        lp, gr = potential(Z)
-        lp, gr = lp.detach().cpu(), gr.detach().cpu()
+        Z = torch.stack([req[c] for c in active])
+        if hasattr(potential, "host"):
+            lp, gr = potential.host(Z)
+        else:
+            lp, gr = potential(Z.to(dev))
+            lp, gr = lp.detach().cpu(), gr.detach().cpu()
         still = []
         for k, c in enumerate(active):
             g_ = torch.nan_to_num(gr[k], nan=0.0, posinf=0.0, neginf=0.0)
