@@ -88,44 +88,56 @@ LQG_DEV R tc_step(const R* __restrict__ op, const R (&xt)[ND], R (&xprev)[ND], R
   return zz;
 }
 
-// grid: (trial blocks + 1, n_sys, n_chunks - 1); the last block in x carries the unit vectors
-template <typename R, int M, int ND, class FMP>
+// grid: (trial blocks + 1, n_sys, n_chunks - 1); the last block in x carries the unit vectors.  TPL trials per lane share
+// the step's operator loads (the passes wait on their scalar loads more than half of the time: SQ_WAIT_ANY / SQ_WAVE_CYCLES =
+// 0.57 at one trial per lane, scripts/pmc_trial.sh).
+template <typename R, int M, int ND, class FMP, int TPL>
 __global__ void __launch_bounds__(LQG_BLOCK) k_trial_zs(const R* __restrict__ ops_all, const TrialChunkArgs<R> a) {
   constexpr int O = ND, RR = M - ND;
   using Ops = TrialOps<M, ND>;
   const long sys = blockIdx.y;
   const int c = blockIdx.z;
   const bool hom = blockIdx.x == gridDim.x - 1;
-  const long n = hom ? (long)threadIdx.x : (long)blockIdx.x * LQG_BLOCK + threadIdx.x;
-  const bool live = n < (hom ? (long)M : a.n_trials);
+  const long n0 = hom ? (long)threadIdx.x : (long)blockIdx.x * (LQG_BLOCK * TPL) + threadIdx.x;
   const int t0 = c * a.chunk_len, t1 = t0 + a.chunk_len;               // (c <= n_chunks - 2: the chunk is complete)
   const R* __restrict__ op = ops_all + (sys * (long)(a.T + 1) + t0) * Ops::N;
-  const R* xr = a.x.p + sys * a.x.sb + ((live && !hom) ? n : 0) * a.x.sn;
-  R xprev[O], dO[O], muR[RR], xq[O];
-  LQG_UNROLL for (int i = 0; i < O; ++i) {
-    xprev[i] = hom ? R(0) : xr[(long)(t0 > 0 ? t0 - 1 : 0) * a.x.st + i * a.x.sd];
-    xq[i] = hom ? R(0) : xr[(long)t0 * a.x.st + i * a.x.sd];
-    dO[i] = (hom && n == i) ? R(1) : R(0);
+  const R* xr[TPL];
+  bool live[TPL];
+  R xprev[TPL][O], dO[TPL][O], muR[TPL][RR], xq[TPL][O];
+  LQG_UNROLL for (int k = 0; k < TPL; ++k) {
+    const long n = n0 + (long)k * LQG_BLOCK;
+    live[k] = hom ? (k == 0 && n < (long)M) : (n < a.n_trials);
+    xr[k] = a.x.p + sys * a.x.sb + ((live[k] && !hom) ? n : 0) * a.x.sn;
+    LQG_UNROLL for (int i = 0; i < O; ++i) {
+      xprev[k][i] = hom ? R(0) : xr[k][(long)(t0 > 0 ? t0 - 1 : 0) * a.x.st + i * a.x.sd];
+      xq[k][i] = hom ? R(0) : xr[k][(long)t0 * a.x.st + i * a.x.sd];
+      dO[k][i] = (hom && k == 0 && n == i) ? R(1) : R(0);
+    }
+    LQG_UNROLL for (int p = 0; p < RR; ++p) muR[k][p] = (hom && k == 0 && n == O + p) ? R(1) : R(0);
   }
-  LQG_UNROLL for (int p = 0; p < RR; ++p) muR[p] = (hom && n == O + p) ? R(1) : R(0);
   for (int t = t0; t < t1; ++t) {
-    R xt[O];
-    LQG_UNROLL for (int i = 0; i < O; ++i) xt[i] = xq[i];
     const long row = (t + 1 < a.T) ? (long)(t + 1) : (long)a.T;          // data row one step ahead
-    LQG_UNROLL for (int i = 0; i < O; ++i) xq[i] = hom ? R(0) : xr[row * a.x.st + i * a.x.sd];
-    (void)tc_step<R, M, ND, FMP>(op, xt, xprev, dO, muR, true);
+    LQG_UNROLL for (int k = 0; k < TPL; ++k) {
+      R xt[O];
+      LQG_UNROLL for (int i = 0; i < O; ++i) xt[i] = xq[k][i];
+      LQG_UNROLL for (int i = 0; i < O; ++i) xq[k][i] = hom ? R(0) : xr[k][row * a.x.st + i * a.x.sd];
+      (void)tc_step<R, M, ND, FMP>(op, xt, xprev[k], dO[k], muR[k], true);
+    }
     op += Ops::N;
   }
-  if (!live) return;
   const long slot = sys * (a.n_chunks - 1) + c;
-  if (hom) {
-    R* ph = a.phi + slot * (M * M) + n;
-    LQG_UNROLL for (int i = 0; i < O; ++i) ph[i * M] = dO[i];
-    LQG_UNROLL for (int p = 0; p < RR; ++p) ph[(O + p) * M] = muR[p];
-  } else {
-    R* sp = a.state + slot * M * a.n_trials + n;
-    LQG_UNROLL for (int i = 0; i < O; ++i) sp[i * a.n_trials] = dO[i];
-    LQG_UNROLL for (int p = 0; p < RR; ++p) sp[(O + p) * a.n_trials] = muR[p];
+  LQG_UNROLL for (int k = 0; k < TPL; ++k) {
+    if (!live[k]) continue;
+    const long n = n0 + (long)k * LQG_BLOCK;
+    if (hom) {
+      R* ph = a.phi + slot * (M * M) + n;
+      LQG_UNROLL for (int i = 0; i < O; ++i) ph[i * M] = dO[k][i];
+      LQG_UNROLL for (int p = 0; p < RR; ++p) ph[(O + p) * M] = muR[k][p];
+    } else {
+      R* sp = a.state + slot * M * a.n_trials + n;
+      LQG_UNROLL for (int i = 0; i < O; ++i) sp[i * a.n_trials] = dO[k][i];
+      LQG_UNROLL for (int p = 0; p < RR; ++p) sp[(O + p) * a.n_trials] = muR[k][p];
+    }
   }
 }
 
@@ -155,48 +167,60 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial_fix(const R* __restrict__ p
 }
 
 // grid: (trial blocks, n_sys, n_chunks)
-template <typename R, int M, int ND, class FMP>
+template <typename R, int M, int ND, class FMP, int TPL>
 __global__ void __launch_bounds__(LQG_BLOCK) k_trial_ll(const R* __restrict__ ops_all, const TrialChunkArgs<R> a) {
   constexpr int O = ND, RR = M - ND;
   constexpr int kAccChunk = 8;
   using Ops = TrialOps<M, ND>;
   const long sys = blockIdx.y;
   const int c = blockIdx.z;
-  const long n = (long)blockIdx.x * LQG_BLOCK + threadIdx.x;
-  const bool live = n < a.n_trials;
-  const long nn = live ? n : a.n_trials - 1;
+  const long n0 = (long)blockIdx.x * (LQG_BLOCK * TPL) + threadIdx.x;
   const int t0 = c * a.chunk_len;
   const bool last = c == a.n_chunks - 1;
   const int t1 = last ? a.T : t0 + a.chunk_len;
   const R* __restrict__ op = ops_all + (sys * (long)(a.T + 1) + t0) * Ops::N;
-  const R* xr = a.x.p + sys * a.x.sb + nn * a.x.sn;
-  R xprev[O], dO[O], muR[RR], xq[O];
-  LQG_UNROLL for (int i = 0; i < O; ++i) {
-    xprev[i] = xr[(long)(t0 > 0 ? t0 - 1 : 0) * a.x.st + i * a.x.sd];
-    xq[i] = xr[(long)t0 * a.x.st + i * a.x.sd];
+  const R* xr[TPL];
+  bool live[TPL];
+  R xprev[TPL][O], dO[TPL][O], muR[TPL][RR], xq[TPL][O];
+  double acc[TPL];
+  R part[TPL];
+  LQG_UNROLL for (int k = 0; k < TPL; ++k) {
+    const long n = n0 + (long)k * LQG_BLOCK;
+    live[k] = n < a.n_trials;
+    const long nn = live[k] ? n : a.n_trials - 1;
+    xr[k] = a.x.p + sys * a.x.sb + nn * a.x.sn;
+    LQG_UNROLL for (int i = 0; i < O; ++i) {
+      xprev[k][i] = xr[k][(long)(t0 > 0 ? t0 - 1 : 0) * a.x.st + i * a.x.sd];
+      xq[k][i] = xr[k][(long)t0 * a.x.st + i * a.x.sd];
+    }
+    if (c == 0) {
+      LQG_UNROLL for (int i = 0; i < O; ++i) dO[k][i] = R(0);
+      LQG_UNROLL for (int p = 0; p < RR; ++p) muR[k][p] = R(0);
+    } else {
+      const R* sp = a.state + (sys * (a.n_chunks - 1) + (c - 1)) * M * a.n_trials + nn;
+      LQG_UNROLL for (int i = 0; i < O; ++i) dO[k][i] = sp[i * a.n_trials];
+      LQG_UNROLL for (int p = 0; p < RR; ++p) muR[k][p] = sp[(O + p) * a.n_trials];
+    }
+    acc[k] = 0.0;
+    part[k] = R(0);
   }
-  if (c == 0) {
-    LQG_UNROLL for (int i = 0; i < O; ++i) dO[i] = R(0);
-    LQG_UNROLL for (int p = 0; p < RR; ++p) muR[p] = R(0);
-  } else {
-    const R* sp = a.state + (sys * (a.n_chunks - 1) + (c - 1)) * M * a.n_trials + nn;
-    LQG_UNROLL for (int i = 0; i < O; ++i) dO[i] = sp[i * a.n_trials];
-    LQG_UNROLL for (int p = 0; p < RR; ++p) muR[p] = sp[(O + p) * a.n_trials];
-  }
-  double acc = 0.0;
-  R part = R(0);
   const int tend = last ? t1 + 1 : t1;                                   // the last chunk also scores x_T
   for (int t = t0; t < tend; ++t) {
-    R xt[O];
-    LQG_UNROLL for (int i = 0; i < O; ++i) xt[i] = xq[i];
     const long row = (t + 1 < a.T) ? (long)(t + 1) : (long)a.T;
-    LQG_UNROLL for (int i = 0; i < O; ++i) xq[i] = xr[row * a.x.st + i * a.x.sd];
-    const R zz = tc_step<R, M, ND, FMP>(op, xt, xprev, dO, muR, t < a.T);
-    if (t > 0) part += R(0.5) * zz + op[Ops::H_OFF];
-    if (((t & (kAccChunk - 1)) == 0) || t + 1 == tend) { acc -= (double)part; part = R(0); }
+    const R hlc = op[Ops::H_OFF];
+    const bool flush = ((t & (kAccChunk - 1)) == 0) || t + 1 == tend;
+    LQG_UNROLL for (int k = 0; k < TPL; ++k) {
+      R xt[O];
+      LQG_UNROLL for (int i = 0; i < O; ++i) xt[i] = xq[k][i];
+      LQG_UNROLL for (int i = 0; i < O; ++i) xq[k][i] = xr[k][row * a.x.st + i * a.x.sd];
+      const R zz = tc_step<R, M, ND, FMP>(op, xt, xprev[k], dO[k], muR[k], t < a.T);
+      if (t > 0) part[k] += R(0.5) * zz + hlc;
+      if (flush) { acc[k] -= (double)part[k]; part[k] = R(0); }
+    }
     op += Ops::N;
   }
-  if (live) a.part[(sys * a.n_chunks + c) * a.n_trials + n] = acc;
+  LQG_UNROLL for (int k = 0; k < TPL; ++k)
+    if (live[k]) a.part[(sys * a.n_chunks + c) * a.n_trials + n0 + (long)k * LQG_BLOCK] = acc[k];
 }
 
 template <typename R>
@@ -278,11 +302,17 @@ hipError_t launch_trial_chunked(const lqg_problem* p, const void* ops, lqg_traj 
   const unsigned tb = (unsigned)((p->n_trials + LQG_BLOCK - 1) / LQG_BLOCK), B = (unsigned)p->n_sys;
   const dim3 block(LQG_BLOCK);
   const R* o = static_cast<const R*>(ops);
-  hipLaunchKernelGGL((lqg::k_trial_zs<R, M, ND, FMP>), dim3(tb + 1, B, nc - 1), block, 0, st, o, k);
+  // two trials per lane once (trial, chunk) pairs alone over-fill the chip (> 8 waves per SIMD at one per lane)
+  static const int tpl_mode = [] { const char* e = getenv("LQG_TRIAL_CHUNK_TPL"); return e ? atoi(e) : 0; }();
+  const bool two = tpl_mode == 2 || (tpl_mode == 0 && (long)tb * B * nc > 8192L);
+  const unsigned tb2 = (unsigned)((p->n_trials + 2 * LQG_BLOCK - 1) / (2 * LQG_BLOCK));
+  if (two) hipLaunchKernelGGL((lqg::k_trial_zs<R, M, ND, FMP, 2>), dim3(tb2 + 1, B, nc - 1), block, 0, st, o, k);
+  else hipLaunchKernelGGL((lqg::k_trial_zs<R, M, ND, FMP, 1>), dim3(tb + 1, B, nc - 1), block, 0, st, o, k);
   if (nc > 2)
     hipLaunchKernelGGL((lqg::k_trial_fix<R, M>), dim3(tb, B), block, 0, st, static_cast<const R*>(k.phi), k.state,
                        (long)p->n_trials, nc - 1);
-  hipLaunchKernelGGL((lqg::k_trial_ll<R, M, ND, FMP>), dim3(tb, B, nc), block, 0, st, o, k);
+  if (two) hipLaunchKernelGGL((lqg::k_trial_ll<R, M, ND, FMP, 2>), dim3(tb2, B, nc), block, 0, st, o, k);
+  else hipLaunchKernelGGL((lqg::k_trial_ll<R, M, ND, FMP, 1>), dim3(tb, B, nc), block, 0, st, o, k);
   hipLaunchKernelGGL((lqg::k_trial_sum<R>), dim3(tb, B), block, 0, st, static_cast<const double*>(k.part),
                      static_cast<R*>(ll), ll_sb, ll_sn, (long)p->n_trials, nc);
   return hipGetLastError();
