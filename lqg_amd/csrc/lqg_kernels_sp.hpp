@@ -504,19 +504,10 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial_sp(const R* __restrict__ op
     LQG_UNROLL for (int i = 0; i < O; ++i) xq[k][i] = xprev[k][i];
   constexpr bool PF = LQG_TRIAL_OPS_PREFETCH && (Ops::N * (int)(sizeof(R) / 4) <= 32);
   constexpr int NPF = PF ? Ops::N : 1;
-  R opn[NPF], opc[NPF];
-  if (PF) {
-    LQG_UNROLL for (int i = 0; i < NPF; ++i) opn[i] = op[i];
-  } else {
-    opc[0] = R(0);
-  }
-  for (int t = 0; t <= a.T; ++t) {
-    if (PF) {
-      LQG_UNROLL for (int i = 0; i < NPF; ++i) opc[i] = opn[i];
-      const R* __restrict__ nx = op + ((t < a.T) ? Ops::N : 0);
-      LQG_UNROLL for (int i = 0; i < NPF; ++i) opn[i] = nx[i];
-    }
-#define LQG_OP(i_) (PF ? opc[PF ? (i_) : 0] : op[i_])
+  // one step of the sweep; `cur` holds the step's operator block when it is prefetched into SGPRs (PF), else the block is
+  // read through `opt`
+  auto body = [&](int t, const R (&cur)[NPF], const R* __restrict__ opt) {
+#define LQG_OP(i_) (PF ? cur[PF ? (i_) : 0] : opt[i_])
     R Li[O * (O + 1) / 2];
     LQG_UNROLL for (int i = 0; i < O * (O + 1) / 2; ++i) Li[i] = LQG_OP(Ops::L_OFF + i);
     const R hlc = LQG_OP(Ops::H_OFF);
@@ -547,13 +538,33 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial_sp(const R* __restrict__ op
           cv[O + p] = v;
         }
         R mn[M];
-        trial_mean_rows<R, M, ND, FM, PF, NPF, 0>(opc, op, cv, mn);
+        trial_mean_rows<R, M, ND, FM, PF, NPF, 0>(cur, opt, cv, mn);
         LQG_UNROLL for (int i = 0; i < O; ++i) { dO[k][i] = mn[i]; xprev[k][i] = cv[i]; }
         LQG_UNROLL for (int p = 0; p < RR; ++p) muR[k][p] = mn[O + p];
       }
     }
-    op += Ops::N;
 #undef LQG_OP
+  };
+  if constexpr (PF) {
+    // Double-buffered operator blocks in SGPRs, the loop unrolled by two so that the buffers trade places instead of being
+    // copied (the copy was Ops::N s_mov per step: 44 scalar instructions per step against 68 vector ones on config 3)
+    R bufA[NPF], bufB[NPF];
+    auto fetch = [&](R (&dst)[NPF], int row) {
+      const R* __restrict__ src = op + (long)(row <= a.T ? row : a.T) * Ops::N;
+      LQG_UNROLL for (int i = 0; i < NPF; ++i) dst[i] = src[i];
+    };
+    fetch(bufA, 0);
+    int t = 0;
+    for (; t + 1 <= a.T; t += 2) {
+      fetch(bufB, t + 1);
+      body(t, bufA, op);
+      fetch(bufA, t + 2);
+      body(t + 1, bufB, op);
+    }
+    if (t <= a.T) body(t, bufA, op);
+  } else {
+    const R none[1] = {R(0)};
+    for (int t = 0; t <= a.T; ++t) body(t, none, op + (long)t * Ops::N);
   }
   if (a.ll) {
     LQG_UNROLL for (int k = 0; k < TPL; ++k)
