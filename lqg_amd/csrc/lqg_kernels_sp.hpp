@@ -454,6 +454,9 @@ struct MaskPolicy {
   static constexpr bool at(int i, int j) { return FM.b[i * M + j]; }
 };
 
+#ifndef LQG_TRIAL_OPS_PREFETCH_MAX
+#define LQG_TRIAL_OPS_PREFETCH_MAX 36      // dwords per operator block held twice in SGPRs (m = 5 in fp32: config 5 per-trial sweep 1.67 -> 1.46 ms)
+#endif
 template <bool PF, int NPF, int IDX, typename R>
 LQG_DEV R trial_op_at(const R (&opc)[NPF], const R* __restrict__ op) {
   if constexpr (PF) return opc[IDX];
@@ -502,7 +505,7 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial_sp(const R* __restrict__ op
   R xq[TPL][O];                                           // data rows one step ahead
   LQG_UNROLL for (int k = 0; k < TPL; ++k)
     LQG_UNROLL for (int i = 0; i < O; ++i) xq[k][i] = xprev[k][i];
-  constexpr bool PF = LQG_TRIAL_OPS_PREFETCH && (Ops::N * (int)(sizeof(R) / 4) <= 32);
+  constexpr bool PF = LQG_TRIAL_OPS_PREFETCH && (Ops::N * (int)(sizeof(R) / 4) <= LQG_TRIAL_OPS_PREFETCH_MAX);
   constexpr int NPF = PF ? Ops::N : 1;
   // one step of the sweep; `cur` holds the step's operator block when it is prefetched into SGPRs (PF), else the block is
   // read through `opt`
