@@ -38,7 +38,7 @@ constexpr int kWave = 64;
 
 template <typename F>
 LQG_DEV void each(int n, F f) {
-  for (int e = threadIdx.x; e < n; e += kWave) f(e);
+  for (int e = threadIdx.x; e < n; e += (int)blockDim.x) f(e);     // blockDim.x = lanes per element (see elem_index)
 }
 LQG_DEV void wsync() { __syncthreads(); }   // one wave per workgroup: a fence, no barrier instruction
 
@@ -208,6 +208,7 @@ struct Args {
   long n_sys;
   int T, x, b, u, y, d, nva, nwa, nvd, nwd, nops;
   D eps;
+  int lds_elem;            // doubles of LDS per element of the launch (set per launch by the host)
 };
 
 template <typename R>
@@ -246,6 +247,13 @@ LQG_DEV void small_inverse(const D* src, int n, D* dst, D eps, bool floor_) {
   });
   wsync();
 }
+
+// The per-step kernels run one ELEMENT (system, step) on blockDim.x lanes and blockDim.y elements per 64-thread workgroup:
+// (64, 1) when there are few elements (latency matters), (16, 4) when a launch holds thousands of small ones (the 4 x 4
+// matrices of a tracking model keep 16 lanes busy, not 64).  A workgroup is always ONE wave, so the fences inside
+// element-dependent branches are harmless.  `lds_elem`: doubles of LDS per element.
+LQG_DEV int elem_index() { return (int)(blockIdx.x * blockDim.y + threadIdx.y); }
+LQG_DEV D* elem_lds(double* base, int lds_elem) { return base + (int)threadIdx.y * lds_elem; }
 
 // Riccati elements, reversed index j: j = 0 terminal (0, 0, Qf); j >= 1 <-> step t = T - j: (A_t, B R^-1 B', Q_t)
 template <typename R>
@@ -380,16 +388,20 @@ LQG_DEV void kgain_step(const Args<R>& a, D* sm, int t, long s) {
 template <typename R>
 __global__ void __launch_bounds__(kWave) k_scan_build_rk(const Args<R> a) {
   extern __shared__ double lqg_coop_smem[];
-  const int k = blockIdx.x;
-  if (k <= a.T) build_riccati(a, lqg_coop_smem, k, (long)blockIdx.y);
-  else build_kalman(a, lqg_coop_smem, k - (a.T + 1), (long)blockIdx.y);
+  const int k = elem_index();
+  if (k > 2 * a.T) return;
+  D* sm = elem_lds(lqg_coop_smem, a.lds_elem);
+  if (k <= a.T) build_riccati(a, sm, k, (long)blockIdx.y);
+  else build_kalman(a, sm, k - (a.T + 1), (long)blockIdx.y);
 }
 template <typename R>
 __global__ void __launch_bounds__(kWave) k_scan_gains_rk(const Args<R> a) {
   extern __shared__ double lqg_coop_smem[];
-  const int k = blockIdx.x;
-  if (k < a.T) gains_step(a, lqg_coop_smem, k, (long)blockIdx.y);
-  else kgain_step(a, lqg_coop_smem, k - a.T, (long)blockIdx.y);
+  const int k = elem_index();
+  if (k >= 2 * a.T) return;
+  D* sm = elem_lds(lqg_coop_smem, a.lds_elem);
+  if (k < a.T) gains_step(a, sm, k, (long)blockIdx.y);
+  else kgain_step(a, sm, k - a.T, (long)blockIdx.y);
 }
 
 // joint system of step t into LDS: Fj[m,m], GG[m,m]                                          system.py:167-207
@@ -459,8 +471,9 @@ inline __host__ __device__ long joint_scratch(int x, int b, int u, int y) {
 template <typename R>
 __global__ void __launch_bounds__(kWave) k_scan_build_sigma(const Args<R> a) {
   extern __shared__ double lqg_coop_smem[];
-  D* sm = lqg_coop_smem;
-  const int k = blockIdx.x, m = a.x + a.b, o = a.d, mm2 = m * m;
+  const int k = elem_index(), m = a.x + a.b, o = a.d, mm2 = m * m;
+  if (k > a.T) return;
+  D* sm = elem_lds(lqg_coop_smem, a.lds_elem);
   const long s = blockIdx.y;
   D *Fj = sm, *GG = Fj + mm2, *Qi = GG + mm2, *Kk = Qi + o * o, *IKH = Kk + m * o, *scratch = IKH + mm2;
   const int st = (k == 0) ? 0 : k - 1;
@@ -500,8 +513,9 @@ __global__ void __launch_bounds__(kWave) k_scan_build_sigma(const Args<R> a) {
 template <typename R>
 __global__ void __launch_bounds__(kWave) k_scan_ops(const Args<R> a) {
   extern __shared__ double lqg_coop_smem[];
-  D* sm = lqg_coop_smem;
-  const int t = blockIdx.x, m = a.x + a.b, o = a.d, rr = m - o, mm2 = m * m;
+  const int t = elem_index(), m = a.x + a.b, o = a.d, rr = m - o, mm2 = m * m;
+  if (t > a.T) return;
+  D* sm = elem_lds(lqg_coop_smem, a.lds_elem);
   const long s = blockIdx.y;
   D *Sg = sm, *T1 = Sg + mm2, *Lis = T1 + mm2, *hls = Lis + o * o;
   if (t == 0) {

@@ -44,7 +44,7 @@ void launch_level_v(const scan::Seg& s0, const scan::Seg& s1, long n_sys, hipStr
 template <int N>
 void launch_level(const scan::Seg& s0, const scan::Seg& s1, long n_sys, hipStream_t st) {
   // sub-wave packing of small windows once a level holds enough elements to be throughput-bound
-  if (scan::scan_level_threads(N, true) != scan::scan_level_threads(N, false) && n_sys * (long)(s0.len + s1.len) >= 8192)
+  if (scan::scan_level_threads(N, true) != scan::scan_level_threads(N, false) && n_sys * (long)(s0.len + s1.len) >= 4096)
     launch_level_v<N, true>(s0, s1, n_sys, st);
   else
     launch_level_v<N, false>(s0, s1, n_sys, st);
@@ -119,8 +119,15 @@ hipError_t scan_system_sweeps(const lqg_problem* p, lqg_view Sig, void* workspac
   *ops_out = k.ops;
   const int T = p->T, x = p->dims.x, b = p->dims.b, u = p->dims.u, y = p->dims.y, o = p->dims.d, m = x + b;
   const unsigned B = (unsigned)p->n_sys;
-  const dim3 blk(scan::kWave);
   const int mx = b > y ? b : y;
+  // lanes per element x elements per (single-wave) workgroup of the per-step kernels: sub-wave once a launch holds
+  // thousands of small elements (36 candidates of a 4 x 4 model: the four kernels 168 -> ~60 us)
+  const bool packed = (long)p->n_sys * T >= 4096 && m <= 8;
+  const dim3 blk(packed ? 16 : 64, packed ? 4 : 1);
+  auto launch = [&](auto kern, int count, long lds_doubles) {
+    k.lds_elem = (int)lds_doubles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((count + blk.y - 1) / blk.y), B), blk, (size_t)lds_doubles * blk.y * sizeof(D), st, k);
+  };
   // ---- Riccati (suffix scan over T + 1 elements, reversed storage) and Kalman (prefix scan over T elements) side by side
   {
     D* const in[2] = {rk, rk + 2 * sp.rk_reals};
@@ -129,13 +136,11 @@ hipError_t scan_system_sweeps(const lqg_problem* p, lqg_view Sig, void* workspac
     const D* res[2];
     k.elems = in[0];
     k.elems2 = in[1];
-    const size_t lds_build = (size_t)(12 * mx * mx + 2 * b * u + 2 * u * u + 8) * sizeof(D);
-    hipLaunchKernelGGL((scan::k_scan_build_rk<R>), dim3(2 * T + 1, B), blk, lds_build, st, k);
+    launch(scan::k_scan_build_rk<R>, 2 * T + 1, 12L * mx * mx + 2 * b * u + 2 * u * u + 8);
     run_scan(b, 2, in, out, len, left, p->n_sys, res, st);
     k.res = res[0];
     k.res2 = res[1];
-    const size_t lds_gain = (size_t)(12 * mx * mx + 3 * b * u + 3 * u * u + 8) * sizeof(D);
-    hipLaunchKernelGGL((scan::k_scan_gains_rk<R>), dim3(2 * T, B), blk, lds_gain, st, k);
+    launch(scan::k_scan_gains_rk<R>, 2 * T, 12L * mx * mx + 3 * b * u + 3 * u * u + 8);
   }
   // ---- moment recursion: joint system per step, prefix scan over T elements of m x m, operators
   {
@@ -144,12 +149,11 @@ hipError_t scan_system_sweeps(const lqg_problem* p, lqg_view Sig, void* workspac
     const int len[2] = {T, 0}, left[2] = {0, 0};
     const D* res[2];
     k.elems = in[0];
-    const size_t lds_sig = (size_t)(3 * m * m + o * o + m * o + scan::joint_scratch(x, b, u, y) + 16) * sizeof(D);
-    hipLaunchKernelGGL((scan::k_scan_build_sigma<R>), dim3(T + 1, B), blk, lds_sig, st, k);
+    launch(scan::k_scan_build_sigma<R>, T + 1, 3L * m * m + o * o + m * o + scan::joint_scratch(x, b, u, y) + 16);
     run_scan(m, 1, in, out, len, left, p->n_sys, res, st);
     k.res = res[0];
   }
-  hipLaunchKernelGGL((scan::k_scan_ops<R>), dim3(T + 1, B), blk, (size_t)(2 * m * m + o * o + 8) * sizeof(D), st, k);
+  launch(scan::k_scan_ops<R>, T + 1, 2L * m * m + o * o + 8);
   return hipGetLastError();
 }
 

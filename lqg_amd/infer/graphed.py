@@ -15,7 +15,7 @@ other kernel) and an evaluation becomes: copy the parameters in, replay, read th
 What makes the capture legal: the zoo constructors are sync-free and copy nothing from the host once their constants are
 cached (lqg_amd/tracking/_build.py); every decision that needs host values — which library, scan path or lane kernels, the
 pattern library — is taken in an EAGER warm-up evaluation of the same shapes and frozen (the time-parallel scans are taken
-for up to three times the systems of the eager rule in fp64: their host-side checks are paid once here).  PointMassBoundedActor's
+for up to six times (fp64; twice in fp32) the systems of the eager rule: their host-side checks are paid once here).  PointMassBoundedActor's
 discretisation runs as one kernel (csrc/lqg_setup.hip) instead of host-synchronising torch.linalg calls.  What is not
 captured: a user model whose constructor synchronises or copies from the host, a model that decouples into several
 components (LogLikelihoodPlan merges them; here the joint problem would run), an initialised process group (the all-reduce
@@ -152,7 +152,7 @@ class GraphedLogLik:
         lib = ln.require_gpu()
         main = _abi.load()
         self.use_scan = lib is main and plan.scan_eligible(main, ln, model, self.eps,
-                                                           systems_scale=3 if self.x.dtype == torch.float64 else 1)
+                                                           systems_scale=6 if self.x.dtype == torch.float64 else 2)
         spl = _hip.specialised_library(ln, model, self.d, check_strategy=not self.use_scan)
         self.sp_lib = spl
         if os.environ.get("LQG_GRAPH_AFFINE") != "0":

@@ -68,8 +68,8 @@ def _observed_noise_cond(sub, d):
 def scan_eligible(lib, ln, sub, eps, systems_scale=1):
     """True when the time-parallel sweeps may serve this launch (include/lqg_hip.h: lqg_log_likelihood_scan).
     systems_scale: a caller whose decisions are taken once and replayed (infer/graphed.py) does not pay the scan route's
-    host checks per evaluation and can afford the GPU-timeline crossover instead of the end-to-end one (3x for fp64:
-    BoundedActor, fp64, graph replay with 18 / 36 systems: 0.29 / 0.41 ms scans, 0.40 / 0.37 ms lane kernels)."""
+    host checks per evaluation and can afford the GPU-timeline crossover instead of the end-to-end one (6x in fp64, 2x in fp32:
+    profiles/r02_*_small_batch_f64.txt — BoundedActor, 32 / 64 systems: 0.28 / 0.41 ms scans, 0.32 / 0.38 ms lane kernels)."""
     mode = os.environ.get("LQG_SCAN", "")
     if mode == "0" or not hasattr(lib, "lqg_log_likelihood_scan"):
         return False
