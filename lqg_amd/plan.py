@@ -21,9 +21,10 @@ OPS_WORKSPACE_LIMIT = 16 << 30
 FUSE_TRIALS_MAX = int(os.environ.get("LQG_FUSE_TRIALS_MAX", "2048"))
 # TIME-PARALLEL system sweeps (csrc/lqg_scan.hpp: Riccati, Kalman and moment recursions as associative scans, log2(T)
 # dependent combines instead of T dependent steps), followed by the time-chunked per-trial sweep.  The sequential sweeps
-# cost T dependent steps whatever the number of systems (one lane each); the scans cost a fixed ~0.14 ms plus ~10 us
-# (m = 4) .. ~18 us (m = 8) per system, one wave per (system, step).  Measured crossover (scripts/small_batch.py, T = 500,
-# fp32): m = 4: ~8 systems (0.20 ms sequential), m = 8: ~40 systems (1.0 ms sequential) — so the default rule takes the
+# cost T dependent steps whatever the number of systems (one lane each); the scans cost a fixed ~0.16 ms plus ~4 us
+# (m = 4) .. ~14 us (m = 8) per system.  Measured crossover ON THE GPU TIMELINE (scripts/small_batch.py, T = 500, fp32):
+# m = 4: ~16 systems (0.21 ms sequential), m = 8: ~55 systems (1.0 ms sequential); a throw-away plan also pays ~0.1 ms of
+# host-side checks for the scan route (eigenvalue floor, conditioning), so the default rule stays below that and takes the
 # scans for at most 8 (m / 4)^2 systems (8 at m <= 4, capped at 64) with at least scan_min_steps(m) steps.
 # LQG_SCAN=0 never, LQG_SCAN=1 wherever the path is defined (no affine terms, floor provably inactive, u, y, d <= 4).
 SCAN_MAX_SYSTEMS = int(os.environ.get("LQG_SCAN_MAX_SYSTEMS", "0"))       # 0: the rule above
