@@ -5,7 +5,7 @@ The reference differentiates the likelihood with JAX reverse mode.  Two gradient
 method="fd" (default): CENTRAL FINITE DIFFERENCES in the unconstrained (log) space evaluated as ONE batched candidate
 sweep of 2P+1 systems through the fused HIP path — for ONE parameter vector this is the faster of the two on MI355X
 (all 2P+1 candidates x trials run in parallel; the whole evaluation is one hipGraph replay, lqg_amd/infer/graphed.py:
-0.27 ms per evaluation at T=500, 50 trials, P=4, and the Adam loop never synchronises with the host);
+0.24 ms per evaluation at T=500, 50 trials, P=4, and the Adam loop never synchronises with the host);
 method="adjoint": the reverse-mode HIP sweep behind torch.autograd (lqg_amd/grad.py; 2.8 ms per evaluation on the same
 workload — one lane walks one trial's 500 steps four times — but exact, and P-independent / 3x cheaper per gradient when
 many parameter vectors are differentiated at once).  fp64 is used throughout.  `candidate_search` is the
