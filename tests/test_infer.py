@@ -253,3 +253,24 @@ def test_nuts_potential_uses_the_graph_and_agrees_with_eager(monkeypatch):
     monkeypatch.setenv("LQG_GRAPH", "0")
     lp0, g0 = Potential(x, lqg_amd.BoundedActor, names, {}, 1.0, 1.0 / 60, prior.default_prior)(z)
     assert torch.allclose(lp, lp0, rtol=1e-12) and torch.allclose(g, g0, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,T", [(1, 200), (2, 200), (7, 12), (40, 97)])
+def test_graphed_evaluation_edge_shapes(n, T, monkeypatch):
+    """One / two trials (the in-lane sweeps, no operator stream), a horizon too short for scans or chunks, an odd horizon."""
+    import lqg_amd
+    from lqg_amd.infer.gradient import value_and_grad
+    truth = lqg_amd.BoundedActor(T=T, device="cuda", dtype=torch.float64)
+    with torch.no_grad():
+        x = truth.simulate(11, n=n)
+    x = torch.cat([x, x[:, -1:]], dim=1)
+    p = dict(action_variability=0.45, sigma_target=7.0, sigma_cursor=2.5, action_cost=0.2)
+    monkeypatch.setenv("LQG_GRAPH", "0")
+    v0, g0 = value_and_grad(x, lqg_amd.BoundedActor, p, method="fd")
+    monkeypatch.setenv("LQG_GRAPH", "1")
+    for _ in range(2):
+        v1, g1 = value_and_grad(x, lqg_amd.BoundedActor, p, method="fd")
+    assert abs(v1 / v0 - 1) < 1e-12
+    scale = max(abs(v) for v in g0.values())
+    assert all(abs(g1[k] - g0[k]) < 1e-6 * scale for k in g0), (g0, g1)
