@@ -24,7 +24,9 @@ def _graphed_fd(x, model_type, names, fixed, process_noise, dt, fd_step, group, 
            tuple(sorted((k, float(v)) for k, v in fixed.items())), float(process_noise), float(dt), float(fd_step), n_points)
     if key not in _graphed:
         if len(_graphed) >= 8:
-            _graphed.pop(next(iter(_graphed)))
+            old = _graphed.pop(next(iter(_graphed)))[0]
+            if old is not None:
+                old.release()               # (a graph must not be destroyed while a replay of it is still in flight)
         x64 = x.to(torch.float64)                # (the objective is evaluated in fp64, as the eager path does)
         ev = graphed.make(graphed.GraphedFiniteDifference, x64, model_type, list(names), n_points, group=group, h=fd_step,
                           fixed=fixed, process_noise=process_noise, dt=dt)

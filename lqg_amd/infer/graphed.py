@@ -101,6 +101,7 @@ class GraphedLogLik:
         self.graph = None
         self._keep = None
         self._affine = None
+        self._merged_cols = None
 
     # ---- the captured region -------------------------------------------------------------------------------------
     def _probe_affine(self):
@@ -113,6 +114,10 @@ class GraphedLogLik:
         rows += [torch.exp(torch.rand(P, generator=g, dtype=torch.float64) * 3.0 - 1.5) for _ in range(2)]
         th = torch.stack(rows).to(device=dev, dtype=dt_)                              # [1 + P + 2, P]
         m = self._construct(th)
+        if self._merged_cols is not None:                    # the composite map parameters -> COMPONENT specs
+            m, _ = self._component(m)
+            if m is None:
+                return None
         fa, fd = _flatten_spec(m.actor, th.shape[0]), _flatten_spec(m.dynamics, th.shape[0])
         if fa is None or fd is None:
             return None
@@ -143,11 +148,30 @@ class GraphedLogLik:
         return self.model_type(process_noise=self.pn, dt=self.dt, T=self.rows - 1, device=self.x.device,
                                dtype=self.x.dtype, **kw)
 
+    def _component(self, model):
+        """The system the kernels solve: the model itself, or — when it decouples into components with identical specs (every
+        dim = 2 tracking model: two copies of one 1-D model) — ONE component, the others' data columns becoming trials of
+        it (what LogLikelihoodPlan's merge does).  None: several DIFFERENT components (the plan's multi-launch path)."""
+        parts = model.decoupled(self.d_full, None, eps=self.eps)
+        if not parts:
+            return model, None
+        from lqg_amd import decouple
+        if len(decouple.identical_groups(model, self.d_full, parts, None)) != 1:
+            return None, None
+        return parts[0][0], [p_[1] for p_ in parts]
+
     def _decide(self, model):
         """Eager, once: everything that needs host values."""
         from lqg_amd import plan
-        if model.decoupled(self.d, None, eps=self.eps):
-            return False                     # several components: LogLikelihoodPlan's merged / stacked launches are the better path
+        self.d_full, self.n_full, self.x_full = self.d, self.n, self.x
+        sub, cols = self._component(model)
+        if sub is None:
+            return False                     # several distinct components: LogLikelihoodPlan's launches are the better path
+        self._merged_cols = cols
+        if cols is not None:                 # the components' columns as trials of one component system
+            self.x = plan._trial_stack(self.x_full, cols)
+            self.n, self.d = self.x.shape[0], self.x.shape[-1]
+            model = sub
         ln = _hip.Launch(model.actor, model.dynamics, d=self.d, n_trials=self.n, eps=self.eps)
         lib = ln.require_gpu()
         main = _abi.load()
@@ -155,8 +179,10 @@ class GraphedLogLik:
                                                            systems_scale=6 if self.x.dtype == torch.float64 else 2)
         spl = _hip.specialised_library(ln, model, self.d, check_strategy=not self.use_scan)
         self.sp_lib = spl
-        if os.environ.get("LQG_GRAPH_AFFINE") != "0":
+        if os.environ.get("LQG_GRAPH_AFFINE") != "0" or cols is not None:
             self._affine = self._probe_affine()
+        if cols is not None and self._affine is None:
+            return False                     # (decoupling inside the graph is only available through the measured affine map)
         return True
 
     def _loglik(self, model):
@@ -209,6 +235,18 @@ class GraphedLogLik:
                     self.out = self._forward()
                 self.graph = g
         return True
+
+    def release(self):
+        """Drop the graph and everything it owns, after the device has finished with it."""
+        if self.graph is not None:
+            torch.cuda.synchronize(self.x.device)
+        self.graph, self.out, self._keep = None, None, None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
     def __call__(self, theta):
         """theta [C, P] (any device / float dtype) -> fp64 [C] on the device (valid until the next call)."""

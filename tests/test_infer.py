@@ -274,3 +274,32 @@ def test_graphed_evaluation_edge_shapes(n, T, monkeypatch):
     assert abs(v1 / v0 - 1) < 1e-12
     scale = max(abs(v) for v in g0.values())
     assert all(abs(g1[k] - g0[k]) < 1e-6 * scale for k in g0), (g0, g1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,params", [
+    ("BoundedActor", dict(action_variability=0.5, sigma_target=6.0, sigma_cursor=3.0, action_cost=0.1)),
+    ("SubjectiveActor", dict(action_cost=0.2, action_variability=0.5, subj_noise=1.0, subj_vel_noise=0.5, sigma_target=6.0,
+                             sigma_cursor=3.0))])
+def test_graphed_evaluation_of_models_that_decouple(model, params, monkeypatch):
+    """dim = 2 tracking models decouple into two identical 1-D components: the graph solves ONE component with the other's
+    data columns as extra trials (the measured affine map goes from the parameters straight to the component's specs)."""
+    import lqg_amd
+    from lqg_amd.infer import graphed
+    from lqg_amd.infer.gradient import value_and_grad
+    cls = getattr(lqg_amd, model)
+    truth = cls(dim=2, T=200, device="cuda", dtype=torch.float64)
+    with torch.no_grad():
+        x = truth.simulate(3, n=30).contiguous()
+    x = torch.cat([x, x[:, -1:]], dim=1)
+    ev = graphed.make(graphed.GraphedFiniteDifference, x, cls, list(params), 1, h=1e-4, fixed=dict(dim=2))
+    assert ev is not None and ev._merged_cols is not None and len(ev._merged_cols) == 2 and ev.n == 60 and ev.d == 2
+    for scale in (1.0, 1.4):
+        p = {k: v * scale for k, v in params.items()}
+        monkeypatch.setenv("LQG_GRAPH", "0")
+        v0, g0 = value_and_grad(x, cls, p, method="fd", dim=2)
+        monkeypatch.setenv("LQG_GRAPH", "1")
+        v1, g1 = value_and_grad(x, cls, p, method="fd", dim=2)
+        assert abs(v1 / v0 - 1) < 1e-12
+        s_ = max(abs(v) for v in g0.values())
+        assert all(abs(g1[k] - g0[k]) < 1e-6 * s_ for k in g0), (g0, g1)
