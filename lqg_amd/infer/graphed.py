@@ -17,9 +17,9 @@ cached (lqg_amd/tracking/_build.py); every decision that needs host values — w
 pattern library — is taken in an EAGER warm-up evaluation of the same shapes and frozen (the time-parallel scans are taken
 for up to six times (fp64; twice in fp32) the systems of the eager rule: their host-side checks are paid once here).  PointMassBoundedActor's
 discretisation runs as one kernel (csrc/lqg_setup.hip) instead of host-synchronising torch.linalg calls.  What is not
-captured: a user model whose constructor synchronises or copies from the host, a model that decouples into several
-components (LogLikelihoodPlan merges them; here the joint problem would run), an initialised process group (the all-reduce
-stays outside).  `make()` returns None in those cases and the callers keep the eager path.  LQG_GRAPH=0 disables.
+captured: a user model whose constructor synchronises or copies from the host, a model that decouples into DIFFERENT
+components (identical ones — the dim = 2 tracking models — are merged as trials of one component, through the measured
+affine map), an initialised process group (the all-reduce stays outside).  `make()` returns None in those cases and the callers keep the eager path.  LQG_GRAPH=0 disables.
 """
 import ctypes as C
 import os
