@@ -88,8 +88,23 @@ def _take(t, rows, cols=None, time_axis=True):
         out._lqg_base = base
         return out
     if cols is None:
-        return t[..., rows]
-    return t[..., rows, :][..., :, cols]
+        return torch.index_select(t, -1, _index(rows, t.device))
+    return torch.index_select(torch.index_select(t, -2, _index(rows, t.device)), -1, _index(cols, t.device))
+
+
+_index_cache = {}
+
+
+def _index(idx, device):
+    """Device index tensor of a Python index list, cached (indexing with the list itself builds the index on the host and
+    copies it to the device on every call: 64 gathers per decoupling plan, 1.5 ms)."""
+    key = (tuple(int(i) for i in idx), str(device))
+    t = _index_cache.get(key)
+    if t is None:
+        if len(_index_cache) > 4096:
+            _index_cache.clear()
+        t = _index_cache[key] = torch.tensor(list(key[0]), dtype=torch.long, device=device)
+    return t
 
 
 def _noise_cols(mask_rows):
@@ -255,6 +270,12 @@ def plan(system, d, Sigma0=None, for_grad=False):
     # noise-factor column masks come from the instance (cheap) — only used to pick columns, never to drop values
     result = split_system(system, entry["comps"], nz(first(system.actor.V)), nz(first(system.actor.W)),
                           nz(first(system.dynamics.V)), nz(first(system.dynamics.W)))
+    zs = specialize.zoo_structure(system)
+    if zs is not None and not for_grad and Sigma0 is None:
+        # the components' sparsity patterns are a property of the constructor too: specialize.system_pattern answers from
+        # a class-level probe instead of reading the component's values back from the device (22 synchronisations)
+        for i, (sub, _, _) in enumerate(result):
+            sub._lqg_zoo_component = (type(system), tuple(sorted(zs.items())), d, i)
     if not for_grad:
         entry["parts"] = result
     return result
