@@ -20,6 +20,8 @@ def _graphed_fd(x, model_type, names, fixed, process_noise, dt, fd_step, group, 
     if group is not None or not x.is_cuda or os.environ.get("LQG_GRAPH") == "0":
         return None
     from lqg_amd.infer import graphed
+    if graphed._sharded():
+        return None
     key = (x.data_ptr(), tuple(x.shape), x.dtype, x._version, model_type, tuple(names),
            tuple(sorted((k, float(v)) for k, v in fixed.items())), float(process_noise), float(dt), float(fd_step), n_points)
     if key not in _graphed:

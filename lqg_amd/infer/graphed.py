@@ -287,9 +287,16 @@ class GraphedFiniteDifference(GraphedLogLik):
 _warned = set()
 
 
+def _sharded():
+    """True under an initialised process group of more than one rank: the objective is then all-reduced over the ranks'
+    trial shards (lqg_amd.dist), which stays outside any graph."""
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 def make(cls, x, model_type, names, n, group=None, **kw):
     """A captured evaluator, or None when this evaluation cannot be captured (the caller keeps its eager path)."""
-    if os.environ.get("LQG_GRAPH") == "0" or group is not None or not x.is_cuda:
+    if os.environ.get("LQG_GRAPH") == "0" or group is not None or not x.is_cuda or _sharded():
         return None
     try:
         ev = cls(x, model_type, names, n, **kw)

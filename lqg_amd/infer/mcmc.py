@@ -58,6 +58,9 @@ class Potential:
         import os
         if self.group is not None or not z.is_cuda or os.environ.get("LQG_GRAPH") == "0":
             return None
+        from lqg_amd.infer import graphed as _g
+        if _g._sharded():
+            return None
         cur = getattr(self, "_gev", None)
         if cur is None or (cur is not False and cur.K < C):
             from lqg_amd.infer import graphed
