@@ -179,7 +179,13 @@ class GraphedLogLik:
                                                            systems_scale=6 if self.x.dtype == torch.float64 else 2)
         spl = _hip.specialised_library(ln, model, self.d, check_strategy=not self.use_scan)
         self.sp_lib = spl
-        if os.environ.get("LQG_GRAPH_AFFINE") != "0" or cols is not None:
+        # The affine shortcut is offered to constructors KNOWN to be affine (the tracking models; a user class opts in with
+        # `_lqg_affine_constructor = True`) and still verified numerically — two random probes cannot prove that an
+        # arbitrary constructor is affine everywhere.
+        import lqg_amd
+        known = self.model_type in (lqg_amd.BoundedActor, lqg_amd.OptimalActor, lqg_amd.RelativeObservationBoundedActor,
+                                    lqg_amd.SubjectiveActor) or getattr(self.model_type, "_lqg_affine_constructor", False)
+        if known and (os.environ.get("LQG_GRAPH_AFFINE") != "0" or cols is not None):
             self._affine = self._probe_affine()
         if cols is not None and self._affine is None:
             return False                     # (decoupling inside the graph is only available through the measured affine map)
@@ -302,7 +308,10 @@ def make(cls, x, model_type, names, n, group=None, **kw):
         ev = cls(x, model_type, names, n, **kw)
         return ev if ev.capture() else None
     except Exception as e:                       # a constructor that synchronises, an allocator / capture restriction, ...
-        torch.cuda.synchronize()
+        try:
+            torch.cuda.synchronize()
+        except Exception:
+            pass
         key = (getattr(model_type, "__name__", str(model_type)), type(e).__name__)
         if key not in _warned:
             _warned.add(key)
