@@ -447,6 +447,37 @@ def extra_legs(torch, args, dev):
         extra[f"config{cfg}_one_system"] = leg
         del x
         torch.cuda.empty_cache()
+    # the inner loop of the reference's inference drivers (lqg/infer/mle.py:17-23, NUTS): value + gradient of ONE parameter
+    # vector on 50 trials, T = 500, fp64 — batched central differences replayed as one hipGraph (lqg_amd/infer/graphed.py),
+    # the same launched from Python, and the reverse-mode sweep; BASELINE.md derives ~54 evaluations/s for the reference
+    import time
+    from lqg_amd.infer import gradient
+    true = dict(sigma_target=25.0, sigma_cursor=1.0, action_cost=0.05, action_variability=0.5)
+    with torch.no_grad():
+        xg = lqg_amd.BoundedActor(T=500, device=dev, dtype=torch.float64, **true).simulate(0, n=50)
+    xg = torch.cat([xg, xg[:, -1:]], dim=1)                       # lqg_model's convention: T rows = T - 1 steps
+    p0 = dict(sigma_target=20.0, sigma_cursor=2.0, action_cost=0.1, action_variability=0.4)
+    leg = {"workload": "BoundedActor T=500, 50 trials, 4 parameters, one parameter vector, fp64", "unit": "ms per value+gradient"}
+    for name, method, env, reps in (("fd_graph", "fd", {}, 300), ("fd_eager", "fd", {"LQG_GRAPH": "0"}, 100), ("adjoint", "adjoint", {}, 50)):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            for i in range(5):
+                gradient.value_and_grad(xg, lqg_amd.BoundedActor, dict(p0, sigma_target=20.0 + 0.01 * i), method=method)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(reps):          # (a different vector every call: nothing is cached across evaluations)
+                gradient.value_and_grad(xg, lqg_amd.BoundedActor, dict(p0, sigma_target=20.0 + 1e-3 * i), method=method)
+            torch.cuda.synchronize()
+            leg[name] = (time.perf_counter() - t0) / reps * 1e3
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    leg["evaluations_per_s"] = 1e3 / leg["fd_graph"]
+    extra["one_vector_value_and_grad"] = leg
     return extra
 
 
