@@ -192,3 +192,18 @@ def test_scan_levels_packed_sub_wave_for_many_candidates(model, monkeypatch):
     assert all(wk["scan"] for wk in p.work)
     got = p.run().clone()
     assert got.shape == (24, 12) and float((got / ref - 1).abs().max()) < 1e-10
+
+
+def test_default_rule_against_sequential_on_random_zoo_models():
+    """scripts/fuzz_time_parallel.py in 'default' mode: 80 random (class, parameters over wide log-uniform ranges, horizon,
+    trials, candidates, chunk count) cases; wherever the default rule takes the time-parallel path the result equals the
+    sequential kernels to 1e-9 — the ill-conditioned fully observed point mass must have been kept on the sequential sweeps."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("LQG_")}
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_time_parallel.py"), "11", "80", "default"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = [ln for ln in r.stdout.splitlines() if ln.startswith("mode default")][-1]
+    assert last.endswith("failures []"), last
+    assert int(last.split("scan path used in")[1].split()[0]) >= 20, last
