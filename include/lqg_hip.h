@@ -33,9 +33,16 @@
 extern "C" {
 #endif
 
-#define LQG_ABI_VERSION 1
+#define LQG_ABI_VERSION 2
 
-typedef enum lqg_dtype { LQG_F32 = 0, LQG_F64 = 1 } lqg_dtype;
+/* LQG_F32 / LQG_F64: arithmetic and storage type of every array of the problem.
+ * LQG_F32_SYS64 (mixed; lqg_log_likelihood / lqg_log_likelihood_sp / lqg_workspace_bytes only, n_trials >= 3): an fp32
+ * problem — trajectories x, results ll and the internal operator stream are float — whose SPEC arrays (and Sigma0) are
+ * handed over as double and whose per-system sweeps (Riccati, Kalman, moment recursion: data-independent, amortised
+ * over the trials) run in fp64; the per-trial sweep stays fp32.  The operators reach the fp32 sweep rounded ONCE
+ * instead of carrying the rounding of three fp32 recursions over T steps: this is what holds 1e-6 relative on the
+ * log-likelihood at horizons >= 1000.  Spec strides are then in elements of double. */
+typedef enum lqg_dtype { LQG_F32 = 0, LQG_F64 = 1, LQG_F32_SYS64 = 2 } lqg_dtype;
 
 /* error codes (negative return values) */
 #define LQG_ERR_NULL        (-1)  /* required pointer missing            */
@@ -80,7 +87,7 @@ typedef struct lqg_dims {
 } lqg_dims;
 
 typedef struct lqg_problem {
-  int32_t  dtype;      /* lqg_dtype: arithmetic and storage type of every array */
+  int32_t  dtype;      /* lqg_dtype: arithmetic and storage type of every array (LQG_F32_SYS64: see above) */
   int32_t  T;          /* number of steps (System.T, lqg/system.py:17-24); data has T+1 rows */
   int64_t  n_sys;      /* B */
   int64_t  n_trials;   /* N trials per system */
@@ -170,7 +177,12 @@ int lqg_conditional_moments_scan(const lqg_problem* p, lqg_traj x, lqg_traj mu, 
 
 /* The per-trial sweep of a structure-specialised library (csrc/lqg_sp_entry.hpp: `lqg_trial_sweep_sp`, the operator's
  * structural zeros compiled out) over an operator stream produced elsewhere.  `ops` points at the stream
- * [n_sys][T+1][ops_reals]; the scratch of the time-chunked sweep follows it (csrc/lqg_trial_chunk.hpp). */
+ * [n_sys][T+1][ops_reals]; the scratch of the time-chunked sweep follows it (csrc/lqg_trial_chunk.hpp).
+ * Stream format (ABI 2), per (system, step), m = x + b, o = d, r = m - o:  (Fj - I)[m,m] row-major | U2[r,o] | Li (lower
+ * triangle of chol(Sigma_oo)^-1, packed by rows) | half log-det + o/2 log(2 pi), padded to a multiple of 4 reals.  The
+ * mean state is (dO, muR) with observed mean = x_{t-1} + dO:  w = Li ((x_t - x_{t-1}) - dO),  c = muR + U2 w,
+ * [dO' ; muR'] = [0 ; c] + (Fj - I) [x_t ; c].  The identity is taken off Fj BEFORE rounding (ABI 1 kept it on the
+ * unobserved rows): fl(F_ii) ~ 1 loses the digits of F_ii - 1 that integrate the mean over the horizon. */
 typedef int (*lqg_trial_sweep_fn)(const lqg_problem* p, lqg_traj x, void* ll, int64_t ll_sb, int64_t ll_sn,
                                   const void* ops, void* stream);
 /* lqg_log_likelihood_scan with the per-trial sweep delegated to `trial_sweep` (NULL: the library's own kernels; a

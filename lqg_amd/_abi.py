@@ -6,8 +6,8 @@ compute entry point raises (no CPU fallback, by design — see DESIGN.md "Bounda
 import ctypes as C
 import os
 
-ABI_VERSION = 1
-F32, F64 = 0, 1
+ABI_VERSION = 2
+F32, F64, F32_SYS64 = 0, 1, 2      # F32_SYS64: include/lqg_hip.h (fp32 problem, fp64 spec arrays and system sweeps)
 OP_LOG_LIKELIHOOD, OP_CONDITIONAL_MOMENTS = 0, 1
 FAM_FORWARD, FAM_RICCATI, FAM_KALMAN, FAM_TRIAL, FAM_SIMULATE, FAM_ADJOINT = range(6)
 # which of (x, b, u, y, d) a kernel family is instantiated on (include/lqg_hip.h: lqg_kernel_supported)

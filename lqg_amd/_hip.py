@@ -41,12 +41,19 @@ def _field_view(t, name, batched):
 class Launch:
     """One problem description plus the tensors it points into (kept alive for the call)."""
 
-    def __init__(self, actor: LQGSpec, dynamics: LQGSpec = None, d=None, n_trials=1, Sigma0=None, eps=1e-8):
+    def __init__(self, actor: LQGSpec, dynamics: LQGSpec = None, d=None, n_trials=1, Sigma0=None, eps=1e-8,
+                 traj_dtype=None):
+        """traj_dtype=torch.float32 with float64 specs describes the MIXED problem LQG_F32_SYS64 (include/lqg_hip.h):
+        trajectories, results and the operator stream are float, the spec arrays double."""
         dynamics = actor if dynamics is None else dynamics
         A = actor.A
         if A.dtype not in _DT:
             raise LqgHipError(f"unsupported dtype {A.dtype}: float32 or float64")
-        self.dtype, self.device = A.dtype, A.device
+        self.spec_dtype = A.dtype
+        self.dtype, self.device = (traj_dtype or A.dtype), A.device     # dtype: trajectories / results
+        self.mixed = self.dtype != self.spec_dtype
+        if self.mixed and (self.dtype, self.spec_dtype) != (torch.float32, torch.float64):
+            raise LqgHipError(f"mixed precision is float32 trajectories over float64 specs, got {self.dtype} / {self.spec_dtype}")
         self.batched = spec_is_batched(actor) or spec_is_batched(dynamics)
         self.B = 1
         for sp in (actor, dynamics):
@@ -58,7 +65,7 @@ class Launch:
                          nwa=actor.W.shape[-1], nvd=dynamics.V.shape[-1], nwd=dynamics.W.shape[-1])
         self.m = x + b
         p = _abi.Problem()
-        p.dtype, p.T, p.n_sys, p.n_trials, p.eps = _DT[A.dtype], self.T, self.B, n_trials, float(eps)
+        p.dtype, p.T, p.n_sys, p.n_trials, p.eps = (_abi.F32_SYS64 if self.mixed else _DT[A.dtype]), self.T, self.B, n_trials, float(eps)
         p.dims = _abi.Dims(**self.dims)
         self._keep = []
         for spec, dst, fields in ((actor, p.actor, _abi.SPEC_FIELDS), (dynamics, p.dynamics, ("A", "B", "F", "V", "W"))):
@@ -67,12 +74,12 @@ class Launch:
                 if t is None or (f in ("q", "qf", "P", "r") and _is_zero(t)):
                     setattr(dst, f, _abi.NULL_VIEW)
                     continue
-                if t.dtype != self.dtype or t.device != self.device:
+                if t.dtype != self.spec_dtype or t.device != self.device:
                     raise LqgHipError(f"spec field {f}: dtype/device {t.dtype}/{t.device} differs from A's")
                 self._keep.append(t)
                 setattr(dst, f, _field_view(t, f, self.batched))
         if Sigma0 is not None:
-            S0 = Sigma0.to(dtype=self.dtype, device=self.device)
+            S0 = Sigma0.to(dtype=self.spec_dtype, device=self.device)
             self._keep.append(S0)
             p.Sigma0 = _abi.mat_view(S0.data_ptr(), S0.shape, _es(S0), S0.dim() == 3, False, False)
         else:

@@ -41,6 +41,11 @@ LQG_KALMAN_DIMS(X)
       hipStream_t);
 LQG_FORWARD_DIMS(X)
 #undef X
+#define X(X_, B_, U_, Y_, D_)                                                                                   \
+  extern template hipError_t lqg::host::launch_forward_ops32<X_, B_, U_, Y_, D_>(const lqg_problem*, const void*, long, \
+                                                                                  void*, hipStream_t);
+LQG_FORWARD_DIMS(X)
+#undef X
 #define X(M_, D_)                                                                                              \
   extern template hipError_t lqg::host::launch_trial<float, M_, D_>(const lqg_problem*, const void*, lqg_traj, \
                                                                      lqg_traj, void*, long, long, hipStream_t); \
@@ -118,6 +123,17 @@ hipError_t dispatch_forward(const lqg_problem* p, const void* Ls, long ldb, bool
   *found = false;
   return hipSuccess;
 }
+hipError_t dispatch_forward_ops32(const lqg_problem* p, const void* Ls, long ldb, void* ops, hipStream_t st, bool* found) {
+  *found = true;
+  const lqg_dims& d = p->dims;
+#define X(X_, B_, U_, Y_, D_)                                                  \
+  if (d.x == X_ && d.b == B_ && d.u == U_ && d.y == Y_ && d.d == D_)          \
+    return launch_forward_ops32<X_, B_, U_, Y_, D_>(p, Ls, ldb, ops, st);
+  LQG_FORWARD_DIMS(X)
+#undef X
+  *found = false;
+  return hipSuccess;
+}
 template <typename R>
 hipError_t dispatch_trial(const lqg_problem* p, const void* ops, lqg_traj x, lqg_traj mu, void* ll, long ll_sb,
                           long ll_sn, hipStream_t st, bool* found) {
@@ -178,9 +194,13 @@ bool use_coop(const lqg_problem* p) {
   return p->n_sys <= LQG_COOP_MAX_SYS && p->dims.x + p->dims.b >= LQG_COOP_MIN_M;
 }
 
-int check_problem(const lqg_problem* p, const char* who) {
+// mixed: the entry point serves LQG_F32_SYS64 (include/lqg_hip.h) — every other one reads all arrays in ONE type
+int check_problem(const lqg_problem* p, const char* who, bool mixed = false) {
   if (!p) return fail(LQG_ERR_NULL, "%s: problem is NULL", who);
-  if (p->dtype != LQG_F32 && p->dtype != LQG_F64) return fail(LQG_ERR_ARG, "%s: bad dtype %d", who, p->dtype);
+  if (p->dtype == LQG_F32_SYS64 && !mixed)
+    return fail(LQG_ERR_ARG, "%s: dtype LQG_F32_SYS64 is served by lqg_log_likelihood only", who);
+  if (p->dtype != LQG_F32 && p->dtype != LQG_F64 && p->dtype != LQG_F32_SYS64)
+    return fail(LQG_ERR_ARG, "%s: bad dtype %d", who, p->dtype);
   if (p->T < 1) return fail(LQG_ERR_ARG, "%s: T=%d < 1", who, p->T);
   if (p->n_sys < 0 || p->n_trials < 0) return fail(LQG_ERR_ARG, "%s: negative batch", who);
   const lqg_dims& d = p->dims;
@@ -204,8 +224,8 @@ int done(hipError_t e, const char* who) {
   return (int)e;
 }
 
-int check_full(const lqg_problem* p, const char* who) {
-  if (int rc = check_problem(p, who)) return rc;
+int check_full(const lqg_problem* p, const char* who, bool mixed = false) {
+  if (int rc = check_problem(p, who, mixed)) return rc;
   const lqg_spec& a = p->actor;
   const lqg_spec& d = p->dynamics;
   if (need(a.Q, who, "actor.Q") || need(a.Qf, who, "actor.Qf") || need(a.R, who, "actor.R") ||
@@ -264,6 +284,39 @@ int run_moments(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_view Sigma, v
     e = dispatch_trial<R>(p, ops, x, mu, ll, ll_sb, ll_sn, st, &found);
     if (!found) return unsupported(p, who);
   }
+  mark(3);
+  return done(e, who);
+}
+
+// LQG_F32_SYS64: Riccati and forward sweeps in fp64 over the double spec arrays, operator stream rounded to float on the
+// way out, per-trial sweep in fp32 (lane kernels only; time-invariant or not, affine terms or not).
+int run_mixed(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll_sn, void* workspace, size_t workspace_bytes,
+              hipStream_t st, const char* who) {
+  if (p->n_trials < 3) return fail(LQG_ERR_ARG, "%s: LQG_F32_SYS64 needs n_trials >= 3 (operator-stream path)", who);
+  if (use_coop(p)) return fail(LQG_ERR_ARG, "%s: LQG_F32_SYS64 is served by the lane kernels only", who);
+  const Workspace w = carve(p, true);
+  if (!workspace || workspace_bytes < w.total)
+    return fail(LQG_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B", who, workspace_bytes, w.total);
+  char* base = static_cast<char*>(workspace);
+  void* Ls = base + w.ls_off;
+  void* ops = base + w.ops_off;
+  bool found;
+  auto mark = [&](int i) {
+    if (p->phase_events[i]) (void)hipEventRecord(static_cast<hipEvent_t>(p->phase_events[i]), st);
+  };
+  const lqg_view none{nullptr, 0, 0, 0, 0};
+  const lqg_traj no_mu{nullptr, 0, 0, 0, 0};
+  mark(0);
+  hipError_t e = dispatch_riccati<double>(p, none, none, none, Ls, w.ldb, st, &found);
+  if (!found) return unsupported(p, who);
+  if (e != hipSuccess) return done(e, who);
+  mark(1);
+  e = dispatch_forward_ops32(p, Ls, w.ldb, ops, st, &found);
+  if (!found) return unsupported(p, who);
+  if (e != hipSuccess) return done(e, who);
+  mark(2);
+  e = dispatch_trial<float>(p, ops, x, no_mu, ll, ll_sb, ll_sn, st, &found);
+  if (!found) return unsupported(p, who);
   mark(3);
   return done(e, who);
 }
@@ -498,10 +551,12 @@ int lqg_solve_materialised(const lqg_problem* p, lqg_traj x, lqg_view L, lqg_vie
 int lqg_log_likelihood(const lqg_problem* p, lqg_traj x, void* ll, int64_t ll_sb, int64_t ll_sn, void* workspace,
                        size_t workspace_bytes, void* stream) {
   static const char* who = "lqg_log_likelihood";
-  if (int rc = check_full(p, who)) return rc;
+  if (int rc = check_full(p, who, true)) return rc;
   if (p->n_sys == 0 || p->n_trials == 0) return 0;   // empty batch: nothing to do (pointers may be NULL)
   if (!x.ptr) return fail(LQG_ERR_NULL, "%s: x.ptr is NULL", who);
   if (!ll) return fail(LQG_ERR_NULL, "%s: ll is NULL", who);
+  if (p->dtype == LQG_F32_SYS64)
+    return run_mixed(p, x, ll, ll_sb, ll_sn, workspace, workspace_bytes, (hipStream_t)stream, who);
   const lqg_traj no_mu{nullptr, 0, 0, 0, 0};
   const lqg_view no_sig{nullptr, 0, 0, 0, 0};
   const GainOutputs none{};

@@ -551,7 +551,7 @@ __global__ void __launch_bounds__(BLOCK) k_coop_forward(const Args<R> a) {
       C[p * rr + q2] = acc;
     });
   };
-  auto sig1 = [&](int t) {                                   // T1 = Fj[:, o:] C ; emit Fj - [[I_o,0],[0,0]]
+  auto sig1 = [&](int t) {                                   // T1 = Fj[:, o:] C ; emit Fj - I (diagonal assembled as a deviation)
     if (on(0)) mr.each([&](int i, int q2) {
       R acc = R(0);
       acc = dot4(Fj + i * m + o, 1, C + q2, rr, rr, acc);
@@ -559,7 +559,18 @@ __global__ void __launch_bounds__(BLOCK) k_coop_forward(const Args<R> a) {
     });
     if (a.ops && on(1)) {
       R* op = a.ops + (s * (a.T + 1) + t) * (long)a.nops;
-      mm_.each([&](int i, int j) { op[i * m + j] = (i < o && i == j) ? Fj[i * m + j] - R(1) : Fj[i * m + j]; });
+      mm_.each([&](int i, int j) {
+        R f = Fj[i * m + j];
+        if (i == j) {                                        // (A_ii - 1) first, then the small terms: see k_forward
+          if (i < x) {
+            f = Ad[i * x + i] - R(1);
+          } else {
+            const int ib = i - x;
+            f = dot4(BK + ib * u, 1, Lm + ib, b, u, (Aa[ib * b + ib] - R(1)) - KFAa[ib * b + ib]);
+          }
+        }
+        op[i * m + j] = f;
+      });
     }
   };
   auto sig2 = [&](int t) {                                   // Sigma' = T1 Fj[:, o:]' + GG          system.py:223-230
@@ -707,10 +718,10 @@ __global__ void __launch_bounds__(BLOCK) k_coop_trial(const R* __restrict__ ops_
         AT(mn, i) = v;
       }
       for (int i = 0; i < o; ++i) { AT(dO, i) = AT(mn, i); AT(xprev, i) = AT(xt, i); }
-      for (int p = 0; p < rr; ++p) AT(muR, p) = AT(mn, o + p);
+      for (int p = 0; p < rr; ++p) AT(muR, p) = AT(c, p) + AT(mn, o + p);      // (the stream holds Fj - I)
       if (a.mu.p && live) {
         R* dst = const_cast<R*>(a.mu.p) + sys * a.mu.sb + n * a.mu.sn + (long)t * a.mu.st;
-        for (int i = 0; i < m; ++i) dst[i * a.mu.sd] = (i < o) ? AT(xt, i) + AT(mn, i) : AT(mn, i);
+        for (int i = 0; i < m; ++i) dst[i * a.mu.sd] = (i < o) ? AT(xt, i) + AT(mn, i) : AT(muR, i - o);
       }
     }
   }

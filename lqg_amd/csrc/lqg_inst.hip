@@ -54,6 +54,18 @@ LQG_FWD_UNIT(float)
 #endif
 #ifdef LQG_INST_F64
 LQG_FWD_UNIT(double)
+// the mixed-precision operator-stream variants (LQG_F32_SYS64) ride in the fp64 units of the same FUSED = false quarters
+#define LQG_FWD_OPS32_V(T_) \
+  launch_forward_ops32_v<LQG_INST_FORWARD, T_>(const lqg::ForwardArgs<double>&, long, hipStream_t)
+#if LQG_INST_VARIANT == 3
+extern template hipError_t LQG_FWD_OPS32_V(false);
+extern template hipError_t LQG_FWD_OPS32_V(true);
+template hipError_t launch_forward_ops32<LQG_INST_FORWARD>(const lqg_problem*, const void*, long, void*, hipStream_t);
+#elif LQG_INST_VARIANT == 1
+template hipError_t LQG_FWD_OPS32_V(true);
+#elif LQG_INST_VARIANT == 0
+template hipError_t LQG_FWD_OPS32_V(false);
+#endif
 #endif
 #endif
 #ifdef LQG_INST_TRIAL

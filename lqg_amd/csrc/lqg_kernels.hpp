@@ -49,7 +49,7 @@ namespace lqg {
 template <int M, int ND>
 struct TrialOps {
   static constexpr int O = ND, RR = M - ND;
-  static constexpr int F_OFF = 0;                       // Fj[M,M] - [[I_o, 0],[0, 0]]  (deviation form)
+  static constexpr int F_OFF = 0;                       // Fj[M,M] - I  (deviation form, see k_trial)
   static constexpr int U_OFF = M * M;                   // U2[RR,O]
   static constexpr int L_OFF = U_OFF + RR * O;          // Li lower, packed by rows
   static constexpr int H_OFF = L_OFF + O * (O + 1) / 2; // half log-det + d/2 log(2 pi)
@@ -277,7 +277,9 @@ struct ForwardArgs {
 
 // MAT = materialise (Sigma / mu / K outputs requested): kept out of the pure log-likelihood instantiation so that the
 // hot kernel carries no store code, no output address arithmetic and no extra live pointers.
-template <typename R, int NX, int NB, int NU, int NY, int ND, bool TI, bool FUSED, bool MAT>
+// OT: element type of the operator stream (!FUSED).  OT = float with R = double is the MIXED mode of an fp32 problem whose
+// per-system sweeps run in fp64 (include/lqg_hip.h: LQG_F32_SYS64): the operators are rounded to fp32 ONCE, on the way out.
+template <typename R, int NX, int NB, int NU, int NY, int ND, bool TI, bool FUSED, bool MAT, typename OT = R>
 __global__ void __launch_bounds__(LQG_BLOCK, LQG_FWD_WAVES) k_forward(const ForwardArgs<R> a) {
   constexpr int M = NX + NB, O = ND, RR = M - ND;
   using Ops = TrialOps<M, ND>;
@@ -378,9 +380,8 @@ __global__ void __launch_bounds__(LQG_BLOCK, LQG_FWD_WAVES) k_forward(const Forw
       LQG_UNROLL for (int e = 0; e < NU * NB; ++e) L[e] = src[e * a.ldb];
     }
     // ---- joint dynamics Fj = [[Ad, Bd L],[K Fd Ad, Aa - K Fa Aa + (Ba + K (Fd Bd - Fa Ba)) L]]   system.py:167-187
-    R Fj[M * M];
+    R Fj[M * M], BK[NB * NU];
     {
-      R BK[NB * NU];
       LQG_UNROLL for (int i = 0; i < NB; ++i)
         LQG_UNROLL for (int j = 0; j < NU; ++j) {
           R v = Ba[i * NU + j];
@@ -457,17 +458,31 @@ __global__ void __launch_bounds__(LQG_BLOCK, LQG_FWD_WAVES) k_forward(const Forw
         LQG_UNROLL for (int i = 0; i < M; ++i) dst[i * a.mu.sd] = (i < O) ? xt[i] + mn[i] : mn[i];
       }
     } else if (a.ops) {
-      R* op = a.ops + ((long)s * (a.T + 1) + t) * Ops::N;
-      LQG_UNROLL for (int i = 0; i < M; ++i)      // Fj with the identity removed from the observed block (deviation form)
-        LQG_UNROLL for (int j = 0; j < M; ++j)
-          op[Ops::F_OFF + i * M + j] = (i < O && i == j) ? Fj[i * M + j] - R(1) : Fj[i * M + j];
-      LQG_UNROLL for (int i = 0; i < RR * O; ++i) op[Ops::U_OFF + i] = U2[i];
+      OT* op = reinterpret_cast<OT*>(a.ops) + ((long)s * (a.T + 1) + t) * Ops::N;
+      // Fj - I.  The diagonal is ASSEMBLED as a deviation — (A_ii - 1) first (exact for A_ii in [1/2, 2]), then the small
+      // terms — instead of subtracting 1 from the rounded entry: fl(F_ii) carries an absolute error of eps/2, i.e. a relative
+      // error of eps / |F_ii - 1| on the deviation, and it multiplies the mean state at EVERY step with the same sign.
+      LQG_UNROLL for (int i = 0; i < M; ++i)
+        LQG_UNROLL for (int j = 0; j < M; ++j) {
+          if (i != j) { op[Ops::F_OFF + i * M + j] = (OT)Fj[i * M + j]; continue; }
+          R v;
+          if (i < NX) {
+            v = Ad[i * NX + i] - R(1);
+          } else {
+            const int ib = i - NX;
+            v = Aa[ib * NB + ib] - R(1);
+            LQG_UNROLL for (int k = 0; k < NY; ++k) v -= K[ib * NY + k] * FAa[k * NB + ib];
+            LQG_UNROLL for (int k = 0; k < NU; ++k) v += BK[ib * NU + k] * L[k * NB + ib];
+          }
+          op[Ops::F_OFF + i * M + i] = (OT)v;
+        }
+      LQG_UNROLL for (int i = 0; i < RR * O; ++i) op[Ops::U_OFF + i] = (OT)U2[i];
       {
         int e = 0;
         LQG_UNROLL for (int i = 0; i < O; ++i)
-          LQG_UNROLL for (int j = 0; j <= i; ++j) op[Ops::L_OFF + (e++)] = Li[i * O + j];
+          LQG_UNROLL for (int j = 0; j <= i; ++j) op[Ops::L_OFF + (e++)] = (OT)Li[i * O + j];
       }
-      op[Ops::H_OFF] = hl + kLogNorm;
+      op[Ops::H_OFF] = (OT)(hl + kLogNorm);
     }
     // ---- Sigma' = Fj[:, o:] C Fj[:, o:]^T + GG,  C = Srr - U2 U2^T                              system.py:223-230
     {
@@ -502,13 +517,13 @@ __global__ void __launch_bounds__(LQG_BLOCK, LQG_FWD_WAVES) k_forward(const Forw
     innovate(a.T, true);
     if (a.ll) a.ll[s * a.ll_sb] = (R)acc;
   } else if (a.ops) {
-    R* op = a.ops + ((long)s * (a.T + 1) + a.T) * Ops::N;
+    OT* op = reinterpret_cast<OT*>(a.ops) + ((long)s * (a.T + 1) + a.T) * Ops::N;
     {
       int e = 0;
       LQG_UNROLL for (int i = 0; i < O; ++i)
-        LQG_UNROLL for (int j = 0; j <= i; ++j) op[Ops::L_OFF + (e++)] = Li[i * O + j];
+        LQG_UNROLL for (int j = 0; j <= i; ++j) op[Ops::L_OFF + (e++)] = (OT)Li[i * O + j];
     }
-    op[Ops::H_OFF] = hl + kLogNorm;
+    op[Ops::H_OFF] = (OT)(hl + kLogNorm);
   }
 }
 
@@ -624,12 +639,13 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial(const R* __restrict__ ops_a
           LQG_UNROLL for (int p = 0; p < RR; ++p) v += LQG_OP(Ops::F_OFF + i * M + O + p) * c[p];
           mn[i] = v;
         }
+        // the stream holds Fj - I: mn is the DEVIATION of the new mean from [x_t ; c]
         LQG_UNROLL for (int i = 0; i < O; ++i) { dO[k][i] = mn[i]; xprev[k][i] = xt[i]; }
-        LQG_UNROLL for (int p = 0; p < RR; ++p) muR[k][p] = mn[O + p];
+        LQG_UNROLL for (int p = 0; p < RR; ++p) muR[k][p] = c[p] + mn[O + p];
         if (STORE_MU && live[k]) {
           long n = n0 + (long)k * LQG_BLOCK;
           R* dst = const_cast<R*>(a.mu.p) + sys * a.mu.sb + n * a.mu.sn + (long)t * a.mu.st;
-          LQG_UNROLL for (int i = 0; i < M; ++i) dst[i * a.mu.sd] = (i < O) ? xt[i] + mn[i] : mn[i];
+          LQG_UNROLL for (int i = 0; i < M; ++i) dst[i * a.mu.sd] = (i < O) ? xt[i] + mn[i] : muR[k][i - O];
         }
       }
     }

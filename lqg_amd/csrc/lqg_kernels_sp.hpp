@@ -159,15 +159,16 @@ constexpr Mask<NB, NB> kalman_state_mask() {
   return P;
 }
 
-// Structural mask of the per-step trial operator  Fj - [[I_o, 0], [0, 0]]  that k_forward_sp<NTR = 0> writes to the
-// operator stream: the mask algebra of the joint system (system.py:167-187) on the pattern's masks, the loop-carried
-// Kalman mask included.  k_forward_sp static_asserts that it equals the mask of the matrix it really builds.  The diagonal
-// of the observed block is F_ii - 1: structurally zero where the dynamics' A has a unit diagonal (PAT::AdmI = mask of Ad - I).
+// Structural masks of the joint dynamics Fj (system.py:167-187) and of the per-step trial operator  Fj - I  that
+// k_forward_sp<NTR = 0> writes to the operator stream: the mask algebra of the joint system on the pattern's masks, the
+// loop-carried Kalman mask included.  k_forward_sp static_asserts that they equal the masks of the matrices it really
+// builds.  DEV (the operator): the diagonal blocks start from A - I — Ad - I carries the pattern's numerically observed
+// mask PAT::AdmI (structurally zero where the dynamics' A has a unit diagonal), Aa - I keeps its diagonal.
 template <int N>
 constexpr Mask<N, N> mask_sym(const Mask<N, N>& a) { return mask_or(a, mask_t(a)); }
 
-template <typename PAT, int NX, int NB, int NU, int NY, bool DENSE_P>
-constexpr Mask<NX + NB, NX + NB> joint_dynamics_mask() {
+template <typename PAT, int NX, int NB, int NU, int NY, bool DENSE_P, bool DEV>
+constexpr Mask<NX + NB, NX + NB> joint_mask_impl() {
   const auto P = kalman_state_mask<PAT, NB, NY, DENSE_P>();
   const auto AP = mask_mul(PAT::Aa, P);
   const auto Pp = mask_or(mask_sym(mask_mul(AP, mask_t(PAT::Aa))), PAT::VVa);
@@ -180,21 +181,26 @@ constexpr Mask<NX + NB, NX + NB> joint_dynamics_mask() {
   const auto DB = mask_and(mask_or(mask_mul(PAT::Fd, PAT::Bd), mask_mul(PAT::Fa, PAT::Ba)), PAT::DB);
   const auto BK = mask_or(PAT::Ba, mask_mul(K, DB));
   const auto Lf = mask_full<NU, NB>();
-  return mask_block(PAT::Ad, mask_mul(PAT::Bd, Lf), mask_mul(K, FAd),
-                    mask_or(mask_or(PAT::Aa, mask_mul(K, FAa)), mask_mul(BK, Lf)));
+  const auto A11 = DEV ? mask_and(mask_or(PAT::Ad, mask_eye<NX>()), PAT::AdmI) : PAT::Ad;
+  const auto A22 = DEV ? mask_or(PAT::Aa, mask_eye<NB>()) : PAT::Aa;
+  return mask_block(A11, mask_mul(PAT::Bd, Lf), mask_mul(K, FAd),
+                    mask_or(mask_or(A22, mask_mul(K, FAa)), mask_mul(BK, Lf)));
+}
+template <typename PAT, int NX, int NB, int NU, int NY, bool DENSE_P>
+constexpr Mask<NX + NB, NX + NB> joint_dynamics_mask() {
+  return joint_mask_impl<PAT, NX, NB, NU, NY, DENSE_P, false>();
 }
 template <typename PAT, int NX, int NB, int NU, int NY, int ND, bool DENSE_P>
 constexpr Mask<NX + NB, NX + NB> trial_operator_mask() {
-  auto m = joint_dynamics_mask<PAT, NX, NB, NU, NY, DENSE_P>();
-  for (int i = 0; i < ND; ++i) m.b[i * (NX + NB) + i] = PAT::AdmI(i, i);
-  return m;
+  return joint_mask_impl<PAT, NX, NB, NU, NY, DENSE_P, true>();
 }
 
 // NTR >= 1 (fused): the NTR trials of each system are swept in-lane (1: the headline; 2: two identical decoupled
 // components solved as ONE system with two trials, lqg_amd/plan.py); NTR == 0: the per-step trial operators are written
 // to the operator stream for k_trial (many trials per system), exactly as k_forward does.  ll_sn: trial stride of ll.
 // CK > 0: checkpointed gains (see k_riccati_sp): `rc` carries the actor's cost matrices and the checkpoint stream.
-template <typename R, int NX, int NB, int NU, int NY, int ND, typename PAT, int NTR, bool DENSE_P, int CK>
+// OT: element type of the operator stream (NTR == 0), see k_forward.
+template <typename R, int NX, int NB, int NU, int NY, int ND, typename PAT, int NTR, bool DENSE_P, int CK, typename OT = R>
 __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F32 : LQG_SP_FWD_WAVES_F64)
     k_forward_sp(const ForwardArgs<R> a, const long ll_sn, const RiccatiArgs<R> rc) {
   constexpr bool FUSED = NTR > 0;
@@ -374,15 +380,20 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
         LQG_UNROLL for (int p = 0; p < RR; ++p) muR[n][p] = mn[O + p];
       }
     } else {
-      R* op = a.ops + ((long)s * (a.T + 1) + t) * Ops::N;
-      store_dev_dense<O, 0>(Fj, op + Ops::F_OFF);
-      LQG_UNROLL for (int i = 0; i < RR * O; ++i) op[Ops::U_OFF + i] = U2[i];
+      OT* op = reinterpret_cast<OT*>(a.ops) + ((long)s * (a.T + 1) + t) * Ops::N;
+      // Fj - I assembled as a deviation (the diagonal blocks start from A - I, then the small terms): see k_forward
+      const auto FjD = block2x2(restrict_to<PAT::AdmI>(minus_identity(Ad)), mul(Bd, L), mul(K, FAd),
+                                add(sub(minus_identity(Aa), mul(K, FAa)), mul(BK, L)));
+      static_assert(mask_eq(decltype(FjD)::mask, trial_operator_mask<PAT, NX, NB, NU, NY, ND, DENSE_P>()),
+                    "trial_operator_mask() must mirror the mask algebra of the operator built here");
+      store_dense<0>(FjD, op + Ops::F_OFF);
+      LQG_UNROLL for (int i = 0; i < RR * O; ++i) op[Ops::U_OFF + i] = (OT)U2[i];
       {
         int e = 0;
         LQG_UNROLL for (int i = 0; i < O; ++i)
-          LQG_UNROLL for (int j = 0; j <= i; ++j) op[Ops::L_OFF + (e++)] = Li[i * O + j];
+          LQG_UNROLL for (int j = 0; j <= i; ++j) op[Ops::L_OFF + (e++)] = (OT)Li[i * O + j];
       }
-      op[Ops::H_OFF] = hl + kLogNorm;
+      op[Ops::H_OFF] = (OT)(hl + kLogNorm);
     }
     // ---- Sigma' = F2 C F2^T + GG,  C = Srr - U2 U2^T                    system.py:223-230
     Mat<R, RR, RR> C;
@@ -434,16 +445,16 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
       a.ll[s * a.ll_sb + n * ll_sn] = (R)acc[n];
     }
   } else {
-    R* op = a.ops + ((long)s * (a.T + 1) + a.T) * Ops::N;
+    OT* op = reinterpret_cast<OT*>(a.ops) + ((long)s * (a.T + 1) + a.T) * Ops::N;
     int e = 0;
     LQG_UNROLL for (int i = 0; i < O; ++i)
-      LQG_UNROLL for (int j = 0; j <= i; ++j) op[Ops::L_OFF + (e++)] = Li[i * O + j];
-    op[Ops::H_OFF] = hl + kLogNorm;
+      LQG_UNROLL for (int j = 0; j <= i; ++j) op[Ops::L_OFF + (e++)] = (OT)Li[i * O + j];
+    op[Ops::H_OFF] = (OT)(hl + kLogNorm);
   }
 }
 
 // ---------------------------------------------------------------- per-trial sweep with the operator's structure
-// k_trial (lqg_kernels.hpp) with the structural zeros of the operator Fj - [[I_o,0],[0,0]] (FM) resolved at compile time:
+// k_trial (lqg_kernels.hpp) with the structural zeros of the operator Fj - I (FM) resolved at compile time:
 // the mean update is ~half of a trial-step's instructions and the tracking models' operators are 40-60 % dense (unit
 // diagonal of A, a single control row, selection-shaped K Fd Ad).  Same operator stream, same arithmetic order for the
 // terms that remain; rows without any term make their deviation a compile-time zero.  (Compile-time recursion instead
@@ -543,7 +554,7 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial_sp(const R* __restrict__ op
         R mn[M];
         trial_mean_rows<R, M, ND, FM, PF, NPF, 0>(cur, opt, cv, mn);
         LQG_UNROLL for (int i = 0; i < O; ++i) { dO[k][i] = mn[i]; xprev[k][i] = cv[i]; }
-        LQG_UNROLL for (int p = 0; p < RR; ++p) muR[k][p] = mn[O + p];
+        LQG_UNROLL for (int p = 0; p < RR; ++p) muR[k][p] = cv[O + p] + mn[O + p];   // (the stream holds Fj - I)
       }
     }
 #undef LQG_OP

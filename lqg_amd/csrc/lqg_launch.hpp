@@ -58,16 +58,19 @@ inline size_t ops_reals(const lqg_dims& d) {
   const size_t raw = m * m + rr * o + o * (o + 1) / 2 + 1;
   return (raw + 3) / 4 * 4;
 }
+// element sizes: trajectories / results / operator stream, and spec arrays / gain scratch (they differ for LQG_F32_SYS64)
+inline size_t traj_esz(const lqg_problem* p) { return p->dtype == LQG_F64 ? 8 : 4; }
+inline size_t spec_esz(const lqg_problem* p) { return p->dtype == LQG_F32 ? 4 : 8; }
 inline Workspace carve(const lqg_problem* p, bool need_ops) {
   Workspace w{};
-  const size_t esz = p->dtype == LQG_F64 ? 8 : 4;
+  const size_t esz = traj_esz(p);
   w.ldb = round_up(p->n_sys, 64);
   w.ls_off = 0;
   // gain scratch: L_t per step, or (structure-specialised libraries with checkpointed gains, chunk >= 4) the packed
   // cost-to-go S every chunk — whichever is larger, so that every library agrees on the layout of the workspace
   const size_t per_step = (size_t)p->T * p->dims.u * p->dims.b;
   const size_t ckpt = ((size_t)p->T / 4 + 1) * (size_t)(p->dims.b * (p->dims.b + 1) / 2);
-  w.ls_bytes = (per_step > ckpt ? per_step : ckpt) * (size_t)w.ldb * esz;
+  w.ls_bytes = (per_step > ckpt ? per_step : ckpt) * (size_t)w.ldb * spec_esz(p);
   w.ops_off = (w.ls_bytes + 255) / 256 * 256;
   w.ops_bytes = need_ops ? (size_t)p->n_sys * (size_t)(p->T + 1) * ops_reals(p->dims) * esz : 0;
   // (+ the scratch of the time-chunked per-trial sweep, lqg_trial_chunk.hpp: by convention it FOLLOWS the operator stream)
@@ -130,6 +133,30 @@ hipError_t launch_forward(const lqg_problem* p, const void* Ls, long ldb, bool f
                        : launch_forward_v<R, NX, NB, NU, NY, ND, true, false>(k, n, mat, st);
   return ti ? launch_forward_v<R, NX, NB, NU, NY, ND, false, true>(k, n, mat, st)
             : launch_forward_v<R, NX, NB, NU, NY, ND, false, false>(k, n, mat, st);
+}
+
+// LQG_F32_SYS64 (include/lqg_hip.h): the forward sweep in fp64 over double spec arrays, the operator stream written as
+// float for the fp32 per-trial sweep.  Split by TI like launch_forward_v (separate translation units).
+template <int NX, int NB, int NU, int NY, int ND, bool TI>
+hipError_t launch_forward_ops32_v(const lqg::ForwardArgs<double>& k, long n_sys, hipStream_t st) {
+  const dim3 grid(blocks_for(n_sys)), block(LQG_BLOCK);
+  hipLaunchKernelGGL((lqg::k_forward<double, NX, NB, NU, NY, ND, TI, false, false, float>), grid, block, 0, st, k);
+  return hipGetLastError();
+}
+template <int NX, int NB, int NU, int NY, int ND>
+hipError_t launch_forward_ops32(const lqg_problem* p, const void* Ls, long ldb, void* ops, hipStream_t st) {
+  using R = double;
+  const lqg_spec& a = p->actor;
+  const lqg_spec& d = p->dynamics;
+  const lqg_view none{nullptr, 0, 0, 0, 0};
+  const lqg_traj no_traj{nullptr, 0, 0, 0, 0};
+  lqg::ForwardArgs<R> k{dv<R>(a.A), dv<R>(a.B), dv<R>(a.F), dv<R>(a.V), dv<R>(a.W),
+                        dv<R>(d.A), dv<R>(d.B), dv<R>(d.F), dv<R>(d.V), dv<R>(d.W),
+                        dv<R>(p->Sigma0), static_cast<const R*>(Ls), ldb, dt<R>(no_traj), nullptr, 0,
+                        static_cast<R*>(ops), dv<R>(none), dt<R>(no_traj), dv<R>(none), (long)p->n_sys, p->T,
+                        p->dims.nva, p->dims.nwa, p->dims.nvd, p->dims.nwd};
+  return forward_ti(p) ? launch_forward_ops32_v<NX, NB, NU, NY, ND, true>(k, (long)p->n_sys, st)
+                       : launch_forward_ops32_v<NX, NB, NU, NY, ND, false>(k, (long)p->n_sys, st);
 }
 
 #ifndef LQG_TRIALS_PER_LANE

@@ -558,7 +558,7 @@ __global__ void __launch_bounds__(kWave) k_scan_ops(const Args<R> a) {
     const D* fg = a.FG + (s * a.T + t) * 2L * mm2;
     each(mm2, [&](int e) {
       const int i = e / m, j = e - i * m;
-      op[e] = (R)((i < o && i == j) ? fg[e] - 1.0 : fg[e]);
+      op[e] = (R)((i == j) ? fg[e] - 1.0 : fg[e]);                  // Fj - I, rounded to the problem dtype once
     });
   }
 }

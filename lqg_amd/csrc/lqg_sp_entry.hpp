@@ -32,7 +32,7 @@ hipError_t trial_sweep_sp(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb
   constexpr auto FM_noise = lqg::trial_operator_mask<PAT, NX, NB, NU, NY, ND, false>();
   const bool dense_p = p->Sigma0.ptr != nullptr;
   if (trial_chunks(p) > 1) {
-    const size_t esz = p->dtype == LQG_F64 ? 8 : 4;
+    const size_t esz = traj_esz(p);
     const size_t ops_bytes = (size_t)p->n_sys * (size_t)(p->T + 1) * ops_reals(p->dims) * esz;
     void* scratch = static_cast<char*>(const_cast<void*>(ops)) + (ops_bytes + 255) / 256 * 256;
     if (dense_p)
@@ -125,6 +125,52 @@ int run_sp_ck(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll_sn
   return e == hipSuccess ? 0 : (int)e;
 }
 
+// LQG_F32_SYS64 (include/lqg_hip.h): k_riccati_sp / k_forward_sp<NTR = 0> in fp64 over the double spec arrays, the
+// operator stream written as float, then the fp32 per-trial sweep.
+template <typename PAT, int NX, int NB, int NU, int NY, int ND>
+int run_sp_mixed(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll_sn, void* workspace, size_t workspace_bytes,
+                 hipStream_t st) {
+  using R = double;
+  constexpr int CK = 0;                           // (fp64 sweeps stream their gains: sp_chunk<double>() is 0 too)
+  if (p->n_trials < 3) return LQG_ERR_ARG;
+  const Workspace w = carve(p, true);
+  if (!workspace || workspace_bytes < w.total) return LQG_ERR_WORKSPACE;
+  char* base = static_cast<char*>(workspace);
+  R* Ls = reinterpret_cast<R*>(base + w.ls_off);
+  R* ops = reinterpret_cast<R*>(base + w.ops_off);  // (written as float by the kernel: OT)
+  auto mark = [&](int i) {
+    if (p->phase_events[i]) (void)hipEventRecord(static_cast<hipEvent_t>(p->phase_events[i]), st);
+  };
+  const lqg_spec& a = p->actor;
+  const lqg_spec& d = p->dynamics;
+  const lqg_view none{nullptr, 0, 0, 0, 0};
+  const lqg_traj no_traj{nullptr, 0, 0, 0, 0};
+  const dim3 grid(blocks_for(p->n_sys)), block(LQG_BLOCK);
+  const lqg::RiccatiArgs<R> rc{dv<R>(a.Q), dv<R>(a.q), dv<R>(a.Qf), dv<R>(a.qf), dv<R>(a.P), dv<R>(a.R), dv<R>(a.r),
+                               dv<R>(a.A), dv<R>(a.B), dv<R>(none), dv<R>(none), dv<R>(none), Ls, w.ldb,
+                               (long)p->n_sys, p->T, (R)p->eps};
+  mark(0);
+  hipLaunchKernelGGL((lqg::k_riccati_sp<R, NB, NU, PAT, CK>), grid, block, 0, st, rc);
+  mark(1);
+  {
+    lqg::ForwardArgs<R> k{dv<R>(a.A), dv<R>(a.B), dv<R>(a.F), dv<R>(a.V), dv<R>(a.W),
+                          dv<R>(d.A), dv<R>(d.B), dv<R>(d.F), dv<R>(d.V), dv<R>(d.W),
+                          dv<R>(p->Sigma0), Ls, w.ldb, dt<R>(no_traj), nullptr, 0, ops, dv<R>(none),
+                          dt<R>(no_traj), dv<R>(none), (long)p->n_sys, p->T,
+                          p->dims.nva, p->dims.nwa, p->dims.nvd, p->dims.nwd};
+    if (p->Sigma0.ptr)
+      hipLaunchKernelGGL((lqg::k_forward_sp<R, NX, NB, NU, NY, ND, PAT, 0, true, CK, float>), grid, block, 0, st, k, ll_sn, rc);
+    else
+      hipLaunchKernelGGL((lqg::k_forward_sp<R, NX, NB, NU, NY, ND, PAT, 0, false, CK, float>), grid, block, 0, st, k, ll_sn, rc);
+  }
+  mark(2);
+  const hipError_t te = trial_sweep_sp<float, PAT, NX, NB, NU, NY, ND>(p, x, ll, ll_sb, ll_sn, ops, st);
+  if (te != hipSuccess) return (int)te;
+  mark(3);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
 template <typename PAT, int NX, int NB, int NU, int NY, int ND>
 int log_likelihood_sp(const lqg_problem* p, lqg_traj x, void* ll, int64_t ll_sb, int64_t ll_sn, void* workspace,
                       size_t workspace_bytes, void* stream) {
@@ -140,6 +186,9 @@ int log_likelihood_sp(const lqg_problem* p, lqg_traj x, void* ll, int64_t ll_sb,
   if (p->dtype == LQG_F32)
     return run_sp<float, PAT, NX, NB, NU, NY, ND>(p, x, ll, (long)ll_sb, (long)ll_sn, workspace, workspace_bytes,
                                                   (hipStream_t)stream);
+  if (p->dtype == LQG_F32_SYS64)
+    return run_sp_mixed<PAT, NX, NB, NU, NY, ND>(p, x, ll, (long)ll_sb, (long)ll_sn, workspace, workspace_bytes,
+                                                 (hipStream_t)stream);
   return LQG_ERR_ARG;
 }
 

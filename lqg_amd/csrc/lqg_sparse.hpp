@@ -27,6 +27,13 @@ constexpr Mask<M, N> mask_full() {
   for (int i = 0; i < M * N; ++i) r.b[i] = true;
   return r;
 }
+template <int N>
+constexpr Mask<N, N> mask_eye() {
+  Mask<N, N> r{};
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) r.b[i * N + j] = i == j;
+  return r;
+}
 template <int M, int N>
 constexpr Mask<M, N> mask_none() {
   Mask<M, N> r{};
@@ -405,16 +412,25 @@ LQG_DEV void dev_matvec_row(const Mat<R, M, M, MK>& a, const R (&x)[M], R (&y)[M
   }
 }
 
-// dense row-major image of A - [[I_O, 0], [0, 0]] at p (the operator stream's F block), masks resolved at compile time
-template <int O, int I, typename R, int M, Mask<M, M> MK>
-LQG_DEV void store_dev_dense(const Mat<R, M, M, MK>& a, R* __restrict__ p) {
-  if constexpr (I < M * M) {
-    constexpr int r = I / M, c = I % M;
-    R f = R(0);
-    if constexpr (MK.b[I]) f = a.v[I];
-    if constexpr (r < O && r == c) f -= R(1);
-    p[I] = f;
-    store_dev_dense<O, I + 1>(a, p);
+// A - I with the diagonal formed as a DEVIATION (a_ii - 1 is exact for a_ii in [1/2, 2]; a structurally zero diagonal
+// entry becomes -1): the starting point of the operator stream's F block, Fj - I (lqg_kernels.hpp, k_trial)
+template <typename R, int N, Mask<N, N> MK>
+LQG_DEV auto minus_identity(const Mat<R, N, N, MK>& a) {
+  constexpr auto MR = mask_or(MK, mask_eye<N>());
+  Mat<R, N, N, MR> r;
+  LQG_UNROLL for (int i = 0; i < N; ++i)
+    LQG_UNROLL for (int j = 0; j < N; ++j)
+      if (MR(i, j)) r.v[i * N + j] = (i == j) ? (MK(i, i) ? a.v[i * N + i] - R(1) : R(-1)) : a.v[i * N + j];
+  return r;
+}
+// dense row-major image of a masked matrix at p in the element type OT (structural zeros written out), masks resolved
+// at compile time
+template <int I, typename OT, typename R, int M, int N, Mask<M, N> MK>
+LQG_DEV void store_dense(const Mat<R, M, N, MK>& a, OT* __restrict__ p) {
+  if constexpr (I < M * N) {
+    if constexpr (MK.b[I]) p[I] = (OT)a.v[I];
+    else p[I] = OT(0);
+    store_dense<I + 1>(a, p);
   }
 }
 

@@ -4,7 +4,7 @@
 // trials: the inner loop of MLE / NUTS, BASELINE configs 2 and 4) that is one dependent chain of T steps on a handful of
 // waves — a latency-bound sweep on a nearly empty chip.  The recursion of the conditional mean is AFFINE in its state
 // s_t = (dO_t, muR_t) with operators that do not depend on the trial,
-//     s_{t+1} = Phi_t s_t + g_t(x_t, x_{t-1}),        Phi_t = Fm[:, O:] [ -U2 Li | I ],
+//     s_{t+1} = Phi_t s_t + g_t(x_t, x_{t-1}),        Phi_t = [0 ; I_r] [ -U2 Li | I ] + Fm[:, O:] [ -U2 Li | I ],  Fm = Fj - I,
 // so the horizon is cut into chunks that run side by side:
 //   1. k_trial_zs   one lane per (trial, chunk): the chunk's recursion from s = 0 (zero-state response z_c); one extra
 //                   block per (system, chunk) pushes the M unit vectors through the chunk with the data set to zero —
@@ -83,7 +83,7 @@ LQG_DEV R tc_step(const R* __restrict__ op, const R (&xt)[ND], R (&xprev)[ND], R
     R mn[M];
     tc_mean_rows<R, M, ND, FMP, 0>(op, cv, mn);
     LQG_UNROLL for (int i = 0; i < O; ++i) { dO[i] = mn[i]; xprev[i] = cv[i]; }
-    LQG_UNROLL for (int p = 0; p < RR; ++p) muR[p] = mn[O + p];
+    LQG_UNROLL for (int p = 0; p < RR; ++p) muR[p] = cv[O + p] + mn[O + p];      // (the stream holds Fj - I)
   }
   return zz;
 }

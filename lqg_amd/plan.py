@@ -36,6 +36,17 @@ SCAN_MIN_STEPS = int(os.environ.get("LQG_SCAN_MIN_STEPS", "0"))           # 0: t
 SCAN_MAX_COND = float(os.environ.get("LQG_SCAN_MAX_COND", "1e7"))
 
 
+# MIXED precision (include/lqg_hip.h: LQG_F32_SYS64).  An fp32 problem scored on many trials per system runs its per-system
+# sweeps (Riccati, Kalman, moment recursion: data-independent, amortised over the trials) in fp64 over an fp64 image of the
+# specs and rounds the per-step trial operators to fp32 ONCE; the per-trial sweep stays fp32.  With the fp32 recursions the
+# operators carry their accumulated rounding into every trial: config 3 (T = 1067) max 1.7e-6 relative on the log-likelihood
+# against the fp64 path, 5e-7 with the fp64 system sweeps.  Default: WHENEVER the operator stream is used
+# (3 or more trials per system) — the result of a trial then does not depend on how many other trials were scored with it
+# (shards of a trial split agree bitwise); LQG_MIXED_MIN_TRIALS raises the threshold for workloads of many systems with a
+# handful of trials each, where the system sweeps dominate and doubling their cost is not amortised; LQG_MIXED=0 disables.
+MIXED_MIN_TRIALS = int(os.environ.get("LQG_MIXED_MIN_TRIALS", "3"))
+
+
 def scan_min_steps(m):
     """Horizon from which the scans beat one lane walking the recursion: the sequential step costs ~0.4 us at m = 4 and
     ~2 us at m = 8 (~m^2), the scans ~0.11-0.15 ms whatever T (config 1, m = 4, T = 100: 0.064 ms sequential, 0.11 ms
@@ -132,8 +143,16 @@ class LogLikelihoodPlan:
                 n_pairs, n = n, 1
             ln = _hip.Launch(sub.actor, sub.dynamics, d=len(cols), n_trials=n, Sigma0=S0, eps=eps)
             lib = ln.require_gpu()               # liblqg_hip.so, or the auxiliary library of an unlisted shape
-            xb, is_b = _hip._prep_x(ln, xs)
             nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
+            mixed = ((not use_scan) and ln.dtype == torch.float32 and n >= max(3, MIXED_MIN_TRIALS)
+                     and os.environ.get("LQG_MIXED", "1") != "0" and nbytes <= OPS_WORKSPACE_LIMIT
+                     and lib.lqg_strategy(C.byref(ln.p)) == _abi.STRATEGY_LANE)
+            if mixed:                            # fp64 image of the specs (a few kB per system), float trajectories
+                sub = sub.to(torch.float64)
+                ln = _hip.Launch(sub.actor, sub.dynamics, d=len(cols), n_trials=n, Sigma0=S0, eps=eps,
+                                 traj_dtype=torch.float32)
+                nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
+            xb, is_b = _hip._prep_x(ln, xs)
             sp = None if use_scan else _hip.specialised_entry(ln, sub0, len(cols))
             if use_scan:
                 use_scan = lib is _abi.load()            # (an auxiliary lane-kernel library has no scan entry)
@@ -169,7 +188,7 @@ class LogLikelihoodPlan:
                                   entry=(scan_entry if use_scan else (sp or lib.lqg_log_likelihood)),
                                   scan_sp=bool(use_scan and scan_sp),
                                   generic=lib.lqg_log_likelihood, scan=use_scan,
-                                  specialised=sp is not None, n=n, fused_pairs=fuse_pairs,
+                                  specialised=sp is not None, n=n, fused_pairs=fuse_pairs, mixed=mixed,
                                   pattern_key=(specialize.system_pattern(sub0, len(cols))[2] if sp is not None else None),
                                   loop_trials=loop_trials, is_b=is_b, group=(self.merged[ip] if self.merged else 1),
                                   dims=(sub.xdim, sub.bdim, sub.udim, sub.ydim, len(cols))))
@@ -209,6 +228,8 @@ class LogLikelihoodPlan:
             return kind
         kind = ("structure-specialised (k_riccati_sp + k_forward_sp" if all(k["specialised"] for k in w) else
                 "generic dense (k_riccati + k_forward") + tail
+        if all(k.get("mixed") for k in w):
+            kind += " [system sweeps in fp64, operators rounded to fp32 once, per-trial sweep fp32]"
         if len(w) > 1:
             kind += f", {len(w)} decoupled components of dims (x,b,u,y,d)={w[0]['dims']}"
         if self.n_stacked > 1:

@@ -23,9 +23,16 @@ def _oracle_sample(system, x, ll, n_samples):
 
 
 def _fp32_vs_fp64(m64, x64):
+    """fp32 path against fp64 path ON THE SAME INPUTS (north star: "results match the reference on the same inputs"): the
+    fp32 problem's specs and data are the fp32-rounded ones, and the fp64 comparison runs on exactly those numbers
+    promoted to double.  (Round 2 compared against the UNROUNDED fp64 problem; rounding the inputs alone moves the fp64
+    result of config 4 by up to 1.9e-6 — scripts/fp32_tail.py — which is a property of the question, not of the kernels.)
+    Returns (fp64 result on the unrounded inputs, fp32 result, relative difference on the same inputs)."""
     ll64 = m64.log_likelihood(workload.pack_trials(x64)).clone()
-    ll32 = m64.to(torch.float32).log_likelihood(workload.pack_trials(x64.float())).clone()
-    rel = (ll32.double() / ll64 - 1).abs().flatten()
+    m32, x32 = m64.to(torch.float32), x64.float()
+    ll32 = m32.log_likelihood(workload.pack_trials(x32)).clone()
+    same = m32.to(torch.float64).log_likelihood(workload.pack_trials(x32.double())).clone()
+    rel = (ll32.double() / same - 1).abs().flatten()
     return ll64, ll32, rel
 
 
@@ -83,13 +90,15 @@ def test_config3_4096_candidates_x_1024_trials_T1067(oracle_lib):
     assert torch.equal(torch.cat(parts, dim=1), ll)
     red = sum(_hip.sum_trials(p_) for p_ in parts)
     assert float(((red - obj).abs() / obj.abs()).max()) < 1e-12
-    # fp32 against fp64 over ALL 4 M (candidate, trial) pairs.  At this horizon (1067 steps, twice the headline's) the
-    # fp32 recursions hold the north-star 1e-6 for 99.9 % of the pairs, not for the extreme tail (measured: median 3e-8,
-    # p99 2.7e-7, p99.9 4.9e-7, max 1.7e-6; the reference's own default precision is fp32)
+    # fp32 against fp64 (same inputs) over ALL 4 M (candidate, trial) pairs: the north-star 1e-6 for EVERY pair.  The
+    # fp32 problem runs MIXED (include/lqg_hip.h LQG_F32_SYS64: system sweeps in fp64, operators Fj - I rounded to fp32
+    # once, fp32 per-trial sweep); with fp32 system sweeps the tail reached 1.7e-6 (round 2, scripts/fp32_tail.py)
+    from lqg_amd.plan import LogLikelihoodPlan
+    assert all(wk["mixed"] for wk in LogLikelihoodPlan(m, xp).work)
     ll64 = m.to(torch.float64).log_likelihood(workload.pack_trials(x.double())).clone()
     rel = (ll.double() / ll64 - 1).abs().flatten()
     sample = rel[torch.randperm(rel.numel(), device=rel.device)[: 1 << 20]]
-    assert float(torch.quantile(sample, 0.999)) < 1e-6 and float(rel.max()) < 4e-6 and float(sample.median()) < 1e-7
+    assert float(rel.max()) < 1e-6 and float(torch.quantile(sample, 0.999)) < 5e-7 and float(sample.median()) < 1e-7
 
 
 def test_config4_hand2d_32768_trials_T1000(oracle_lib, monkeypatch):
@@ -100,9 +109,9 @@ def test_config4_hand2d_32768_trials_T1000(oracle_lib, monkeypatch):
     ll64, ll32, rel = _fp32_vs_fp64(m64, x64)
     assert ll64.shape == (32768,) and torch.isfinite(ll64).all() and torch.isfinite(ll32).all()
     assert _oracle_sample(m64, x64, ll64, 8) < 1e-10
-    # fp32 at T=1000 with an 8-dimensional unobserved state per axis: median 1.8e-7, p99 9.4e-7, max 2.0e-6 (measured) —
-    # the north-star 1e-6 holds for 99 % of the trials at this horizon; asserted with head-room against regressions
-    assert float(rel.max()) < 5e-6 and float(torch.quantile(rel, 0.99)) < 1.5e-6 and float(rel.median()) < 4e-7
+    # fp32 at T=1000 with an 8-dimensional unobserved state per axis, same inputs in both precisions: the north-star 1e-6
+    # for EVERY trial (measured max 2.9e-7 before the operator stream moved to Fj - I)
+    assert float(rel.max()) < 1e-6 and float(torch.quantile(rel, 0.99)) < 3e-7 and float(rel.median()) < 1e-7
     xp = workload.pack_trials(x64)
     _shard_invariance(m64, xp, ll64, [(i * 8192, (i + 1) * 8192) for i in range(4)], monkeypatch)   # 8 GPUs x 4096 in the config
     # decoupled (two identical 1-D hand models) == joint m=20 problem
