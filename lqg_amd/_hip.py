@@ -149,8 +149,9 @@ def _prep_x(ln, x):
     return x, xb
 
 
-def conditional_moments(actor, dynamics, x, Sigma0=None, eps=1e-8, want_mu=True, want_sigma=True):
-    """x[n,T+1,d] | [B,n,T+1,d] -> mu[(B,)n,T,m], Sigma[(B,)T,m,m]."""
+def conditional_moments(actor, dynamics, x, Sigma0=None, eps=1e-8, want_mu=True, want_sigma=True, system=None):
+    """x[n,T+1,d] | [B,n,T+1,d] -> mu[(B,)n,T,m], Sigma[(B,)T,m,m].  system: the System that owns the two specs — the
+    scan-eligibility checks (eigenvalue floor, conditioning: one host synchronisation each) are cached on it."""
     d, n = x.shape[-1], x.shape[-3]
     ln = Launch(actor, dynamics, d=d, n_trials=n, Sigma0=Sigma0, eps=eps)
     lib = ln.require_gpu()
@@ -161,7 +162,7 @@ def conditional_moments(actor, dynamics, x, Sigma0=None, eps=1e-8, want_mu=True,
     if lib is _abi.load() and hasattr(lib, "lqg_conditional_moments_scan"):
         from lqg_amd import plan as _plan          # (same rule as the log-likelihood: few systems, long horizon)
         from lqg_amd.system import System
-        use_scan = _plan.scan_eligible(lib, ln, System(actor=actor, dynamics=dynamics), eps)
+        use_scan = _plan.scan_eligible(lib, ln, system if system is not None else System(actor=actor, dynamics=dynamics), eps)
     with torch.cuda.device(ln.device):
         if use_scan:                     # time-parallel system sweeps (csrc/lqg_scan.hpp)
             nbytes = lib.lqg_scan_workspace_bytes(C.byref(ln.p))

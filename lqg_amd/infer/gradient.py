@@ -62,7 +62,8 @@ def value_and_grad(x, model_type, params, process_noise=1.0, dt=1.0 / 60, fd_ste
     if ev is not None:            # the whole evaluation replayed as one hipGraph (lqg_amd/infer/graphed.py)
         import math
         out = ev(torch.tensor([[math.log(float(params[k])) for k in names]], dtype=torch.float64)).cpu()
-        return float(out[0, 0]), {k: float(out[0, 1 + i]) / float(params[k]) for i, k in enumerate(names)}
+        if not bool(torch.isnan(out).any()):      # (NaN: a precondition of the frozen graph failed at these values — eager path)
+            return float(out[0, 0]), {k: float(out[0, 1 + i]) / float(params[k]) for i, k in enumerate(names)}
     z = torch.log(torch.tensor([float(params[k]) for k in names], dtype=torch.float64, device=x.device))
     eye = torch.eye(P, dtype=torch.float64, device=x.device)
     Z = torch.cat([z[None], z[None] + fd_step * eye, z[None] - fd_step * eye])

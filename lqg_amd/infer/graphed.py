@@ -15,7 +15,14 @@ other kernel) and an evaluation becomes: copy the parameters in, replay, read th
 What makes the capture legal: the zoo constructors are sync-free and copy nothing from the host once their constants are
 cached (lqg_amd/tracking/_build.py); every decision that needs host values — which library, scan path or lane kernels, the
 pattern library — is taken in an EAGER warm-up evaluation of the same shapes and frozen (the time-parallel scans are taken
-for up to six times (fp64; twice in fp32) the systems of the eager rule: their host-side checks are paid once here).  PointMassBoundedActor's
+for up to six times (fp64; twice in fp32) the systems of the eager rule: their host-side checks are paid once here).
+Frozen decisions must hold for EVERY parameter vector a replay will see, so (i) everything read off spec VALUES — the
+sparsity pattern of a non-zoo class, its decoupling — is derived from >= 8 random positive probe vectors OR-ed together,
+never from one (degenerate) point such as theta = 1 where A = a I, a (theta - 1) term or coinciding subjective dynamics
+would narrow it; (ii) the value-dependent PRECONDITIONS of the frozen path (eigenvalue floor of lqr.py:27-28 provably
+inactive — decoupling and the scans rest on it —, conditioning of the observed noise block for the scans) are
+re-evaluated ON THE DEVICE inside the graph (Gershgorin bounds, elementwise ops) and a violated one turns the result
+into NaN: consumers that read the result re-evaluate on the eager path, nothing is ever silently wrong.  PointMassBoundedActor's
 discretisation runs as one kernel (csrc/lqg_setup.hip) instead of host-synchronising torch.linalg calls.  What is not
 captured: a user model whose constructor synchronises or copies from the host, a model that decouples into DIFFERENT
 components (identical ones — the dim = 2 tracking models — are merged as trials of one component, through the measured
@@ -100,8 +107,10 @@ class GraphedLogLik:
         self.out = None                                                                        # static output, fp64 [C]
         self.graph = None
         self._keep = None
+        self._pins = None                # cached constructor constants the graph reads by address (tracking/_build.py)
         self._affine = None
         self._merged_cols = None
+        self._guarded = False
 
     # ---- the captured region -------------------------------------------------------------------------------------
     def _probe_affine(self):
@@ -160,25 +169,69 @@ class GraphedLogLik:
             return None, None
         return parts[0][0], [p_[1] for p_ in parts]
 
-    def _decide(self, model):
-        """Eager, once: everything that needs host values."""
+    def _probe_theta(self, n):
+        """n random positive parameter vectors, log-uniform in [e^-1.5, e^1.5] (seeded): what structure is read off."""
+        g = torch.Generator().manual_seed(4321)
+        th = torch.exp(torch.rand(n, self.P, generator=g, dtype=torch.float64) * 3.0 - 1.5)
+        return th.to(device=self.x.device, dtype=self.x.dtype)
+
+    def _guards(self, model):
+        """Device-side restatement of the host checks the frozen decisions rest on (decouple.floor_provably_inactive:
+        lambda_min(R) >= eps, Q, Qf >= 0; plan._observed_noise_cond <= SCAN_MAX_COND for the scans) with Gershgorin
+        bounds — elementwise ops only, no synchronisation, capturable.  -> 0-dim bool tensor (True: all hold)."""
+        from lqg_amd import plan
+        a = model.actor
+
+        def bounds(M):                               # [C, k, k] -> Gershgorin (lower, upper) per candidate
+            M = 0.5 * (M + M.transpose(-1, -2))
+            diag = torch.diagonal(M, dim1=-2, dim2=-1)
+            off = M.abs().sum(-1) - diag.abs()
+            return (diag - off).amin(-1), (diag + off).amax(-1)
+
+        first = lambda t: t.select(-3, 0)
+        ok = (bounds(first(a.R))[0] >= self.eps) & (bounds(first(a.Q))[0] >= -1e-12) & (bounds(a.Qf)[0] >= -1e-12)
+        if self.use_scan:
+            V = first(model.dynamics.V)[..., :self.d, :]
+            lo, hi = bounds(V @ V.transpose(-1, -2))
+            ok = ok & (lo > 0) & (hi <= plan.SCAN_MAX_COND * lo)
+        return ok.all()
+
+    def _decide(self):
+        """Eager, once: everything that needs host values.  Structure (decoupling, sparsity pattern) is read off a model
+        built from >= 8 random positive probe vectors; rules that count systems see the launch-shaped model (C vectors)."""
         from lqg_amd import plan
         self.d_full, self.n_full, self.x_full = self.d, self.n, self.x
-        sub, cols = self._component(model)
-        if sub is None:
+        probes = self._probe_theta(max(self.C, 8))
+        model_s = self._construct(probes)                    # structure
+        model = model_s if probes.shape[0] == self.C else self._construct(probes[:self.C])
+        sub_s, cols = self._component(model_s)
+        if sub_s is None:
             return False                     # several distinct components: LogLikelihoodPlan's launches are the better path
+        if model is not model_s:
+            sub, cols_c = self._component(model)
+            if sub is None or cols_c != cols:
+                return False                 # (the subset of probes decouples differently: no frozen structure to trust)
+        else:
+            sub = sub_s
         self._merged_cols = cols
         if cols is not None:                 # the components' columns as trials of one component system
             self.x = plan._trial_stack(self.x_full, cols)
             self.n, self.d = self.x.shape[0], self.x.shape[-1]
-            model = sub
+            model, model_s = sub, sub_s
         ln = _hip.Launch(model.actor, model.dynamics, d=self.d, n_trials=self.n, eps=self.eps)
         lib = ln.require_gpu()
         main = _abi.load()
         self.use_scan = lib is main and plan.scan_eligible(main, ln, model, self.eps,
                                                            systems_scale=6 if self.x.dtype == torch.float64 else 2)
-        spl = _hip.specialised_library(ln, model, self.d, check_strategy=not self.use_scan)
+        spl = _hip.specialised_library(ln, model_s, self.d, check_strategy=not self.use_scan)
         self.sp_lib = spl
+        # the frozen path rests on value-dependent preconditions when it decouples or scans: guard them inside the graph
+        self._guarded = bool(self.use_scan or cols is not None)
+        if self._guarded and not bool(self._guards(model)):
+            # the host checks passed (exact eigenvalues) where the device bounds are inconclusive: nothing to replay safely
+            if cols is not None:
+                return False
+            self.use_scan, self._guarded = False, False
         # The affine shortcut is offered to constructors KNOWN to be affine (the tracking models; a user class opts in with
         # `_lqg_affine_constructor = True`) and still verified numerically — two random probes cannot prove that an
         # arbitrary constructor is affine everywhere.
@@ -217,7 +270,10 @@ class GraphedLogLik:
             rc = lib.lqg_log_likelihood(*args)            # the specialised library refused (checked in the eager warm-up too)
         _abi.check(rc, "lqg_log_likelihood (graphed)")
         self._keep = (model, ln, ws, ll)
-        return _hip.sum_trials(ll)                        # fp64 [C]
+        obj = _hip.sum_trials(ll)                         # fp64 [C]
+        if self._guarded:                                 # a violated precondition of the frozen path poisons the result
+            obj = torch.where(self._guards(model), obj, torch.full_like(obj, float("nan")))
+        return obj
 
     def _forward(self):
         return self._loglik(self._model(self.theta))
@@ -227,7 +283,7 @@ class GraphedLogLik:
         dev = self.x.device
         with torch.cuda.device(dev):
             with torch.no_grad():
-                if not self._decide(self._construct(self.theta)):
+                if not self._decide():
                     return False
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
@@ -240,13 +296,15 @@ class GraphedLogLik:
                 with torch.cuda.graph(g):
                     self.out = self._forward()
                 self.graph = g
+                from lqg_amd.tracking import _build
+                self._pins = _build.cached_tensors()      # constants the captured constructor reads by address
         return True
 
     def release(self):
         """Drop the graph and everything it owns, after the device has finished with it."""
         if self.graph is not None:
             torch.cuda.synchronize(self.x.device)
-        self.graph, self.out, self._keep = None, None, None
+        self.graph, self.out, self._keep, self._pins = None, None, None, None
 
     def __del__(self):
         try:

@@ -12,6 +12,7 @@ separate XLA host devices, main.py:8, lqg/infer/utils.py:37).  Gradients: method
 behind torch.autograd, lqg_amd/grad.py).  fp64 throughout.
 """
 import math
+import os
 
 import torch
 
@@ -106,7 +107,15 @@ class Potential:
                 zp = z if C == ev.K else torch.cat([z, z[:1].expand(ev.K - C, P)])
                 out = ev(zp)[:C].cpu()
                 self.evaluations += C * (2 * P + 1)
-                return out[:, 0], out[:, 1:]
+                if not bool(torch.isnan(out).any()):      # (NaN: a frozen precondition failed at these values: eager path)
+                    return out[:, 0], out[:, 1:]
+                os.environ["LQG_GRAPH"], prev = "0", os.environ.get("LQG_GRAPH")
+                try:
+                    lp, gr = self(z)
+                finally:
+                    os.environ.pop("LQG_GRAPH") if prev is None else os.environ.__setitem__("LQG_GRAPH", prev)
+                both = torch.cat([lp.detach()[:, None], gr.detach()], dim=1).cpu()
+                return both[:, 0], both[:, 1:]
         lp, gr = self(z)
         both = torch.cat([lp.detach()[:, None], gr.detach()], dim=1).cpu()
         return both[:, 0], both[:, 1:]

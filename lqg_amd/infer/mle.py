@@ -53,6 +53,7 @@ def max_likelihood(x, model=BoundedActor, process_noise=1.0, dt=1.0 / 60, steps=
         elif ev is not None:
             out = ev(z[None])                                 # [1, 1 + P]: objective, d objective / d z
             loss, grad = -out[0, 0].clone(), -out[0, 1:].clone()
+            poisoned = torch.isnan(out).any() if it == 0 else (poisoned | torch.isnan(out).any())
         else:
             # one sweep over 2P+1 candidates: z, z + h e_i, z - h e_i
             Z = torch.cat([z[None], z[None] + fd_step * eye, z[None] - fd_step * eye])
@@ -64,5 +65,16 @@ def max_likelihood(x, model=BoundedActor, process_noise=1.0, dt=1.0 / 60, steps=
         m1 = b1 * m1 + (1 - b1) * grad
         m2 = b2 * m2 + (1 - b2) * grad * grad
         z = z - step_size * (m1 / (1 - b1 ** (it + 1))) / (torch.sqrt(m2 / (1 - b2 ** (it + 1))) + eps)
+    if ev is not None and bool(poisoned):
+        # a precondition of the frozen graph (infer/graphed.py: eigenvalue floor inactive, conditioning) failed somewhere
+        # along the path: its results were NaN from there on — refit on the eager path, which re-decides per evaluation
+        import os
+        prev = os.environ.get("LQG_GRAPH")
+        os.environ["LQG_GRAPH"] = "0"
+        try:
+            return max_likelihood(x, model, process_noise=process_noise, dt=dt, steps=steps, step_size=step_size,
+                                  fd_step=fd_step, group=group, method=method, **fixed)
+        finally:
+            os.environ.pop("LQG_GRAPH") if prev is None else os.environ.__setitem__("LQG_GRAPH", prev)
     params = {k: float(v) for k, v in zip(names, torch.exp(z).cpu())}
     return params, losses.cpu()

@@ -13,6 +13,7 @@ default_prior = {
     "sigma": ("halfnormal", 50.0),
     "subj_noise": ("halfnormal", 1.0),
     "subj_vel_noise": ("halfnormal", 2.0),
+    **{f"sigma_target_{k}": ("halfnormal", 50.0) for k in range(6)},       # per-condition noise levels, prior.py:16-21
 }
 
 

@@ -6,10 +6,17 @@ from lqg_amd.infer import prior
 from lqg_amd.infer.models import get_model_params
 
 
-def infer(x, num_samples, num_warmup, model=None, process_noise=1., dt=1. / 60, method="nuts", progress_bar=True,
-          num_chains=1, seed=0, grad_method="fd", **fixed):
-    """lqg/infer/utils.py:14-41.  x[n, T, d] (T rows = T-1 steps, as lqg_model); returns an object with
-    get_samples(group_by_chain=False) / print_summary() / get_extra_fields() like numpyro's MCMC."""
+def infer(x, num_samples, num_warmup, model=None, numpyro_fn=None, process_noise=1., dt=1. / 60, method="nuts",
+          progress_bar=True, num_chains=1, seed=0, grad_method="fd", **fixed):
+    """lqg/infer/utils.py:14-41, same positional order.  x[n, T, d] (T rows = T-1 steps, as lqg_model); returns an object
+    with get_samples(group_by_chain=False) / print_summary() / get_extra_fields() like numpyro's MCMC.
+    numpyro_fn: the reference's 5th positional parameter (a NumPyro model function, default `lifted_model`).  There is no
+    NumPyro here; None or this package's `lqg_model` / `lifted_model` select the built-in potential, anything else raises."""
+    if numpyro_fn is not None:
+        from lqg_amd.infer import models as _models
+        if numpyro_fn not in (getattr(_models, "lqg_model", None), getattr(_models, "lifted_model", None)):
+            raise NotImplementedError("infer(numpyro_fn=...): custom NumPyro model functions are not supported (NumPyro is not "
+                                      "part of lqg_amd); pass None for the lqg_model potential")
     if method not in ("nuts", "neutra"):
         raise ValueError("Please specify a valid inference method (nuts, neutra).")      # lqg/infer/utils.py:33-34
     if method == "neutra":

@@ -70,11 +70,16 @@ def _observed_noise_cond(sub, d):
     the eigenvalues are taken on the host (a batched eigvalsh of 2x2..4x4 blocks costs ~0.3 ms on the GPU, more than the
     evaluation it guards)."""
     import numpy as np
+    cache = sub.__dict__.setdefault("_lqg_noise_cond", {})
+    key = (int(d), specialize.spec_versions(sub))
+    if key in cache:
+        return cache[key]
     V = specialize._first(sub.dynamics.V.detach())[..., :d, :]       # (one time slice when the spec is time-invariant)
     VV = (V @ V.transpose(-1, -2)).double().cpu().numpy()
     ev = np.linalg.eigvalsh(VV)
     lo, hi = np.maximum(ev[..., 0], 0.0), ev[..., -1]
-    return float(np.max(hi / np.maximum(lo, 1e-300)))
+    cache[key] = float(np.max(hi / np.maximum(lo, 1e-300)))
+    return cache[key]
 
 
 def scan_eligible(lib, ln, sub, eps, systems_scale=1):

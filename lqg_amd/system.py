@@ -181,11 +181,11 @@ class System:
         """p(x_{t+1}, xhat_{t+1} | x_{1:t}) for ONE trajectory x[T+1, d] -> mu[T, m], Sigma[T, m, m]
         (lqg/system.py:142-235).  With B systems: x[B, T+1, d] -> mu[B, T, m], Sigma[B, T, m, m]."""
         xx = x.unsqueeze(-3)
-        mu, Sig = _hip.conditional_moments(self.actor, self.dynamics, xx, Sigma0=Sigma0)
+        mu, Sig = _hip.conditional_moments(self.actor, self.dynamics, xx, Sigma0=Sigma0, system=self)
         return mu.squeeze(-3), Sig
 
     def _moments(self, x, Sigma0):
-        return _hip.conditional_moments(self.actor, self.dynamics, x, Sigma0=Sigma0)
+        return _hip.conditional_moments(self.actor, self.dynamics, x, Sigma0=Sigma0, system=self)
 
     def conditional_distribution(self, x, Sigma0=None):
         """x[n, T+1, d] -> Gaussian over x[:, 1:] with event shape (T, d) (lqg/system.py:237-244)."""

@@ -31,6 +31,13 @@ _CACHE_MAX = 512
 _scalar_cache, _const_cache = {}, {}
 
 
+def cached_tensors():
+    """Every tensor the two caches hold right now.  A captured hipGraph of a constructor reads these by ADDRESS: the
+    evaluator keeps this list alive for as long as its graph exists (lqg_amd/infer/graphed.py), so that a later wholesale
+    clear() of a full cache drops the dictionary entries but never frees memory a graph still replays from."""
+    return list(_scalar_cache.values()) + list(_const_cache.values())
+
+
 def _scalar(v, dtype, device):
     if isinstance(v, torch.Tensor):
         return torch.as_tensor(v, dtype=dtype, device=device)

@@ -303,3 +303,110 @@ def test_graphed_evaluation_of_models_that_decouple(model, params, monkeypatch):
         assert abs(v1 / v0 - 1) < 1e-12
         s_ = max(abs(v) for v in g0.values())
         assert all(abs(g1[k] - g0[k]) < 1e-6 * s_ for k in g0), (g0, g1)
+
+
+class _LeakyTracking:
+    """A USER model (not a zoo class) whose structure is degenerate at theta = 1: the target leaks toward the cursor at
+    rate 0.05 (leak - 1), so A[0, 1] is exactly zero at leak = 1 and non-zero everywhere else."""
+
+    @staticmethod
+    def make():
+        from lqg_amd.system import Actor, System
+        from lqg_amd.tracking import _build as bd
+
+        class LeakyTracking(System):
+            def __init__(self, leak=1.0, sigma=6.0, action_cost=0.5, action_variability=0.5, process_noise=1.0,
+                         dt=1.0 / 60, T=1000, device=None, dtype=None):
+                device, dtype = bd.resolve(device, dtype, leak, sigma, action_cost, action_variability, process_noise)
+                (lk, sg, ac, av, pn), lead = bd.params(device, dtype, leak, sigma, action_cost, action_variability,
+                                                       process_noise)
+                one, zero = torch.ones_like(lk), torch.zeros_like(lk)
+                A = torch.stack([torch.stack([one, 0.05 * (lk - 1.0)], -1), torch.stack([zero, one], -1)], -2)
+                B = dt * bd.const([[0.0], [1.0]], lead, device, dtype)
+                F = bd.const([[1.0, 0.0], [0.0, 1.0]], lead, device, dtype)
+                V, W = bd.diag([pn, av]), bd.diag([sg, sg])
+                Q = bd.const([[1.0, -1.0], [-1.0, 1.0]], lead, device, dtype)
+                R = bd.diag([ac])
+                spec = Actor(A=A, B=B, F=F, V=V, W=W, Q=Q, R=R, T=T)
+                super().__init__(actor=spec, dynamics=spec)
+
+        return LeakyTracking
+
+
+@pytest.mark.gpu
+def test_graphed_user_model_structure_is_not_read_off_theta_equal_one(monkeypatch):
+    """Advisor (round 2, high): the frozen sparsity pattern of a non-zoo class must come from random positive probes, not
+    from theta = 1 where a (theta - 1) entry vanishes — the replay at leak != 1 must equal the eager evaluation."""
+    from lqg_amd.infer import graphed
+    from lqg_amd.infer.gradient import value_and_grad
+    cls = _LeakyTracking.make()
+    truth = cls(leak=1.6, T=150, device="cuda", dtype=torch.float64)
+    with torch.no_grad():
+        x = truth.simulate(3, n=24).contiguous()
+    x = torch.cat([x, x[:, -1:]], dim=1)
+    names = ["leak", "sigma", "action_cost", "action_variability"]
+    ev = graphed.make(graphed.GraphedFiniteDifference, x, cls, names, 1, h=1e-4)
+    assert ev is not None
+    for p in (dict(leak=1.6, sigma=5.0, action_cost=0.4, action_variability=0.6),
+              dict(leak=1.0, sigma=6.0, action_cost=0.5, action_variability=0.5),
+              dict(leak=0.4, sigma=8.0, action_cost=0.2, action_variability=0.4)):
+        monkeypatch.setenv("LQG_GRAPH", "0")
+        v0, g0 = value_and_grad(x, cls, p, method="fd")
+        monkeypatch.setenv("LQG_GRAPH", "1")
+        v1, g1 = value_and_grad(x, cls, p, method="fd")
+        assert abs(v1 / v0 - 1) < 1e-11, (p, v0, v1)
+        s_ = max(abs(v) for v in g0.values())
+        assert all(abs(g1[k] - g0[k]) < 1e-6 * s_ for k in g0), (g0, g1)
+
+
+@pytest.mark.gpu
+def test_graphed_guard_trips_when_the_eigenvalue_floor_becomes_active(monkeypatch):
+    """Advisor (round 2, medium): a dim = 2 model is captured DECOUPLED (exact only while the floor of lqr.py:27-28 is
+    inactive).  With action_cost < eps the floor is active: the device-side guard inside the graph turns the replay into
+    NaN and value_and_grad answers from the eager path (which solves the joint problem)."""
+    import math
+    import lqg_amd
+    from lqg_amd.infer import graphed
+    from lqg_amd.infer.gradient import value_and_grad, _graphed_fd
+    truth = lqg_amd.BoundedActor(dim=2, T=60, device="cuda", dtype=torch.float64)
+    with torch.no_grad():
+        x = truth.simulate(3, n=12).contiguous()
+    x = torch.cat([x, x[:, -1:]], dim=1)
+    names = ["action_variability", "sigma_target", "sigma_cursor", "action_cost"]
+    good = dict(action_variability=0.5, sigma_target=6.0, sigma_cursor=3.0, action_cost=0.1)
+    bad = dict(good, action_cost=2e-9)
+    monkeypatch.setenv("LQG_GRAPH", "1")
+    ev = _graphed_fd(x, lqg_amd.BoundedActor, names, dict(dim=2), 1.0, 1.0 / 60, 1e-4, None)
+    assert ev is not None and ev._guarded and ev._merged_cols is not None
+    z = lambda p: torch.tensor([[math.log(p[k]) for k in names]], dtype=torch.float64)
+    assert torch.isfinite(ev(z(good))).all()
+    assert torch.isnan(ev(z(bad))).all()                          # poisoned, never silently wrong
+    v1, g1 = value_and_grad(x, lqg_amd.BoundedActor, bad, method="fd", dim=2)
+    monkeypatch.setenv("LQG_GRAPH", "0")
+    v0, g0 = value_and_grad(x, lqg_amd.BoundedActor, bad, method="fd", dim=2)
+    assert math.isfinite(v0) and v1 == v0 and g1 == g0
+
+
+@pytest.mark.gpu
+def test_graph_survives_eviction_of_the_constructor_constant_caches():
+    """Advisor (round 2, medium): the captured constructor of a non-affine model reads cached scalars / constants by
+    address; clearing the full caches afterwards must not free them under the graph."""
+    import lqg_amd
+    from lqg_amd.infer import graphed
+    from lqg_amd.tracking import _build
+    truth = lqg_amd.PointMassBoundedActor(T=80, device="cuda", dtype=torch.float64)
+    with torch.no_grad():
+        x = truth.simulate(3, n=16)[..., :2].contiguous()
+    x = torch.cat([x, x[:, -1:]], dim=1)
+    names = ["action_variability", "sigma_target", "sigma_cursor", "action_cost"]
+    ev = graphed.make(graphed.GraphedFiniteDifference, x, lqg_amd.PointMassBoundedActor, names, 1, h=1e-4)
+    assert ev is not None and ev._affine is None and ev._pins
+    z = torch.log(torch.tensor([[0.5, 6.0, 3.0, 0.1]], dtype=torch.float64))
+    before = ev(z).clone()
+    for i in range(2 * _build._CACHE_MAX + 8):                   # overflow both caches: wholesale clear()
+        _build._scalar(1.0 + 1e-3 * i, torch.float64, torch.device("cuda"))
+        _build.const([[float(i)]], (), torch.device("cuda"), torch.float64)
+    junk = [torch.full((1 << 12,), float(i), dtype=torch.float64, device="cuda") for i in range(256)]   # reuse freed blocks
+    torch.cuda.synchronize()
+    assert torch.equal(ev(z), before)
+    del junk
