@@ -13,6 +13,9 @@ the summed log-likelihood (the objective of lqg.infer / lqg.optim), issued once 
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
     python bench.py --config 3 [--gpus N]    # BASELINE config 3: 4096 candidates x 1024 trials, trial axis split
                                              # over the ranks, all-reduce of the [4096] fp64 objective (strong scaling)
+    python bench.py --gpus 2 --share-gpu     # the same N-rank flow on ONE GPU: every rank computes on device 0 and the
+                                             # reduce goes through gloo on a host tensor (multi-rank evidence without a
+                                             # multi-GPU node; the per-GPU rates are NOT a scaling measurement)
 """
 import argparse
 import json
@@ -73,7 +76,38 @@ def parse_args():
     ap.add_argument("--no-stack", action="store_true",
                     help="launch decoupled components separately instead of stacked into one launch")
     ap.add_argument("--cpu-sample", type=int, default=0, help="solves in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="all ranks compute on device 0 (backend gloo, the objective reduced on a host tensor): runs the N>1 "
+                         "flow with the HIP kernels on a single-GPU box")
     return ap.parse_args()
+
+
+class HostReduce:
+    """--share-gpu: the three collectives of this file (all_reduce of the fp64 objective, barrier, all_gather of one
+    timing) over gloo on HOST tensors, behind the torch.distributed calls the RCCL path makes on device tensors."""
+
+    def __init__(self, torch, dist):
+        self._t, self._d = torch, dist
+
+    def get_world_size(self):
+        return self._d.get_world_size()
+
+    def barrier(self):
+        self._d.barrier()
+
+    def all_reduce(self, t):
+        h = t.detach().cpu()                      # (stream-ordered copy: waits for the partial sums)
+        self._d.all_reduce(h)
+        t.copy_(h)
+
+    def all_gather(self, outs, t):
+        hs = [self._t.zeros_like(t, device="cpu") for _ in outs]
+        self._d.all_gather(hs, t.detach().cpu())
+        for o, h in zip(outs, hs):
+            o.copy_(h)
+
+    def destroy_process_group(self):
+        self._d.destroy_process_group()
 
 
 def launch_ranks(args):
@@ -237,6 +271,12 @@ def headline_leg(torch, dist, args, dev, rank, world, dtype_name, log2_batch, st
     fwd_ms = [sum(e[1].elapsed_ms(e[2]) for e in es) for es in ev_sets]
     ll_host = ll[:, 0].double().cpu().numpy()
     ar_us = allreduce_us(torch, dist, 1)
+    local_obj = _hip.sum_trials(ll.view(1, B)).reshape(1)      # this rank's partial objective (what it fed the all-reduce)
+    per_rank_obj = [float(local_obj.item())]
+    if dist is not None:
+        allo = [torch.zeros_like(local_obj) for _ in range(dist.get_world_size())]
+        dist.all_gather(allo, local_obj)
+        per_rank_obj = [float(v.item()) for v in allo]
     if rank != 0:
         return None
 
@@ -272,6 +312,7 @@ def headline_leg(torch, dist, args, dev, rank, world, dtype_name, log2_batch, st
                    "parallelism": f"candidate-sharded x{world}, all-reduce of the summed log-likelihood"},
         "world_size": world if dist is None else dist.get_world_size(),
         "per_rank_solves_per_s": [float(B) * steps / t for t in per_rank], "allreduce_us": ar_us,
+        "share_gpu": bool(args.share_gpu),
         # Contract form: achieved = ALGORITHMIC bytes per launch (mode M1: trajectory in, specs in, one
         # scalar out) / the dominant kernel's HIP-event time; traffic = PMC bytes of that launch (null unless the
         # committed profile was taken on exactly this build).
@@ -284,6 +325,7 @@ def headline_leg(torch, dist, args, dev, rank, world, dtype_name, log2_batch, st
                      "kernel_launches_per_step": n_launch, "limits": limits,
                      "algorithmic_flops_per_solve": fl["total"] * T},
         "all_finite": bool(np.isfinite(ll_host).all()), "objective_sum": float(total.item()),
+        "per_rank_objective": per_rank_obj,
     }
     # ---- parity spot check against the CPU oracle (not timed) and, on the main leg, the CPU baseline
     try:
@@ -379,7 +421,8 @@ def config3(torch, dist, args, dev, rank, world):
                    "candidates": Bc, "trials": Nt, "trials_per_rank": Nt // world, "T": T, "path": plan.description,
                    "parallelism": f"trial-split x{world}, all-reduce of the [{Bc}] fp64 objective"},
         "world_size": world if dist is None else dist.get_world_size(),
-        "per_rank_s": per_rank, "allreduce_us": ar_us,
+        "per_rank_s": per_rank, "allreduce_us": ar_us, "share_gpu": bool(args.share_gpu),
+        "objective_checksum": float(obj.sum()),
         "phase_ms": {"riccati": ph[0], "forward": ph[1], "trial": ph[2]},
         "roofline": {"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                      "kernel": "k_trial (per-trial mean recursion + density over the operator stream)",
@@ -495,6 +538,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    if args.share_gpu:
+        local_rank = 0                             # every rank computes on device 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
@@ -503,7 +548,11 @@ def main():
     if world > 1 or "RANK" in os.environ:      # under torchrun the collective path is exercised even at world == 1
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.share_gpu:                     # one GPU for all ranks: RCCL needs a device per rank, gloo does not
+            dist.init_process_group("gloo")
+            dist = HostReduce(torch, dist)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     if args.config == 3:
         out = config3(torch, dist, args, dev, rank, world)

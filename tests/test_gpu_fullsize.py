@@ -152,3 +152,49 @@ def test_unlisted_model_shape(oracle_lib, monkeypatch, big_batch):
     with pytest.raises(_abi.LqgHipError, match="no hipcc"):
         _abi.library_for(dict(x=3, b=4, u=1, y=2, d=3), family=_abi.FAM_ADJOINT)
     assert _abi.library_for(dict(x=3, b=4, u=1, y=2, d=3)) is _abi.load()  # the likelihood itself needs no compiler
+
+
+def _run_bench(*flags):
+    """bench.py as a CHILD process (never re-exec a process that touched the GPU); returns rank 0's JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *flags], capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_ranks_share_the_gpu_headline_weak_scaling():
+    """The N > 1 bench flow WITH the HIP kernels on the one GPU there is: `bench.py --gpus 2 --share-gpu` starts two
+    ranks (torch.distributed.run, child processes), both compute on device 0, the objective is all-reduced (gloo, host
+    tensor).  Rank r's data is seeded 1234 + r: rank 0's partial objective equals the single-rank run's, and the
+    all-reduced objective is the sum of the two partials."""
+    common = ["--log2-batch", "14", "--steps", "3", "--warmup", "1", "--no-extra", "--no-cpu-baseline"]
+    one = _run_bench(*common)
+    two = _run_bench("--gpus", "2", "--share-gpu", *common)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["world_size"] == 2 and two["share_gpu"]
+    assert len(two["per_rank_solves_per_s"]) == 2 and len(two["per_rank_objective"]) == 2
+    assert two["scaling"] == "weak" and two["all_finite"]
+    assert abs(two["per_rank_objective"][0] / one["objective_sum"] - 1) < 1e-12
+    assert abs(sum(two["per_rank_objective"]) / two["objective_sum"] - 1) < 1e-12
+    assert two["per_rank_objective"][0] != two["per_rank_objective"][1]          # different shards
+    assert two["value"] > 0 and two["parity"]["max_rel_err_vs_fp64_oracle"] < 1e-6
+
+
+def test_two_ranks_share_the_gpu_config3_trial_split():
+    """`--config 3` (4096 candidates x 1024 trials, T = 1067) with the TRIAL axis split over two ranks: the all-reduced
+    [4096] objective equals the single-rank one to fp64 rounding (strong scaling: same work, same answer)."""
+    common = ["--config", "3", "--steps", "2", "--warmup", "1"]
+    one = _run_bench(*common)
+    two = _run_bench("--gpus", "2", "--share-gpu", *common)
+    assert two["n_gpus"] == 2 and two["world_size"] == 2 and two["share_gpu"] and two["scaling"] == "strong"
+    assert len(two["per_rank_s"]) == 2 and two["config"]["trials_per_rank"] == 512
+    assert two["best_candidate"] == one["best_candidate"]
+    assert abs(two["objective_checksum"] / one["objective_checksum"] - 1) < 1e-12
+    assert abs(two["objective_max"] / one["objective_max"] - 1) < 1e-12
