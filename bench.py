@@ -521,6 +521,68 @@ def extra_legs(torch, args, dev):
                     os.environ[k] = v
     leg["evaluations_per_s"] = 1e3 / leg["fd_graph"]
     extra["one_vector_value_and_grad"] = leg
+    torch.cuda.empty_cache()
+    # ---- the measurement claims of DESIGN.md §6 that used to be builder-run only (round-2 review item 4) -------------------
+    # mode M2 of SURVEY 8(d): genuinely time-varying specs in, L, H, K, mu, Sigma out, [T][element][system] storage
+    try:
+        import bench_m2
+        extra["m2_f32"] = bench_m2.run(dev, "f32", 17, 500, 3)
+    except Exception as e:
+        extra["m2_f32"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
+    # BASELINE config 3 at its literal shape (4096 candidates x 1024 trials, T = 1067): trial-evals/s, k_trial_sp time
+    try:
+        class A3:
+            dtype, steps, warmup, share_gpu = "f32", 10, 2, False
+        c3 = config3(torch, None, A3, dev, 0, 1)
+        w3 = 4
+        tb = 4096 * 1024 * (1067 + 1) * 2 * w3                 # one data row per (candidate, trial, step) as the sweep reads it
+        c3["roofline"] = {"bound": "valu", "kernel": "k_trial_sp (per-trial mean recursion + density over the operator stream)",
+                          "kernel_ms": c3["phase_ms"]["trial"], "system_sweeps_ms": c3["phase_ms"]["riccati"] + c3["phase_ms"]["forward"],
+                          "achieved": tb / (c3["phase_ms"]["trial"] * 1e-3) / 1e9, "unit": "GB/s of data rows through L2 (x is 8.7 MB: "
+                          "HBM sees it once per pass)", "peak": None, "frac": None, "traffic": None,
+                          "trial_steps_per_s": 4096 * 1024 * 1067 / (c3["phase_ms"]["trial"] * 1e-3)}
+        extra["config3"] = {k: c3[k] for k in ("metric", "value", "unit", "ms_per_step", "phase_ms", "roofline", "config",
+                                                "best_candidate")}
+    except Exception as e:
+        extra["config3"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
+    # BASELINE config 5 in its literal form: ONE system x 2^20 trials (the per-trial sweep streams x once: HBM-bound)
+    try:
+        m5 = lqg_amd.SubjectiveActor(dim=2, T=500, device=dev, dtype=torch.float32)
+        x5 = workload.pack_trials(m5.simulate(15, n=1 << 20))
+        ll5, ph5 = bc.timed_loglik(m5, x5, 10)
+        b5 = (1 << 20) * 501 * 4 * 4 + (1 << 20) * 4
+        extra["config5_one_system"] = {
+            "systems": 1, "trials": 1 << 20, "T": 500, "dtype": "f32", "wall_ms": ph5["wall_ms"], "path": ph5["path"],
+            "value": (1 << 20) / (ph5["wall_ms"] * 1e-3), "unit": "trial-evals/s",
+            "roofline": {"bound": "hbm", "kernel": "per-trial sweep (k_trial_sp) over 2^20 trajectories", "kernel_ms": ph5["trial_ms"],
+                         "system_sweeps_ms": ph5["riccati_ms"] + ph5["forward_ms"],
+                         "achieved": b5 / (ph5["trial_ms"] * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": b5 / (ph5["trial_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": b5},
+            "max_rel_err_vs_fp64_oracle": bc.oracle_check(m5, x5, ll5, n_samples=4)}
+        del x5
+    except Exception as e:
+        extra["config5_one_system"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
+    # the reference's largest model: DelayedSubjectiveActor (delay 12: x = 26, b = 39, m = 65), cooperative kernels
+    try:
+        from lqg_amd.tracking.delay import DelayedSubjectiveActor
+        md = DelayedSubjectiveActor(T=500, device=dev, dtype=torch.float32)
+        legd = {"model": "DelayedSubjectiveActor (lqg/tracking/delay.py:44-51): x=26 b=39 m=65, T=500", "dtype": "f32",
+                "unit": "ms per log-likelihood evaluation"}
+        xd_all = md.simulate(21, n=256)[..., :2].contiguous()
+        for nt in (1, 256):
+            xd = xd_all[:nt].contiguous()
+            lld, phd = bc.timed_loglik(md, xd, 5)
+            legd[f"trials_{nt}"] = {"wall_ms": phd["wall_ms"], "riccati_ms": phd["riccati_ms"], "forward_ms": phd["forward_ms"],
+                                    "trial_ms": phd["trial_ms"], "path": phd["path"]}
+        legd["max_rel_err_vs_fp64_oracle"] = bc.oracle_check(md, xd_all[:2].contiguous(),
+                                                             md.log_likelihood(xd_all[:2].contiguous()), n_samples=2)
+        extra["delay12"] = legd
+    except Exception as e:
+        extra["delay12"] = {"error": repr(e)}
     return extra
 
 

@@ -38,17 +38,12 @@ def soa(base, T, B, gen, jitter, sym=False, positive_diag=False):
     return phys.permute(3, 0, 1, 2)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--log2-batch", type=int, default=14)
-    ap.add_argument("--T", type=int, default=500)
-    ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
-    args = ap.parse_args()
-    dev = torch.device("cuda", 0)
-    dtype = torch.float32 if args.dtype == "f32" else torch.float64
-    w = 4 if args.dtype == "f32" else 8
-    B, T = 1 << args.log2_batch, args.T
+def run(dev, dtype_name="f32", log2_batch=17, T=500, reps=5):
+    """One M2 measurement -> dict (the line main() prints; bench.py's `extra.m2_f32` leg)."""
+    from lqg_amd import _hipev
+    dtype = torch.float32 if dtype_name == "f32" else torch.float64
+    w = 4 if dtype_name == "f32" else 8
+    B = 1 << log2_batch
     gen = torch.Generator(device=dev)
     gen.manual_seed(4321)
 
@@ -83,6 +78,9 @@ def main():
     nbytes = lib.lqg_workspace_bytes(C.byref(lnm.p), _abi.OP_CONDITIONAL_MOMENTS)
     ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
     ll = torch.empty((B, 1), dtype=dtype, device=dev)
+    evs = [_hipev.Event() for _ in range(4)]             # phase events the library records on the launch stream
+    for i in range(4):
+        lnm.p.phase_events[i] = evs[i].h
 
     def one_pass():
         # one ABI call, two kernels: k_riccati (L, H out + gain scratch) -> k_forward (K, mu, Sigma, ll out)
@@ -94,13 +92,15 @@ def main():
     one_pass()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ms = []
-    for _ in range(args.reps):
+    ms, ric, fwd = [], [], []
+    for _ in range(reps):
         e0.record()
         one_pass()
         e1.record()
         e1.synchronize()
         ms.append(e0.elapsed_time(e1))
+        ric.append(evs[0].elapsed_ms(evs[1]))
+        fwd.append(evs[1].elapsed_ms(evs[2]))
     ms = float(np.median(ms))
 
     b, u, y, xx_, m, d = dm["b"], dm["u"], dm["y"], dm["x"], dm["m"], dm["d"]
@@ -110,6 +110,7 @@ def main():
     gbs = bytes_solve * B / (ms * 1e-3) / 1e9
     # parity spot check of the time-varying path against the fp64 oracle
     import oracle as OC
+    OC.build()
     sel = [0, B // 2, B - 1]
     idx = torch.as_tensor(sel, device=dev)
     host = lambda spec: {f: (getattr(spec, f)[idx] if getattr(spec, f).dim() == workload._batched_ndim(f)
@@ -121,15 +122,28 @@ def main():
     mur, Sr = OC.conditional_moments(a64, d64, x[idx].double().cpu().numpy())
     rel = lambda got, ref: float(np.abs(got.double().cpu().numpy() - ref).max() / np.abs(ref).max())
     parity = dict(L=rel(L[idx], Lr), H=rel(H[idx], Hr), K=rel(K[idx], Kr), mu=rel(mu[idx], mur), Sigma=rel(Sig[idx], Sr))
-    print(json.dumps({
-        "mode": "M2 (time-varying [T,...] specs in; L,H,K,mu,Sigma materialised out)", "dtype": args.dtype,
+    return {
+        "mode": "M2 (time-varying [T,...] specs in; L,H,K,mu,Sigma materialised out)", "dtype": dtype_name,
         "systems": B, "T": T, "ms_per_pass": ms, "solves_per_s": B / (ms * 1e-3),
         "algorithmic_bytes_per_solve": bytes_solve,
         "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                      "frac_of_measured_copy_rate": gbs / 6290.0,
-                     "algorithmic_bytes_per_pass": bytes_solve * B},
+                     "algorithmic_bytes_per_pass": bytes_solve * B, "traffic": None,
+                     "kernel": "k_riccati<TI=false> + k_forward<TI=false, FUSED, MAT> (one pass = both)",
+                     "kernel_ms": float(np.median(ric)) + float(np.median(fwd)),
+                     "riccati_kernel_ms": float(np.median(ric)), "forward_kernel_ms": float(np.median(fwd))},
         "calls": "lqg_solve_materialised (1 ABI call, 2 kernels: k_riccati -> k_forward)",
-        "workspace_GB": nbytes / 1e9, "parity_rel_maxnorm_vs_fp64_oracle": parity}))
+        "workspace_GB": nbytes / 1e9, "parity_rel_maxnorm_vs_fp64_oracle": parity}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log2-batch", type=int, default=14)
+    ap.add_argument("--T", type=int, default=500)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    args = ap.parse_args()
+    print(json.dumps(run(torch.device("cuda", 0), args.dtype, args.log2_batch, args.T, args.reps)))
 
 
 if __name__ == "__main__":

@@ -730,6 +730,117 @@ __global__ void __launch_bounds__(BLOCK) k_coop_trial(const R* __restrict__ ops_
 }
 
 // ======================================================================================================================
+// Row-parallel per-trial sweep for LARGE joint dimensions (run-time m, d), same operator stream, same arithmetic per row.
+// k_coop_trial walks a trial with ONE thread: m^2 dependent multiply-adds per step behind LDS round trips — at m = 65 (the
+// reference's DelayedSubjectiveActor) 210 us per step, 105 ms per evaluation whatever the number of trials (measured,
+// profiles/r03_b_bench.json).  Here a group of RT = BLOCK / tpb threads owns a trial and splits the ROWS of the mean update
+// (thread r: rows r, r + RT, ...); the step's operator block is staged in LDS once per workgroup (double-buffered: the loads
+// of step t + 1 are in flight while step t computes) and shared by the tpb trials of the block; two barriers per step.
+template <typename R, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_coop_trial_rows(const R* __restrict__ ops_all, const TrialArgsRT<R> a, const int tpb) {
+  extern __shared__ double lqg_coop_smem[];
+  constexpr int MAXO = 6, MAXPF = 24;                        // d <= 6 (coop_supported); operator reals per thread per step
+  const int m = a.m, o = a.d, rr = m - a.d, tid = threadIdx.x, nops = a.nops;
+  const int RT = BLOCK / tpb, g = tid / RT, r = tid - g * RT;
+  const long sys = blockIdx.y;
+  long n = (long)blockIdx.x * tpb + g;
+  const bool live = n < a.n_trials;
+  n = live ? n : a.n_trials - 1;
+  R* sm = reinterpret_cast<R*>(lqg_coop_smem);
+  R* opb[2] = {sm, sm + nops};
+  R* cv = sm + 2 * nops + (long)g * 2 * m;                   // [x_t ; c] of this group's trial
+  R* st = cv + m;                                            // state: dO (o) | muR (rr)
+  const int U_OFF = m * m, L_OFF = U_OFF + rr * o, H_OFF = L_OFF + o * (o + 1) / 2;
+  const R* op = ops_all + sys * (long)(a.T + 1) * nops;
+  const R* xr = a.x.p + sys * a.x.sb + n * a.x.sn;
+  for (int i = r; i < m; i += RT) st[i] = R(0);
+  R pf[MAXPF];
+  const int npf = (nops + BLOCK - 1) / BLOCK;                // <= MAXPF (host-checked)
+  LQG_UNROLL for (int k = 0; k < MAXPF; ++k)
+    if (k < npf && tid + k * BLOCK < nops) opb[0][tid + k * BLOCK] = op[tid + k * BLOCK];
+  R xprev[MAXO], xnx[MAXO];
+  LQG_UNROLL for (int j = 0; j < MAXO; ++j) {
+    xprev[j] = j < o ? xr[j * a.x.sd] : R(0);
+    xnx[j] = xprev[j];
+  }
+  double acc = 0.0;
+  __syncthreads();
+  for (int t = 0; t <= a.T; ++t) {
+    const R* __restrict__ ob = opb[t & 1];
+    const bool more = t < a.T;
+    // requests of step t + 1: its operator block (into registers, parked in LDS at the end of the step) and its data row
+    if (more) {
+      const R* nx = op + (long)(t + 1) * nops;
+      LQG_UNROLL for (int k = 0; k < MAXPF; ++k)
+        if (k < npf && tid + k * BLOCK < nops) pf[k] = nx[tid + k * BLOCK];
+    }
+    R xt[MAXO], w[MAXO], e[MAXO];
+    LQG_UNROLL for (int j = 0; j < MAXO; ++j) xt[j] = xnx[j];
+    {
+      const long row = (t + 1 <= a.T) ? (long)(t + 1) : (long)a.T;
+      LQG_UNROLL for (int j = 0; j < MAXO; ++j)
+        if (j < o) xnx[j] = xr[row * a.x.st + j * a.x.sd];
+    }
+    // whitened innovation (every thread of the group, redundantly: d^2 / 2 multiply-adds) and its density
+    LQG_UNROLL for (int j = 0; j < MAXO; ++j) e[j] = j < o ? (xt[j] - xprev[j]) - st[j] : R(0);
+    R zz = R(0);
+    {
+      int q = 0;
+      LQG_UNROLL for (int i = 0; i < MAXO; ++i) {
+        R v = R(0);
+        LQG_UNROLL for (int j = 0; j < MAXO; ++j)
+          if (j <= i && i < o) v += ob[L_OFF + (q++)] * e[j];
+        w[i] = v;
+        zz += v * v;
+      }
+    }
+    if (t > 0 && r == 0) acc -= (double)(R(0.5) * zz + ob[H_OFF]);
+    if (more) {
+      // c = muR + U2 w (row-parallel), [x_t ; c] into LDS
+      for (int p = r; p < rr; p += RT) {
+        R v = st[o + p];
+        LQG_UNROLL for (int j = 0; j < MAXO; ++j)
+          if (j < o) v += ob[U_OFF + p * o + j] * w[j];
+        cv[o + p] = v;
+      }
+      if (r == 0) {
+        LQG_UNROLL for (int j = 0; j < MAXO; ++j)
+          if (j < o) cv[j] = xt[j];
+      }
+    }
+    __syncthreads();                                         // cv complete; every thread has read st[0:o] of this step
+    if (more) {
+      // (Fj - I) [x_t ; c], row-parallel; new state = [0 ; c] + that
+      for (int i = r; i < m; i += RT) {
+        const R* __restrict__ fr = ob + (long)i * m;
+        R v0 = R(0), v1 = R(0), v2 = R(0), v3 = R(0);
+        int j = 0;
+        for (; j + 3 < m; j += 4) {
+          v0 += fr[j] * cv[j];
+          v1 += fr[j + 1] * cv[j + 1];
+          v2 += fr[j + 2] * cv[j + 2];
+          v3 += fr[j + 3] * cv[j + 3];
+        }
+        for (; j < m; ++j) v0 += fr[j] * cv[j];
+        const R mn = (v0 + v1) + (v2 + v3);
+        const R ns = i < o ? mn : cv[i] + mn;
+        st[i] = ns;
+        if (a.mu.p && live) {
+          R* dst = const_cast<R*>(a.mu.p) + sys * a.mu.sb + n * a.mu.sn + (long)t * a.mu.st;
+          dst[i * a.mu.sd] = i < o ? cv[i] + mn : ns;            // (cv[0:o] holds x_t)
+        }
+      }
+      LQG_UNROLL for (int j = 0; j < MAXO; ++j) xprev[j] = xt[j];
+      R* nb = opb[(t + 1) & 1];
+      LQG_UNROLL for (int k = 0; k < MAXPF; ++k)
+        if (k < npf && tid + k * BLOCK < nops) nb[tid + k * BLOCK] = pf[k];
+    }
+    __syncthreads();                                         // new state + next operator block visible
+  }
+  if (a.ll && live && r == 0) a.ll[sys * a.ll_sb + n * a.ll_sn] = (R)acc;
+}
+
+// ======================================================================================================================
 // Run-time-dims twin of k_simulate (System.simulate's per-trial scan, lqg/system.py:106-128): one (system, trial) per
 // thread, the two state vectors and the per-step temporaries in LDS columns [element][thread]; gains and spec matrices
 // are read straight from global memory (every thread of a system reads the same address: broadcast).  For shapes

@@ -207,6 +207,24 @@ hipError_t coop_trial(const lqg_problem* p, const void* ops, lqg_traj x, lqg_tra
   const int m = p->dims.x + p->dims.b, o = p->dims.d, rr = m - o;
   coop::TrialArgsRT<R> k{dt<R>(x), dt<R>(mu), static_cast<R*>(ll), ll_sb, ll_sn, (long)p->n_trials, p->T, m, o,
                          (int)ops_reals(p->dims)};
+  // large joint dimension: a group of threads per trial splits the rows of the mean update (k_coop_trial_rows); trials
+  // per block: the smallest power of two that keeps the grid within ~2048 workgroups, at most 16 (>= 16 threads per trial)
+  {
+    constexpr int BR = 256, MAXPF = 24;
+    const int nops = (int)ops_reals(p->dims);
+    int tpb = 1;
+    while (tpb < 16 && (long)p->n_sys * ((p->n_trials + tpb - 1) / tpb) > 2048) tpb *= 2;
+    const size_t lds_r = ((size_t)2 * nops + (size_t)tpb * 2 * m) * sizeof(R);
+    static const bool rows_off = [] { const char* e = getenv("LQG_COOP_TRIAL_ROWS"); return e && atoi(e) == 0; }();
+    if (!rows_off && m >= 16 && o <= 6 && (nops + BR - 1) / BR <= MAXPF && lds_r <= kLdsLimit) {
+      auto kr = coop::k_coop_trial_rows<R, BR>;
+      hipError_t er = raise_lds(kr, lds_r);
+      if (er != hipSuccess) return er;
+      const dim3 gr((unsigned)((p->n_trials + tpb - 1) / tpb), (unsigned)p->n_sys);
+      hipLaunchKernelGGL(kr, gr, dim3(BR), lds_r, st, static_cast<const R*>(ops), k, tpb);
+      return hipGetLastError();
+    }
+  }
   constexpr int B = 64;
   const size_t lds = (size_t)B * (size_t)(4 * o + 2 * rr + m) * sizeof(R);
   if (lds > kLdsLimit) return hipErrorInvalidValue;

@@ -124,6 +124,27 @@ def test_config4_hand2d_32768_trials_T1000(oracle_lib, monkeypatch):
     assert float((joint / ll64[:2048] - 1).abs().max()) < 1e-10
 
 
+def test_config5_one_system_1048576_trials_fp32_vs_fp64_sweep(oracle_lib, monkeypatch):
+    """Config 5 in its literal form: ONE system (SubjectiveActor(dim=2), n = 6) x 1 048 576 trials, T = 500, "fp32 vs fp64
+    tolerance sweep" — quantiles of the fp32 result against the fp64 one over ALL trials (same inputs), a C-oracle sample at
+    the full horizon, and invariance under the 8-way trial split of the multi-GPU path."""
+    n = 1 << 20
+    m64 = lqg_amd.SubjectiveActor(dim=2, T=500, device=DEV, dtype=torch.float64)
+    x64 = m64.simulate(15, n=n)
+    ll64, ll32, rel = _fp32_vs_fp64(m64, x64)
+    assert ll64.shape == (n,) and torch.isfinite(ll64).all() and torch.isfinite(ll32).all()
+    assert _oracle_sample(m64, x64, ll64, 8) < 1e-10
+    sample = rel[torch.randperm(rel.numel(), device=rel.device)[: 1 << 20]]
+    assert float(rel.max()) < 1e-6 and float(torch.quantile(sample, 0.99)) < 3e-7 and float(sample.median()) < 1e-7
+    xp = workload.pack_trials(x64)
+    del x64
+    cuts = [(i * (n // 8), (i + 1) * (n // 8)) for i in range(8)]
+    _shard_invariance(m64, xp, ll64, cuts, monkeypatch)
+    obj = _hip.sum_trials(ll64)
+    parts = sum(_hip.sum_trials(ll64[a:b]) for a, b in cuts)
+    assert abs(float(parts) / float(obj) - 1) < 1e-12
+
+
 @pytest.mark.parametrize("same_axes", [True, False], ids=["identical-axes", "different-axes"])
 def test_active_eigenvalue_floor_on_a_decoupling_model(oracle_lib, same_axes):
     """lqr.py:27-28 regularises the JOINT H: Ht = H + max(0, eps - lambda_min(H)) I.  With R = 0 on an axis, H = B'SB is

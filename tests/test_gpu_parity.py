@@ -18,8 +18,12 @@ pytestmark = pytest.mark.gpu
 TOL = {torch.float64: dict(ll=1e-10, mat=1e-9), torch.float32: dict(ll=1e-6, mat=2e-5)}
 # pointmass_d4: the observed 4x4 block has condition number ~1e12 (1e-3 process noise on velocity/activation),
 # the reference's own fp64 result is only reproducible to ~1e-10 and fp32 cannot represent it (the literal
-# fp32 oracle returns NaN).  fp64 is checked at a looser tolerance, fp32 only for finiteness of the gains.
+# fp32 oracle returns NaN).  fp64 is checked at a looser tolerance.  fp32: an all-fp32 moment recursion cannot carry this
+# conditioning — the in-lane one / two-trial sweeps return 1.5e-3 or NaN depending on the instantiation's rounding
+# (scripts/pointmass_d4_fp32.py) — so the log-likelihood is asserted on the path an fp32 caller gets with >= 3 trials:
+# MIXED (system sweeps in fp64, operators rounded once, fp32 per-trial sweep; include/lqg_hip.h LQG_F32_SYS64).
 ILL = {"pointmass_d4_T50"}
+ILL_F32_LL_TOL = 5e-5
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
@@ -48,6 +52,16 @@ def test_golden(name, dtype):
     else:
         assert np.abs(np_(gains.l)).max() == 0.0
     if tol is None:
+        from lqg_amd.plan import LogLikelihoodPlan
+        x = torch.as_tensor(g["x"], dtype=dtype, device="cuda")
+        x4 = torch.cat([x, x], dim=0)[:4] if x.shape[0] < 4 else x          # >= 3 trials: the operator-stream path
+        ref4 = np.concatenate([g["ll"], g["ll"]])[:x4.shape[0]]
+        plan = LogLikelihoodPlan(sys_, x4)
+        assert all(wk["mixed"] or wk["scan"] for wk in plan.work), plan.description
+        ll4 = np_(plan.run())
+        assert np.isfinite(ll4).all() and np.abs(ll4 / ref4 - 1).max() < ILL_F32_LL_TOL, (ll4, ref4)
+        ll1 = np_(sys_.log_likelihood(x[:1]))                                # in-lane fp32 sweep: no accuracy claim
+        assert np.isnan(ll1).all() or np.abs(ll1 / g["ll"][:1] - 1).max() < 2e-2
         return
 
     x = torch.as_tensor(g["x"], dtype=dtype, device="cuda")
