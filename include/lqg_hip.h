@@ -120,7 +120,7 @@ int lqg_dims_supported(int32_t dtype, const lqg_dims* dims);
 int lqg_kernel_supported(int32_t family, const lqg_dims* dims);
 /* Two kernel strategies serve every entry point below.  LANE: one system per lane, matrices in registers, kernels
  * instantiated per model shape (lqg_kernel_supported) — the throughput path for >= 10^4 systems.  COOP: one
- * workgroup per system, matrices staged in LDS, dimensions are run-time arguments (any x, b; u, y, d <= 6) — for few
+ * workgroup per system, matrices staged in LDS, dimensions are run-time arguments (any x, b; u, y, d <= 4) — for few
  * systems (one parameter vector x many trials) and for shapes no lane kernel holds (x + b > 20: the reference's
  * DelayedSubjectiveActor, lqg/tracking/delay.py:44-51).  lqg_strategy(p) tells which one THIS library runs for p
  * (environment LQG_COOP=0/1 overrides the default rule); lqg_workspace_bytes accounts for it. */
@@ -232,6 +232,15 @@ int lqg_point_mass_setup(int64_t n, const double* damping, const double* mass, c
 int lqg_simulate(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view K, lqg_traj eps, lqg_traj eta,
                  lqg_view x0, lqg_view xhat0, lqg_traj xs, lqg_traj xhat, lqg_traj ys, lqg_traj us,
                  void* stream);
+
+/* lqg_simulate with the draws of lqg/system.py:100-105 (eps ~ N(0, I), eta ~ N(0, I) per (trial, step), jax.random in the
+ * reference) made IN THE KERNEL: counter-based Philox4x32-10 keyed by `seed`, counter = (pair, step, block) with
+ * pair = system * n_trials + trial, Box-Muller normals in fp32 (csrc/lqg_rng.hpp).  A trajectory is a pure function of
+ * (seed, pair): it does not depend on the batch size, on which kernel serves the shape, or on the mapping of pairs to
+ * lanes (pairs are numbered within the call: ranks that simulate disjoint shards use distinct seeds).
+ * Nothing but the trajectories crosses HBM (lqg_simulate reads 2 T (x + y) reals per trial it was handed). */
+int lqg_simulate_rng(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view K, uint64_t seed, lqg_view x0,
+                     lqg_view xhat0, lqg_traj xs, lqg_traj xhat, lqg_traj ys, lqg_traj us, void* stream);
 
 /* Replaces numpyro MultivariateNormal(mu, Sigma).to_event(1).log_prob(value) as used by
  * System.conditional_distribution [lqg/system.py:244,248]: value[B,N,T,k], mu[B,N,T,k] (k = dims.d

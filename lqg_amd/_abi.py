@@ -67,6 +67,7 @@ def declare(lib, prefix="lqg_", with_stream=True):
         "log_likelihood": [P, Traj, C.c_void_p, C.c_int64, C.c_int64] + ws + tail,
         "solve_materialised": [P, Traj, View, View, View, View, Traj, View, C.c_void_p, C.c_int64, C.c_int64] + ws + tail,
         "simulate": [P, View, View, View, Traj, Traj, View, View, Traj, Traj, Traj, Traj] + tail,
+        "simulate_rng": [P, View, View, View, C.c_uint64, View, View, Traj, Traj, Traj, Traj] + tail,
     }
     for name, args in sig.items():
         if not hasattr(lib, prefix + name):
@@ -163,7 +164,7 @@ def library_for(dims, family=FAM_FORWARD, n_sys=None):
     kf.forward on (b, y), simulate on (x, b, u, y) — they are resolved per FAMILY, so e.g. the Riccati sweep of a
     SubjectiveActor's actor spec (b=6, u=2) is served by the main library whatever x, y, d are.  Order: lane kernels of
     liblqg_hip.so; auxiliary libraries already loaded or cached on disk; the COOPERATIVE kernels of liblqg_hip.so
-    (run-time dims: any x, b with u, y, d <= 6 — no compile) for small batches, shapes beyond the lane kernels' range
+    (run-time dims: any x, b with u, y, d <= 4 — no compile) for small batches, shapes beyond the lane kernels' range
     (x + b > 20) or when no compiler is there; finally an auxiliary lane-kernel library compiled on demand for exactly
     this shape (lqg_amd.build.build_dims_library; needs hipcc).  Never a CPU fallback."""
     lib = load()

@@ -272,9 +272,14 @@ def gaussian_logprob(value, mu, Sigma, k):
     return out
 
 
-def simulate(actor, dynamics, L, l, K, eps_noise, eta_noise, x0=None, xhat0=None, return_all=True):
-    """eps_noise[(B,)n,T,x], eta_noise[(B,)n,T,y] -> x[(B,)n,T+1,x] (and xhat, y, u)."""
-    n = eps_noise.shape[-3]
+def simulate(actor, dynamics, L, l, K, eps_noise=None, eta_noise=None, x0=None, xhat0=None, return_all=True, seed=None,
+             n=None):
+    """eps_noise[(B,)n,T,x], eta_noise[(B,)n,T,y] -> x[(B,)n,T+1,x] (and xhat, y, u); or, with seed (an int) and n
+    instead of the draws, the same recursion with the normals drawn in-kernel (lqg_simulate_rng: counter-based Philox)."""
+    rng = eps_noise is None and eta_noise is None
+    if rng and (seed is None or n is None):
+        raise LqgHipError("simulate: pass the draws (eps_noise, eta_noise) or seed and n")
+    n = n if rng else eps_noise.shape[-3]
     ln = Launch(actor, dynamics, n_trials=n)
     lib = ln.require_gpu(_abi.FAM_SIMULATE)         # k_simulate is instantiated per (x, b, u, y) only
     dm = ln.dims
@@ -297,10 +302,15 @@ def simulate(actor, dynamics, L, l, K, eps_noise, eta_noise, x0=None, xhat0=None
     lview = _abi.NULL_VIEW if (l is None or _is_zero(l)) else _abi.mat_view(l.data_ptr(), l.shape, _es(l),
                                                                            l.dim() == 3, True, True)
     gview = lambda t: _abi.mat_view(t.data_ptr(), t.shape, _es(t), t.dim() == 4, True, False)
-    eb = eps_noise.dim() == 4
+    outs = (ln.traj(xs), ln.traj(xh) if return_all else nt, ln.traj(ys) if return_all else nt,
+            ln.traj(us) if return_all else nt)
     with torch.cuda.device(ln.device):
-        _abi.check(lib.lqg_simulate(
-            C.byref(ln.p), gview(L), lview, gview(K), ln.traj(eps_noise, eb), ln.traj(eta_noise, eb), v0, vh,
-            ln.traj(xs), ln.traj(xh) if return_all else nt, ln.traj(ys) if return_all else nt,
-            ln.traj(us) if return_all else nt, ln.stream()), "lqg_simulate")
+        if rng:
+            _abi.check(lib.lqg_simulate_rng(C.byref(ln.p), gview(L), lview, gview(K), C.c_uint64(int(seed) & (2 ** 64 - 1)),
+                                            v0, vh, *outs, ln.stream()), "lqg_simulate_rng")
+        else:
+            eb = eps_noise.dim() == 4
+            _abi.check(lib.lqg_simulate(
+                C.byref(ln.p), gview(L), lview, gview(K), ln.traj(eps_noise, eb), ln.traj(eta_noise, eb), v0, vh,
+                *outs, ln.stream()), "lqg_simulate")
     return xs, xh, ys, us

@@ -23,8 +23,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # half the instruction rate (no flop gain) and costs ~450 v_mov per step of operand shuffling plus ~300 extra
 # live registers in k_forward (measured: 42.5 ms -> 12.3 ms per 2^18 solves, profiles/README.md).
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-slp-vectorize"]
-HEADERS = ["lqg_small.hpp", "lqg_kernels.hpp", "lqg_launch.hpp", "lqg_trial_chunk.hpp", "lqg_dims.def", "../../include/lqg_hip.h"]
-COOP_HEADERS = ["lqg_small.hpp", "lqg_kernels.hpp", "lqg_launch.hpp", "lqg_trial_chunk.hpp", "lqg_coop.hpp", "lqg_coop_launch.hpp",
+HEADERS = ["lqg_small.hpp", "lqg_rng.hpp", "lqg_kernels.hpp", "lqg_launch.hpp", "lqg_trial_chunk.hpp", "lqg_dims.def", "../../include/lqg_hip.h"]
+COOP_HEADERS = ["lqg_small.hpp", "lqg_rng.hpp", "lqg_kernels.hpp", "lqg_launch.hpp", "lqg_trial_chunk.hpp", "lqg_coop.hpp", "lqg_coop_launch.hpp",
                 "../../include/lqg_hip.h"]
 SCAN_HEADERS = COOP_HEADERS + ["lqg_scan.hpp"]
 ADJ_HEADERS = ["lqg_small.hpp", "lqg_adjoint.hpp", "lqg_adjoint_launch.hpp", "../../include/lqg_hip.h"]

@@ -56,10 +56,10 @@ LQG_TRIAL_DIMS(X)
 #define X(X_, B_, U_, Y_)                                                                                       \
   extern template hipError_t lqg::host::launch_simulate<float, X_, B_, U_, Y_>(                                 \
       const lqg_problem*, lqg_view, lqg_view, lqg_view, lqg_traj, lqg_traj, lqg_view, lqg_view, lqg_traj,       \
-      lqg_traj, lqg_traj, lqg_traj, hipStream_t);                                                               \
+      lqg_traj, lqg_traj, lqg_traj, hipStream_t, unsigned long long);                                           \
   extern template hipError_t lqg::host::launch_simulate<double, X_, B_, U_, Y_>(                                \
       const lqg_problem*, lqg_view, lqg_view, lqg_view, lqg_traj, lqg_traj, lqg_view, lqg_view, lqg_traj,       \
-      lqg_traj, lqg_traj, lqg_traj, hipStream_t);
+      lqg_traj, lqg_traj, lqg_traj, hipStream_t, unsigned long long);
 LQG_SIM_DIMS(X)
 #undef X
 
@@ -149,12 +149,12 @@ hipError_t dispatch_trial(const lqg_problem* p, const void* ops, lqg_traj x, lqg
 template <typename R>
 hipError_t dispatch_simulate(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view K, lqg_traj eps, lqg_traj eta,
                              lqg_view x0, lqg_view xhat0, lqg_traj xs, lqg_traj xhat, lqg_traj ys, lqg_traj us,
-                             hipStream_t st, bool* found) {
+                             hipStream_t st, bool* found, unsigned long long seed = 0) {
   *found = true;
   const lqg_dims& d = p->dims;
 #define X(X_, B_, U_, Y_)                                     \
   if (d.x == X_ && d.b == B_ && d.u == U_ && d.y == Y_)      \
-    return launch_simulate<R, X_, B_, U_, Y_>(p, L, l, K, eps, eta, x0, xhat0, xs, xhat, ys, us, st);
+    return launch_simulate<R, X_, B_, U_, Y_>(p, L, l, K, eps, eta, x0, xhat0, xs, xhat, ys, us, st, seed);
   LQG_SIM_DIMS(X)
 #undef X
   *found = false;
@@ -596,9 +596,25 @@ int lqg_sum_trials(int32_t dtype, const void* ll, int64_t n_sys, int64_t n_trial
   return done(hipGetLastError(), who);
 }
 
+static int simulate_impl(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view K, lqg_traj eps, lqg_traj eta, lqg_view x0,
+                         lqg_view xhat0, lqg_traj xs, lqg_traj xhat, lqg_traj ys, lqg_traj us, void* stream, bool rng,
+                         unsigned long long seed, const char* who);
+
 int lqg_simulate(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view K, lqg_traj eps, lqg_traj eta, lqg_view x0,
                  lqg_view xhat0, lqg_traj xs, lqg_traj xhat, lqg_traj ys, lqg_traj us, void* stream) {
-  static const char* who = "lqg_simulate";
+  return simulate_impl(p, L, l, K, eps, eta, x0, xhat0, xs, xhat, ys, us, stream, false, 0, "lqg_simulate");
+}
+
+int lqg_simulate_rng(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view K, uint64_t seed, lqg_view x0, lqg_view xhat0,
+                     lqg_traj xs, lqg_traj xhat, lqg_traj ys, lqg_traj us, void* stream) {
+  const lqg_traj none{nullptr, 0, 0, 0, 0};
+  return simulate_impl(p, L, l, K, none, none, x0, xhat0, xs, xhat, ys, us, stream, true, (unsigned long long)seed,
+                       "lqg_simulate_rng");
+}
+
+static int simulate_impl(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view K, lqg_traj eps, lqg_traj eta, lqg_view x0,
+                         lqg_view xhat0, lqg_traj xs, lqg_traj xhat, lqg_traj ys, lqg_traj us, void* stream, bool rng,
+                         unsigned long long seed, const char* who) {
   if (int rc = check_problem(p, who)) return rc;
   const lqg_spec& a = p->actor;
   const lqg_spec& d = p->dynamics;
@@ -606,18 +622,19 @@ int lqg_simulate(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view K, lqg_t
       need(d.A, who, "dynamics.A") || need(d.B, who, "dynamics.B") || need(d.F, who, "dynamics.F") ||
       need(d.V, who, "dynamics.V") || need(d.W, who, "dynamics.W") || need(L, who, "L") || need(K, who, "K"))
     return LQG_ERR_NULL;
-  if (!eps.ptr || !eta.ptr || !xs.ptr) return fail(LQG_ERR_NULL, "%s: eps/eta/xs must be non-NULL", who);
+  if (!rng && (!eps.ptr || !eta.ptr)) return fail(LQG_ERR_NULL, "%s: eps/eta must be non-NULL", who);
+  if (!xs.ptr) return fail(LQG_ERR_NULL, "%s: xs must be non-NULL", who);
   if (p->n_sys == 0 || p->n_trials == 0) return 0;
   bool found;
   hipError_t e = p->dtype == LQG_F64
                      ? dispatch_simulate<double>(p, L, l, K, eps, eta, x0, xhat0, xs, xhat, ys, us,
-                                                 (hipStream_t)stream, &found)
+                                                 (hipStream_t)stream, &found, seed)
                      : dispatch_simulate<float>(p, L, l, K, eps, eta, x0, xhat0, xs, xhat, ys, us,
-                                                (hipStream_t)stream, &found);
+                                                (hipStream_t)stream, &found, seed);
   if (!found)                   // no (x, b, u, y) instantiation: the run-time-dims kernel (per-thread state in LDS)
     e = p->dtype == LQG_F64
-            ? coop_simulate<double>(p, L, l, K, eps, eta, x0, xhat0, xs, xhat, ys, us, (hipStream_t)stream)
-            : coop_simulate<float>(p, L, l, K, eps, eta, x0, xhat0, xs, xhat, ys, us, (hipStream_t)stream);
+            ? coop_simulate<double>(p, L, l, K, eps, eta, x0, xhat0, xs, xhat, ys, us, (hipStream_t)stream, seed)
+            : coop_simulate<float>(p, L, l, K, eps, eta, x0, xhat0, xs, xhat, ys, us, (hipStream_t)stream, seed);
   return done(e, who);
 }
 

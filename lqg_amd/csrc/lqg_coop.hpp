@@ -845,7 +845,7 @@ __global__ void __launch_bounds__(BLOCK) k_coop_trial_rows(const R* __restrict__
 // thread, the two state vectors and the per-step temporaries in LDS columns [element][thread]; gains and spec matrices
 // are read straight from global memory (every thread of a system reads the same address: broadcast).  For shapes
 // without an instantiated k_simulate<x,b,u,y> (e.g. the delay-12 model, x=26 b=39).
-template <typename R, int BLOCK>
+template <typename R, int BLOCK, bool RNG = false>
 __global__ void __launch_bounds__(BLOCK) k_coop_simulate(const SimArgs<R> a, const int nx, const int nb, const int nu,
                                                          const int ny) {
   extern __shared__ double lqg_coop_smem[];
@@ -873,17 +873,27 @@ __global__ void __launch_bounds__(BLOCK) k_coop_simulate(const SimArgs<R> a, con
       for (int k = 0; k < nb; ++k) v += M(a.L, t, i, k) * AT(xh, k);
       AT(uu, i) = v;
     }
-    const R* ep = a.eps.p + s * a.eps.sb + n * a.eps.sn + (long)t * a.eps.st;
-    const R* et = a.eta.p + s * a.eta.sb + n * a.eta.sn + (long)t * a.eta.st;
+    const R* ep = RNG ? nullptr : a.eps.p + s * a.eps.sb + n * a.eps.sn + (long)t * a.eps.st;
+    const R* et = RNG ? nullptr : a.eta.p + s * a.eta.sb + n * a.eta.sn + (long)t * a.eta.st;
     for (int i = 0; i < nx; ++i) {                           // x = A x + B u + V eps   system.py:113-117
       R v = R(0);
       for (int k = 0; k < nx; ++k) v += M(a.dA, t, i, k) * AT(x, k);
       for (int k = 0; k < nu; ++k) v += M(a.dB, t, i, k) * AT(uu, k);
       AT(xn, i) = v;
     }
-    for (int k = 0; k < a.nvd; ++k) {
-      const R e = ep[k * a.eps.sd];
-      for (int i = 0; i < nx; ++i) AT(xn, i) += M(a.dV, t, i, k) * e;
+    if constexpr (RNG) {                                     // the same draws as k_simulate<RNG> (lqg_rng.hpp)
+      for (int k0 = 0; k0 < a.nvd; k0 += 4) {
+        float z[4];
+        rng::normal4(a.seed, (unsigned long long)gid, (uint32_t)t, (uint32_t)(k0 >> 2), z);
+        LQG_UNROLL for (int j = 0; j < 4; ++j)
+          if (k0 + j < a.nvd)
+            for (int i = 0; i < nx; ++i) AT(xn, i) += M(a.dV, t, i, k0 + j) * (R)z[j];
+      }
+    } else {
+      for (int k = 0; k < a.nvd; ++k) {
+        const R e = ep[k * a.eps.sd];
+        for (int i = 0; i < nx; ++i) AT(xn, i) += M(a.dV, t, i, k) * e;
+      }
     }
     for (int i = 0; i < nx; ++i) AT(x, i) = AT(xn, i);
     for (int i = 0; i < ny; ++i) {                           // y = F x + W eta          system.py:120
@@ -891,9 +901,19 @@ __global__ void __launch_bounds__(BLOCK) k_coop_simulate(const SimArgs<R> a, con
       for (int k = 0; k < nx; ++k) v += M(a.dF, t, i, k) * AT(x, k);
       AT(yy, i) = v;
     }
-    for (int k = 0; k < a.nwd; ++k) {
-      const R e = et[k * a.eta.sd];
-      for (int i = 0; i < ny; ++i) AT(yy, i) += M(a.dW, t, i, k) * e;
+    if constexpr (RNG) {
+      for (int k0 = 0; k0 < a.nwd; k0 += 4) {
+        float z[4];
+        rng::normal4(a.seed, (unsigned long long)gid, (uint32_t)t, rng::kEtaBlock + (uint32_t)(k0 >> 2), z);
+        LQG_UNROLL for (int j = 0; j < 4; ++j)
+          if (k0 + j < a.nwd)
+            for (int i = 0; i < ny; ++i) AT(yy, i) += M(a.dW, t, i, k0 + j) * (R)z[j];
+      }
+    } else {
+      for (int k = 0; k < a.nwd; ++k) {
+        const R e = et[k * a.eta.sd];
+        for (int i = 0; i < ny; ++i) AT(yy, i) += M(a.dW, t, i, k) * e;
+      }
     }
     for (int i = 0; i < nb; ++i) {                           // x_pred = A xhat + B u     system.py:123
       R v = R(0);

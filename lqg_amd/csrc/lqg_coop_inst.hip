@@ -238,18 +238,20 @@ hipError_t coop_trial(const lqg_problem* p, const void* ops, lqg_traj x, lqg_tra
 
 template <typename R>
 hipError_t coop_simulate(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view K, lqg_traj eps, lqg_traj eta, lqg_view x0,
-                         lqg_view xhat0, lqg_traj xs, lqg_traj xhat, lqg_traj ys, lqg_traj us, hipStream_t st) {
+                         lqg_view xhat0, lqg_traj xs, lqg_traj xhat, lqg_traj ys, lqg_traj us, hipStream_t st,
+                         unsigned long long seed) {
   const lqg_spec& a = p->actor;
   const lqg_spec& d = p->dynamics;
   lqg::SimArgs<R> k{dv<R>(a.A), dv<R>(a.B), dv<R>(a.F), dv<R>(d.A), dv<R>(d.B), dv<R>(d.F), dv<R>(d.V), dv<R>(d.W),
                     dv<R>(L), dv<R>(l), dv<R>(K), dt<R>(eps), dt<R>(eta), dv<R>(x0), dv<R>(xhat0),
                     dt<R>(xs), dt<R>(xhat), dt<R>(ys), dt<R>(us), (long)p->n_sys, (long)p->n_trials, p->T,
-                    p->dims.nvd, p->dims.nwd};
+                    p->dims.nvd, p->dims.nwd, seed};
   constexpr int B = 64;
   const lqg_dims& dm = p->dims;
   const size_t lds = (size_t)B * (size_t)(2 * dm.x + 2 * dm.b + dm.u + dm.y) * sizeof(R);
   if (lds > kLdsLimit) return hipErrorInvalidValue;
-  auto kern = coop::k_coop_simulate<R, B>;
+  const bool rng = !eps.ptr && !eta.ptr;                     // draws made in-kernel from `seed` (lqg_simulate_rng)
+  auto kern = rng ? coop::k_coop_simulate<R, B, true> : coop::k_coop_simulate<R, B, false>;
   hipError_t e = raise_lds(kern, lds);
   if (e != hipSuccess) return e;
   const long lanes = (long)p->n_sys * (long)p->n_trials;
@@ -258,9 +260,9 @@ hipError_t coop_simulate(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view 
 }
 
 template hipError_t coop_simulate<float>(const lqg_problem*, lqg_view, lqg_view, lqg_view, lqg_traj, lqg_traj, lqg_view,
-                                         lqg_view, lqg_traj, lqg_traj, lqg_traj, lqg_traj, hipStream_t);
+                                         lqg_view, lqg_traj, lqg_traj, lqg_traj, lqg_traj, hipStream_t, unsigned long long);
 template hipError_t coop_simulate<double>(const lqg_problem*, lqg_view, lqg_view, lqg_view, lqg_traj, lqg_traj, lqg_view,
-                                          lqg_view, lqg_traj, lqg_traj, lqg_traj, lqg_traj, hipStream_t);
+                                          lqg_view, lqg_traj, lqg_traj, lqg_traj, lqg_traj, hipStream_t, unsigned long long);
 template hipError_t coop_riccati<float>(const lqg_problem*, lqg_view, lqg_view, lqg_view, void*, void*, hipStream_t);
 template hipError_t coop_riccati<double>(const lqg_problem*, lqg_view, lqg_view, lqg_view, void*, void*, hipStream_t);
 template hipError_t coop_forward<float>(const lqg_problem*, const void*, void*, lqg_view, lqg_view, void*, hipStream_t);

@@ -9,7 +9,7 @@
 namespace lqg {
 namespace host {
 
-// dims the cooperative kernels serve: u, y, d <= 6 (their small factorizations run in registers); x, b unbounded
+// dims the cooperative kernels serve: u, y, d <= 4 (coop::kMaxSmall: their small factorizations run in registers); x, b unbounded
 bool coop_supported(const lqg_dims& d);
 // bytes of the global working set the cooperative path needs BEHIND the gain scratch + operator stream of carve():
 // 0 when the per-system working set fits LDS
@@ -29,7 +29,8 @@ hipError_t coop_trial(const lqg_problem* p, const void* ops, lqg_traj x, lqg_tra
 // run-time-dims twin of launch_simulate (any x, b, u, y whose per-thread state fits LDS)
 template <typename R>
 hipError_t coop_simulate(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view K, lqg_traj eps, lqg_traj eta, lqg_view x0,
-                         lqg_view xhat0, lqg_traj xs, lqg_traj xhat, lqg_traj ys, lqg_traj us, hipStream_t st);
+                         lqg_view xhat0, lqg_traj xs, lqg_traj xhat, lqg_traj ys, lqg_traj us, hipStream_t st,
+                         unsigned long long seed = 0);
 
 // ---- time-parallel system sweeps (lqg_scan.hpp / lqg_scan_inst.hip)
 // dims and problem class the scan path serves (u, y, d <= 4, x + b <= 24, no affine cost terms); the caller additionally

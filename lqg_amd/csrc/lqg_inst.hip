@@ -82,12 +82,12 @@ template hipError_t launch_trial<double, LQG_INST_TRIAL>(const lqg_problem*, con
 #ifdef LQG_INST_F32
 template hipError_t launch_simulate<float, LQG_INST_SIM>(const lqg_problem*, lqg_view, lqg_view, lqg_view, lqg_traj,
                                                          lqg_traj, lqg_view, lqg_view, lqg_traj, lqg_traj, lqg_traj,
-                                                         lqg_traj, hipStream_t);
+                                                         lqg_traj, hipStream_t, unsigned long long);
 #endif
 #ifdef LQG_INST_F64
 template hipError_t launch_simulate<double, LQG_INST_SIM>(const lqg_problem*, lqg_view, lqg_view, lqg_view, lqg_traj,
                                                           lqg_traj, lqg_view, lqg_view, lqg_traj, lqg_traj, lqg_traj,
-                                                          lqg_traj, hipStream_t);
+                                                          lqg_traj, hipStream_t, unsigned long long);
 #endif
 #endif
 }  // namespace host

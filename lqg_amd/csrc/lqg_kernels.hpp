@@ -24,6 +24,7 @@
 // which is algebraically identical to system.py:219-230, needs ~3x fewer flops and shares one Cholesky of
 // Soo between the conditioning step and the log-density of the same innovation.
 #pragma once
+#include "lqg_rng.hpp"
 #include "lqg_small.hpp"
 
 #ifndef LQG_BLOCK
@@ -664,15 +665,18 @@ struct SimArgs {
   DView<R> aA, aB, aF;           // actor model used for the belief update
   DView<R> dA, dB, dF, dV, dW;   // true dynamics
   DView<R> L, l, K;              // gains (l may be null)
-  DTraj<R> eps, eta;             // standard-normal draws
+  DTraj<R> eps, eta;             // standard-normal draws; both null = drawn in-kernel (lqg_rng.hpp) from `seed`
   DView<R> x0, xh0;              // initial state / belief (may be null = 0)
   DTraj<R> xs, xh, ys, us;       // outputs (xh, ys, us may be null)
   long n_sys, n_trials;
   int T, nvd, nwd;
+  unsigned long long seed;       // RNG variants only
 };
 
 // one (system, trial) per lane; trials are the fast index so x-loads of a shared system broadcast.
-template <typename R, int NX, int NB, int NU, int NY>
+// RNG: the draws of system.py:100-105 are made in-kernel (counter-based Philox, lqg_rng.hpp) instead of being read from
+// eps / eta — nothing but the trajectories crosses HBM.
+template <typename R, int NX, int NB, int NU, int NY, bool RNG = false>
 __global__ void __launch_bounds__(LQG_BLOCK) k_simulate(const SimArgs<R> a) {
   const long gid = blockIdx.x * (long)LQG_BLOCK + threadIdx.x;
   if (gid >= a.n_sys * a.n_trials) return;
@@ -698,8 +702,8 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_simulate(const SimArgs<R> a) {
     R A[NX * NX], Bm[NX * NU], xn[NX];
     load_mat<R, NX, NX>(a.dA.p + s * a.dA.sb + t * a.dA.st, a.dA.sr, a.dA.sc, A);
     load_mat<R, NX, NU>(a.dB.p + s * a.dB.sb + t * a.dB.st, a.dB.sr, a.dB.sc, Bm);
-    const R* ep = a.eps.p + s * a.eps.sb + n * a.eps.sn + (long)t * a.eps.st;
-    const R* et = a.eta.p + s * a.eta.sb + n * a.eta.sn + (long)t * a.eta.st;
+    const R* ep = RNG ? nullptr : a.eps.p + s * a.eps.sb + n * a.eps.sn + (long)t * a.eps.st;
+    const R* et = RNG ? nullptr : a.eta.p + s * a.eta.sb + n * a.eta.sn + (long)t * a.eta.st;
     LQG_UNROLL for (int i = 0; i < NX; ++i) {               // x = A x + B u + V eps   system.py:113-117
       R v = R(0);
       LQG_UNROLL for (int k = 0; k < NX; ++k) v += A[i * NX + k] * x[k];
@@ -708,9 +712,20 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_simulate(const SimArgs<R> a) {
     }
     {
       const R* Vp = a.dV.p + s * a.dV.sb + t * a.dV.st;
-      for (int k = 0; k < a.nvd; ++k) {
-        R e = ep[k * a.eps.sd];
-        LQG_UNROLL for (int i = 0; i < NX; ++i) xn[i] += Vp[i * a.dV.sr + k * a.dV.sc] * e;
+      if constexpr (RNG) {
+        for (int k0 = 0; k0 < a.nvd; k0 += 4) {
+          float z[4];
+          rng::normal4(a.seed, (unsigned long long)gid, (uint32_t)t, (uint32_t)(k0 >> 2), z);
+          LQG_UNROLL for (int j = 0; j < 4; ++j)
+            if (k0 + j < a.nvd) {
+              LQG_UNROLL for (int i = 0; i < NX; ++i) xn[i] += Vp[i * a.dV.sr + (k0 + j) * a.dV.sc] * (R)z[j];
+            }
+        }
+      } else {
+        for (int k = 0; k < a.nvd; ++k) {
+          R e = ep[k * a.eps.sd];
+          LQG_UNROLL for (int i = 0; i < NX; ++i) xn[i] += Vp[i * a.dV.sr + k * a.dV.sc] * e;
+        }
       }
     }
     LQG_UNROLL for (int i = 0; i < NX; ++i) x[i] = xn[i];
@@ -723,9 +738,20 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_simulate(const SimArgs<R> a) {
     }
     {
       const R* Wp = a.dW.p + s * a.dW.sb + t * a.dW.st;
-      for (int k = 0; k < a.nwd; ++k) {
-        R e = et[k * a.eta.sd];
-        LQG_UNROLL for (int i = 0; i < NY; ++i) y[i] += Wp[i * a.dW.sr + k * a.dW.sc] * e;
+      if constexpr (RNG) {
+        for (int k0 = 0; k0 < a.nwd; k0 += 4) {
+          float z[4];
+          rng::normal4(a.seed, (unsigned long long)gid, (uint32_t)t, rng::kEtaBlock + (uint32_t)(k0 >> 2), z);
+          LQG_UNROLL for (int j = 0; j < 4; ++j)
+            if (k0 + j < a.nwd) {
+              LQG_UNROLL for (int i = 0; i < NY; ++i) y[i] += Wp[i * a.dW.sr + (k0 + j) * a.dW.sc] * (R)z[j];
+            }
+        }
+      } else {
+        for (int k = 0; k < a.nwd; ++k) {
+          R e = et[k * a.eta.sd];
+          LQG_UNROLL for (int i = 0; i < NY; ++i) y[i] += Wp[i * a.dW.sr + k * a.dW.sc] * e;
+        }
       }
     }
     R Aa[NB * NB], Ba[NB * NU], Fa[NY * NB], xp[NB], inn[NY];

@@ -191,18 +191,20 @@ hipError_t launch_trial(const lqg_problem* p, const void* ops, lqg_traj x, lqg_t
   return hipGetLastError();
 }
 
+// eps.ptr == eta.ptr == NULL: the draws are made in-kernel from `seed` (lqg_simulate_rng)
 template <typename R, int NX, int NB, int NU, int NY>
 hipError_t launch_simulate(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view K, lqg_traj eps, lqg_traj eta,
                            lqg_view x0, lqg_view xhat0, lqg_traj xs, lqg_traj xhat, lqg_traj ys, lqg_traj us,
-                           hipStream_t st) {
+                           hipStream_t st, unsigned long long seed = 0) {
   const lqg_spec& a = p->actor;
   const lqg_spec& d = p->dynamics;
   lqg::SimArgs<R> k{dv<R>(a.A), dv<R>(a.B), dv<R>(a.F), dv<R>(d.A), dv<R>(d.B), dv<R>(d.F), dv<R>(d.V), dv<R>(d.W),
                     dv<R>(L), dv<R>(l), dv<R>(K), dt<R>(eps), dt<R>(eta), dv<R>(x0), dv<R>(xhat0),
                     dt<R>(xs), dt<R>(xhat), dt<R>(ys), dt<R>(us), (long)p->n_sys, (long)p->n_trials, p->T,
-                    p->dims.nvd, p->dims.nwd};
+                    p->dims.nvd, p->dims.nwd, seed};
   const dim3 grid(blocks_for(p->n_sys * p->n_trials)), block(LQG_BLOCK);
-  hipLaunchKernelGGL((lqg::k_simulate<R, NX, NB, NU, NY>), grid, block, 0, st, k);
+  if (!eps.ptr && !eta.ptr) hipLaunchKernelGGL((lqg::k_simulate<R, NX, NB, NU, NY, true>), grid, block, 0, st, k);
+  else hipLaunchKernelGGL((lqg::k_simulate<R, NX, NB, NU, NY, false>), grid, block, 0, st, k);
   return hipGetLastError();
 }
 

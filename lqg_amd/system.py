@@ -161,11 +161,17 @@ class System:
         """Simulate n trials.
 
         rng_key: int seed or torch.Generator (the reference takes a jax PRNGKey; the stream of normal draws
-        necessarily differs, the recursion does not).  Returns x[n, T+1, xdim]; with return_all also
-        x_hat[n, T+1, bdim], y[n, T, ydim], u[n, T, udim]."""
+        necessarily differs, the recursion does not).  An int seed (or None = 0) draws IN THE KERNEL (counter-based
+        Philox keyed by the seed, csrc/lqg_rng.hpp: trial k of system s gets the same draws whatever the batch around it,
+        and no [n, T, x + y] noise arrays pass through HBM); a torch.Generator supplies the draws from torch's stream.
+        Returns x[n, T+1, xdim]; with return_all also x_hat[n, T+1, bdim], y[n, T, ydim], u[n, T, udim]."""
         gains = lqr.backward(self.actor)
         K = kf.forward(self.actor, Sigma0=Sigma0)
         dev, dt = self.actor.A.device, self.actor.A.dtype
+        if not isinstance(rng_key, torch.Generator):
+            x, x_hat, y, u = _hip.simulate(self.actor, self.dynamics, gains.L, gains.l, K, x0=x0, xhat0=xhat0,
+                                           return_all=return_all, seed=0 if rng_key is None else int(rng_key), n=n)
+            return (x, x_hat, y, u) if return_all else x
         gen = _generator(rng_key, dev)
         lead = () if self.n_systems is None else (self.n_systems,)
         eps = torch.randn(lead + (n, self.T, self.xdim), dtype=dt, device=dev, generator=gen)

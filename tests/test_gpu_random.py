@@ -189,3 +189,77 @@ def test_zoo_models_over_wide_parameter_ranges(oracle_lib, ctor, dim, names):
                              else getattr(spec, f).expand(C_, *getattr(spec, f).shape)).double().cpu().numpy().copy() for f in F}
     ref = oracle_lib.log_likelihood(host(m.actor), host(m.dynamics), x.cpu().numpy())
     assert np.abs(ll / ref - 1).max() < 1e-9
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# in-kernel draws of System.simulate (lqg_simulate_rng: counter-based Philox4x32-10 + Box-Muller, csrc/lqg_rng.hpp)
+def _identity_noise_system(xdim, T, dtype, n_sys=None, ydim=None):
+    """A = 0, B = 0, V = I, F = [I 0], W = I: x_{t+1} = eps_t and y_t = x_{t+1}[:y] + eta_t — simulate() hands back its draws."""
+    from lqg_amd.system import Actor, System
+    dev = torch.device("cuda")
+    ydim = xdim if ydim is None else ydim
+    lead = () if n_sys is None else (n_sys,)
+    z = torch.zeros(lead + (xdim, xdim), dtype=dtype, device=dev)
+    e = torch.eye(xdim, dtype=dtype, device=dev).expand(lead + (xdim, xdim)).contiguous()
+    F = torch.eye(ydim, xdim, dtype=dtype, device=dev).expand(lead + (ydim, xdim)).contiguous()
+    W = torch.eye(ydim, dtype=dtype, device=dev).expand(lead + (ydim, ydim)).contiguous()
+    B = torch.zeros(lead + (xdim, 1), dtype=dtype, device=dev)
+    spec = Actor(A=z, B=B, F=F, V=e, W=W, Q=e, R=torch.ones(lead + (1, 1), dtype=dtype, device=dev), T=T)
+    return System(actor=spec, dynamics=spec)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+def test_in_kernel_normal_draws_are_standard_normal(dtype):
+    """Distributional checks of the draws (reference: jax.random.normal at lqg/system.py:102-105): moments, a
+    Kolmogorov-Smirnov test, independence across steps / trials / components / eps-eta, seed sensitivity."""
+    from scipy import stats
+    T, n = 64, 4096
+    m = _identity_noise_system(2, T, dtype)
+    x, xh, y, u = m.simulate(1234, n=n, return_all=True)
+    eps = x[:, 1:].double().cpu().numpy()                    # [n, T, 2]
+    eta = (y - x[:, 1:]).double().cpu().numpy()
+    for z in (eps, eta):
+        flat = z.reshape(-1)
+        assert abs(flat.mean()) < 5e-3 and abs(flat.var() - 1) < 1e-2
+        assert abs(stats.skew(flat)) < 2e-2 and abs(stats.kurtosis(flat)) < 5e-2
+        assert stats.kstest(flat[:200000], "norm").pvalue > 1e-3
+        assert np.abs(z).max() < 7.0 and np.isfinite(z).all()
+    c = lambda a, b: abs(np.corrcoef(a.reshape(-1), b.reshape(-1))[0, 1])
+    assert c(eps[:, :-1], eps[:, 1:]) < 6e-3                 # consecutive steps
+    assert c(eps[:-1], eps[1:]) < 6e-3                       # neighbouring trials
+    assert c(eps[..., 0], eps[..., 1]) < 6e-3                # components of one block
+    assert c(eps, eta) < 6e-3                                # process vs observation noise
+    x2 = m.simulate(1235, n=n)
+    assert c(x[:, 1:].double().cpu().numpy(), x2[:, 1:].double().cpu().numpy()) < 6e-3   # another seed: another stream
+    assert torch.equal(m.simulate(1234, n=n), x)             # same seed: same trajectories
+
+
+def test_in_kernel_draws_do_not_depend_on_batch_kernel_or_dtype():
+    """A trajectory is a pure function of (seed, pair index): the first trials of a larger batch, the lane kernels and the
+    run-time-dims cooperative kernel, fp32 and fp64 all see the same normals."""
+    m = _identity_noise_system(2, 40, torch.float64)
+    a = m.simulate(7, n=300)
+    b = m.simulate(7, n=64)
+    assert torch.equal(a[:64], b)
+    m32 = _identity_noise_system(2, 40, torch.float32)
+    assert torch.equal(m32.simulate(7, n=64).double(), b)     # (draws are made in fp32 and widened)
+    # a shape with no lane kernel (x = b = 5, y = 4): k_coop_simulate<RNG>; its first two components' stream equals the x = 2 one
+    from lqg_amd import _abi
+    assert not _abi.load().lqg_kernel_supported(_abi.FAM_SIMULATE, _abi._dims_struct(dict(x=5, b=5, u=1, y=4, d=5)))
+    m5 = _identity_noise_system(5, 40, torch.float64, ydim=4)
+    c = m5.simulate(7, n=64)
+    assert c.shape == (64, 41, 5) and torch.equal(c[..., :2], b)
+    # many systems: pair = system * n_trials + trial
+    ms = _identity_noise_system(2, 40, torch.float64, n_sys=5)
+    d = ms.simulate(7, n=60)                                  # [5, 60, 41, 2] = pairs 0 .. 299
+    assert torch.equal(d.reshape(300, 41, 2), a)
+
+
+def test_bounded_equals_subjective_under_a_shared_seed():
+    """lqg/tests/lqg_test.py:69-93 with the in-kernel draws: both models have x = y = 2, hence the same counters."""
+    import lqg_amd
+    kw = dict(process_noise=1.0, sigma_target=6.0, action_cost=0.1, action_variability=0.5, sigma_cursor=3.0, T=500,
+              device="cuda", dtype=torch.float64)
+    x_b = lqg_amd.BoundedActor(**kw).simulate(rng_key=0, n=20)
+    x_s = lqg_amd.SubjectiveActor(subj_noise=1.0, subj_vel_noise=0.0, **kw).simulate(rng_key=0, n=20)
+    assert torch.allclose(x_b, x_s, rtol=1e-9, atol=1e-9)
