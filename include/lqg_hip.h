@@ -224,6 +224,14 @@ int lqg_point_mass_setup(int64_t n, const double* damping, const double* mass, c
                          const double* action_variability, double dt, double psd_eps, double* A, double* B, double* V,
                          void* stream);
 
+/* Device-side check of the value-dependent preconditions of the exact shortcuts (block decoupling, lqg_amd/decouple.py;
+ * the time-parallel entries above): the eigenvalue floor of lqr.py:27-28 can never be active (Gershgorin lower bound of
+ * sym(R) >= p->eps and of sym(Q), sym(Qf) >= 0 for every system and step) and, with check_cond != 0, the Gershgorin
+ * condition bound of (V V')[:d, :d] of the dynamics is <= max_cond.  ok[0] (device memory) = 1 when all hold, else 0.
+ * Conservative (Gershgorin), elementwise, stream-ordered, no synchronisation: usable inside a captured hipGraph whose
+ * frozen decisions rest on these preconditions (lqg_amd/infer/graphed.py poisons its result with NaN when ok == 0). */
+int lqg_precondition_flags(const lqg_problem* p, double max_cond, int32_t check_cond, int32_t* ok, void* stream);
+
 /* Replaces the per-trial scan of System.simulate [lqg/system.py:106-128] with the standard-normal
  * draws supplied by the caller (the reference draws them from jax.random, :102-105).
  * gains L[B,T,u,b], l[B,T,u] (l.ptr NULL = 0), K[B,T,b,y] as produced by the two calls above;

@@ -98,6 +98,9 @@ def _bind(path):
         lib.lqg_log_likelihood_scan_with.restype = C.c_int
         lib.lqg_conditional_moments_scan.argtypes = [C.POINTER(Problem), Traj, Traj, View, C.c_void_p, C.c_size_t, C.c_void_p]
         lib.lqg_conditional_moments_scan.restype = C.c_int
+    if hasattr(lib, "lqg_precondition_flags"):
+        lib.lqg_precondition_flags.argtypes = [C.POINTER(Problem), C.c_double, C.c_int32, C.c_void_p, C.c_void_p]
+        lib.lqg_precondition_flags.restype = C.c_int
     if hasattr(lib, "lqg_point_mass_setup"):
         lib.lqg_point_mass_setup.argtypes = [C.c_int64] + [C.c_void_p] * 4 + [C.c_double, C.c_double] + [C.c_void_p] * 4
         lib.lqg_point_mass_setup.restype = C.c_int

@@ -174,3 +174,102 @@ extern "C" int lqg_point_mass_setup(int64_t n, const double* damping, const doub
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// lqg_precondition_flags (include/lqg_hip.h): the value-dependent preconditions a FROZEN evaluation path rests on, checked
+// on the device so that a captured hipGraph (lqg_amd/infer/graphed.py) can poison its result instead of being silently
+// wrong.  Gershgorin bounds only (elementwise; conservative): every eigenvalue of a symmetric M lies in
+// [min_i (M_ii - sum_{j != i} |M_ij|), max_i (M_ii + sum_{j != i} |M_ij|)].
+namespace {
+
+template <typename R>
+struct GuardArgs {
+  const R *Rm, *Q, *Qf, *V;
+  long R_sb, R_st, R_sr, R_sc, Q_sb, Q_st, Q_sr, Q_sc, Qf_sb, Qf_sr, Qf_sc, V_sb, V_st, V_sr, V_sc;
+  long n_sys;
+  int T, b, u, d, nv;
+  double eps, max_cond;
+  int check_cond;
+  int32_t* ok;
+};
+
+template <typename R>
+__device__ void gersh(const R* p, long sr, long sc, int n, double& lo, double& hi) {
+  lo = 1e300;
+  hi = -1e300;
+  for (int i = 0; i < n; ++i) {
+    double diag = (double)p[i * sr + i * sc], off = 0.0;
+    for (int j = 0; j < n; ++j)
+      if (j != i) off += fabs(0.5 * ((double)p[i * sr + j * sc] + (double)p[j * sr + i * sc]));
+    lo = fmin(lo, diag - off);
+    hi = fmax(hi, diag + off);
+  }
+}
+
+template <typename R>
+__global__ void __launch_bounds__(256) k_precondition_flags(const GuardArgs<R> a) {
+  __shared__ int bad;
+  if (threadIdx.x == 0) bad = 0;
+  __syncthreads();
+  int mine = 0;
+  for (long s = threadIdx.x; s < a.n_sys; s += blockDim.x) {
+    double lo, hi;
+    gersh(a.Qf + s * a.Qf_sb, a.Qf_sr, a.Qf_sc, a.b, lo, hi);
+    if (!(lo >= -1e-12)) mine = 1;
+    const int tr = a.R_st ? a.T : 1, tq = a.Q_st ? a.T : 1, tv = a.V_st ? a.T : 1;
+    for (int t = 0; t < tr; ++t) {
+      gersh(a.Rm + s * a.R_sb + t * a.R_st, a.R_sr, a.R_sc, a.u, lo, hi);
+      if (!(lo >= a.eps)) mine = 1;
+    }
+    for (int t = 0; t < tq; ++t) {
+      gersh(a.Q + s * a.Q_sb + t * a.Q_st, a.Q_sr, a.Q_sc, a.b, lo, hi);
+      if (!(lo >= -1e-12)) mine = 1;
+    }
+    if (a.check_cond) {
+      for (int t = 0; t < tv; ++t) {                          // Gershgorin bounds of (V V')[:d, :d]
+        const R* V = a.V + s * a.V_sb + t * a.V_st;
+        lo = 1e300;
+        hi = -1e300;
+        for (int i = 0; i < a.d; ++i) {
+          double diag = 0.0, off = 0.0;
+          for (int j = 0; j < a.d; ++j) {
+            double g = 0.0;
+            for (int k = 0; k < a.nv; ++k) g += (double)V[i * a.V_sr + k * a.V_sc] * (double)V[j * a.V_sr + k * a.V_sc];
+            if (j == i) diag = g; else off += fabs(g);
+          }
+          lo = fmin(lo, diag - off);
+          hi = fmax(hi, diag + off);
+        }
+        if (!(lo > 0.0 && hi <= a.max_cond * lo)) mine = 1;
+      }
+    }
+  }
+  if (mine) atomicOr(&bad, 1);
+  __syncthreads();
+  if (threadIdx.x == 0) a.ok[0] = bad ? 0 : 1;
+}
+
+}  // namespace
+
+extern "C" int lqg_precondition_flags(const lqg_problem* p, double max_cond, int32_t check_cond, int32_t* ok, void* stream) {
+  if (!p || !ok) return LQG_ERR_NULL;
+  if (p->dtype != LQG_F32 && p->dtype != LQG_F64) return LQG_ERR_ARG;
+  const lqg_spec& a = p->actor;
+  const lqg_view& V = p->dynamics.V;
+  if (!a.R.ptr || !a.Q.ptr || !a.Qf.ptr || (check_cond && !V.ptr)) return LQG_ERR_NULL;
+  if (p->n_sys <= 0) return 0;
+#define LQG_GUARD(R_)                                                                                                      \
+  {                                                                                                                        \
+    GuardArgs<R_> g{static_cast<const R_*>(a.R.ptr), static_cast<const R_*>(a.Q.ptr), static_cast<const R_*>(a.Qf.ptr),   \
+                    static_cast<const R_*>(V.ptr), a.R.sb, p->T > 1 ? a.R.st : 0, a.R.sr, a.R.sc, a.Q.sb,                 \
+                    p->T > 1 ? a.Q.st : 0, a.Q.sr, a.Q.sc, a.Qf.sb, a.Qf.sr, a.Qf.sc, V.sb, p->T > 1 ? V.st : 0, V.sr,    \
+                    V.sc, (long)p->n_sys, p->T, p->dims.b, p->dims.u, p->dims.d, p->dims.nvd, p->eps, max_cond,           \
+                    check_cond, ok};                                                                                       \
+    hipLaunchKernelGGL(k_precondition_flags<R_>, dim3(1), dim3(256), 0, (hipStream_t)stream, g);                           \
+  }
+  if (p->dtype == LQG_F64) LQG_GUARD(double) else LQG_GUARD(float)
+#undef LQG_GUARD
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}

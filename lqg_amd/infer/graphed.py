@@ -178,9 +178,18 @@ class GraphedLogLik:
     def _guards(self, model):
         """Device-side restatement of the host checks the frozen decisions rest on (decouple.floor_provably_inactive:
         lambda_min(R) >= eps, Q, Qf >= 0; plan._observed_noise_cond <= SCAN_MAX_COND for the scans) with Gershgorin
-        bounds — elementwise ops only, no synchronisation, capturable.  -> 0-dim bool tensor (True: all hold)."""
+        bounds — no synchronisation, capturable.  -> 0-dim bool tensor (True: all hold).  One kernel of the library
+        (lqg_precondition_flags); the torch restatement below serves libraries without that entry."""
         from lqg_amd import plan
         a = model.actor
+        lib = _abi.load()
+        if hasattr(lib, "lqg_precondition_flags"):
+            ln = _hip.Launch(model.actor, model.dynamics, d=self.d, n_trials=1, eps=self.eps)
+            flag = torch.empty(1, dtype=torch.int32, device=self.x.device)
+            _abi.check(lib.lqg_precondition_flags(C.byref(ln.p), float(plan.SCAN_MAX_COND), 1 if self.use_scan else 0,
+                                                  C.c_void_p(flag.data_ptr()), ln.stream()), "lqg_precondition_flags")
+            self._guard_keep = (ln, flag)
+            return flag[0] != 0
 
         def bounds(M):                               # [C, k, k] -> Gershgorin (lower, upper) per candidate
             M = 0.5 * (M + M.transpose(-1, -2))
