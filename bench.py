@@ -578,8 +578,11 @@ def extra_legs(torch, args, dev):
             lld, phd = bc.timed_loglik(md, xd, 5)
             legd[f"trials_{nt}"] = {"wall_ms": phd["wall_ms"], "riccati_ms": phd["riccati_ms"], "forward_ms": phd["forward_ms"],
                                     "trial_ms": phd["trial_ms"], "path": phd["path"]}
+        t0 = time.perf_counter()
         legd["max_rel_err_vs_fp64_oracle"] = bc.oracle_check(md, xd_all[:2].contiguous(),
                                                              md.log_likelihood(xd_all[:2].contiguous()), n_samples=2)
+        # (the same evaluation by the literal dense C port on ONE host core, two trials — context, not a target)
+        legd["cpu_port_ms_two_trials_incl_check"] = (time.perf_counter() - t0) * 1e3
         extra["delay12"] = legd
     except Exception as e:
         extra["delay12"] = {"error": repr(e)}

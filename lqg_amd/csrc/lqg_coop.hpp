@@ -40,6 +40,9 @@ struct Args {
   long n_sys;
   int T, x, b, u, y, d, nva, nwa, nvd, nwd, nops;
   int ti;           // 1: every spec field time-invariant
+  int sparse;       // 1: run-time sparsity lists (RowLists) for the large products, at the START of the dynamic LDS
+  long lists_bytes; // bytes of those lists (0 when !sparse): the LDS part of the arena starts behind them
+  long lds_reals;   // GLOBAL (hybrid) variant: reals of LDS the arena may use before it continues in `arena` (L2-resident)
   R eps;
 };
 
@@ -47,19 +50,26 @@ struct Args {
 // (row, col) of this lane's first element of an r x c result; later elements (r*c > STRIDE) by division.
 template <int STRIDE>
 struct Shape {
-  int rows, cols, n, ln, i0, j0;
+  int rows, cols, n, ln, i0, j0, qs, rs;
   LQG_DEV Shape(int lane, int r, int c) : rows(r), cols(c), n(r * c), ln(lane) {
-    i0 = lane / (c > 0 ? c : 1);
+    const int cc = c > 0 ? c : 1;
+    i0 = lane / cc;
     j0 = lane - i0 * c;
+    qs = STRIDE / cc;                      // (row, col) advance of one stride: the division is paid once per Shape, not
+    rs = STRIDE - qs * cc;                 // once per element (a run-time integer division is ~35 instructions)
   }
   template <typename F>
   LQG_DEV void each(F f) const {
     if (ln < n) f(i0, j0);
-    if (n > STRIDE)
+    if (n > STRIDE) {
+      int i = i0, j = j0;
       for (int e = ln + STRIDE; e < n; e += STRIDE) {
-        const int i = e / cols;
-        f(i, e - i * cols);
+        i += qs;
+        j += rs;
+        if (j >= cols) { j -= cols; ++i; }
+        f(i, j);
       }
+    }
   }
 };
 
@@ -85,6 +95,57 @@ LQG_DEV R dot4(const R* __restrict__ a, int sa, const R* __restrict__ b, int sb,
     acc += a0 * b0;
     acc += (r > 1) ? a1 * b1 : R(0);
     acc += (r > 2) ? a2 * b2 : R(0);
+  }
+  return acc;
+}
+
+// ---- run-time sparsity of the LEFT operand of the large products ---------------------------------------------------------
+// The reference's largest models are delay augmentations (lqg/tracking/delay.py:9-33): A = blockdiag(A0, 0) + a shifted
+// identity, so A, and with it the joint dynamics Fj, hold one or two non-zeros per row — at m = 65 the dense b^3 / m^3
+// products of a step are 95 % multiplications by an exact zero (37 ms per forward sweep of T = 500, measured).  Per row
+// of such an operand the columns of its non-zeros are listed once (per step for matrices that change with the step);
+// a product then walks the list.  Exact: the terms are added in the same (increasing) order as dot4 adds them and a
+// skipped term is an exact zero times a finite number.
+struct RowLists {
+  unsigned char* cnt;      // [rows]
+  unsigned char* idx;      // [rows][cols]
+  int cols;
+};
+inline __host__ __device__ long row_lists_bytes(int rows, int cols) { return ((long)rows * cols + rows + 15) / 16 * 16; }
+LQG_DEV RowLists take_lists(unsigned char*& p, int rows, int cols) {
+  RowLists r{p, p + rows, cols};
+  p += row_lists_bytes(rows, cols);
+  return r;
+}
+// lists of the rows of the rows x cols matrix M(i, k) = M[i * rs + k * cs]
+template <int STRIDE, typename R>
+LQG_DEV void build_lists(int ln, const R* __restrict__ M, int rs, int cs, int rows, int cols, const RowLists& rl) {
+  for (int i = ln; i < rows; i += STRIDE) {
+    int n = 0;
+    unsigned char* ix = rl.idx + i * rl.cols;
+    for (int k = 0; k < cols; ++k)
+      if (M[i * rs + k * cs] != R(0)) ix[n++] = (unsigned char)k;
+    rl.cnt[i] = (unsigned char)n;
+  }
+}
+// acc + sum over the listed k of a[k sa] b[k sb] (a: the listed row), four terms' operands in flight together
+template <typename R>
+LQG_DEV R dot_list(const RowLists& rl, int row, const R* __restrict__ a, int sa, const R* __restrict__ b, int sb, R acc) {
+  const unsigned char* __restrict__ ix = rl.idx + row * rl.cols;
+  const int n = rl.cnt[row];
+  int q = 0;
+  for (; q + 4 <= n; q += 4) {
+    const int k0 = ix[q], k1 = ix[q + 1], k2 = ix[q + 2], k3 = ix[q + 3];
+    const R a0 = a[k0 * sa], a1 = a[k1 * sa], a2 = a[k2 * sa], a3 = a[k3 * sa];
+    const R b0 = b[k0 * sb], b1 = b[k1 * sb], b2 = b[k2 * sb], b3 = b[k3 * sb];
+    acc += a0 * b0;
+    acc += a1 * b1;
+    acc += a2 * b2;
+    acc += a3 * b3;
+  }
+  for (; q < n; ++q) {
+    const int k = ix[q];
+    acc += a[k * sa] * b[k * sb];
   }
   return acc;
 }
@@ -198,15 +259,32 @@ __global__ void __launch_bounds__(BLOCK) k_coop_riccati(const Args<R> a) {
   const int wv = WAVES ? (int)(threadIdx.x >> 6) : 0;
   const int ln = WAVES ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
   auto on = [&](int w) { return !WAVES || wv == (w % NW); };
-  R* ar = GLOBAL ? a.arena + s * a.arena_reals : reinterpret_cast<R*>(lqg_coop_smem);
+  // the working set: in LDS behind the sparsity lists; GLOBAL = HYBRID: the arrays are handed out from LDS in the order of
+  // the take() calls below until a.lds_reals are used, the rest lives in the global arena (L2-resident)
+  R* ar = reinterpret_cast<R*>(reinterpret_cast<unsigned char*>(lqg_coop_smem) + a.lists_bytes);
+  [[maybe_unused]] R* gar = GLOBAL ? a.arena + s * a.arena_reals : nullptr;
+  [[maybe_unused]] long lds_left = GLOBAL ? a.lds_reals : 0;
   const int b = CB ? CB : a.b, u = CU ? CU : a.u;
   const bool affine = a.aq.p || a.aqf.p || a.aP.p || a.ar.p;
-  auto take = [&](long n) { R* p = ar; ar += n; return p; };
+  auto take = [&](long n) {
+    if constexpr (GLOBAL) {
+      if (n > lds_left) { R* p = gar; gar += n; return p; }
+      lds_left -= n;
+    }
+    R* p = ar;
+    ar += n;
+    return p;
+  };
   R *S = take(b * b), *A = take(b * b), *Q = take(b * b), *SA = take(b * b);
   R *Bm = take(b * u), *SB = take(b * u), *P = take(b * u), *G = take(b * u), *Lm = take(b * u), *W1 = take(b * u);
   R *Rm = take(u * u), *H = take(u * u), *His = take(u * u), *Hts = take(u * u);
   R *sv = take(b), *sn = take(b), *q = take(b), *gv = take(u), *lv = take(u), *Hl = take(u), *r = take(u);
   const Shape<STRIDE> bb(ln, b, b), bu(ln, b, u), ub(ln, u, b), uu(ln, u, u);
+  // run-time sparsity (RowLists): the columns of A, i.e. the rows of A' (LDS behind the arena, or alone in LDS when the
+  // arena is global)
+  const bool sp = !WAVES && CB == 0 && a.sparse;
+  unsigned char* slp = reinterpret_cast<unsigned char*>(lqg_coop_smem);
+  const RowLists colA = sp ? take_lists(slp, b, b) : RowLists{nullptr, nullptr, 0};
 
   auto load_step = [&](int t) {
     if (on(0)) ld_mat(bb, a.aA, s, t, A);
@@ -224,13 +302,18 @@ __global__ void __launch_bounds__(BLOCK) k_coop_riccati(const Args<R> a) {
   if (affine && on(1)) ld_vec<STRIDE>(ln, a.aqf, s, 0, b, sv);
   if (a.ti) load_step(0);
   stage_end<BLOCK>();
+  if (sp && a.ti) { build_lists<STRIDE>(ln, A, 1, b, b, b, colA); stage_end<BLOCK>(); }
 
   for (int t = a.T - 1; t >= 0; --t) {                      // reverse=True  lqr.py:40
-    if (!a.ti) { load_step(t); stage_end<BLOCK>(); }
+    if (!a.ti) {
+      load_step(t);
+      stage_end<BLOCK>();
+      if (sp) { build_lists<STRIDE>(ln, A, 1, b, b, b, colA); stage_end<BLOCK>(); }
+    }
     // ---- R1: SA = S A, SB = S B
     if (on(0)) bb.each([&](int i, int j) {
       R acc = R(0);
-      acc = dot4(S + i * b, 1, A + j, b, b, acc);
+      acc = sp ? dot_list(colA, j, A + j, b, S + i * b, 1, acc) : dot4(S + i * b, 1, A + j, b, b, acc);
       SA[i * b + j] = acc;
     });
     if (on(1)) bu.each([&](int i, int j) {
@@ -302,7 +385,7 @@ __global__ void __launch_bounds__(BLOCK) k_coop_riccati(const Args<R> a) {
     if (on(0)) bb.each([&](int i, int j) {
       const int lo = i < j ? i : j, hi = i < j ? j : i;
       R acc = Q[lo * b + hi];
-      acc = dot4(A + lo, b, SA + hi, b, b, acc);
+      acc = sp ? dot_list(colA, lo, A + lo, b, SA + hi, b, acc) : dot4(A + lo, b, SA + hi, b, b, acc);
       acc = dot4(Lm + lo, b, W1 + hi, b, u, acc);
       acc = dot4(G + lo, b, Lm + hi, b, u, acc);
       S[i * b + j] = acc;
@@ -341,10 +424,22 @@ __global__ void __launch_bounds__(BLOCK) k_coop_forward(const Args<R> a) {
   const int wv = WAVES ? (int)(threadIdx.x >> 6) : 0;
   const int ln = WAVES ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
   auto on = [&](int w) { return !WAVES || wv == (w % NW); };
-  R* ar = GLOBAL ? a.arena + s * a.arena_reals : reinterpret_cast<R*>(lqg_coop_smem);
+  // the working set: in LDS behind the sparsity lists; GLOBAL = HYBRID: the arrays are handed out from LDS in the order of
+  // the take() calls below until a.lds_reals are used, the rest lives in the global arena (L2-resident)
+  R* ar = reinterpret_cast<R*>(reinterpret_cast<unsigned char*>(lqg_coop_smem) + a.lists_bytes);
+  [[maybe_unused]] R* gar = GLOBAL ? a.arena + s * a.arena_reals : nullptr;
+  [[maybe_unused]] long lds_left = GLOBAL ? a.lds_reals : 0;
   const int x = CX ? CX : a.x, b = CB ? CB : a.b, u = CU ? CU : a.u, y = CY ? CY : a.y, o = CD ? CD : a.d, m = x + b,
             rr = m - o;
-  auto take = [&](long n) { R* p = ar; ar += n; return p; };
+  auto take = [&](long n) {
+    if constexpr (GLOBAL) {
+      if (n > lds_left) { R* p = gar; gar += n; return p; }
+      lds_left -= n;
+    }
+    R* p = ar;
+    ar += n;
+    return p;
+  };
   // (the arrays of the Kalman recursion come first: a gains-only call, kf.forward, needs kalman_arena_reals only)
   R *Aa = take(b * b), *VVa = take(b * b), *P = take(b * b), *AP = take(b * b), *Pp = take(b * b);
   R *Fa = take(y * b), *FP = take(y * b), *WWa = take(y * y), *Gk = take(y * y), *Gis = take(y * y), *K = take(b * y);
@@ -360,6 +455,11 @@ __global__ void __launch_bounds__(BLOCK) k_coop_forward(const Args<R> a) {
       yu(ln, y, u), by(ln, b, y), bx(ln, b, x), xb(ln, x, b), mm_(ln, m, m), ro(ln, rr, o), rrs(ln, rr, rr), mr(ln, m, rr);
   const bool joint = a.ops || a.Sig.p;                      // false: only the Kalman gains are wanted (kf.forward)
   const R kLogNorm = R(0.5 * 1.8378770664093453) * (R)o;
+  // run-time sparsity (RowLists): the rows of Aa (Kalman products) and of F2 = Fj[:, o:] (moment recursion)
+  const bool sp = !WAVES && CB == 0 && a.sparse;
+  unsigned char* slp = reinterpret_cast<unsigned char*>(lqg_coop_smem);
+  const RowLists rowA = sp ? take_lists(slp, b, b) : RowLists{nullptr, nullptr, 0};
+  const RowLists rowF = sp ? take_lists(slp, m, rr) : RowLists{nullptr, nullptr, 0};
 
   auto load_consts = [&](int t) {                            // stage L1: direct loads and Gram matrices
     if (on(0)) ld_mat(bb, a.aA, s, t, Aa);
@@ -407,7 +507,7 @@ __global__ void __launch_bounds__(BLOCK) k_coop_forward(const Args<R> a) {
   auto kal1 = [&]() {                                        // AP = A P
     if (on(3)) bb.each([&](int i, int j) {
       R acc = R(0);
-      acc = dot4(Aa + i * b, 1, P + j, b, b, acc);
+      acc = sp ? dot_list(rowA, i, Aa + i * b, 1, P + j, b, acc) : dot4(Aa + i * b, 1, P + j, b, b, acc);
       AP[i * b + j] = acc;
     });
   };
@@ -415,7 +515,7 @@ __global__ void __launch_bounds__(BLOCK) k_coop_forward(const Args<R> a) {
     if (on(3)) bb.each([&](int i, int j) {
       const int lo = i < j ? i : j, hi = i < j ? j : i;
       R acc = VVa[lo * b + hi];
-      acc = dot4(AP + lo * b, 1, Aa + hi * b, 1, b, acc);
+      acc = sp ? dot_list(rowA, hi, Aa + hi * b, 1, AP + lo * b, 1, acc) : dot4(AP + lo * b, 1, Aa + hi * b, 1, b, acc);
       Pp[i * b + j] = acc;
     });
   };
@@ -543,7 +643,8 @@ __global__ void __launch_bounds__(BLOCK) k_coop_forward(const Args<R> a) {
       if (a.ops) a.ops[(s * (a.T + 1) + t) * (long)a.nops + m * m + p * o + j] = v;
     });
   };
-  auto cond2 = [&]() {                                       // C = S_rr - U2 U2'
+  auto cond2 = [&]() {                                       // C = S_rr - U2 U2'  (+ the row lists of this step's F2)
+    if (sp) build_lists<STRIDE>(ln, Fj + o, m, 1, m, rr, rowF);
     if (on(0)) rrs.each([&](int p, int q2) {
       const int lo = p < q2 ? p : q2, hi = p < q2 ? q2 : p;
       R acc = Sg[(o + lo) * m + o + hi];
@@ -554,7 +655,7 @@ __global__ void __launch_bounds__(BLOCK) k_coop_forward(const Args<R> a) {
   auto sig1 = [&](int t) {                                   // T1 = Fj[:, o:] C ; emit Fj - I (diagonal assembled as a deviation)
     if (on(0)) mr.each([&](int i, int q2) {
       R acc = R(0);
-      acc = dot4(Fj + i * m + o, 1, C + q2, rr, rr, acc);
+      acc = sp ? dot_list(rowF, i, Fj + i * m + o, 1, C + q2, rr, acc) : dot4(Fj + i * m + o, 1, C + q2, rr, rr, acc);
       T1[i * rr + q2] = acc;
     });
     if (a.ops && on(1)) {
@@ -577,7 +678,7 @@ __global__ void __launch_bounds__(BLOCK) k_coop_forward(const Args<R> a) {
     if (on(0)) mm_.each([&](int i, int j) {
       const int lo = i < j ? i : j, hi = i < j ? j : i;
       R acc = GG[lo * m + hi];
-      acc = dot4(T1 + lo * rr, 1, Fj + hi * m + o, 1, rr, acc);
+      acc = sp ? dot_list(rowF, hi, Fj + hi * m + o, 1, T1 + lo * rr, 1, acc) : dot4(T1 + lo * rr, 1, Fj + hi * m + o, 1, rr, acc);
       Sg[i * m + j] = acc;
       if (a.Sig.p) const_cast<R*>(a.Sig.p)[s * a.Sig.sb + (long)t * a.Sig.st + i * a.Sig.sr + j * a.Sig.sc] = acc;
     });
@@ -604,6 +705,7 @@ __global__ void __launch_bounds__(BLOCK) k_coop_forward(const Args<R> a) {
   }
   load_consts(0);
   stage_end<BLOCK>();
+  if (sp) build_lists<STRIDE>(ln, Aa, b, 1, b, b, rowA);
   hoist1();
   stage_end<BLOCK>();
   hoist2();
@@ -633,6 +735,7 @@ __global__ void __launch_bounds__(BLOCK) k_coop_forward(const Args<R> a) {
         if (!a.ti) {
           load_consts(t + 1);
           stage_end<BLOCK>();
+          if (sp) build_lists<STRIDE>(ln, Aa, b, 1, b, b, rowA);
           hoist1();
           stage_end<BLOCK>();
           hoist2();

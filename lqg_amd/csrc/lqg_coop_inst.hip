@@ -18,6 +18,10 @@ namespace host {
 namespace {
 constexpr size_t kLdsLimit = 160 * 1024 - 512;     // gfx950: 160 KB LDS per CU
 constexpr size_t kLdsDefault = 64 * 1024;          // above this the kernel needs the dynamic-LDS attribute raised
+#ifndef LQG_COOP_BIG_BLOCK
+#define LQG_COOP_BIG_BLOCK 1024
+#endif
+constexpr int kBigBlock = LQG_COOP_BIG_BLOCK;      // lanes per workgroup of the whole-workgroup (large-matrix) mode
 
 inline size_t esz(const lqg_problem* p) { return p->dtype == LQG_F64 ? 8 : 4; }
 inline long ric_reals(const lqg_problem* p) { return coop::riccati_arena_reals(p->dims.b, p->dims.u); }
@@ -136,13 +140,22 @@ hipError_t coop_riccati(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view H
   k.Ls = static_cast<R*>(Ls);
   k.ti = actor_ti_riccati(p) ? 1 : 0;
   const long reals = ric_reals(p);
-  const size_t lds = (size_t)reals * sizeof(R);
+  size_t lds = (size_t)reals * sizeof(R);
   const bool global = lds > kLdsLimit;
   if (global && !arena) return hipErrorInvalidValue;
   k.arena = static_cast<R*>(arena);
   k.arena_reals = reals;
   const dim3 grid((unsigned)p->n_sys);
   const bool waves = waves_for(p->dims.b * p->dims.b);
+  // run-time sparsity lists (large models only: the whole-workgroup mode), in LDS behind the arena / alone when it is global
+  static const bool sparse_off = [] { const char* e = getenv("LQG_COOP_SPARSE"); return e && atoi(e) == 0; }();
+  const size_t lists = (size_t)coop::row_lists_bytes(p->dims.b, p->dims.b);
+  k.sparse = (!waves && !sparse_off && p->dims.b <= 255 && (global ? lists : lds + lists) <= kLdsLimit) ? 1 : 0;
+  k.lists_bytes = k.sparse ? (long)lists : 0;
+  // hybrid placement when the working set exceeds LDS: as much of it as fits stays in LDS, the rest in the global arena
+  k.lds_reals = global ? (long)((kLdsLimit - (size_t)k.lists_bytes) / sizeof(R)) : 0;
+  const size_t lds_global = (size_t)k.lists_bytes + (size_t)k.lds_reals * sizeof(R);
+  if (k.sparse && !global) lds += lists;
   if (waves && !global && k.ti) {             // a fixed-dims instantiation of this shape (time-invariant specs)
 #define X(B_, U_) \
   if (p->dims.b == B_ && p->dims.u == U_) return coop_riccati_fixed<R, B_, U_>(k, lds, st);
@@ -151,9 +164,12 @@ hipError_t coop_riccati(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view H
   }
 #define LQG_GO(G_, W_)                                                                     \
   {                                                                                         \
-    auto kern = coop::k_coop_riccati<R, 256, G_, W_>;                                       \
-    if (!(G_)) { hipError_t e = raise_lds(kern, lds); if (e != hipSuccess) return e; }      \
-    hipLaunchKernelGGL(kern, grid, dim3(256), (G_) ? 0 : lds, st, k);                       \
+    /* whole-workgroup mode (large matrices): 1024 lanes = 4 waves per SIMD hide the LDS latency of the per-element */ \
+    /* chains (one workgroup owns the CU anyway: its arena fills the LDS)                                            */ \
+    constexpr int NTH = (W_) ? 256 : kBigBlock;                                             \
+    auto kern = coop::k_coop_riccati<R, NTH, G_, W_>;                                       \
+    { hipError_t e = raise_lds(kern, (G_) ? lds_global : lds); if (e != hipSuccess) return e; } \
+    hipLaunchKernelGGL(kern, grid, dim3(NTH), (G_) ? lds_global : lds, st, k);              \
   }
   if (waves) { if (global) LQG_GO(true, true) else LQG_GO(false, true) }
   else { if (global) LQG_GO(true, false) else LQG_GO(false, false) }
@@ -171,7 +187,7 @@ hipError_t coop_forward(const lqg_problem* p, const void* Ls, void* ops, lqg_vie
   k.ti = forward_ti(p) ? 1 : 0;
   const bool kalman_only = !ops && !Sig.ptr;
   const long reals = fwd_reals(p, kalman_only);
-  const size_t lds = (size_t)reals * sizeof(R);
+  size_t lds = (size_t)reals * sizeof(R);
   const bool global = lds > kLdsLimit;
   if (global && !arena) return hipErrorInvalidValue;
   k.arena = static_cast<R*>(arena);
@@ -179,6 +195,13 @@ hipError_t coop_forward(const lqg_problem* p, const void* Ls, void* ops, lqg_vie
   const dim3 grid((unsigned)p->n_sys);
   const int m = p->dims.x + p->dims.b;
   const bool waves = waves_for(kalman_only ? p->dims.b * p->dims.b : m * m);
+  static const bool sparse_off = [] { const char* e = getenv("LQG_COOP_SPARSE"); return e && atoi(e) == 0; }();
+  const size_t lists = (size_t)coop::row_lists_bytes(p->dims.b, p->dims.b) + (size_t)coop::row_lists_bytes(m, m - p->dims.d);
+  k.sparse = (!waves && !sparse_off && m <= 255 && (global ? lists : lds + lists) <= kLdsLimit) ? 1 : 0;
+  k.lists_bytes = k.sparse ? (long)lists : 0;
+  k.lds_reals = global ? (long)((kLdsLimit - (size_t)k.lists_bytes) / sizeof(R)) : 0;
+  const size_t lds_global = (size_t)k.lists_bytes + (size_t)k.lds_reals * sizeof(R);
+  if (k.sparse && !global) lds += lists;
   if (waves && !global && k.ti && !kalman_only) {
     const lqg_dims& d = p->dims;
 #define X(X_, B_, U_, Y_, D_)                                                  \
@@ -191,9 +214,10 @@ hipError_t coop_forward(const lqg_problem* p, const void* Ls, void* ops, lqg_vie
   }
 #define LQG_GO(G_, W_)                                                                     \
   {                                                                                         \
-    auto kern = coop::k_coop_forward<R, 256, G_, W_>;                                       \
-    if (!(G_)) { hipError_t e = raise_lds(kern, lds); if (e != hipSuccess) return e; }      \
-    hipLaunchKernelGGL(kern, grid, dim3(256), (G_) ? 0 : lds, st, k);                       \
+    constexpr int NTH = (W_) ? 256 : kBigBlock;                                             \
+    auto kern = coop::k_coop_forward<R, NTH, G_, W_>;                                       \
+    { hipError_t e = raise_lds(kern, (G_) ? lds_global : lds); if (e != hipSuccess) return e; } \
+    hipLaunchKernelGGL(kern, grid, dim3(NTH), (G_) ? lds_global : lds, st, k);              \
   }
   if (waves) { if (global) LQG_GO(true, true) else LQG_GO(false, true) }
   else { if (global) LQG_GO(true, false) else LQG_GO(false, false) }
