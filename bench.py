@@ -583,6 +583,24 @@ def extra_legs(torch, args, dev):
                                                              md.log_likelihood(xd_all[:2].contiguous()), n_samples=2)
         # (the same evaluation by the literal dense C port on ONE host core, two trials — context, not a target)
         legd["cpu_port_ms_two_trials_incl_check"] = (time.perf_counter() - t0) * 1e3
+        # value + gradient of the same model: central differences over its 6 parameters = 13 systems, each its own
+        # workgroup, evaluated concurrently (one launch set) — the gradient route for shapes without adjoint lane kernels
+        try:
+            from lqg_amd.infer.models import get_model_params
+            pd = {k: float(v) for k, v in get_model_params(DelayedSubjectiveActor).items()
+                  if k in ("c", "action_variability", "subj_noise", "subj_vel_noise", "sigma_target", "sigma_cursor")}
+            xg2 = torch.cat([xd_all[:50], xd_all[:50, -1:]], dim=1).double()
+            for i in range(2):
+                gradient.value_and_grad(xg2, DelayedSubjectiveActor, pd, method="fd")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(5):
+                v_, g_ = gradient.value_and_grad(xg2, DelayedSubjectiveActor, dict(pd, sigma_target=pd["sigma_target"] + 1e-3 * i), method="fd")
+            torch.cuda.synchronize()
+            legd["value_and_grad_fd"] = {"ms": (time.perf_counter() - t0) / 5 * 1e3, "parameters": len(pd), "systems": 2 * len(pd) + 1,
+                                         "trials": 50, "dtype": "f64", "finite": bool(all(v == v for v in g_.values()))}
+        except Exception as e:
+            legd["value_and_grad_fd"] = {"error": repr(e)[:300]}
         extra["delay12"] = legd
     except Exception as e:
         extra["delay12"] = {"error": repr(e)}

@@ -15,8 +15,11 @@ def get_model_params(model_class):
     (Cached per class: the signature walk costs ~40 us, once per objective evaluation in an optimiser loop.)"""
     if model_class not in _model_params_cache:
         init_signature = inspect.signature(model_class.__init__)
+        # (*args / **kw catch-alls are not parameters: the reference's loop would list `kw` with an empty default and then
+        # fail to sample it; DelayedSubjectiveActor forwards device / dtype / T through **kw here)
         _model_params_cache[model_class] = {name: param.default for name, param in init_signature.parameters.items()
-                                            if name not in _NOT_INFERRED}
+                                            if name not in _NOT_INFERRED
+                                            and param.kind not in (param.VAR_POSITIONAL, param.VAR_KEYWORD)}
     return dict(_model_params_cache[model_class])
 
 

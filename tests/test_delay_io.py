@@ -130,3 +130,30 @@ def test_out_of_range_shapes_go_to_the_cooperative_kernels_never_to_a_compile():
     assert _abi.shape_in_range(10, 10, 2, 4, 4) and _abi.shape_in_range(6, 6, 1, 2, 2)
     with pytest.raises(_abi.LqgHipError, match="outside the dims"):      # u = 7: beyond both kernel families
         _abi.library_for(dict(x=30, b=30, u=7, y=2, d=2))
+
+
+@pytest.mark.gpu
+def test_delayed_model_value_and_gradient_through_batched_finite_differences():
+    """The reference differentiates DelayedSubjectiveActor with jax.grad (lqg/infer/utils.py:14-41 runs NUTS on any model).
+    Here shapes without adjoint lane kernels (m = 65) take central differences in log-space with the 2P + 1 perturbed
+    systems as the candidate axis of ONE evaluation (every system is its own workgroup of the cooperative kernels): check
+    it against differences of separately constructed models, one parameter at a time."""
+    import math
+    from lqg_amd.infer.gradient import value_and_grad
+    from lqg_amd.infer.models import get_model_params
+    from lqg_amd.tracking.delay import DelayedSubjectiveActor
+    names = sorted(get_model_params(DelayedSubjectiveActor))
+    assert names == sorted(["c", "action_variability", "subj_noise", "subj_vel_noise", "sigma_target", "sigma_cursor"])
+    T = 60
+    truth = DelayedSubjectiveActor(T=T, device="cuda", dtype=torch.float64)
+    x = truth.simulate(3, n=6)[..., :2].contiguous()
+    p = dict(c=0.4, action_variability=0.6, subj_noise=1.2, subj_vel_noise=8.0, sigma_target=5.0, sigma_cursor=2.5)
+    v, g = value_and_grad(x, DelayedSubjectiveActor, p, method="fd")      # (x has T + 1 rows = T steps, lqg_model's convention)
+    ll = lambda q: float(DelayedSubjectiveActor(T=T, device="cuda", dtype=torch.float64, **q).log_likelihood(x).sum())
+    assert abs(v / ll(p) - 1) < 1e-12
+    h = 1e-4
+    for k in ("c", "sigma_target", "subj_vel_noise"):
+        up, dn = dict(p), dict(p)
+        up[k], dn[k] = p[k] * math.exp(h), p[k] * math.exp(-h)
+        fd = (ll(up) - ll(dn)) / (2 * h) / p[k]
+        assert abs(g[k] - fd) < 1e-6 * max(1.0, abs(fd)), (k, g[k], fd)
