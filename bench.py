@@ -33,7 +33,7 @@ PEAK_FP64_TFLOPS = 78.6    # datasheet FP64 vector == FP64 matrix peak
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 COPY_HBM_GBS = 6290.0      # MI355X_MICROARCH.md: measured device copy rate
 VALU_WAVE_INSTS_PER_S = 1024 * 2.4e9 / 2    # 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 
 
 def algorithmic_flops_per_step(x, b, u, y, d):

@@ -13,12 +13,14 @@ bash scripts/profile_m2.sh ${TAG}m2 f32 17 > /dev/null 2>&1
 # profiles/ does not travel back from the box, so the record is also left under gpurun_out/ to be copied into profiles/
 python3 scripts/make_pmc_record.py ${TAG} f32 20 > /dev/null 2>&1
 python3 scripts/make_pmc_record.py ${TAG}64 f64 20 > /dev/null 2>&1
-cp profiles/r02_pmc_traffic.json gpurun_out/${TAG}_pmc_traffic.json
+cp profiles/r03_pmc_traffic.json gpurun_out/${TAG}_pmc_traffic.json
 python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 python3 bench_configs.py > gpurun_out/${TAG}_configs.jsonl 2> gpurun_out/${TAG}_configs.err
 python3 bench_grad.py > gpurun_out/${TAG}_grad_f64.jsonl 2> gpurun_out/${TAG}_grad.err
 python3 scripts/small_batch.py 2> /dev/null | grep -v amdgpu > gpurun_out/${TAG}_small_batch_f32.txt
 python3 scripts/small_batch.py f64 2> /dev/null | grep -v amdgpu > gpurun_out/${TAG}_small_batch_f64.txt
+python3 scripts/delay12_time.py 2> /dev/null | grep -v amdgpu > gpurun_out/${TAG}_delay12.txt
+python3 scripts/fp32_tail.py 2> /dev/null | grep -v amdgpu > gpurun_out/${TAG}_fp32_tail.txt
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_cfg2 -o p -- python3 bench_configs.py --configs 2 > /dev/null 2>&1
 python3 - <<PY > gpurun_out/${TAG}_timeline_config2.txt

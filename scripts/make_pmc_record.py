@@ -1,5 +1,5 @@
 """gpurun_out/prof_<tag>_{FETCH_SIZE,WRITE_SIZE,SQ_INSTS_VALU}/ -> one record per hot-path kernel in
-profiles/r02_pmc_traffic.json (what bench.py's `roofline.traffic` reads) + the trimmed kernel-stats table.
+profiles/r03_pmc_traffic.json (what bench.py's `roofline.traffic` reads) + the trimmed kernel-stats table.
 
 HBM bytes per launch = 2 x FETCH_SIZE (gfx950: the counter tallies 128-B requests at 64 B —
 /opt/skills/guides/MI355X_MICROARCH.md "HBM"; calibrated in round 1 on k_riccati's exactly-known byte count) + WRITE_SIZE,
@@ -40,7 +40,7 @@ def main():
     sp = "structure-specialised" in path
     import lqg_amd
     key = specialize.class_pattern(lqg_amd.SubjectiveActor, 2, dim=1)[2] if sp else "generic"
-    out_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    out_path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     doc = json.load(open(out_path)) if os.path.exists(out_path) else {"records": []}
     fetch, write, valu = table(tag, "FETCH_SIZE"), table(tag, "WRITE_SIZE"), table(tag, "SQ_INSTS_VALU")
     for kern, pat in (("forward", r"k_forward_sp<" if sp else r"k_forward<"), ("riccati", r"k_riccati_sp<" if sp else r"k_riccati<")):
@@ -56,7 +56,7 @@ def main():
                    sp_headers_hash=specialize._headers_hash(), fetch_size_kib_raw=f, write_size_kib_raw=w,
                    hbm_bytes_per_launch=(2.0 * f + (w or 0.0)) * 1024.0, launches_averaged=nf,
                    valu_wave_insts_per_launch=v, valu_insts_per_step_per_wave=(v / waves / T if v else None),
-                   profile=f"profiles/r02_{tag}_*  (rocprofv3 --pmc passes of `python bench.py --dtype {dtype} --log2-batch {log2b}`)",
+                   profile=f"profiles/r03_{tag}_*  (rocprofv3 --pmc passes of `python bench.py --dtype {dtype} --log2-batch {log2b}`)",
                    bench_value_under_rocprof=bench["value"])
         doc["records"] = [r for r in doc["records"] if not (r["kernel"] == name and r["dtype"] == dtype and r["log2_batch"] == log2b)]
         doc["records"].append(rec)
@@ -64,8 +64,8 @@ def main():
     json.dump(doc, open(out_path, "w"), indent=1)
     stats = glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_kt", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
-        os.system(f"python {ROOT}/profiles/summarize.py {stats[0]} {ROOT}/profiles/r02_{tag}_kernel_stats.csv 10")
-        os.system(f"cp {ROOT}/gpurun_out/prof_{tag}_kt.json {ROOT}/profiles/r02_{tag}_bench_under_rocprof.json")
+        os.system(f"python {ROOT}/profiles/summarize.py {stats[0]} {ROOT}/profiles/r03_{tag}_kernel_stats.csv 10")
+        os.system(f"cp {ROOT}/gpurun_out/prof_{tag}_kt.json {ROOT}/profiles/r03_{tag}_bench_under_rocprof.json")
 
 
 if __name__ == "__main__":
