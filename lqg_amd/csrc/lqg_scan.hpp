@@ -483,7 +483,14 @@ __global__ void __launch_bounds__(kWave) k_scan_build_sigma(const Args<R> a) {
     each(mm2, [&](int e) { fg[e] = Fj[e]; fg[mm2 + e] = GG[e]; });
   }
   if (k >= a.T) return;
-  D* e = a.elems + (s * a.T + k) * 3L * mm2;
+  // The scan runs on the UNOBSERVED block only (round 3).  With the first o components observed exactly, (I - K H) has
+  // zero observed rows and every conditional covariance a zero observed block, and the combine closes on the [r, r]
+  // sub-blocks: M = I + C1 J2 is block triangular, M^-1 C1 = blockdiag(0, (I + C1rr J2rr)^-1 C1rr), hence
+  // C = A2[r,r] (I + C1rr J2rr)^-1 C1rr A2[r,r]' + C2rr, A = A2[r,r] (..)^-1 A1[r,r], J = A1[r,r]' J2rr (..)^-1 A1[r,r] + J1rr —
+  // the observed COLUMNS of A and the observed rows / columns of J only ever meet the zero block.  Elements are
+  // rr x rr (rr = m - o): (m / rr)^3 fewer multiply-adds per combine (config 2: 8 -> 6, 2.4x; BoundedActor: 4 -> 2).
+  const int rr = m - o, rr2 = rr * rr;
+  D* e = a.elems + (s * a.T + k) * 3L * rr2;
   // Q_oo^-1, K = Q[:, :o] Q_oo^-1, I - K H (H = [I_o 0])
   each(o * o, [&](int i2) { const int i = i2 / o, j = i2 - i * o; IKH[i2] = GG[i * m + j]; });   // (IKH as temp for Q_oo)
   wsync();
@@ -495,17 +502,17 @@ __global__ void __launch_bounds__(kWave) k_scan_build_sigma(const Args<R> a) {
     IKH[i2] = ((i == j) ? 1.0 : 0.0) - ((j < o) ? Kk[i * o + j] : 0.0);
   });
   wsync();
-  mm_sym(e + mm2, m, m, IKH, m, 1, GG, m, 1, zero_init);            // C = (I - K H) Q   (k = 0: Q = Sigma_0 = GG_0)
+  mm_sym(e + rr2, rr, m, IKH + o * m, m, 1, GG + o, m, 1, zero_init);   // C = ((I - K H) Q)[r, r]   (k = 0: Q = Sigma_0 = GG_0)
   if (k == 0) {
-    each(mm2, [&](int i) { e[i] = 0.0; e[2 * mm2 + i] = 0.0; });
+    each(rr2, [&](int i) { e[i] = 0.0; e[2 * rr2 + i] = 0.0; });
   } else {
-    mm(e, m, m, m, m, IKH, m, 1, Fj, m, 1, zero_init);              // A = (I - K H) F
-    // J = F[:o, :]' Q_oo^-1 F[:o, :]
+    mm(e, rr, rr, rr, m, IKH + o * m, m, 1, Fj + o, m, 1, zero_init);   // A = ((I - K H) F)[r, r]
+    // J = (F[:o, r])' Q_oo^-1 F[:o, r]
     D* T1 = Kk;                                                      // [o, m] temp (Kk is dead after IKH)
     wsync();
     mm(T1, m, o, m, o, Qi, o, 1, Fj, m, 1, zero_init);
     wsync();
-    mm_sym(e + 2 * mm2, m, o, Fj, 1, m, T1, m, 1, zero_init);
+    mm_sym(e + 2 * rr2, rr, o, Fj + o, 1, m, T1 + o, m, 1, zero_init);
   }
 }
 
@@ -523,10 +530,10 @@ __global__ void __launch_bounds__(kWave) k_scan_ops(const Args<R> a) {
     each(mm2, [&](int e) { Sg[e] = fg[mm2 + e]; });                  // Sigma_0 = G_0 G_0'   system.py:212
   } else {
     const D* fg = a.FG + (s * a.T + t - 1) * 2L * mm2;
-    const D* C = a.res + (s * a.T + t - 1) * 3L * mm2 + mm2;
-    mm(T1, m, m, m, m, fg, m, 1, C, m, 1, zero_init);               // F C
+    const D* C = a.res + (s * a.T + t - 1) * 3L * (rr * rr) + rr * rr;      // conditional covariance, unobserved block
+    mm(T1, rr, m, rr, rr, fg + o, m, 1, C, rr, 1, zero_init);       // F[:, o:] C        [m, rr]
     wsync();
-    mm_sym(Sg, m, m, T1, m, 1, fg, 1, m, [&](int i, int j) { return fg[mm2 + i * m + j]; });   // F C F' + GG
+    mm_sym(Sg, m, rr, T1, rr, 1, fg + o, 1, m, [&](int i, int j) { return fg[mm2 + i * m + j]; });   // F2 C F2' + GG
     if (a.Sig.p) {
       wsync();
       R* out = const_cast<R*>(a.Sig.p) + s * a.Sig.sb + (long)(t - 1) * a.Sig.st;

@@ -150,7 +150,7 @@ hipError_t scan_system_sweeps(const lqg_problem* p, lqg_view Sig, void* workspac
     const D* res[2];
     k.elems = in[0];
     launch(scan::k_scan_build_sigma<R>, T + 1, 3L * m * m + o * o + m * o + scan::joint_scratch(x, b, u, y) + 16);
-    run_scan(m, 1, in, out, len, left, p->n_sys, res, st);
+    run_scan(m - o, 1, in, out, len, left, p->n_sys, res, st);     // (elements on the unobserved block: lqg_scan.hpp)
     k.res = res[0];
   }
   launch(scan::k_scan_ops<R>, T + 1, 2L * m * m + o * o + 8);
