@@ -148,3 +148,58 @@ def test_product_does_not_import_the_oracle():
                 if re.search(r"(import\s+oracle|from\s+oracle|lqg_np|lqg_oracle|jax_standin)", t):
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_mixed_dtype_is_served_by_the_log_likelihood_entry_only(lib, monkeypatch):
+    """ABI 2: LQG_F32_SYS64 (fp32 problem, fp64 spec arrays and system sweeps) — accepted by lqg_log_likelihood /
+    lqg_workspace_bytes, refused (before any launch) everywhere a single dtype is assumed; its workspace holds an fp64
+    gain scratch and an fp32 operator stream."""
+    from lqg_amd import _hip
+    import lqg_amd
+    monkeypatch.setenv("LQG_TRIAL_CHUNKS", "0")
+    m32 = lqg_amd.SubjectiveActor(dim=2, T=500, sigma_target=torch.linspace(1, 2, 100), device="cpu", dtype=torch.float32)
+    m64 = m32.to(torch.float64)
+    ln32 = _hip.Launch(m32.actor, m32.dynamics, d=4, n_trials=16)
+    mix = _hip.Launch(m64.actor, m64.dynamics, d=4, n_trials=16, traj_dtype=torch.float32)
+    assert mix.mixed and mix.p.dtype == _abi.F32_SYS64 and mix.dtype == torch.float32 and mix.spec_dtype == torch.float64
+    w32 = lib.lqg_workspace_bytes(C.byref(ln32.p), _abi.OP_LOG_LIKELIHOOD)
+    wmx = lib.lqg_workspace_bytes(C.byref(mix.p), _abi.OP_LOG_LIKELIHOOD)
+    gains32 = 500 * 2 * 6 * 128 * 4
+    assert wmx - w32 == gains32                     # the gain scratch doubles (fp64), the operator stream stays fp32
+    nv, nt = _abi.NULL_VIEW, _abi.NULL_TRAJ
+    assert lib.lqg_kalman_forward(C.byref(mix.p), nv, None) == -3 and b"LQG_F32_SYS64" in lib.lqg_last_error()
+    assert lib.lqg_riccati_backward(C.byref(mix.p), nv, nv, nv, None) == -3
+    assert lib.lqg_conditional_moments(C.byref(mix.p), nt, nt, nv, None, 0, None) == -3
+    assert lib.lqg_scan_supported(C.byref(mix.p)) == 0
+    # the entry that serves it still validates its arguments before launching anything
+    assert lib.lqg_log_likelihood(C.byref(mix.p), nt, None, 0, 1, None, 0, None) == -1        # x.ptr NULL
+    mix.p.n_trials = 2                              # the in-lane one / two-trial sweeps are single-precision paths
+    x = torch.zeros(2, 501, 4)
+    rc = lib.lqg_log_likelihood(C.byref(mix.p), mix.traj(x, False), C.c_void_p(x.data_ptr()), 0, 1,
+                                C.c_void_p(x.data_ptr()), 1 << 40, None)
+    assert rc == -3 and b"n_trials >= 3" in lib.lqg_last_error()
+    with pytest.raises(_abi.LqgHipError):
+        _hip.Launch(m32.actor, m32.dynamics, d=4, n_trials=16, traj_dtype=torch.float64)      # (only f32 over f64 specs)
+
+
+def test_new_entries_check_their_arguments(lib):
+    nv, nt = _abi.NULL_VIEW, _abi.NULL_TRAJ
+    assert lib.lqg_simulate_rng(None, nv, nv, nv, 0, nv, nv, nt, nt, nt, nt, None) == -1
+    p = _abi.Problem()
+    p.dtype, p.T, p.n_sys, p.n_trials = _abi.F32, 10, 1, 1
+    p.dims = _abi.Dims(2, 2, 1, 2, 2, 2, 2, 2, 2)
+    assert lib.lqg_simulate_rng(C.byref(p), nv, nv, nv, 7, nv, nv, nt, nt, nt, nt, None) == -1   # missing spec pointers
+    assert lib.lqg_precondition_flags(None, 1e7, 1, None, None) == -1
+    assert lib.lqg_precondition_flags(C.byref(p), 1e7, 1, None, None) == -1                      # ok pointer missing
+    p.dtype = _abi.F32_SYS64
+    flag = (C.c_int32 * 1)()
+    assert lib.lqg_precondition_flags(C.byref(p), 1e7, 1, flag, None) == -3                      # single-dtype entry
+
+
+def test_get_model_params_skips_catch_all_arguments():
+    """lqg/infer/models.py:9-17 lists every constructor argument but a fixed few; a **kw catch-all (DelayedSubjectiveActor
+    forwards T / device / dtype through it) is not a parameter."""
+    from lqg_amd.infer.models import get_model_params
+    from lqg_amd.tracking.delay import DelayedSubjectiveActor
+    assert sorted(get_model_params(DelayedSubjectiveActor)) == ["action_variability", "c", "sigma_cursor", "sigma_target",
+                                                                "subj_noise", "subj_vel_noise"]

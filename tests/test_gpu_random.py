@@ -263,3 +263,41 @@ def test_bounded_equals_subjective_under_a_shared_seed():
     x_b = lqg_amd.BoundedActor(**kw).simulate(rng_key=0, n=20)
     x_s = lqg_amd.SubjectiveActor(subj_noise=1.0, subj_vel_noise=0.0, **kw).simulate(rng_key=0, n=20)
     assert torch.allclose(x_b, x_s, rtol=1e-9, atol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# ABI 2: the MIXED problem LQG_F32_SYS64 straight through the C ABI (generic dense kernels: time-varying specs and affine cost
+# terms included), against the fp64 C oracle and against the all-fp32 problem on the same inputs
+@pytest.mark.parametrize("case", [0, 1, 2, 3, 7])
+def test_mixed_precision_entry_on_random_dense_systems(oracle_lib, case, monkeypatch):
+    import ctypes as C
+    import oracle as OC
+    from lqg_amd import _abi, _hip
+    monkeypatch.setenv("LQG_NO_SPECIALIZE", "1")
+    rng = np.random.default_rng(1000 + case)          # (the systems of test_random_systems_match_the_oracle: known well-posed)
+    x, b, u, y = SHAPES[case % len(SHAPES)]
+    T, n = int(rng.integers(5, 60)), 5
+    tv, affine = bool(case & 1), bool(case & 2)
+    actor, dyn = random_system(rng, x, b, u, y, T, tv, affine)
+    rd = lambda spec: {k: v.astype(np.float32).astype(np.float64) for k, v in spec.items()}      # fp32-representable inputs
+    actor, dyn = rd(actor), rd(dyn)
+    X, _, _, _ = OC.simulate(actor, dyn, rng.standard_normal((n, T, x)), rng.standard_normal((n, T, y)))
+    xs = X.astype(np.float32)
+    ref = OC.log_likelihood(actor, dyn, xs.astype(np.float64))
+    a64, d64 = to_spec(actor, torch.float64), to_spec(dyn, torch.float64)
+    x32 = torch.as_tensor(xs, device="cuda")
+    ln = _hip.Launch(a64, d64, d=x, n_trials=n, traj_dtype=torch.float32)
+    lib = ln.require_gpu()
+    assert ln.p.dtype == _abi.F32_SYS64
+    ll = torch.empty(n, dtype=torch.float32, device="cuda")
+    nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device="cuda")
+    _abi.check(lib.lqg_log_likelihood(C.byref(ln.p), ln.traj(x32, False), C.c_void_p(ll.data_ptr()), 0, 1,
+                                      C.c_void_p(ws.data_ptr()), nbytes, ln.stream()), "lqg_log_likelihood (mixed)")
+    err_mixed = np.abs(np_(ll) - ref).max() / np.abs(ref).max()
+    # the all-fp32 problem on the same inputs, same entry point
+    monkeypatch.setenv("LQG_MIXED", "0")
+    sys32 = lqg_amd.System(actor=to_spec(actor, torch.float32), dynamics=to_spec(dyn, torch.float32))
+    err_f32 = np.abs(np_(sys32.log_likelihood(x32)) - ref).max() / np.abs(ref).max()
+    assert err_mixed < 1e-6, (err_mixed, err_f32)
+    assert err_mixed < 2.0 * err_f32 + 2e-7          # never meaningfully worse than the fp32 recursions
