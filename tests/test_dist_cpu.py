@@ -150,3 +150,32 @@ def test_bench_gpus_n_starts_n_ranks_itself():
     assert r.returncode != 0
     out = r.stdout + r.stderr
     assert out.count("bench.py needs an MI355X") >= 2 or "local_rank: 1" in out or "rank      : 1" in out, out[-2000:]
+
+
+def _host_reduce_worker(rank, world, port, out_dir):
+    for p in (ROOT,):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    hr = bench.HostReduce(torch, dist)
+    assert hr.get_world_size() == world
+    t = torch.tensor([1.0 + rank, 10.0 * (rank + 1)], dtype=torch.float64)
+    hr.all_reduce(t)                                         # in place, like dist.all_reduce on a device tensor
+    assert t.tolist() == [sum(1.0 + r for r in range(world)), sum(10.0 * (r + 1) for r in range(world))]
+    mine = torch.tensor([float(rank) + 0.25], dtype=torch.float64)
+    outs = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    hr.all_gather(outs, mine)
+    assert [float(o) for o in outs] == [r + 0.25 for r in range(world)]
+    hr.barrier()
+    np.save(os.path.join(out_dir, f"hr{rank}.npy"), t.numpy())
+    hr.destroy_process_group()
+
+
+def test_share_gpu_host_reduce_shim_world2(tmp_path):
+    """bench.py --share-gpu routes its three collectives through gloo on host tensors (bench.HostReduce) with the call
+    shapes of the RCCL path; here on CPU tensors, world size 2 (the GPU test runs the whole flow with HIP kernels)."""
+    world, port = 2, _free_port()
+    mp.spawn(_host_reduce_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert np.array_equal(np.load(tmp_path / "hr0.npy"), np.load(tmp_path / "hr1.npy"))
