@@ -194,6 +194,8 @@ class LogLikelihoodPlan:
                                   scan_sp=bool(use_scan and scan_sp),
                                   generic=lib.lqg_log_likelihood, scan=use_scan,
                                   specialised=sp is not None, n=n, fused_pairs=fuse_pairs, mixed=mixed,
+                                  coop=bool(not use_scan and sp is None
+                                            and lib.lqg_strategy(C.byref(ln.p)) == _abi.STRATEGY_COOP),
                                   pattern_key=(specialize.system_pattern(sub0, len(cols))[2] if sp is not None else None),
                                   loop_trials=loop_trials, is_b=is_b, group=(self.merged[ip] if self.merged else 1),
                                   dims=(sub.xdim, sub.bdim, sub.udim, sub.ydim, len(cols))))
@@ -230,6 +232,12 @@ class LogLikelihoodPlan:
                 kind += f", {len(w)} decoupled components of dims (x,b,u,y,d)={w[0]['dims']}"
             if self.merged and max(self.merged) > 1:
                 kind += f"; {max(self.merged)} identical components as trials of one system"
+            return kind
+        if all(k.get("coop") for k in w):
+            kind = ("cooperative, one workgroup per system, run-time dims (k_coop_riccati + k_coop_forward + per-trial sweep "
+                    "k_trial / k_coop_trial_rows)")
+            if len(w) > 1:
+                kind += f", {len(w)} decoupled components of dims (x,b,u,y,d)={w[0]['dims']}"
             return kind
         kind = ("structure-specialised (k_riccati_sp + k_forward_sp" if all(k["specialised"] for k in w) else
                 "generic dense (k_riccati + k_forward") + tail
