@@ -45,6 +45,7 @@ SCAN_MAX_COND = float(os.environ.get("LQG_SCAN_MAX_COND", "1e7"))
 # (shards of a trial split agree bitwise); LQG_MIXED_MIN_TRIALS raises the threshold for workloads of many systems with a
 # handful of trials each, where the system sweeps dominate and doubling their cost is not amortised; LQG_MIXED=0 disables.
 MIXED_MIN_TRIALS = int(os.environ.get("LQG_MIXED_MIN_TRIALS", "3"))
+MIXED_LONG_HORIZON = 600        # steps beyond which small fp32 (system, trial) batches are not run as all-fp32 fused pairs
 
 
 def scan_min_steps(m):
@@ -142,7 +143,12 @@ class LogLikelihoodPlan:
             sub0 = sub                           # (keeps the zoo class: its sparsity pattern is cached per class)
             use_scan = scan_eligible(_abi.load(), _hip.Launch(sub.actor, sub.dynamics, d=len(cols), n_trials=n, Sigma0=S0,
                                                                eps=eps), sub, eps) if sub.actor.A.is_cuda else False
-            fuse_pairs = (not use_scan) and 2 < n and n_sys0 * n <= FUSE_TRIALS_MAX and _time_invariant(sub)
+            # (an fp32 problem over a long horizon keeps the operator-stream path: its system sweeps then run in fp64 —
+            # MIXED, below — where the fused pairs would run every recursion in fp32; §6a: the fp32 tail passes 1e-6 near T = 1000)
+            long_f32 = (sub.actor.A.dtype == torch.float32 and sub.T > MIXED_LONG_HORIZON
+                        and os.environ.get("LQG_MIXED", "1") != "0" and n >= max(3, MIXED_MIN_TRIALS))
+            fuse_pairs = ((not use_scan) and 2 < n and n_sys0 * n <= FUSE_TRIALS_MAX and _time_invariant(sub)
+                          and not long_f32)
             if fuse_pairs:                       # (system, trial) pairs as n_sys0 * n one-trial systems
                 sub, xs, S0 = _pairs_as_systems(sub, xs, S0, n_sys0, n)
                 n_pairs, n = n, 1

@@ -124,6 +124,24 @@ def test_config4_hand2d_32768_trials_T1000(oracle_lib, monkeypatch):
     assert float((joint / ll64[:2048] - 1).abs().max()) < 1e-10
 
 
+def test_small_fp32_batch_over_a_long_horizon_keeps_the_mixed_path():
+    """A few candidates x a few trials would run as all-fp32 fused (system, trial) pairs; beyond plan.MIXED_LONG_HORIZON
+    steps an fp32 problem keeps the operator-stream path so that its system sweeps run in fp64."""
+    from lqg_amd.plan import LogLikelihoodPlan
+    T = 1000
+    m, _ = workload.bounded_system(16, T, seed=9, device=DEV, dtype=torch.float32)
+    truth = lqg_amd.BoundedActor(T=T, sigma_target=20.0, sigma_cursor=3.0, action_cost=0.3, action_variability=0.5,
+                                 device=DEV, dtype=torch.float32)
+    x = truth.simulate(5, n=20)
+    plan = LogLikelihoodPlan(m, x)
+    assert all(wk["mixed"] and not wk["fused_pairs"] for wk in plan.work), plan.description
+    ll = plan.run().clone()
+    ll64 = m.to(torch.float64).log_likelihood(x.double())
+    assert float((ll.double() / ll64 - 1).abs().max()) < 1e-6
+    short, _ = workload.bounded_system(16, 200, seed=9, device=DEV, dtype=torch.float32)
+    assert all(wk["fused_pairs"] for wk in LogLikelihoodPlan(short, x[:, :201].contiguous()).work)
+
+
 def test_config5_one_system_1048576_trials_fp32_vs_fp64_sweep(oracle_lib, monkeypatch):
     """Config 5 in its literal form: ONE system (SubjectiveActor(dim=2), n = 6) x 1 048 576 trials, T = 500, "fp32 vs fp64
     tolerance sweep" — quantiles of the fp32 result against the fp64 one over ALL trials (same inputs), a C-oracle sample at
