@@ -36,7 +36,8 @@ extern "C" {
 #define LQG_ABI_VERSION 2
 
 /* LQG_F32 / LQG_F64: arithmetic and storage type of every array of the problem.
- * LQG_F32_SYS64 (mixed; lqg_log_likelihood / lqg_log_likelihood_sp / lqg_workspace_bytes only, n_trials >= 3): an fp32
+ * LQG_F32_SYS64 (mixed; lqg_log_likelihood / lqg_log_likelihood_sp / lqg_workspace_bytes only; always through the operator
+ * stream, whatever n_trials — the in-lane one / two-trial sweeps are single-precision paths): an fp32
  * problem — trajectories x, results ll and the internal operator stream are float — whose SPEC arrays (and Sigma0) are
  * handed over as double and whose per-system sweeps (Riccati, Kalman, moment recursion: data-independent, amortised
  * over the trials) run in fp64; the per-trial sweep stays fp32.  The operators reach the fp32 sweep rounded ONCE

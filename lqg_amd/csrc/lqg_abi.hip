@@ -292,7 +292,7 @@ int run_moments(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_view Sigma, v
 // way out, per-trial sweep in fp32 (lane kernels only; time-invariant or not, affine terms or not).
 int run_mixed(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll_sn, void* workspace, size_t workspace_bytes,
               hipStream_t st, const char* who) {
-  if (p->n_trials < 3) return fail(LQG_ERR_ARG, "%s: LQG_F32_SYS64 needs n_trials >= 3 (operator-stream path)", who);
+  if (p->n_trials < 1) return fail(LQG_ERR_ARG, "%s: LQG_F32_SYS64 needs n_trials >= 1", who);
   if (use_coop(p)) return fail(LQG_ERR_ARG, "%s: LQG_F32_SYS64 is served by the lane kernels only", who);
   const Workspace w = carve(p, true);
   if (!workspace || workspace_bytes < w.total)
@@ -516,7 +516,7 @@ size_t lqg_workspace_bytes(const lqg_problem* p, int32_t op) {
   if (!p) return 0;
   (void)op;   // every op runs fused (no operator stream) when there is one trial per system
   if (use_coop(p)) return carve(p, true).total + coop_arena_bytes(p, false, false);
-  return carve(p, p->n_trials != 1).total;
+  return carve(p, p->n_trials != 1 || p->dtype == LQG_F32_SYS64).total;     // (mixed: always through the operator stream)
 }
 
 int lqg_conditional_moments(const lqg_problem* p, lqg_traj x, lqg_traj mu, lqg_view Sigma, void* workspace,

@@ -132,7 +132,7 @@ int run_sp_mixed(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll
                  hipStream_t st) {
   using R = double;
   constexpr int CK = 0;                           // (fp64 sweeps stream their gains: sp_chunk<double>() is 0 too)
-  if (p->n_trials < 3) return LQG_ERR_ARG;
+  if (p->n_trials < 1) return LQG_ERR_ARG;
   const Workspace w = carve(p, true);
   if (!workspace || workspace_bytes < w.total) return LQG_ERR_WORKSPACE;
   char* base = static_cast<char*>(workspace);

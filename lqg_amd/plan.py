@@ -146,7 +146,7 @@ class LogLikelihoodPlan:
             # (an fp32 problem over a long horizon keeps the operator-stream path: its system sweeps then run in fp64 —
             # MIXED, below — where the fused pairs would run every recursion in fp32; §6a: the fp32 tail passes 1e-6 near T = 1000)
             long_f32 = (sub.actor.A.dtype == torch.float32 and sub.T > MIXED_LONG_HORIZON
-                        and os.environ.get("LQG_MIXED", "1") != "0" and n >= max(3, MIXED_MIN_TRIALS))
+                        and os.environ.get("LQG_MIXED", "1") != "0")
             fuse_pairs = ((not use_scan) and 2 < n and n_sys0 * n <= FUSE_TRIALS_MAX and _time_invariant(sub)
                           and not long_f32)
             if fuse_pairs:                       # (system, trial) pairs as n_sys0 * n one-trial systems
@@ -155,14 +155,22 @@ class LogLikelihoodPlan:
             ln = _hip.Launch(sub.actor, sub.dynamics, d=len(cols), n_trials=n, Sigma0=S0, eps=eps)
             lib = ln.require_gpu()               # liblqg_hip.so, or the auxiliary library of an unlisted shape
             nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
-            mixed = ((not use_scan) and ln.dtype == torch.float32 and n >= max(3, MIXED_MIN_TRIALS)
-                     and os.environ.get("LQG_MIXED", "1") != "0" and nbytes <= OPS_WORKSPACE_LIMIT
+            # MIXED: from MIXED_MIN_TRIALS trials per system on (the operator stream is used anyway), and for ANY number of
+            # trials beyond MIXED_LONG_HORIZON steps (one or two trials per system then leave the in-lane fp32 sweeps for
+            # the stream path) — while the stream fits the workspace limit (2^20 systems x T = 1000 would need 150 GB: such a
+            # batch keeps the in-lane fp32 sweeps, whose tail passes 1e-6 near T = 1000; fp64 is the remedy there)
+            mixed = ((not use_scan) and ln.dtype == torch.float32 and os.environ.get("LQG_MIXED", "1") != "0"
+                     and (n >= max(3, MIXED_MIN_TRIALS) or (long_f32 and n >= 1))
                      and lib.lqg_strategy(C.byref(ln.p)) == _abi.STRATEGY_LANE)
             if mixed:                            # fp64 image of the specs (a few kB per system), float trajectories
-                sub = sub.to(torch.float64)
-                ln = _hip.Launch(sub.actor, sub.dynamics, d=len(cols), n_trials=n, Sigma0=S0, eps=eps,
-                                 traj_dtype=torch.float32)
-                nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
+                sub_m = sub.to(torch.float64)
+                ln_m = _hip.Launch(sub_m.actor, sub_m.dynamics, d=len(cols), n_trials=n, Sigma0=S0, eps=eps,
+                                   traj_dtype=torch.float32)
+                nbytes_m = lib.lqg_workspace_bytes(C.byref(ln_m.p), _abi.OP_LOG_LIKELIHOOD)
+                if nbytes_m <= OPS_WORKSPACE_LIMIT:
+                    sub, ln, nbytes = sub_m, ln_m, nbytes_m
+                else:
+                    mixed = False
             xb, is_b = _hip._prep_x(ln, xs)
             sp = None if use_scan else _hip.specialised_entry(ln, sub0, len(cols))
             if use_scan:
@@ -176,7 +184,7 @@ class LogLikelihoodPlan:
                 fn = C.cast(spl.lqg_trial_sweep_sp, C.c_void_p) if spl is not None else C.c_void_p(None)
                 scan_entry = (lambda *a, _f=lib.lqg_log_likelihood_scan_with, _t=fn: _f(*a, _t))
                 scan_sp = spl is not None
-            if sp is not None and n == 2:        # the specialised library sweeps two trials in-lane: no operator stream
+            if sp is not None and n == 2 and not mixed:   # the specialised library sweeps two trials in-lane: no operator stream
                 ln.p.n_trials = 1
                 nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
                 ln.p.n_trials = 2

@@ -173,11 +173,13 @@ def test_mixed_dtype_is_served_by_the_log_likelihood_entry_only(lib, monkeypatch
     assert lib.lqg_scan_supported(C.byref(mix.p)) == 0
     # the entry that serves it still validates its arguments before launching anything
     assert lib.lqg_log_likelihood(C.byref(mix.p), nt, None, 0, 1, None, 0, None) == -1        # x.ptr NULL
-    mix.p.n_trials = 2                              # the in-lane one / two-trial sweeps are single-precision paths
-    x = torch.zeros(2, 501, 4)
+    mix.p.n_trials = 1                              # mixed always goes through the operator stream, one trial included
+    assert lib.lqg_workspace_bytes(C.byref(mix.p), _abi.OP_LOG_LIKELIHOOD) == \
+        2 * gains32 + (100 * 501 * 136 * 4 + 255) // 256 * 256
+    x = torch.zeros(1, 501, 4)
     rc = lib.lqg_log_likelihood(C.byref(mix.p), mix.traj(x, False), C.c_void_p(x.data_ptr()), 0, 1,
-                                C.c_void_p(x.data_ptr()), 1 << 40, None)
-    assert rc == -3 and b"n_trials >= 3" in lib.lqg_last_error()
+                                C.c_void_p(x.data_ptr()), 16, None)
+    assert rc == -4 and b"workspace" in lib.lqg_last_error()                                  # too small: refused
     with pytest.raises(_abi.LqgHipError):
         _hip.Launch(m32.actor, m32.dynamics, d=4, n_trials=16, traj_dtype=torch.float64)      # (only f32 over f64 specs)
 

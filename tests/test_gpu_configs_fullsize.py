@@ -140,6 +140,15 @@ def test_small_fp32_batch_over_a_long_horizon_keeps_the_mixed_path():
     assert float((ll.double() / ll64 - 1).abs().max()) < 1e-6
     short, _ = workload.bounded_system(16, 200, seed=9, device=DEV, dtype=torch.float32)
     assert all(wk["fused_pairs"] for wk in LogLikelihoodPlan(short, x[:, :201].contiguous()).work)
+    # one trial per system over the long horizon: the stream path + fp64 system sweeps instead of the in-lane fp32 sweep
+    B1 = 4096
+    m1, _ = workload.bounded_system(B1, T, seed=10, device=DEV, dtype=torch.float32)
+    x1 = workload.simulate_one_trial_each(m1, seed=3)
+    p1 = LogLikelihoodPlan(m1, x1)
+    assert all(wk["mixed"] for wk in p1.work), p1.description
+    l1 = p1.run().clone()
+    l64 = m1.to(torch.float64).log_likelihood(x1.double())
+    assert float((l1.double() / l64 - 1).abs().max()) < 1e-6
 
 
 def test_config5_one_system_1048576_trials_fp32_vs_fp64_sweep(oracle_lib, monkeypatch):
