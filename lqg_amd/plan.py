@@ -45,7 +45,8 @@ SCAN_MAX_COND = float(os.environ.get("LQG_SCAN_MAX_COND", "1e7"))
 # (shards of a trial split agree bitwise); LQG_MIXED_MIN_TRIALS raises the threshold for workloads of many systems with a
 # handful of trials each, where the system sweeps dominate and doubling their cost is not amortised; LQG_MIXED=0 disables.
 MIXED_MIN_TRIALS = int(os.environ.get("LQG_MIXED_MIN_TRIALS", "3"))
-MIXED_LONG_HORIZON = 600        # steps beyond which small fp32 (system, trial) batches are not run as all-fp32 fused pairs
+MIXED_LONG_HORIZON = 600        # steps beyond which an fp32 problem leaves the in-lane sweeps for the stream path, any n
+FUSE_F32_MAX_STEPS = 256        # steps up to which small fp32 (system, trial) batches run as all-fp32 fused pairs
 
 
 def scan_min_steps(m):
@@ -147,8 +148,13 @@ class LogLikelihoodPlan:
             # MIXED, below — where the fused pairs would run every recursion in fp32; §6a: the fp32 tail passes 1e-6 near T = 1000)
             long_f32 = (sub.actor.A.dtype == torch.float32 and sub.T > MIXED_LONG_HORIZON
                         and os.environ.get("LQG_MIXED", "1") != "0")
+            # (fused pairs in fp32 only up to FUSE_F32_MAX_STEPS: worst pair of scripts/fuzz_mixed.py 8.7e-7 at T = 500 —
+            # too close to the north star's 1e-6 for a path that exists for speed on tiny problems; beyond, the stream path
+            # runs MIXED: worst 2.8e-7)
+            short_f32 = not (sub.actor.A.dtype == torch.float32 and sub.T > FUSE_F32_MAX_STEPS
+                             and os.environ.get("LQG_MIXED", "1") != "0")
             fuse_pairs = ((not use_scan) and 2 < n and n_sys0 * n <= FUSE_TRIALS_MAX and _time_invariant(sub)
-                          and not long_f32)
+                          and not long_f32 and short_f32)
             if fuse_pairs:                       # (system, trial) pairs as n_sys0 * n one-trial systems
                 sub, xs, S0 = _pairs_as_systems(sub, xs, S0, n_sys0, n)
                 n_pairs, n = n, 1
