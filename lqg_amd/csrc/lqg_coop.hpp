@@ -159,6 +159,22 @@ LQG_DEV R dot_list(const RowLists& rl, int row, const R* __restrict__ a, int sa,
   return acc;
 }
 
+#ifdef LQG_COOP_STAMP
+// developer build (-DLQG_COOP_STAMP, variant library): cycles per stage of the pipelined forward loop, accumulated by lane 0 of
+// system 0 (read back with lqg_debug_coop_stamps of lqg_coop_inst.hip; scripts/coop_stamps.py)
+__device__ unsigned long long g_coop_stamps[16];
+#define LQG_STAMP(slot_)                                                     \
+  do {                                                                       \
+    if (threadIdx.x == 0 && blockIdx.x == 0) {                               \
+      const unsigned long long now_ = __builtin_readcyclecounter();          \
+      g_coop_stamps[slot_] += now_ - stamp_prev_;                            \
+      stamp_prev_ = now_;                                                    \
+    }                                                                        \
+  } while (0)
+#else
+#define LQG_STAMP(slot_) do { } while (0)
+#endif
+
 template <int BLOCK>
 LQG_DEV void stage_end() {
   __syncthreads();   // workgroup barrier + LDS/global visibility inside the workgroup
@@ -719,6 +735,9 @@ __global__ void __launch_bounds__(BLOCK) k_coop_forward(const Args<R> a) {
   stage_end<BLOCK>();
   hoist2();
   kalman_step(0);
+#ifdef LQG_COOP_STAMP
+  unsigned long long stamp_prev_ = __builtin_readcyclecounter();
+#endif
 
   for (int t = 0; t < a.T; ++t) {
     const bool more = t + 1 < a.T;
@@ -755,21 +774,32 @@ __global__ void __launch_bounds__(BLOCK) k_coop_forward(const Args<R> a) {
     }
     // ---- time-invariant, t > 0: six stages per step, Kalman step t+1 under the joint / Sigma stages of step t
     if (joint) { joint1(t); condF(t); }                      // A
+    LQG_STAMP(0);
     if (more) kal1();
     stage_end<BLOCK>();
+    LQG_STAMP(1);
     if (joint) { joint2(false); cond1(t); }                  // B   (K_t is dead after this stage)
+    LQG_STAMP(2);
     if (more) kal2();
     stage_end<BLOCK>();
+    LQG_STAMP(3);
     if (joint) cond2();                                      // C
+    LQG_STAMP(4);
     if (more) kal3();
     stage_end<BLOCK>();
+    LQG_STAMP(5);
     if (joint) sig1(t);                                      // D
+    LQG_STAMP(6);
     if (more) kal4();
     stage_end<BLOCK>();
+    LQG_STAMP(7);
     if (joint) sig2(t);                                      // E
+    LQG_STAMP(8);
     if (more) kalF();
     stage_end<BLOCK>();
+    LQG_STAMP(9);
     if (more) { kal5(t + 1); stage_end<BLOCK>(); }           // F
+    LQG_STAMP(10);
   }
   // ---- last row: only the density operators of x_T
   if (joint && a.ops) condF(a.T);

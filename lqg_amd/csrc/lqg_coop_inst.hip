@@ -297,3 +297,15 @@ template hipError_t coop_trial<double>(const lqg_problem*, const void*, lqg_traj
 }  // namespace host
 }  // namespace lqg
 #endif  // base translation unit
+
+#if defined(LQG_COOP_STAMP) && !defined(LQG_INST_COOPF) && !defined(LQG_INST_COOPR)
+extern "C" int lqg_debug_coop_stamps(unsigned long long* out16, int reset) {
+  (void)hipDeviceSynchronize();
+  hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(lqg::coop::g_coop_stamps), 16 * sizeof(unsigned long long));
+  if (reset) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(lqg::coop::g_coop_stamps), z, sizeof(z));
+  }
+  return (int)e;
+}
+#endif
