@@ -100,6 +100,14 @@ class Launch:
     def empty(self, *shape):
         return torch.empty(self.lead() + tuple(shape), dtype=self.dtype, device=self.device)
 
+    def empty_system_fastest(self, *shape):
+        """Logical [(B,) *shape] with the SYSTEM index fastest in memory (storage [*shape][B]): one system per lane then
+        reads / writes 64 consecutive elements per (step, entry) — for intermediates that only kernels of this library touch."""
+        if not self.batched:
+            return self.empty(*shape)
+        t = torch.empty(tuple(shape) + (self.B,), dtype=self.dtype, device=self.device)
+        return t.permute(len(shape), *range(len(shape)))
+
     def view(self, t, vector=False):
         return _abi.mat_view(t.data_ptr(), t.shape, _es(t), self.batched, True, vector)
 
@@ -115,21 +123,24 @@ class Launch:
         return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device), nbytes
 
 
-def riccati_backward(spec: LQGSpec, eps=1e-8):
+def riccati_backward(spec: LQGSpec, eps=1e-8, system_fastest=False):
+    """system_fastest: lay the gains out [T][u][b][B] in memory (same logical shape): callers that only hand them on to
+    another kernel of this library (System.simulate) get coalesced writes here and coalesced reads there."""
     ln = Launch(spec, eps=eps)
     lib = ln.require_gpu(_abi.FAM_RICCATI)          # k_riccati is instantiated per (b, u) only
     dm = ln.dims
-    L, l, H = ln.empty(ln.T, dm["u"], dm["b"]), ln.empty(ln.T, dm["u"]), ln.empty(ln.T, dm["u"], dm["u"])
+    mk = ln.empty_system_fastest if system_fastest else ln.empty
+    L, l, H = mk(ln.T, dm["u"], dm["b"]), mk(ln.T, dm["u"]), mk(ln.T, dm["u"], dm["u"])
     with torch.cuda.device(ln.device):
         _abi.check(lib.lqg_riccati_backward(C.byref(ln.p), ln.view(L), ln.view(l, vector=True), ln.view(H),
                                             ln.stream()), "lqg_riccati_backward")
     return L, l, H
 
 
-def kalman_forward(spec: LQGSpec, Sigma0=None):
+def kalman_forward(spec: LQGSpec, Sigma0=None, system_fastest=False):
     ln = Launch(spec, Sigma0=Sigma0)
     lib = ln.require_gpu(_abi.FAM_KALMAN)           # k_kalman is instantiated per (b, y) only
-    K = ln.empty(ln.T, ln.dims["b"], ln.dims["y"])
+    K = (ln.empty_system_fastest if system_fastest else ln.empty)(ln.T, ln.dims["b"], ln.dims["y"])
     with torch.cuda.device(ln.device):
         _abi.check(lib.lqg_kalman_forward(C.byref(ln.p), ln.view(K), ln.stream()), "lqg_kalman_forward")
     return K

@@ -165,8 +165,10 @@ class System:
         Philox keyed by the seed, csrc/lqg_rng.hpp: trial k of system s gets the same draws whatever the batch around it,
         and no [n, T, x + y] noise arrays pass through HBM); a torch.Generator supplies the draws from torch's stream.
         Returns x[n, T+1, xdim]; with return_all also x_hat[n, T+1, bdim], y[n, T, ydim], u[n, T, udim]."""
-        gains = lqr.backward(self.actor)
-        K = kf.forward(self.actor, Sigma0=Sigma0)
+        # (the gains only travel from the two sweeps to the simulate kernel: system-fastest storage, coalesced both ways)
+        L_, l_, H_ = _hip.riccati_backward(self.actor, system_fastest=True)
+        gains = lqr.Gains(L=L_, l=l_, H=H_)
+        K = _hip.kalman_forward(self.actor, Sigma0=Sigma0, system_fastest=True)
         dev, dt = self.actor.A.device, self.actor.A.dtype
         if not isinstance(rng_key, torch.Generator):
             x, x_hat, y, u = _hip.simulate(self.actor, self.dynamics, gains.L, gains.l, K, x0=x0, xhat0=xhat0,
