@@ -566,7 +566,8 @@ def extra_legs(torch, args, dev):
     except Exception as e:
         extra["config5_one_system"] = {"error": repr(e)}
     torch.cuda.empty_cache()
-    # the reference's largest model: DelayedSubjectiveActor (delay 12: x = 26, b = 39, m = 65), cooperative kernels
+    # the reference's largest model: DelayedSubjectiveActor (delay 12: x = 26, b = 39, m = 65): time-parallel system sweeps on
+    # windows of 39 / 63 (k_scan_level_rt) + the row-parallel per-trial sweep
     try:
         from lqg_amd.tracking.delay import DelayedSubjectiveActor
         md = DelayedSubjectiveActor(T=500, device=dev, dtype=torch.float32)
@@ -578,6 +579,18 @@ def extra_legs(torch, args, dev):
             lld, phd = bc.timed_loglik(md, xd, 5)
             legd[f"trials_{nt}"] = {"wall_ms": phd["wall_ms"], "riccati_ms": phd["riccati_ms"], "forward_ms": phd["forward_ms"],
                                     "trial_ms": phd["trial_ms"], "path": phd["path"]}
+        # the same evaluation on the sequential (workgroup-per-system) sweeps, which the default rule leaves for few long systems
+        prev = os.environ.get("LQG_SCAN")
+        os.environ["LQG_SCAN"] = "0"
+        try:
+            _, phs = bc.timed_loglik(md, xd_all[:1].contiguous(), 5)
+            legd["trials_1_sequential_sweeps"] = {"wall_ms": phs["wall_ms"], "riccati_ms": phs["riccati_ms"],
+                                                  "forward_ms": phs["forward_ms"], "trial_ms": phs["trial_ms"], "path": phs["path"]}
+        finally:
+            if prev is None:
+                os.environ.pop("LQG_SCAN", None)
+            else:
+                os.environ["LQG_SCAN"] = prev
         t0 = time.perf_counter()
         legd["max_rel_err_vs_fp64_oracle"] = bc.oracle_check(md, xd_all[:2].contiguous(),
                                                              md.log_likelihood(xd_all[:2].contiguous()), n_samples=2)

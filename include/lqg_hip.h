@@ -167,7 +167,9 @@ int lqg_log_likelihood(const lqg_problem* p, lqg_traj x, void* ll, int64_t ll_sb
  * — then the same per-trial sweep.  For few systems with many steps (one parameter vector x many trials).  Same
  * arguments, same results to rounding (fp64 arithmetic inside, whatever the problem dtype).  Preconditions the CALLER
  * guarantees: the eigenvalue floor of lqr.py:27-28 is inactive (lambda_min(R) >= eps, Q, Qf >= 0 suffice); checked here:
- * no affine cost terms (q, qf, P, r NULL), u, y, d <= 4, y <= b, x + b <= 24, T >= 2 (lqg_scan_supported).
+ * no affine cost terms (q, qf, P, r NULL), u, y, d <= 4, y <= b, T >= 2, and x + b <= 24 (windows in LDS) or b <= 64,
+ * x + b - d <= 64 with the per-step working sets within 160 KB of LDS (windows in registers: the delay-augmented models
+ * of lqg/tracking/delay.py, b = 39, x + b = 65) (lqg_scan_supported).
  * Workspace: lqg_scan_workspace_bytes(p). */
 int lqg_scan_supported(const lqg_problem* p);
 size_t lqg_scan_workspace_bytes(const lqg_problem* p);

@@ -403,7 +403,7 @@ int lqg_log_likelihood_scan_with(const lqg_problem* p, lqg_traj x, void* ll, int
                                  size_t workspace_bytes, void* stream, lqg_trial_sweep_fn trial_sweep) {
   static const char* who = "lqg_log_likelihood_scan";
   if (int rc = check_full(p, who)) return rc;
-  if (!scan_supported(p)) return fail(LQG_ERR_DIMS, "%s: needs u, y, d <= 4, x + b <= 24, no affine cost terms, T >= 2", who);
+  if (!scan_supported(p)) return fail(LQG_ERR_DIMS, "%s: needs u, y, d <= 4, x + b <= 24 (or b <= 64, x + b - d <= 64 with per-step working sets within LDS), no affine cost terms, T >= 2", who);
   if (p->n_sys == 0 || p->n_trials == 0) return 0;
   if (!x.ptr) return fail(LQG_ERR_NULL, "%s: x.ptr is NULL", who);
   if (!ll) return fail(LQG_ERR_NULL, "%s: ll is NULL", who);
@@ -419,7 +419,7 @@ int lqg_conditional_moments_scan(const lqg_problem* p, lqg_traj x, lqg_traj mu, 
                                  size_t workspace_bytes, void* stream) {
   static const char* who = "lqg_conditional_moments_scan";
   if (int rc = check_full(p, who)) return rc;
-  if (!scan_supported(p)) return fail(LQG_ERR_DIMS, "%s: needs u, y, d <= 4, x + b <= 24, no affine cost terms, T >= 2", who);
+  if (!scan_supported(p)) return fail(LQG_ERR_DIMS, "%s: needs u, y, d <= 4, x + b <= 24 (or b <= 64, x + b - d <= 64 with per-step working sets within LDS), no affine cost terms, T >= 2", who);
   if (!x.ptr) return fail(LQG_ERR_NULL, "%s: x.ptr is NULL", who);
   if (p->n_sys == 0) return 0;
   return p->dtype == LQG_F64 ? run_scan_path<double>(p, x, mu, Sigma, nullptr, 0, 0, workspace, workspace_bytes,

@@ -35,6 +35,7 @@ namespace scan {
 
 using D = double;
 constexpr int kWave = 64;
+constexpr int kStepMax = 256;        // lanes per element of the per-step kernels: 64 (16 when packed), 256 for m > 24
 
 template <typename F>
 LQG_DEV void each(int n, F f) {
@@ -189,6 +190,278 @@ constexpr int scan_level_threads(int n, bool packed) {
 }
 constexpr int scan_level_epb(int n, bool packed) { return 256 / scan_level_threads(n, packed); }
 inline size_t scan_level_lds(int n, bool packed) { return (size_t)(14 * n * n + 8) * sizeof(D) * scan_level_epb(n, packed); }
+
+// ---------------------------------------------------------------- one level of the scan, windows of 25 .. 64
+// The delay-augmented models (lqg/tracking/delay.py:9-51: b = 39, m - d = 64 for the reference's DelayedSubjectiveActor)
+// have windows whose 14 n^2 doubles do not fit LDS.  Same combine, same pivoting rule, other data placement — run-time n,
+// ONE element per workgroup of NW waves:
+//   * the n x 3n elimination matrix [I + C1 J2 | A1 | C1] lives in REGISTERS: wave w owns rows w TI .. w TI + TI - 1
+//     (TI = 64 / NW), lane l the columns l, n + l, 2n + l of them — an elimination step costs each lane 3 TI multiply-adds
+//     and TI + 6 LDS reads (the pivot row, the row it displaces and the pivot column are published through LDS; every
+//     wave finds the pivot itself by a wave reduction of the published column: two barriers per column);
+//   * in the five products the left operand of a wave's rows is wave-uniform (scalar loads from the elements in global
+//     memory / L2), the right operand is read from LDS with the lane as the fast index: one LDS read per TI multiply-adds;
+//   * LDS holds two n x (n + 1) panels: J2, then X1 = M^-1 A1 | X2 = M^-1 C1, then T1' | U, then the unsymmetrised C and J
+//     whose mirror entries are averaged through LDS (an odd leading dimension keeps the transposed reads conflict-free).
+// 70 KB of LDS at n = 64 (two workgroups per CU), 28 KB at n = 39; ceil(n / TI) waves are launched.
+#ifdef LQG_SCAN_STAMP
+// developer build (-DLQG_SCAN_STAMP, variant library): cycles per phase of k_scan_level_rt, accumulated by lane 0 of the LAST
+// window of system 0 (read back with lqg_debug_scan_stamps of lqg_scan_inst.hip)
+__device__ unsigned long long g_scan_stamps[16];
+#define LQG_SSTAMP(slot_)                                                        \
+  do {                                                                           \
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && n > 48) { \
+      const unsigned long long now_ = __builtin_readcyclecounter();              \
+      g_scan_stamps[slot_] += now_ - stamp_prev_;                                \
+      stamp_prev_ = now_;                                                        \
+    }                                                                            \
+  } while (0)
+#else
+#define LQG_SSTAMP(slot_) do { } while (0)
+#endif
+// maximum of a 32-bit key over the wave by DPP (row rotations, then the two row broadcasts of gfx9): six v_max_u32 with a
+// DPP operand where six rounds of __shfl_xor on (double, int) cost 18 dependent ds_bpermute round trips (1850 cycles per
+// column, measured).  Every lane of row 3 ends with the maximum; lane 63 is read.
+template <int CTRL, int ROW_MASK>
+LQG_DEV unsigned dpp_max_step(unsigned v) {
+  const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
+  return o > v ? o : v;
+}
+LQG_DEV unsigned wave_max_u32(unsigned v) {
+  v = dpp_max_step<0x121, 0xF>(v);      // row_ror:1
+  v = dpp_max_step<0x122, 0xF>(v);      // row_ror:2
+  v = dpp_max_step<0x124, 0xF>(v);      // row_ror:4
+  v = dpp_max_step<0x128, 0xF>(v);      // row_ror:8   -> every lane holds its row's maximum
+  v = dpp_max_step<0x142, 0xA>(v);      // row_bcast:15 into rows 1, 3
+  v = dpp_max_step<0x143, 0xC>(v);      // row_bcast:31 into rows 2, 3
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// 1 / x to fp64 rounding: v_rcp_f64 and two Newton steps (the IEEE division sequence costs ~40 instructions per column on
+// every wave; the quotient only scales the pivot row)
+LQG_DEV D fast_rcp(D x) {
+  D r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
+// (second launch bound = waves per SIMD.  Two workgroups per CU — 64 VGPRs at 16 waves — spill and run 9 % slower: 1)
+#ifndef LQG_SCAN_RT_WGS_PER_CU
+#define LQG_SCAN_RT_WGS_PER_CU 1
+#endif
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, LQG_SCAN_RT_WGS_PER_CU * NW / 4) k_scan_level_rt(const Seg s0, const Seg s1, const int n) {
+  constexpr int TI = 64 / NW;
+  constexpr int CH = TI <= 8 ? 4 : 2;          // columns of the wave's rows held in scalar registers at a time
+  extern __shared__ double lqg_coop_smem[];
+  const int tid = (int)threadIdx.x, lane = tid & 63, NT = (int)blockDim.x;     // (ceil(n / TI) waves: scan_level_rt_threads)
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nn = n * n, ld = n | 1, panel = n * (n + 1);              // (odd leading dimension: transposed reads conflict-free)
+  int k = (int)blockIdx.x;
+  const bool second = k >= s0.len;
+  if (second) k -= s0.len;
+  const D* in = second ? s1.in : s0.in;
+  D* out = second ? s1.out : s0.out;
+  const int len = second ? s1.len : s0.len, d = second ? s1.d : s0.d, left = second ? s1.left : s0.left;
+  const long sys = blockIdx.y;
+  const long es = 3L * nn;
+  const D* ek = in + (sys * len + k) * es;
+  D* eo = out + (sys * len + k) * es;
+  if (k < d) {                                                        // (workgroup-uniform: no barrier is skipped by a part of it)
+    for (int e = tid; e < 3 * nn; e += NT) eo[e] = ek[e];
+    return;
+  }
+  const D* ep = in + (sys * len + (k - d)) * es;
+  const D* __restrict__ e1 = left ? ek : ep;                          // the window that comes FIRST in time
+  const D* __restrict__ e2 = left ? ep : ek;
+  const D *A1 = e1, *C1 = e1 + nn, *J1 = e1 + 2 * nn, *A2 = e2, *C2 = e2 + nn, *J2 = e2 + 2 * nn;
+  D *P0 = lqg_coop_smem, *P1 = P0 + panel;
+  D *pcol = P1 + panel, *prow = pcol + 128, *crow = prow + 192;
+  const bool lv = lane < n;
+  const int lc = lv ? lane : n - 1;                                   // clamped lane for reads whose result is masked
+  // this wave's rows (clamped: the products of rows >= n are computed on row n - 1 and dropped): wave-uniform row offsets,
+  // so that the left operands of the products are SCALAR loads (no global store precedes the last of them)
+  int ro[TI];
+  LQG_UNROLL for (int r = 0; r < TI; ++r) ro[r] = (w * TI + r < n ? w * TI + r : n - 1) * n;
+#ifdef LQG_SCAN_STAMP
+  unsigned long long stamp_prev_ = __builtin_readcyclecounter();
+#endif
+
+  for (int e = tid; e < nn; e += NT) P0[e] = J2[e];
+  __syncthreads();
+  LQG_SSTAMP(0);
+  // ---- rows of [ I + C1 J2 | A1 | C1 ]: every value read from LDS serves the TI rows of the wave
+  D own[TI][3];
+  {
+    D acc[TI];
+    LQG_UNROLL for (int r = 0; r < TI; ++r) acc[r] = 0.0;
+    int q = 0;
+    for (; q + 4 <= n; q += 4) {
+      const D x0 = P0[q * n + lc], x1 = P0[(q + 1) * n + lc], x2 = P0[(q + 2) * n + lc], x3 = P0[(q + 3) * n + lc];
+      LQG_UNROLL for (int r = 0; r < TI; ++r) {
+        const D* __restrict__ cr = C1 + ro[r] + q;
+        acc[r] = fma(cr[0], x0, acc[r]);
+        acc[r] = fma(cr[1], x1, acc[r]);
+        acc[r] = fma(cr[2], x2, acc[r]);
+        acc[r] = fma(cr[3], x3, acc[r]);
+      }
+    }
+    for (; q < n; ++q) {
+      const D x0 = P0[q * n + lc];
+      LQG_UNROLL for (int r = 0; r < TI; ++r) acc[r] = fma(C1[ro[r] + q], x0, acc[r]);
+    }
+    LQG_UNROLL for (int r = 0; r < TI; ++r) {
+      const int i = w * TI + r;
+      const bool live = lv && i < n;
+      own[r][0] = live ? acc[r] + ((lane == i) ? 1.0 : 0.0) : 0.0;
+      own[r][1] = live ? A1[ro[r] + lc] : 0.0;
+      own[r][2] = live ? C1[ro[r] + lc] : 0.0;
+    }
+  }
+  LQG_SSTAMP(1);
+  // ---- Gauss-Jordan with partial pivoting.  The pivot is the largest |entry| of the column compared on the sign-less
+  // high word of the double with its low six bits replaced by the row (exponent + 14 mantissa bits decide, lowest row on
+  // ties): a pivot within 2^-14 of the largest — the growth bound of partial pivoting is unchanged to that factor.
+  for (int c = 0; c < n; ++c) {
+    D* pc = pcol + (c & 1) * 64;
+    if (lane == c) {
+      LQG_UNROLL for (int r = 0; r < TI; ++r) pc[w * TI + r] = own[r][0];
+    }
+    __syncthreads();
+    LQG_SSTAMP(2);
+    const D mine = pc[lane];                                          // (lanes >= n read the zero rows' entries)
+    D ci[TI];                                                         // this wave's column entries
+    LQG_UNROLL for (int r = 0; r < TI; ++r) ci[r] = pc[w * TI + r];
+    const unsigned hi = (unsigned)__double2hiint(mine) & 0x7fffffffu;
+    const unsigned key = (lane >= c && lv) ? ((hi & ~63u) | (unsigned)(63 - lane)) : 0u;
+    const int p = 63 - (int)(wave_max_u32(key) & 63u);
+    LQG_SSTAMP(3);
+    // the pivot and the entry of row c straight from the lanes that hold them (no second LDS round trip)
+    const D pv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine), p), __builtin_amdgcn_readlane(__double2loint(mine), p));
+    const D colc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine), c), __builtin_amdgcn_readlane(__double2loint(mine), c));
+    const D pinv = fast_rcp(pv);
+    const int wp = p / TI, wc = c / TI;
+    if (w == wp) {
+      LQG_UNROLL for (int r = 0; r < TI; ++r)
+        if (r == p % TI) { LQG_UNROLL for (int q = 0; q < 3; ++q) prow[q * 64 + lane] = own[r][q]; }
+    }
+    if (w == wc) {
+      LQG_UNROLL for (int r = 0; r < TI; ++r)
+        if (r == c % TI) { LQG_UNROLL for (int q = 0; q < 3; ++q) crow[q * 64 + lane] = own[r][q]; }
+    }
+    __syncthreads();
+    LQG_SSTAMP(4);
+    D pr[3];
+    LQG_UNROLL for (int q = 0; q < 3; ++q) pr[q] = prow[q * 64 + lane] * pinv;
+    if (w != wp && w != wc) {                                         // (most waves: neither the pivot row nor row c)
+      LQG_UNROLL for (int r = 0; r < TI; ++r)
+        LQG_UNROLL for (int q = 0; q < 3; ++q) own[r][q] = fma(-ci[r], pr[q], own[r][q]);
+    } else {
+      D cr[3];
+      LQG_UNROLL for (int q = 0; q < 3; ++q) cr[q] = crow[q * 64 + lane];
+      LQG_UNROLL for (int r = 0; r < TI; ++r) {
+        const int i = w * TI + r;
+        const bool isp = i == p, isc = i == c;                        // (rows c and p change places)
+        const D coef = isp ? colc : ci[r];
+        LQG_UNROLL for (int q = 0; q < 3; ++q) {
+          const D v = fma(-coef, pr[q], isp ? cr[q] : own[r][q]);
+          own[r][q] = isc ? pr[q] : v;
+        }
+      }
+    }
+    LQG_SSTAMP(5);
+  }
+  // ---- X1 = M^-1 A1 -> P0, X2 = M^-1 C1 -> P1   (J2's copy in P0 was last read before the elimination's barriers)
+  LQG_UNROLL for (int r = 0; r < TI; ++r) {
+    const int i = w * TI + r;
+    if (i < n && lv) { P0[i * n + lane] = own[r][1]; P1[i * n + lane] = own[r][2]; }
+  }
+  __syncthreads();
+  LQG_SSTAMP(6);
+  // ---- A = A2 X1, T1 = A2 X2, U = J2 X1: accumulated in registers, then T1' -> P0 and U -> P1 once X1, X2 are dead
+  D aA[TI], aT[TI], aU[TI];
+  LQG_UNROLL for (int r = 0; r < TI; ++r) { aA[r] = 0.0; aT[r] = 0.0; aU[r] = 0.0; }
+  {                                                                   // (one left operand per loop: its CH-column chunks of the
+    int q = 0;                                                        //  wave's rows fit the scalar registers)
+    for (; q + CH <= n; q += CH) {
+      D x1[CH], x2[CH];
+      LQG_UNROLL for (int j = 0; j < CH; ++j) { x1[j] = P0[(q + j) * n + lc]; x2[j] = P1[(q + j) * n + lc]; }
+      LQG_UNROLL for (int r = 0; r < TI; ++r) {
+        const D* __restrict__ a2 = A2 + ro[r] + q;
+        LQG_UNROLL for (int j = 0; j < CH; ++j) { aA[r] = fma(a2[j], x1[j], aA[r]); aT[r] = fma(a2[j], x2[j], aT[r]); }
+      }
+    }
+    for (; q < n; ++q) {
+      const D x10 = P0[q * n + lc], x20 = P1[q * n + lc];
+      LQG_UNROLL for (int r = 0; r < TI; ++r) {
+        aA[r] = fma(A2[ro[r] + q], x10, aA[r]);
+        aT[r] = fma(A2[ro[r] + q], x20, aT[r]);
+      }
+    }
+    for (q = 0; q + CH <= n; q += CH) {
+      D x1[CH];
+      LQG_UNROLL for (int j = 0; j < CH; ++j) x1[j] = P0[(q + j) * n + lc];
+      LQG_UNROLL for (int r = 0; r < TI; ++r) {
+        const D* __restrict__ j2 = J2 + ro[r] + q;
+        LQG_UNROLL for (int j = 0; j < CH; ++j) aU[r] = fma(j2[j], x1[j], aU[r]);
+      }
+    }
+    for (; q < n; ++q) {
+      const D x10 = P0[q * n + lc];
+      LQG_UNROLL for (int r = 0; r < TI; ++r) aU[r] = fma(J2[ro[r] + q], x10, aU[r]);
+    }
+  }
+  __syncthreads();                                                    // (X1, X2 dead)
+  LQG_UNROLL for (int r = 0; r < TI; ++r) {
+    const int i = w * TI + r;
+    if (i < n && lv) { P0[lane * ld + i] = aT[r]; P1[i * n + lane] = aU[r]; }
+  }
+  __syncthreads();
+  LQG_SSTAMP(7);
+  // ---- unsymmetrised C(b, a) = sum_k T1(b, k) A2(a, k)  (a = this wave's rows, b = lane: rows of A2 are the scalar operand)
+  //      and           J(a, b) = sum_k A1(k, a) U(k, b)   (the TI consecutive entries A1(k, a..) are the scalar operand)
+  D gC[TI], gJ[TI];
+  LQG_UNROLL for (int r = 0; r < TI; ++r) { gC[r] = 0.0; gJ[r] = 0.0; }
+  {
+    int q = 0;
+    for (; q + CH <= n; q += CH) {
+      D t[CH], uq[CH];
+      LQG_UNROLL for (int j = 0; j < CH; ++j) { t[j] = P0[(q + j) * ld + lc]; uq[j] = P1[(q + j) * n + lc]; }
+      const D* __restrict__ a1 = A1 + q * n + w * TI;
+      LQG_UNROLL for (int r = 0; r < TI; ++r) {
+        const D* __restrict__ a2 = A2 + ro[r] + q;
+        LQG_UNROLL for (int j = 0; j < CH; ++j) { gC[r] = fma(t[j], a2[j], gC[r]); gJ[r] = fma(a1[j * n + r], uq[j], gJ[r]); }
+      }
+    }
+    for (; q < n; ++q) {
+      const D t0 = P0[q * ld + lc], u0 = P1[q * n + lc];
+      const D* __restrict__ a1 = A1 + q * n + w * TI;
+      LQG_UNROLL for (int r = 0; r < TI; ++r) {
+        gC[r] = fma(t0, A2[ro[r] + q], gC[r]);
+        gJ[r] = fma(a1[r], u0, gJ[r]);
+      }
+    }
+  }
+  __syncthreads();                                                    // (T1', U dead)
+  LQG_SSTAMP(8);
+  // ---- outputs; the mirror entries of C and J are averaged through LDS (C2, J1 are exactly symmetric: they were made so)
+  LQG_UNROLL for (int r = 0; r < TI; ++r) {
+    const int a = w * TI + r;
+    if (a < n && lv) { eo[a * n + lane] = aA[r]; P0[a * ld + lane] = gC[r]; P1[a * ld + lane] = gJ[r]; }
+  }
+  __syncthreads();
+  LQG_UNROLL for (int r = 0; r < TI; ++r) {
+    const int a = w * TI + r;
+    if (a < n && lv) {
+      eo[nn + a * n + lane] = 0.5 * (P0[a * ld + lane] + P0[lane * ld + a]) + C2[a * n + lane];
+      eo[2 * nn + a * n + lane] = 0.5 * (P1[a * ld + lane] + P1[lane * ld + a]) + J1[a * n + lane];
+    }
+  }
+  LQG_SSTAMP(9);
+}
+constexpr int kScanRtMax = 64;            // largest window of k_scan_level_rt (one lane per column)
+inline size_t scan_level_rt_lds(int n) { return (size_t)(2 * n * (n + 1) + 128 + 192 + 192 + 64) * sizeof(D); }
+inline int scan_level_rt_threads(int n, int nw) { const int ti = 64 / nw; return (n + ti - 1) / ti * 64; }
 
 // ---------------------------------------------------------------- per-step kernels
 template <typename R>
@@ -386,7 +659,7 @@ LQG_DEV void kgain_step(const Args<R>& a, D* sm, int t, long s) {
 // 0 .. T: Riccati, T+1 .. 2T: Kalman), their scans advance in the same launches (k_scan_level's two segments), and one
 // launch turns the results into the gains L_t (blocks 0 .. T-1) and K_t (T .. 2T-1).
 template <typename R>
-__global__ void __launch_bounds__(kWave) k_scan_build_rk(const Args<R> a) {
+__global__ void __launch_bounds__(kStepMax) k_scan_build_rk(const Args<R> a) {
   extern __shared__ double lqg_coop_smem[];
   const int k = elem_index();
   if (k > 2 * a.T) return;
@@ -395,7 +668,7 @@ __global__ void __launch_bounds__(kWave) k_scan_build_rk(const Args<R> a) {
   else build_kalman(a, sm, k - (a.T + 1), (long)blockIdx.y);
 }
 template <typename R>
-__global__ void __launch_bounds__(kWave) k_scan_gains_rk(const Args<R> a) {
+__global__ void __launch_bounds__(kStepMax) k_scan_gains_rk(const Args<R> a) {
   extern __shared__ double lqg_coop_smem[];
   const int k = elem_index();
   if (k >= 2 * a.T) return;
@@ -469,7 +742,7 @@ inline __host__ __device__ long joint_scratch(int x, int b, int u, int y) {
 // moment-recursion elements (index k = 0 .. T-1: the conditional covariance after conditioning on x_k); block k also
 // stores the joint system of step k-1.  Grid: T + 1 blocks (block T only stores the joint system of step T-1).
 template <typename R>
-__global__ void __launch_bounds__(kWave) k_scan_build_sigma(const Args<R> a) {
+__global__ void __launch_bounds__(kStepMax) k_scan_build_sigma(const Args<R> a) {
   extern __shared__ double lqg_coop_smem[];
   const int k = elem_index(), m = a.x + a.b, o = a.d, mm2 = m * m;
   if (k > a.T) return;
@@ -518,7 +791,7 @@ __global__ void __launch_bounds__(kWave) k_scan_build_sigma(const Args<R> a) {
 
 // trial operators of step t (t = 0 .. T) from the predictive covariance Sigma_t                system.py:219-230, 244-248
 template <typename R>
-__global__ void __launch_bounds__(kWave) k_scan_ops(const Args<R> a) {
+__global__ void __launch_bounds__(kStepMax) k_scan_ops(const Args<R> a) {
   extern __shared__ double lqg_coop_smem[];
   const int t = elem_index(), m = a.x + a.b, o = a.d, rr = m - o, mm2 = m * m;
   if (t > a.T) return;

@@ -1,5 +1,7 @@
 // lqg_scan_inst.hip — host side of the time-parallel system sweeps (lqg_scan.hpp): workspace accounting and the launch
 // sequence  elements -> log2(T) scan levels -> per-step finalisers  for the Riccati, Kalman and moment recursions.
+#include <cstdlib>
+
 #include "lqg_scan.hpp"
 #include "lqg_coop_launch.hpp"
 #include "lqg_launch.hpp"
@@ -50,6 +52,25 @@ void launch_level(const scan::Seg& s0, const scan::Seg& s1, long n_sys, hipStrea
     launch_level_v<N, false>(s0, s1, n_sys, st);
 }
 
+template <int NW>
+void launch_level_rt_v(const scan::Seg& s0, const scan::Seg& s1, int n, long n_sys, hipStream_t st) {
+  auto kern = scan::k_scan_level_rt<NW>;
+  const size_t lds = scan::scan_level_rt_lds(n);
+  static size_t raised = 0;           // (an attribute of the kernel, not of the launch: raised once per size)
+  if (lds > 64 * 1024 && lds > raised) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
+      raised = lds;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(s0.len + s1.len), (unsigned)n_sys), dim3(scan::scan_level_rt_threads(n, NW)), lds, st, s0, s1, n);
+}
+void launch_level_rt(const scan::Seg& s0, const scan::Seg& s1, int n, long n_sys, hipStream_t st) {
+  // 16 waves per window (4 rows each): the elimination is bound by its two barriers and LDS round trips per column, not by
+  // issue — delay12 system sweeps 7.0 / 4.5 / 4.1 ms at 4 / 8 / 16 waves (LQG_SCAN_RT_WAVES=8 keeps the A/B)
+  static const int waves = [] { const char* e = getenv("LQG_SCAN_RT_WAVES"); return e ? atoi(e) : 16; }();
+  if (waves == 8) launch_level_rt_v<8>(s0, s1, n, n_sys, st);
+  else launch_level_rt_v<16>(s0, s1, n, n_sys, st);
+}
+
 // Hillis-Steele over one or two independent sequences of n x n triples (segment i: len[i] elements starting in in[i],
 // ping-ponging with out[i]); on return res[i] is the buffer holding segment i's result.
 void run_scan(int n, int nseg, D* const in[2], D* const out[2], const int len[2], const int left[2], long n_sys,
@@ -68,7 +89,9 @@ void run_scan(int n, int nseg, D* const in[2], D* const out[2], const int len[2]
       LQG_SCAN_CASE(13) LQG_SCAN_CASE(14) LQG_SCAN_CASE(15) LQG_SCAN_CASE(16) LQG_SCAN_CASE(17) LQG_SCAN_CASE(18)
       LQG_SCAN_CASE(19) LQG_SCAN_CASE(20) LQG_SCAN_CASE(21) LQG_SCAN_CASE(22) LQG_SCAN_CASE(23) LQG_SCAN_CASE(24)
 #undef LQG_SCAN_CASE
-      default: break;                 // (scan_supported: n <= 24)
+      default:                        // windows of 25 .. 64 (scan_supported): registers + scalar operands, run-time n
+        launch_level_rt(s0, s1, n, n_sys, st);
+        break;
     }
     for (int i = 0; i < 2; ++i) { D* t = a[i]; a[i] = b[i]; b[i] = t; }
   }
@@ -95,11 +118,26 @@ scan::Args<R> make_scan_args(const lqg_problem* p) {
 }
 }  // namespace
 
+// LDS doubles per element of the four per-step kernels
+struct StepLds { long build_rk, gains_rk, build_sigma, ops; };
+StepLds step_lds(const lqg_dims& d) {
+  const long x = d.x, b = d.b, u = d.u, y = d.y, o = d.d, m = x + b, mx = b > y ? b : y;
+  return StepLds{12L * mx * mx + 2 * b * u + 2 * u * u + 8, 12L * mx * mx + 3 * b * u + 3 * u * u + 8,
+                 3L * m * m + o * o + m * o + scan::joint_scratch((int)x, (int)b, (int)u, (int)y) + 16, 2L * m * m + o * o + 8};
+}
+constexpr long kLdsMaxDoubles = 160 * 1024 / 8;
+
 bool scan_supported(const lqg_problem* p) {
   const lqg_dims& d = p->dims;
   const int m = d.x + d.b;
-  return d.u >= 1 && d.y >= 1 && d.d >= 1 && d.u <= 4 && d.y <= 4 && d.d <= 4 && d.y <= d.b && d.d <= d.x && m <= 24 &&
-         p->T >= 2 && !affine(p);
+  if (!(d.u >= 1 && d.y >= 1 && d.d >= 1 && d.u <= 4 && d.y <= 4 && d.d <= 4 && d.y <= d.b && d.d <= d.x && p->T >= 2 &&
+        !affine(p)))
+    return false;
+  if (m <= 24) return true;
+  // larger windows (the delay-augmented models): one lane per column of a window, per-step working sets within LDS
+  const StepLds l = step_lds(d);
+  return d.b <= scan::kScanRtMax && m - d.d <= scan::kScanRtMax && l.build_rk <= kLdsMaxDoubles && l.gains_rk <= kLdsMaxDoubles &&
+         l.build_sigma <= kLdsMaxDoubles && l.ops <= kLdsMaxDoubles;
 }
 
 size_t scan_workspace_bytes(const lqg_problem* p) { return scan_plan(p).total; }
@@ -119,14 +157,20 @@ hipError_t scan_system_sweeps(const lqg_problem* p, lqg_view Sig, void* workspac
   *ops_out = k.ops;
   const int T = p->T, x = p->dims.x, b = p->dims.b, u = p->dims.u, y = p->dims.y, o = p->dims.d, m = x + b;
   const unsigned B = (unsigned)p->n_sys;
-  const int mx = b > y ? b : y;
   // lanes per element x elements per (single-wave) workgroup of the per-step kernels: sub-wave once a launch holds
   // thousands of small elements (36 candidates of a 4 x 4 model: the four kernels 168 -> ~60 us)
   const bool packed = (long)p->n_sys * T >= 4096 && m <= 8;
-  const dim3 blk(packed ? 16 : 64, packed ? 4 : 1);
+  const dim3 blk(packed ? 16 : m > 24 ? scan::kStepMax : 64, packed ? 4 : 1);      // (m > 24: four waves per element)
+  const StepLds sl = step_lds(p->dims);
+  hipError_t attr = hipSuccess;
   auto launch = [&](auto kern, int count, long lds_doubles) {
     k.lds_elem = (int)lds_doubles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((count + blk.y - 1) / blk.y), B), blk, (size_t)lds_doubles * blk.y * sizeof(D), st, k);
+    const size_t lds = (size_t)lds_doubles * blk.y * sizeof(D);
+    if (lds > 64 * 1024) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) attr = e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((count + blk.y - 1) / blk.y), B), blk, lds, st, k);
   };
   // ---- Riccati (suffix scan over T + 1 elements, reversed storage) and Kalman (prefix scan over T elements) side by side
   {
@@ -136,11 +180,11 @@ hipError_t scan_system_sweeps(const lqg_problem* p, lqg_view Sig, void* workspac
     const D* res[2];
     k.elems = in[0];
     k.elems2 = in[1];
-    launch(scan::k_scan_build_rk<R>, 2 * T + 1, 12L * mx * mx + 2 * b * u + 2 * u * u + 8);
+    launch(scan::k_scan_build_rk<R>, 2 * T + 1, sl.build_rk);
     run_scan(b, 2, in, out, len, left, p->n_sys, res, st);
     k.res = res[0];
     k.res2 = res[1];
-    launch(scan::k_scan_gains_rk<R>, 2 * T, 12L * mx * mx + 3 * b * u + 3 * u * u + 8);
+    launch(scan::k_scan_gains_rk<R>, 2 * T, sl.gains_rk);
   }
   // ---- moment recursion: joint system per step, prefix scan over T elements of m x m, operators
   {
@@ -149,12 +193,12 @@ hipError_t scan_system_sweeps(const lqg_problem* p, lqg_view Sig, void* workspac
     const int len[2] = {T, 0}, left[2] = {0, 0};
     const D* res[2];
     k.elems = in[0];
-    launch(scan::k_scan_build_sigma<R>, T + 1, 3L * m * m + o * o + m * o + scan::joint_scratch(x, b, u, y) + 16);
+    launch(scan::k_scan_build_sigma<R>, T + 1, sl.build_sigma);
     run_scan(m - o, 1, in, out, len, left, p->n_sys, res, st);     // (elements on the unobserved block: lqg_scan.hpp)
     k.res = res[0];
   }
-  launch(scan::k_scan_ops<R>, T + 1, 2L * m * m + o * o + 8);
-  return hipGetLastError();
+  launch(scan::k_scan_ops<R>, T + 1, sl.ops);
+  return attr != hipSuccess ? attr : hipGetLastError();
 }
 
 template hipError_t scan_system_sweeps<float>(const lqg_problem*, lqg_view, void*, void**, hipStream_t);
@@ -162,3 +206,15 @@ template hipError_t scan_system_sweeps<double>(const lqg_problem*, lqg_view, voi
 
 }  // namespace host
 }  // namespace lqg
+
+#ifdef LQG_SCAN_STAMP
+extern "C" int lqg_debug_scan_stamps(unsigned long long* out16, int reset) {
+  (void)hipDeviceSynchronize();
+  hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(lqg::scan::g_scan_stamps), 16 * sizeof(unsigned long long));
+  if (reset) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(lqg::scan::g_scan_stamps), z, sizeof(z));
+  }
+  return (int)e;
+}
+#endif

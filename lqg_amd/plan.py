@@ -58,12 +58,18 @@ def scan_min_steps(m):
     return int(max(64, 6000 / (m * m)))
 
 
-def scan_max_systems(m):
+def scan_max_systems(m, fp64=False):
     """(fp64 problems would tolerate twice as many on the GPU timeline — their sequential sweeps are ~1.5x slower, the scans
     are fp64 either way — but for a throw-away plan the scan route's extra host checks eat the difference: one vector's
     central differences, 9 systems x 50 trials at m = 4 in fp64: 1.01 ms fused pairs / 1.12 ms scans end to end.)"""
     if SCAN_MAX_SYSTEMS > 0:
         return SCAN_MAX_SYSTEMS
+    if m > 24:
+        # windows of 25 .. 64 (k_scan_level_rt: one 1024-lane workgroup per window, ~0.1 ms per combine, a level of one system's
+        # 500 windows already fills the chip twice): DelayedSubjectiveActor (m = 65, T = 500) 3.8 ms of system sweeps per
+        # system against 11.7 ms (fp32) / 24.8 ms (fp64) for the cooperative sequential sweeps of ANY number of systems
+        # up to one per CU
+        return 4 if fp64 else 2
     return int(min(64, max(8, 8 * (m / 4.0) ** 2)))
 
 
@@ -92,7 +98,7 @@ def scan_eligible(lib, ln, sub, eps, systems_scale=1):
     mode = os.environ.get("LQG_SCAN", "")
     if mode == "0" or not hasattr(lib, "lqg_log_likelihood_scan"):
         return False
-    if mode != "1" and not (ln.B <= min(64, systems_scale * scan_max_systems(ln.m)) and ln.T >= scan_min_steps(ln.m)):
+    if mode != "1" and not (ln.B <= min(64, (1 if ln.m > 24 else systems_scale) * scan_max_systems(ln.m, ln.dtype == torch.float64)) and ln.T >= scan_min_steps(ln.m)):
         return False
     if not lib.lqg_scan_supported(C.byref(ln.p)):
         return False

@@ -15,12 +15,11 @@ pytestmark = pytest.mark.gpu
 
 TOL = {torch.float64: dict(ll=1e-10, mat=1e-9), torch.float32: dict(ll=1e-6, mat=2e-5)}
 AFFINE = {"timevarying_T30"}                    # q, r, P, qf non-zero: not a scan case (falls back to the sequential kernels)
-BIG = {"delay12_subjective1d_T30"}              # x + b = 65 > 24
 ILL = {"pointmass_d4_T50"}
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
-@pytest.mark.parametrize("name", [n for n in golden_names() if n not in AFFINE | BIG])
+@pytest.mark.parametrize("name", [n for n in golden_names() if n not in AFFINE])
 def test_scan_sweeps_match_golden(name, dtype, monkeypatch):
     from lqg_amd import _hip
     from lqg_amd.plan import LogLikelihoodPlan
@@ -85,6 +84,30 @@ def test_scan_and_sequential_sweeps_agree_at_full_horizon(model, monkeypatch):
     assert e_scan < max(2e-6, 1.5 * e_seq), (e_scan, e_seq)
 
 
+def test_delay_model_windows_of_64_against_the_sequential_kernels(monkeypatch):
+    """The reference's largest model (DelayedSubjectiveActor, lqg/tracking/delay.py:44-51: x = 26, b = 39) at T = 500:
+    windows of 39 (Riccati, Kalman) and 63 (moment recursion) on k_scan_level_rt against the cooperative sequential
+    sweeps, one system and a handful of candidates."""
+    from lqg_amd.plan import LogLikelihoodPlan
+    from lqg_amd.tracking.delay import DelayedSubjectiveActor
+    dev = torch.device("cuda")
+    for kw in (dict(), dict(sigma_target=torch.tensor([3.0, 6.0, 11.0], dtype=torch.float64, device=dev))):
+        m = DelayedSubjectiveActor(T=500, device=dev, dtype=torch.float64, **kw)
+        with torch.no_grad():
+            x = m.simulate(5, n=6)[..., :2].contiguous()
+        monkeypatch.setenv("LQG_SCAN", "0")
+        p0 = LogLikelihoodPlan(m, x)
+        assert not any(wk["scan"] for wk in p0.work)
+        ref = p0.run().clone()
+        monkeypatch.delenv("LQG_SCAN")
+        p1 = LogLikelihoodPlan(m, x)
+        assert all(wk["scan"] for wk in p1.work), p1.description          # (the default for few long systems)
+        got = p1.run().clone()
+        assert got.shape == ref.shape and float((got / ref - 1).abs().max()) < 1e-10
+        got32 = LogLikelihoodPlan(m.to(torch.float32), x.float()).run().clone()
+        assert float((got32.double() / ref - 1).abs().max()) < 1e-6
+
+
 def test_scan_is_the_default_for_one_long_system_and_not_for_batches():
     import lqg_amd
     from lqg_amd.plan import LogLikelihoodPlan
@@ -142,6 +165,39 @@ def test_time_parallel_path_on_random_dense_systems(oracle_lib, case, monkeypatc
         assert np.abs(ll - ref_ll).max() < 1e-9 * np.abs(ref_ll).max(), (chunks, np.abs(ll - ref_ll).max())
     from lqg_amd import _hip
     mu, Sig = _hip.conditional_moments(sys_.actor, sys_.dynamics, xt, Sigma0=S0t)
+    assert np.abs(np_(mu) - ref_mu).max() < 1e-8 * max(1.0, np.abs(ref_mu).max())
+    assert np.abs(np_(Sig) - ref_Sig).max() < 1e-8 * max(1.0, np.abs(ref_Sig).max())
+
+
+@pytest.mark.parametrize("case", range(4))
+def test_windows_of_25_to_64_on_random_dense_systems(oracle_lib, case, monkeypatch):
+    """Dense random systems whose scan windows exceed LDS (k_scan_level_rt: elimination in registers, run-time n), sizes
+    that are not multiples of the 8 rows a wave owns, time-varying specs, partial observation — against the fp64 C oracle."""
+    import lqg_amd
+    from gpu_common import to_spec
+    from lqg_amd.plan import LogLikelihoodPlan
+    from test_gpu_random import random_system
+    rng = np.random.default_rng(7100 + case)
+    x, b, u, y, d = [(9, 25, 2, 3, 3), (12, 31, 1, 2, 1), (26, 39, 1, 1, 2), (18, 33, 3, 4, 4)][case]
+    T = int(rng.integers(40, 90))
+    actor, dyn = random_system(rng, x, b, u, y, T, bool(case & 1), affine=False)
+    for spec in (actor, dyn):
+        rho = max(np.abs(np.linalg.eigvals(spec["A"][t])).max() for t in range(0, T, 7))
+        spec["A"] = spec["A"] * min(1.0, 0.97 / rho)
+    n = 3
+    X, _, _, _ = oracle_lib.simulate(actor, dyn, rng.standard_normal((n, T, x)), rng.standard_normal((n, T, y)))
+    xs = X[..., :d]
+    ref_ll = oracle_lib.log_likelihood(actor, dyn, xs, None)
+    ref_mu, ref_Sig = oracle_lib.conditional_moments(actor, dyn, xs, None)
+    sys_ = lqg_amd.System(actor=to_spec(actor, torch.float64), dynamics=to_spec(dyn, torch.float64))
+    xt = torch.as_tensor(xs, dtype=torch.float64, device="cuda")
+    monkeypatch.setenv("LQG_SCAN", "1")
+    plan = LogLikelihoodPlan(sys_, xt)
+    assert all(wk["scan"] for wk in plan.work), plan.description
+    ll = np_(plan.run().clone())
+    assert np.abs(ll - ref_ll).max() < 1e-9 * np.abs(ref_ll).max(), np.abs(ll - ref_ll).max()
+    from lqg_amd import _hip
+    mu, Sig = _hip.conditional_moments(sys_.actor, sys_.dynamics, xt)
     assert np.abs(np_(mu) - ref_mu).max() < 1e-8 * max(1.0, np.abs(ref_mu).max())
     assert np.abs(np_(Sig) - ref_Sig).max() < 1e-8 * max(1.0, np.abs(ref_Sig).max())
 
