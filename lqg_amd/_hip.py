@@ -215,6 +215,9 @@ def solve_materialised(actor, dynamics, x, Sigma0=None, eps=1e-8, out=None):
     return o
 
 
+LANE_MAX_JOINT = 20             # largest x + b a lane (register-resident) kernel is generated for (tracking/delay.py)
+
+
 def specialised_entry(ln, system, d):
     """The structure-specialised `lqg_log_likelihood_sp` for this launch, or None (lqg_amd/specialize.py)."""
     lib = specialised_library(ln, system, d)
@@ -229,6 +232,8 @@ def specialised_library(ln, system, d, check_strategy=True):
     import os
     if system is None or os.environ.get("LQG_NO_SPECIALIZE") == "1" or ln.p.n_trials < 1:
         return None
+    if ln.m > LANE_MAX_JOINT:
+        return None             # (pattern libraries hold lane kernels: one system's matrices in registers)
     if check_strategy and _abi.load().lqg_strategy(C.byref(ln.p)) == _abi.STRATEGY_COOP:
         return None             # few systems of a large joint dimension: the cooperative kernels of the main library
     p = ln.p

@@ -21,6 +21,9 @@ python3 scripts/small_batch.py 2> /dev/null | grep -v amdgpu > gpurun_out/${TAG}
 python3 scripts/small_batch.py f64 2> /dev/null | grep -v amdgpu > gpurun_out/${TAG}_small_batch_f64.txt
 python3 scripts/delay12_time.py 2> /dev/null | grep -v amdgpu > gpurun_out/${TAG}_delay12.txt
 python3 scripts/fp32_tail.py 2> /dev/null | grep -v amdgpu > gpurun_out/${TAG}_fp32_tail.txt
+# the delay model on the time-parallel sweeps: kernel timeline of one evaluation (+ rocprofv3 stats under prof_delay12/)
+bash scripts/delay12_profile.sh > gpurun_out/${TAG}_delay12_timeline.txt 2>&1
+cp gpurun_out/prof_delay12/p_kernel_stats.csv gpurun_out/${TAG}_delay12_kernel_stats.csv 2> /dev/null
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_cfg2 -o p -- python3 bench_configs.py --configs 2 > /dev/null 2>&1
 python3 - <<PY > gpurun_out/${TAG}_timeline_config2.txt
