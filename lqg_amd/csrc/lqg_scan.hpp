@@ -35,7 +35,7 @@ namespace scan {
 
 using D = double;
 constexpr int kWave = 64;
-constexpr int kStepMax = 256;        // lanes per element of the per-step kernels: 64 (16 when packed), 256 for m > 24
+constexpr int kStepMax = 1024;       // lanes per element of the per-step kernels: 64 (16 when packed), 1024 for m > 24
 
 template <typename F>
 LQG_DEV void each(int n, F f) {

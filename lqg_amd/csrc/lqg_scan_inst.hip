@@ -160,7 +160,7 @@ hipError_t scan_system_sweeps(const lqg_problem* p, lqg_view Sig, void* workspac
   // lanes per element x elements per (single-wave) workgroup of the per-step kernels: sub-wave once a launch holds
   // thousands of small elements (36 candidates of a 4 x 4 model: the four kernels 168 -> ~60 us)
   const bool packed = (long)p->n_sys * T >= 4096 && m <= 8;
-  const dim3 blk(packed ? 16 : m > 24 ? scan::kStepMax : 64, packed ? 4 : 1);      // (m > 24: four waves per element)
+  const dim3 blk(packed ? 16 : m > 24 ? scan::kStepMax : 64, packed ? 4 : 1);      // (m > 24: sixteen waves per element)
   const StepLds sl = step_lds(p->dims);
   hipError_t attr = hipSuccess;
   auto launch = [&](auto kern, int count, long lds_doubles) {
