@@ -28,6 +28,9 @@
 // but P enters G), eigenvalue floor provably inactive (lqr.py:27-28 is not a linear-fractional map when active), u, y,
 // d <= 4.  Time-varying specs are fine (elements are per step).
 #pragma once
+#include <type_traits>
+#include <utility>
+
 #include "lqg_coop.hpp"
 
 namespace lqg {
@@ -199,11 +202,11 @@ inline size_t scan_level_lds(int n, bool packed) { return (size_t)(14 * n * n + 
 //     (TI = 64 / NW), lane l the columns l, n + l, 2n + l of them — an elimination step costs each lane 3 TI multiply-adds
 //     and TI + 6 LDS reads (the pivot row, the row it displaces and the pivot column are published through LDS; every
 //     wave finds the pivot itself by a wave reduction of the published column: two barriers per column);
-//   * in the five products the left operand of a wave's rows is wave-uniform (scalar loads from the elements in global
-//     memory / L2), the right operand is read from LDS with the lane as the fast index: one LDS read per TI multiply-adds;
-//   * LDS holds two n x (n + 1) panels: J2, then X1 = M^-1 A1 | X2 = M^-1 C1, then T1' | U, then the unsymmetrised C and J
-//     whose mirror entries are averaged through LDS (an odd leading dimension keeps the transposed reads conflict-free).
-// 70 KB of LDS at n = 64 (two workgroups per CU), 28 KB at n = 39; ceil(n / TI) waves are launched.
+//   * the six n x n x n products run on the fp64 matrix core: 16 x 16 output tiles dealt to the waves, operands straight from
+//     the elements in global memory (L2) or from LDS panels (mfma_tile);
+//   * LDS holds four n x (n + 1) panels: M, then X1 = M^-1 A1 | X2 = M^-1 C1 | T1 = A2 X2 | U = J2 X1, then the unsymmetrised
+//     C and J whose mirror entries are averaged through LDS (an odd leading dimension keeps the strided reads conflict-free).
+// 137 KB of LDS at n = 64, 54 KB at n = 39; ceil(n / TI) waves are launched.
 #ifdef LQG_SCAN_STAMP
 // developer build (-DLQG_SCAN_STAMP, variant library): cycles per phase of k_scan_level_rt, accumulated by lane 0 of the LAST
 // window of system 0 (read back with lqg_debug_scan_stamps of lqg_scan_inst.hip)
@@ -245,6 +248,49 @@ LQG_DEV D fast_rcp(D x) {
   return r;
 }
 
+// ---- 16 x 16 output tiles of the window products on the fp64 matrix core (v_mfma_f64_16x16x4_f64) ------------------------
+// Register layout, pinned on the hardware by scripts/micro/mfma_f64_layout.hip: A operand — lane l holds A(l % 16, l / 16);
+// B operand — lane l holds B(l / 16, l % 16); accumulator — lane l, register r holds D(4 r + l / 16, l % 16).
+// The reduction index is split so that lane group g = l / 16 owns the CONTIGUOUS quarter g Q .. g Q + Q - 1 of it (Q = padded
+// n / 4): a left operand stored by rows is then Q consecutive doubles per lane.  Operand loaders return 0 outside the n x n
+// matrix (the padding of the last tiles), so no accumulated term is ever NaN-poisoned by what lies behind an operand.
+typedef double mfma_acc_t __attribute__((ext_vector_type(4)));
+struct TileIdx { int i0, j0, li, g; };
+template <int Q, typename LF, typename RF>
+LQG_DEV mfma_acc_t mfma_tile(const TileIdx& t, LF left, RF right) {
+  mfma_acc_t acc = {0.0, 0.0, 0.0, 0.0};
+  D a[Q], b[Q];
+  LQG_UNROLL for (int q = 0; q < Q; ++q) { a[q] = left(t.i0 + t.li, t.g * Q + q); b[q] = right(t.g * Q + q, t.j0 + t.li); }
+  LQG_UNROLL for (int q = 0; q < Q; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
+  return acc;
+}
+// two products sharing their left operand
+template <int Q, typename LF, typename RF1, typename RF2>
+LQG_DEV void mfma_tile2(const TileIdx& t, LF left, RF1 right1, RF2 right2, mfma_acc_t& acc1, mfma_acc_t& acc2) {
+  acc1 = mfma_acc_t{0.0, 0.0, 0.0, 0.0};
+  acc2 = mfma_acc_t{0.0, 0.0, 0.0, 0.0};
+  D a[Q], b1[Q], b2[Q];
+  LQG_UNROLL for (int q = 0; q < Q; ++q) {
+    a[q] = left(t.i0 + t.li, t.g * Q + q);
+    b1[q] = right1(t.g * Q + q, t.j0 + t.li);
+    b2[q] = right2(t.g * Q + q, t.j0 + t.li);
+  }
+  LQG_UNROLL for (int q = 0; q < Q; ++q) {
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b1[q], acc1, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b2[q], acc2, 0, 0, 0);
+  }
+}
+// M(r, c) = p[r * rs + c * cs] inside the n x n matrix, 0 outside (clamped address, masked value)
+struct MatView {
+  const D* p;
+  int rs, cs, n;
+  LQG_DEV D operator()(int r, int c) const {
+    const bool in = r < n && c < n;
+    const D v = p[(in ? r : 0) * rs + (in ? c : 0) * cs];
+    return in ? v : 0.0;
+  }
+};
+
 // (second launch bound = waves per SIMD.  Two workgroups per CU — 64 VGPRs at 16 waves — spill and run 9 % slower: 1)
 #ifndef LQG_SCAN_RT_WGS_PER_CU
 #define LQG_SCAN_RT_WGS_PER_CU 1
@@ -252,7 +298,6 @@ LQG_DEV D fast_rcp(D x) {
 template <int NW>
 __global__ void __launch_bounds__(NW * 64, LQG_SCAN_RT_WGS_PER_CU * NW / 4) k_scan_level_rt(const Seg s0, const Seg s1, const int n) {
   constexpr int TI = 64 / NW;
-  constexpr int CH = TI <= 8 ? 4 : 2;          // columns of the wave's rows held in scalar registers at a time
   extern __shared__ double lqg_coop_smem[];
   const int tid = (int)threadIdx.x, lane = tid & 63, NT = (int)blockDim.x;     // (ceil(n / TI) waves: scan_level_rt_threads)
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -275,48 +320,53 @@ __global__ void __launch_bounds__(NW * 64, LQG_SCAN_RT_WGS_PER_CU * NW / 4) k_sc
   const D* __restrict__ e1 = left ? ek : ep;                          // the window that comes FIRST in time
   const D* __restrict__ e2 = left ? ep : ek;
   const D *A1 = e1, *C1 = e1 + nn, *J1 = e1 + 2 * nn, *A2 = e2, *C2 = e2 + nn, *J2 = e2 + 2 * nn;
-  D *P0 = lqg_coop_smem, *P1 = P0 + panel;
-  D *pcol = P1 + panel, *prow = pcol + 128, *crow = prow + 192;
+  D *P0 = lqg_coop_smem, *P1 = P0 + panel, *P2 = P1 + panel, *P3 = P2 + panel;
+  D *pcol = P3 + panel, *prow = pcol + 128, *crow = prow + 192;
   const bool lv = lane < n;
   const int lc = lv ? lane : n - 1;                                   // clamped lane for reads whose result is masked
-  // this wave's rows (clamped: the products of rows >= n are computed on row n - 1 and dropped): wave-uniform row offsets,
-  // so that the left operands of the products are SCALAR loads (no global store precedes the last of them)
-  int ro[TI];
-  LQG_UNROLL for (int r = 0; r < TI; ++r) ro[r] = (w * TI + r < n ? w * TI + r : n - 1) * n;
+  const int nwv = NT >> 6, nt = (n + 15) >> 4;                        // waves launched, tiles per matrix side
+  const MatView mA1{A1, n, 1, n}, mC1{C1, n, 1, n}, mA2{A2, n, 1, n}, mJ2{J2, n, 1, n};
+  const MatView mA1t{A1, 1, n, n}, mA2t{A2, 1, n, n};                 // transposed views
+  // a product's tiles on this workgroup's waves: f(tile index struct) for tile = w, w + nwv, ...
+  auto tiles = [&](auto f) {
+    for (int tile = w; tile < nt * nt; tile += nwv) {
+      const int ti = tile / nt;
+      f(TileIdx{ti * 16, (tile - ti * nt) * 16, lane & 15, lane >> 4});
+    }
+  };
+  // D(4 r + g, li) of a tile -> dst(row, col)
+  auto scatter = [&](const TileIdx& t, const mfma_acc_t& acc, auto put) {
+    LQG_UNROLL for (int r = 0; r < 4; ++r) {
+      const int i = t.i0 + 4 * r + t.g, j = t.j0 + t.li;
+      if (i < n && j < n) put(i, j, acc[r]);
+    }
+  };
+  auto with_q = [&](auto f) {                                         // padded n / 4 as a compile-time constant
+    if (nt == 4) f(std::integral_constant<int, 16>{});
+    else if (nt == 3) f(std::integral_constant<int, 12>{});
+    else f(std::integral_constant<int, 8>{});
+  };
 #ifdef LQG_SCAN_STAMP
   unsigned long long stamp_prev_ = __builtin_readcyclecounter();
 #endif
-
-  for (int e = tid; e < nn; e += NT) P0[e] = J2[e];
-  __syncthreads();
   LQG_SSTAMP(0);
-  // ---- rows of [ I + C1 J2 | A1 | C1 ]: every value read from LDS serves the TI rows of the wave
+  // ---- M = I + C1 J2 -> P0; rows of [ M | A1 | C1 ] into registers
+  with_q([&](auto qc) {
+    constexpr int Q = decltype(qc)::value;
+    tiles([&](const TileIdx& t) {
+      const mfma_acc_t acc = mfma_tile<Q>(t, mC1, mJ2);
+      scatter(t, acc, [&](int i, int j, D v) { P0[i * n + j] = v + ((i == j) ? 1.0 : 0.0); });
+    });
+  });
+  __syncthreads();
   D own[TI][3];
-  {
-    D acc[TI];
-    LQG_UNROLL for (int r = 0; r < TI; ++r) acc[r] = 0.0;
-    int q = 0;
-    for (; q + 4 <= n; q += 4) {
-      const D x0 = P0[q * n + lc], x1 = P0[(q + 1) * n + lc], x2 = P0[(q + 2) * n + lc], x3 = P0[(q + 3) * n + lc];
-      LQG_UNROLL for (int r = 0; r < TI; ++r) {
-        const D* __restrict__ cr = C1 + ro[r] + q;
-        acc[r] = fma(cr[0], x0, acc[r]);
-        acc[r] = fma(cr[1], x1, acc[r]);
-        acc[r] = fma(cr[2], x2, acc[r]);
-        acc[r] = fma(cr[3], x3, acc[r]);
-      }
-    }
-    for (; q < n; ++q) {
-      const D x0 = P0[q * n + lc];
-      LQG_UNROLL for (int r = 0; r < TI; ++r) acc[r] = fma(C1[ro[r] + q], x0, acc[r]);
-    }
-    LQG_UNROLL for (int r = 0; r < TI; ++r) {
-      const int i = w * TI + r;
-      const bool live = lv && i < n;
-      own[r][0] = live ? acc[r] + ((lane == i) ? 1.0 : 0.0) : 0.0;
-      own[r][1] = live ? A1[ro[r] + lc] : 0.0;
-      own[r][2] = live ? C1[ro[r] + lc] : 0.0;
-    }
+  LQG_UNROLL for (int r = 0; r < TI; ++r) {
+    const int i = w * TI + r;
+    const bool live = lv && i < n;
+    const int at = (i < n ? i : n - 1) * n + lc;
+    own[r][0] = live ? P0[at] : 0.0;
+    own[r][1] = live ? A1[at] : 0.0;
+    own[r][2] = live ? C1[at] : 0.0;
   }
   LQG_SSTAMP(1);
   // ---- Gauss-Jordan with partial pivoting.  The pivot is the largest |entry| of the column compared on the sign-less
@@ -371,85 +421,42 @@ __global__ void __launch_bounds__(NW * 64, LQG_SCAN_RT_WGS_PER_CU * NW / 4) k_sc
     }
     LQG_SSTAMP(5);
   }
-  // ---- X1 = M^-1 A1 -> P0, X2 = M^-1 C1 -> P1   (J2's copy in P0 was last read before the elimination's barriers)
+  // ---- X1 = M^-1 A1 -> P0, X2 = M^-1 C1 -> P1   (every wave passed the elimination's barriers after reading M from P0)
   LQG_UNROLL for (int r = 0; r < TI; ++r) {
     const int i = w * TI + r;
     if (i < n && lv) { P0[i * n + lane] = own[r][1]; P1[i * n + lane] = own[r][2]; }
   }
   __syncthreads();
   LQG_SSTAMP(6);
-  // ---- A = A2 X1, T1 = A2 X2, U = J2 X1: accumulated in registers, then T1' -> P0 and U -> P1 once X1, X2 are dead
-  D aA[TI], aT[TI], aU[TI];
-  LQG_UNROLL for (int r = 0; r < TI; ++r) { aA[r] = 0.0; aT[r] = 0.0; aU[r] = 0.0; }
-  {                                                                   // (one left operand per loop: its CH-column chunks of the
-    int q = 0;                                                        //  wave's rows fit the scalar registers)
-    for (; q + CH <= n; q += CH) {
-      D x1[CH], x2[CH];
-      LQG_UNROLL for (int j = 0; j < CH; ++j) { x1[j] = P0[(q + j) * n + lc]; x2[j] = P1[(q + j) * n + lc]; }
-      LQG_UNROLL for (int r = 0; r < TI; ++r) {
-        const D* __restrict__ a2 = A2 + ro[r] + q;
-        LQG_UNROLL for (int j = 0; j < CH; ++j) { aA[r] = fma(a2[j], x1[j], aA[r]); aT[r] = fma(a2[j], x2[j], aT[r]); }
-      }
-    }
-    for (; q < n; ++q) {
-      const D x10 = P0[q * n + lc], x20 = P1[q * n + lc];
-      LQG_UNROLL for (int r = 0; r < TI; ++r) {
-        aA[r] = fma(A2[ro[r] + q], x10, aA[r]);
-        aT[r] = fma(A2[ro[r] + q], x20, aT[r]);
-      }
-    }
-    for (q = 0; q + CH <= n; q += CH) {
-      D x1[CH];
-      LQG_UNROLL for (int j = 0; j < CH; ++j) x1[j] = P0[(q + j) * n + lc];
-      LQG_UNROLL for (int r = 0; r < TI; ++r) {
-        const D* __restrict__ j2 = J2 + ro[r] + q;
-        LQG_UNROLL for (int j = 0; j < CH; ++j) aU[r] = fma(j2[j], x1[j], aU[r]);
-      }
-    }
-    for (; q < n; ++q) {
-      const D x10 = P0[q * n + lc];
-      LQG_UNROLL for (int r = 0; r < TI; ++r) aU[r] = fma(J2[ro[r] + q], x10, aU[r]);
-    }
-  }
+  // ---- A = A2 X1 (out), T1 = A2 X2 -> P2 (rows padded to ld), U = J2 X1 -> P3
+  with_q([&](auto qc) {
+    constexpr int Q = decltype(qc)::value;
+    const MatView mX1{P0, n, 1, n}, mX2{P1, n, 1, n};
+    tiles([&](const TileIdx& t) {
+      mfma_acc_t aA, aT;
+      mfma_tile2<Q>(t, mA2, mX1, mX2, aA, aT);
+      const mfma_acc_t aU = mfma_tile<Q>(t, mJ2, mX1);
+      scatter(t, aA, [&](int i, int j, D v) { eo[i * n + j] = v; });
+      scatter(t, aT, [&](int i, int j, D v) { P2[i * ld + j] = v; });
+      scatter(t, aU, [&](int i, int j, D v) { P3[i * n + j] = v; });
+    });
+  });
   __syncthreads();                                                    // (X1, X2 dead)
-  LQG_UNROLL for (int r = 0; r < TI; ++r) {
-    const int i = w * TI + r;
-    if (i < n && lv) { P0[lane * ld + i] = aT[r]; P1[i * n + lane] = aU[r]; }
-  }
-  __syncthreads();
   LQG_SSTAMP(7);
-  // ---- unsymmetrised C(b, a) = sum_k T1(b, k) A2(a, k)  (a = this wave's rows, b = lane: rows of A2 are the scalar operand)
-  //      and           J(a, b) = sum_k A1(k, a) U(k, b)   (the TI consecutive entries A1(k, a..) are the scalar operand)
-  D gC[TI], gJ[TI];
-  LQG_UNROLL for (int r = 0; r < TI; ++r) { gC[r] = 0.0; gJ[r] = 0.0; }
-  {
-    int q = 0;
-    for (; q + CH <= n; q += CH) {
-      D t[CH], uq[CH];
-      LQG_UNROLL for (int j = 0; j < CH; ++j) { t[j] = P0[(q + j) * ld + lc]; uq[j] = P1[(q + j) * n + lc]; }
-      const D* __restrict__ a1 = A1 + q * n + w * TI;
-      LQG_UNROLL for (int r = 0; r < TI; ++r) {
-        const D* __restrict__ a2 = A2 + ro[r] + q;
-        LQG_UNROLL for (int j = 0; j < CH; ++j) { gC[r] = fma(t[j], a2[j], gC[r]); gJ[r] = fma(a1[j * n + r], uq[j], gJ[r]); }
-      }
-    }
-    for (; q < n; ++q) {
-      const D t0 = P0[q * ld + lc], u0 = P1[q * n + lc];
-      const D* __restrict__ a1 = A1 + q * n + w * TI;
-      LQG_UNROLL for (int r = 0; r < TI; ++r) {
-        gC[r] = fma(t0, A2[ro[r] + q], gC[r]);
-        gJ[r] = fma(a1[r], u0, gJ[r]);
-      }
-    }
-  }
-  __syncthreads();                                                    // (T1', U dead)
-  LQG_SSTAMP(8);
-  // ---- outputs; the mirror entries of C and J are averaged through LDS (C2, J1 are exactly symmetric: they were made so)
-  LQG_UNROLL for (int r = 0; r < TI; ++r) {
-    const int a = w * TI + r;
-    if (a < n && lv) { eo[a * n + lane] = aA[r]; P0[a * ld + lane] = gC[r]; P1[a * ld + lane] = gJ[r]; }
-  }
+  // ---- unsymmetrised C = T1 A2' -> P0, J = A1' U -> P1 (rows padded to ld)
+  with_q([&](auto qc) {
+    constexpr int Q = decltype(qc)::value;
+    const MatView mT1{P2, ld, 1, n}, mU{P3, n, 1, n};
+    tiles([&](const TileIdx& t) {
+      const mfma_acc_t gC = mfma_tile<Q>(t, mT1, mA2t);
+      const mfma_acc_t gJ = mfma_tile<Q>(t, mA1t, mU);
+      scatter(t, gC, [&](int i, int j, D v) { P0[i * ld + j] = v; });
+      scatter(t, gJ, [&](int i, int j, D v) { P1[i * ld + j] = v; });
+    });
+  });
   __syncthreads();
+  LQG_SSTAMP(8);
+  // ---- the mirror entries of C and J are averaged (C2, J1 are exactly symmetric: they were made so)
   LQG_UNROLL for (int r = 0; r < TI; ++r) {
     const int a = w * TI + r;
     if (a < n && lv) {
@@ -460,7 +467,7 @@ __global__ void __launch_bounds__(NW * 64, LQG_SCAN_RT_WGS_PER_CU * NW / 4) k_sc
   LQG_SSTAMP(9);
 }
 constexpr int kScanRtMax = 64;            // largest window of k_scan_level_rt (one lane per column)
-inline size_t scan_level_rt_lds(int n) { return (size_t)(2 * n * (n + 1) + 128 + 192 + 192 + 64) * sizeof(D); }
+inline size_t scan_level_rt_lds(int n) { return (size_t)(4 * n * (n + 1) + 128 + 192 + 192 + 64) * sizeof(D); }
 inline int scan_level_rt_threads(int n, int nw) { const int ti = 64 / nw; return (n + ti - 1) / ti * 64; }
 
 // ---------------------------------------------------------------- per-step kernels

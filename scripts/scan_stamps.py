@@ -5,8 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lqg_amd import _abi
 from lqg_amd.tracking.delay import DelayedSubjectiveActor
 lib = _abi.load()
-labels = ["stage J2 -> LDS", "M = I + C1 J2 rows, A1, C1", "elim: publish column + barrier", "elim: pivot search", "elim: 1/pivot, publish rows + barrier",
-          "elim: update", "X -> LDS + barrier", "A, T1, U products (+2 barriers)", "C, J products + barrier", "symmetrise + store"]
+labels = ["-", "M = I + C1 J2 (matrix core) -> LDS, rows into registers", "elim: publish column + barrier", "elim: pivot search", "elim: 1/pivot, publish rows + barrier",
+          "elim: update", "X -> LDS + barrier", "A, T1, U products (matrix core) + barrier", "C, J products (matrix core) + barrier", "symmetrise + store"]
 md = DelayedSubjectiveActor(T=500, device="cuda", dtype=torch.float64)
 x = md.simulate(21, n=4)[..., :2].contiguous()
 buf = (C.c_ulonglong * 16)()
