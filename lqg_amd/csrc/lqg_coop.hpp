@@ -878,41 +878,67 @@ __global__ void __launch_bounds__(BLOCK) k_coop_trial(const R* __restrict__ ops_
 // profiles/r03_b_bench.json).  Here a group of RT = BLOCK / tpb threads owns a trial and splits the ROWS of the mean update
 // (thread r: rows r, r + RT, ...); the step's operator block is staged in LDS once per workgroup (double-buffered: the loads
 // of step t + 1 are in flight while step t computes) and shared by the tpb trials of the block; two barriers per step.
+// TIME-CHUNKED use of the same kernel (lqg_trial_chunk.hpp has the scheme and its lane-kernel form): with one or a few
+// hundred trials the sweep is ONE dependent chain of T steps (3.4 us each at m = 65) on a nearly empty chip.  mode 1: every
+// (trial, chunk) runs its chunk from the zero state, and m pseudo-trials per (system, chunk) push the unit vectors through
+// the chunk with the data set to zero (the chunk's transition matrix, column by column); k_coop_trial_fix then walks the chunk
+// boundaries; mode 2: every (trial, chunk) again from its true start state, now evaluating the densities.  grid.z = chunk.
+template <typename R>
+struct TrialChunkRT {
+  int mode;          // 0: one pass over the whole horizon; 1: zero-state pass; 2: density pass
+  int n_chunks, chunk_len;
+  R* state;          // [sys][n_chunks-1][m][n_trials]
+  R* phi;            // [sys][n_chunks-1][m][m]
+  double* part;      // [sys][n_chunks][n_trials]
+};
+
 template <typename R, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) k_coop_trial_rows(const R* __restrict__ ops_all, const TrialArgsRT<R> a, const int tpb) {
+__global__ void __launch_bounds__(BLOCK) k_coop_trial_rows(const R* __restrict__ ops_all, const TrialArgsRT<R> a, const int tpb,
+                                                           const TrialChunkRT<R> ch) {
   extern __shared__ double lqg_coop_smem[];
   constexpr int MAXO = 6, MAXPF = 24;                        // d <= 6 (coop_supported); operator reals per thread per step
   const int m = a.m, o = a.d, rr = m - a.d, tid = threadIdx.x, nops = a.nops;
   const int RT = BLOCK / tpb, g = tid / RT, r = tid - g * RT;
   const long sys = blockIdx.y;
+  const int c = blockIdx.z;
+  const int t0 = ch.mode ? c * ch.chunk_len : 0;
+  const bool lastc = ch.mode == 0 || c == ch.n_chunks - 1;
+  const int t_hi = (ch.mode != 1 && lastc) ? a.T + 1 : t0 + ch.chunk_len;     // (exclusive; the last chunk also scores x_T)
+  const long ntot = ch.mode == 1 ? a.n_trials + m : a.n_trials;
   long n = (long)blockIdx.x * tpb + g;
-  const bool live = n < a.n_trials;
-  n = live ? n : a.n_trials - 1;
+  const bool live = n < ntot;
+  const bool hom = ch.mode == 1 && n >= a.n_trials;          // unit vector n - n_trials, zero data
+  const int unit = (int)(n - a.n_trials);
+  n = (live && !hom) ? n : a.n_trials - 1;
   R* sm = reinterpret_cast<R*>(lqg_coop_smem);
   R* opb[2] = {sm, sm + nops};
   R* cv = sm + 2 * nops + (long)g * 2 * m;                   // [x_t ; c] of this group's trial
   R* st = cv + m;                                            // state: dO (o) | muR (rr)
   const int U_OFF = m * m, L_OFF = U_OFF + rr * o, H_OFF = L_OFF + o * (o + 1) / 2;
-  const R* op = ops_all + sys * (long)(a.T + 1) * nops;
+  const R* op = ops_all + (sys * (long)(a.T + 1) + t0) * nops;
   const R* xr = a.x.p + sys * a.x.sb + n * a.x.sn;
-  for (int i = r; i < m; i += RT) st[i] = R(0);
+  {
+    const R* s0 = (ch.mode == 2 && c > 0) ? ch.state + (sys * (ch.n_chunks - 1) + (c - 1)) * m * a.n_trials + n : nullptr;
+    for (int i = r; i < m; i += RT) st[i] = s0 ? s0[(long)i * a.n_trials] : (hom && i == unit) ? R(1) : R(0);
+  }
   R pf[MAXPF];
   const int npf = (nops + BLOCK - 1) / BLOCK;                // <= MAXPF (host-checked)
   LQG_UNROLL for (int k = 0; k < MAXPF; ++k)
     if (k < npf && tid + k * BLOCK < nops) opb[0][tid + k * BLOCK] = op[tid + k * BLOCK];
   R xprev[MAXO], xnx[MAXO];
   LQG_UNROLL for (int j = 0; j < MAXO; ++j) {
-    xprev[j] = j < o ? xr[j * a.x.sd] : R(0);
-    xnx[j] = xprev[j];
+    xprev[j] = (j < o && !hom) ? xr[(long)(t0 > 0 ? t0 - 1 : 0) * a.x.st + j * a.x.sd] : R(0);
+    xnx[j] = (j < o && !hom) ? xr[(long)t0 * a.x.st + j * a.x.sd] : R(0);
   }
   double acc = 0.0;
   __syncthreads();
-  for (int t = 0; t <= a.T; ++t) {
-    const R* __restrict__ ob = opb[t & 1];
-    const bool more = t < a.T;
+  for (int t = t0; t < t_hi; ++t) {
+    const R* __restrict__ ob = opb[(t - t0) & 1];
+    const bool more_ops = t + 1 < t_hi;                      // another step of this pass follows
+    const bool more = t < a.T && (more_ops || ch.mode == 1); // the state is advanced (the density pass needs no end state)
     // requests of step t + 1: its operator block (into registers, parked in LDS at the end of the step) and its data row
-    if (more) {
-      const R* nx = op + (long)(t + 1) * nops;
+    if (more_ops) {
+      const R* nx = op + (long)(t + 1 - t0) * nops;
       LQG_UNROLL for (int k = 0; k < MAXPF; ++k)
         if (k < npf && tid + k * BLOCK < nops) pf[k] = nx[tid + k * BLOCK];
     }
@@ -921,7 +947,7 @@ __global__ void __launch_bounds__(BLOCK) k_coop_trial_rows(const R* __restrict__
     {
       const long row = (t + 1 <= a.T) ? (long)(t + 1) : (long)a.T;
       LQG_UNROLL for (int j = 0; j < MAXO; ++j)
-        if (j < o) xnx[j] = xr[row * a.x.st + j * a.x.sd];
+        if (j < o && !hom) xnx[j] = xr[row * a.x.st + j * a.x.sd];
     }
     // whitened innovation (every thread of the group, redundantly: d^2 / 2 multiply-adds) and its density
     LQG_UNROLL for (int j = 0; j < MAXO; ++j) e[j] = j < o ? (xt[j] - xprev[j]) - st[j] : R(0);
@@ -936,7 +962,7 @@ __global__ void __launch_bounds__(BLOCK) k_coop_trial_rows(const R* __restrict__
         zz += v * v;
       }
     }
-    if (t > 0 && r == 0) acc -= (double)(R(0.5) * zz + ob[H_OFF]);
+    if (ch.mode != 1 && t > 0 && r == 0) acc -= (double)(R(0.5) * zz + ob[H_OFF]);
     if (more) {
       // c = muR + U2 w (row-parallel), [x_t ; c] into LDS
       for (int p = r; p < rr; p += RT) {
@@ -967,19 +993,70 @@ __global__ void __launch_bounds__(BLOCK) k_coop_trial_rows(const R* __restrict__
         const R mn = (v0 + v1) + (v2 + v3);
         const R ns = i < o ? mn : cv[i] + mn;
         st[i] = ns;
-        if (a.mu.p && live) {
+        if (ch.mode == 0 && a.mu.p && live) {
           R* dst = const_cast<R*>(a.mu.p) + sys * a.mu.sb + n * a.mu.sn + (long)t * a.mu.st;
           dst[i * a.mu.sd] = i < o ? cv[i] + mn : ns;            // (cv[0:o] holds x_t)
         }
       }
       LQG_UNROLL for (int j = 0; j < MAXO; ++j) xprev[j] = xt[j];
-      R* nb = opb[(t + 1) & 1];
+    }
+    if (more_ops) {
+      R* nb = opb[(t + 1 - t0) & 1];
       LQG_UNROLL for (int k = 0; k < MAXPF; ++k)
         if (k < npf && tid + k * BLOCK < nops) nb[tid + k * BLOCK] = pf[k];
     }
     __syncthreads();                                         // new state + next operator block visible
   }
-  if (a.ll && live && r == 0) a.ll[sys * a.ll_sb + n * a.ll_sn] = (R)acc;
+  if (!live) return;
+  if (ch.mode == 1) {
+    const long slot = sys * (ch.n_chunks - 1) + c;
+    if (hom) {
+      R* ph = ch.phi + slot * ((long)m * m) + unit;
+      for (int i = r; i < m; i += RT) ph[(long)i * m] = st[i];
+    } else {
+      R* sp = ch.state + slot * m * a.n_trials + n;
+      for (int i = r; i < m; i += RT) sp[(long)i * a.n_trials] = st[i];
+    }
+  } else if (r == 0) {
+    if (ch.mode == 2) ch.part[(sys * ch.n_chunks + c) * a.n_trials + n] = acc;
+    else if (a.ll) a.ll[sys * a.ll_sb + n * a.ll_sn] = (R)acc;
+  }
+}
+
+// start state of every chunk: s_{c+1} = Phi_c s_c + z_c along the chunk boundaries of one trial (grid: (trials, systems); the
+// rows of the m x m product on the lanes).  Slot c of `state` holds the zero-state end of chunk c on entry and the start state
+// of chunk c + 1 on return (slot 0 is both: chunk 0 starts from zero) — the convention of k_trial_fix.
+template <typename R>
+__global__ void __launch_bounds__(128) k_coop_trial_fix(const R* __restrict__ phi_all, R* state, long n_trials, int n_slots, int m) {
+  extern __shared__ double lqg_coop_smem[];
+  R* sb[2] = {reinterpret_cast<R*>(lqg_coop_smem), reinterpret_cast<R*>(lqg_coop_smem) + m};
+  const long sys = blockIdx.y, n = blockIdx.x;
+  R* sp = state + sys * n_slots * m * n_trials + n;
+  const R* __restrict__ ph = phi_all + sys * n_slots * ((long)m * m);
+  for (int i = threadIdx.x; i < m; i += blockDim.x) sb[0][i] = sp[(long)i * n_trials];
+  __syncthreads();
+  for (int c = 1; c < n_slots; ++c) {
+    sp += (long)m * n_trials;
+    ph += (long)m * m;
+    const R* __restrict__ s = sb[(c - 1) & 1];
+    R* sn = sb[c & 1];
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+      const R* __restrict__ fr = ph + (long)i * m;
+      R v0 = sp[(long)i * n_trials], v1 = R(0), v2 = R(0), v3 = R(0);
+      int j = 0;
+      for (; j + 3 < m; j += 4) {
+        v0 += fr[j] * s[j];
+        v1 += fr[j + 1] * s[j + 1];
+        v2 += fr[j + 2] * s[j + 2];
+        v3 += fr[j + 3] * s[j + 3];
+      }
+      for (; j < m; ++j) v0 += fr[j] * s[j];
+      const R v = (v0 + v1) + (v2 + v3);
+      sn[i] = v;
+      sp[(long)i * n_trials] = v;
+    }
+    __syncthreads();
+  }
 }
 
 // ======================================================================================================================

@@ -244,8 +244,35 @@ hipError_t coop_trial(const lqg_problem* p, const void* ops, lqg_traj x, lqg_tra
       auto kr = coop::k_coop_trial_rows<R, BR>;
       hipError_t er = raise_lds(kr, lds_r);
       if (er != hipSuccess) return er;
+      // time-chunked (few trials, long horizon, log-likelihood only): the scratch follows the operator stream (carve(), scan_plan())
+      const int nc = m > kLaneTrialMaxJoint ? trial_chunks(p) : 1;
+      if (nc > 1 && ll && !mu.ptr) {
+        const TrialChunkScratch sc = trial_chunk_scratch(p);
+        const size_t ops_bytes = ((size_t)p->n_sys * (size_t)(p->T + 1) * (size_t)nops * sizeof(R) + 255) / 256 * 256;
+        char* base = const_cast<char*>(static_cast<const char*>(ops)) + ops_bytes;
+        coop::TrialChunkRT<R> ch{1, nc, trial_chunk_len(p, nc), reinterpret_cast<R*>(base + sc.state_off),
+                                 reinterpret_cast<R*>(base + sc.phi_off), reinterpret_cast<double*>(base + sc.part_off)};
+        int tz = 1;                                          // trials per block of the chunked passes (same rule, their grids)
+        while (tz < 16 && (long)p->n_sys * (nc - 1) * ((p->n_trials + m + tz - 1) / tz) > 2048) tz *= 2;
+        const size_t lds_z = ((size_t)2 * nops + (size_t)tz * 2 * m) * sizeof(R);
+        er = raise_lds(kr, lds_z > lds_r ? lds_z : lds_r);
+        if (er != hipSuccess) return er;
+        const R* o_ = static_cast<const R*>(ops);
+        hipLaunchKernelGGL(kr, dim3((unsigned)((p->n_trials + m + tz - 1) / tz), (unsigned)p->n_sys, (unsigned)(nc - 1)), dim3(BR),
+                           lds_z, st, o_, k, tz, ch);
+        if (nc > 2)
+          hipLaunchKernelGGL(coop::k_coop_trial_fix<R>, dim3((unsigned)p->n_trials, (unsigned)p->n_sys), dim3(128),
+                             (size_t)2 * m * sizeof(R), st, static_cast<const R*>(ch.phi), ch.state, (long)p->n_trials, nc - 1, m);
+        ch.mode = 2;
+        hipLaunchKernelGGL(kr, dim3((unsigned)((p->n_trials + tz - 1) / tz), (unsigned)p->n_sys, (unsigned)nc), dim3(BR), lds_z, st,
+                           o_, k, tz, ch);
+        hipLaunchKernelGGL((lqg::k_trial_sum<R>), dim3((unsigned)((p->n_trials + LQG_BLOCK - 1) / LQG_BLOCK), (unsigned)p->n_sys),
+                           dim3(LQG_BLOCK), 0, st, static_cast<const double*>(ch.part), static_cast<R*>(ll), ll_sb, ll_sn,
+                           (long)p->n_trials, nc);
+        return hipGetLastError();
+      }
       const dim3 gr((unsigned)((p->n_trials + tpb - 1) / tpb), (unsigned)p->n_sys);
-      hipLaunchKernelGGL(kr, gr, dim3(BR), lds_r, st, static_cast<const R*>(ops), k, tpb);
+      hipLaunchKernelGGL(kr, gr, dim3(BR), lds_r, st, static_cast<const R*>(ops), k, tpb, coop::TrialChunkRT<R>{0, 1, 0, nullptr, nullptr, nullptr});
       return hipGetLastError();
     }
   }

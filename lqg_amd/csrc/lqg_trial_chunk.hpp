@@ -245,7 +245,29 @@ namespace host {
 // (scripts/chunk_regime.py): 2^10 trials 0.49 / 0.06, 2^14: 0.50 / 0.11, 2^16 (1024 waves): 0.52 / 0.23, 2^17: 0.55 / 0.44,
 // 2^18 (4096 waves): 0.63 / 0.81, 2^19: 0.93 / 1.5 — the two passes cost ~2x the arithmetic, which only pays while the
 // one-pass sweep is bound by the latency of its dependent steps and not by instruction issue.
+// Joint dimensions without lane kernels (x + b > 24: the delay-augmented models on the row-parallel k_coop_trial_rows, one
+// WORKGROUP per few trials): chunked while the trials leave the chip empty — DelayedSubjectiveActor, T = 500, one trial: 1.72 ms
+// in one pass (500 dependent steps of 3.4 us).  LQG_COOP_TRIAL_CHUNKS=0/1 disables, =k forces k chunks.
+inline int coop_trial_chunks(const lqg_problem* p) {
+  if (p->n_trials < 1 || p->T < 64) return 1;
+  const char* e1 = getenv("LQG_COOP_TRIAL_CHUNKS");
+  long nc = e1 ? atol(e1) : -1;
+  if (nc < 0) {
+    // (every (system, chunk) also pushes m unit vectors through the chunk: pays for a handful of systems only — 64 systems of
+    // one trial each: 2.5 ms in one pass, 16 ms chunked)
+    // trial_ms one pass / chunked, fp32: 1 trial 1.88 / 0.35, 64: 1.87 / 0.45, 256: 1.88 / 0.87, 1024: 2.36 / 2.80
+    if (p->n_sys > 8 || (long)p->n_sys * (long)p->n_trials > 512L) return 1;
+    nc = (long)std::sqrt(2.0 * (double)p->T);
+  }
+  if (nc > p->T / 4) nc = p->T / 4;
+  if (nc < 2) return 1;
+  const int len = (int)((p->T + nc - 1) / nc);
+  return (p->T + len - 1) / len;
+}
+constexpr int kLaneTrialMaxJoint = 24;    // beyond: no lane per-trial kernels exist (lqg_amd/_hip.py LANE_MAX_JOINT = 20)
+
 inline int trial_chunks(const lqg_problem* p) {
+  if (p->dims.x + p->dims.b > kLaneTrialMaxJoint) return coop_trial_chunks(p);
   if (p->n_trials <= 2 || p->T < 16) return 1;
   // (read per call: a test or a tuning script may change them between launches)
   const char* e1 = getenv("LQG_TRIAL_CHUNKS");

@@ -159,8 +159,11 @@ class LogLikelihoodPlan:
             # runs MIXED: worst 2.8e-7)
             short_f32 = not (sub.actor.A.dtype == torch.float32 and sub.T > FUSE_F32_MAX_STEPS
                              and os.environ.get("LQG_MIXED", "1") != "0")
+            # (a lane-kernel route: the cooperative kernels walk one system per WORKGROUP — replicating the system per trial
+            # multiplies their work, and their per-trial sweep is time-chunked for few systems, csrc/lqg_trial_chunk.hpp)
+            lane_dims = sub.actor.A.shape[-1] + sub.dynamics.A.shape[-1] <= _hip.LANE_MAX_JOINT
             fuse_pairs = ((not use_scan) and 2 < n and n_sys0 * n <= FUSE_TRIALS_MAX and _time_invariant(sub)
-                          and not long_f32 and short_f32)
+                          and not long_f32 and short_f32 and lane_dims)
             if fuse_pairs:                       # (system, trial) pairs as n_sys0 * n one-trial systems
                 sub, xs, S0 = _pairs_as_systems(sub, xs, S0, n_sys0, n)
                 n_pairs, n = n, 1

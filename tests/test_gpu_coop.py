@@ -101,6 +101,34 @@ def test_delayed_subjective_actor_runs_by_itself(dtype):
     assert not np.allclose(np_(llb[0]), np_(llb[1]))
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-11), (torch.float32, 3e-6)], ids=["f64", "f32"])
+def test_time_chunked_row_parallel_sweep_equals_the_one_pass_sweep(dtype, tol, monkeypatch):
+    """The per-trial sweep of shapes without lane kernels (k_coop_trial_rows) cut along time (zero-state pass with the unit
+    vectors of the transition matrices, boundary walk, density pass; csrc/lqg_coop.hpp): equal to the one-pass sweep to
+    rounding for chunk counts that do and do not divide T, for 1 .. 40 trials, on the sequential and the time-parallel system
+    sweeps; the default rule chunks few trials of few systems only; the golden vector (T = 30 < 64) is never chunked."""
+    from lqg_amd.plan import LogLikelihoodPlan
+    from lqg_amd.tracking.delay import DelayedSubjectiveActor
+    T = 137
+    sig = torch.tensor([5.0, 8.0], dtype=dtype, device="cuda")
+    m = DelayedSubjectiveActor(T=T, sigma_target=sig, device="cuda", dtype=dtype)
+    with torch.no_grad():
+        x = m.simulate(3, n=40)[..., :2].contiguous()
+    for scan in ("0", "1"):
+        monkeypatch.setenv("LQG_SCAN", scan)
+        monkeypatch.setenv("LQG_COOP_TRIAL_CHUNKS", "0")
+        ref = m.log_likelihood(x).clone()
+        for chunks in ("2", "5", "13", "34", None):
+            if chunks is None:
+                monkeypatch.delenv("LQG_COOP_TRIAL_CHUNKS")
+            else:
+                monkeypatch.setenv("LQG_COOP_TRIAL_CHUNKS", chunks)
+            for n in (1, 2, 7, 40):
+                got = LogLikelihoodPlan(m, x[:, :n].contiguous()).run().clone()
+                assert got.shape == (2, n)
+                assert float((got / ref[:, :n] - 1).abs().max()) < tol, (scan, chunks, n)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 2e-6)], ids=["f64", "f32"])
 @pytest.mark.parametrize("model", ["pointmass", "hand1d", "subjective2d"])
 def test_cooperative_and_lane_kernels_agree_on_a_batch(model, dtype, tol, monkeypatch):
