@@ -169,7 +169,7 @@ def test_time_parallel_path_on_random_dense_systems(oracle_lib, case, monkeypatc
     assert np.abs(np_(Sig) - ref_Sig).max() < 1e-8 * max(1.0, np.abs(ref_Sig).max())
 
 
-@pytest.mark.parametrize("case", range(4))
+@pytest.mark.parametrize("case", range(7))
 def test_windows_of_25_to_64_on_random_dense_systems(oracle_lib, case, monkeypatch):
     """Dense random systems whose scan windows exceed LDS (k_scan_level_rt: elimination in registers, run-time n), sizes
     that are not multiples of the 8 rows a wave owns, time-varying specs, partial observation — against the fp64 C oracle."""
@@ -178,7 +178,9 @@ def test_windows_of_25_to_64_on_random_dense_systems(oracle_lib, case, monkeypat
     from lqg_amd.plan import LogLikelihoodPlan
     from test_gpu_random import random_system
     rng = np.random.default_rng(7100 + case)
-    x, b, u, y, d = [(9, 25, 2, 3, 3), (12, 31, 1, 2, 1), (26, 39, 1, 1, 2), (18, 33, 3, 4, 4)][case]
+    # (the last three: windows that fill their 16 x 16 tiles exactly — 32, 48 and 64 — and the largest b the C oracle holds)
+    x, b, u, y, d = [(9, 25, 2, 3, 3), (12, 31, 1, 2, 1), (26, 39, 1, 1, 2), (18, 33, 3, 4, 4),
+                     (9, 25, 1, 2, 2), (18, 32, 2, 2, 2), (26, 40, 1, 1, 2)][case]
     T = int(rng.integers(40, 90))
     actor, dyn = random_system(rng, x, b, u, y, T, bool(case & 1), affine=False)
     for spec in (actor, dyn):
