@@ -108,6 +108,25 @@ def test_delay_model_windows_of_64_against_the_sequential_kernels(monkeypatch):
         assert float((got32.double() / ref - 1).abs().max()) < 1e-6
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 1e-6)], ids=["f64", "f32"])
+def test_delay_model_evaluation_replays_as_one_graph(dtype, tol):
+    """The whole evaluation of the delay model — time-parallel sweeps on register-resident windows, time-chunked row-parallel
+    per-trial sweep — captured as one hipGraph by the inference loops' evaluator and replayed at other parameters."""
+    from lqg_amd.infer import graphed
+    from lqg_amd.tracking.delay import DelayedSubjectiveActor
+    T = 150
+    with torch.no_grad():
+        x = DelayedSubjectiveActor(T=T, device="cuda", dtype=dtype).simulate(8, n=6)[..., :2].contiguous()
+    names = ["c", "action_variability", "sigma_target", "sigma_cursor"]
+    gl = graphed.GraphedLogLik(x, DelayedSubjectiveActor, names, 1)
+    assert gl.capture()
+    for th in ([0.5, 0.5, 6.0, 3.0], [0.3, 0.7, 9.0, 2.0]):
+        out = gl(torch.tensor([th], dtype=dtype, device="cuda")).clone()
+        m = DelayedSubjectiveActor(T=T, device="cuda", dtype=dtype, **dict(zip(names, th)))
+        eager = m.log_likelihood(x).double().sum()
+        assert float((out[0] / eager - 1).abs()) < tol
+
+
 def test_scan_is_the_default_for_one_long_system_and_not_for_batches():
     import lqg_amd
     from lqg_amd.plan import LogLikelihoodPlan
