@@ -194,6 +194,109 @@ constexpr int scan_level_threads(int n, bool packed) {
 constexpr int scan_level_epb(int n, bool packed) { return 256 / scan_level_threads(n, packed); }
 inline size_t scan_level_lds(int n, bool packed) { return (size_t)(14 * n * n + 8) * sizeof(D) * scan_level_epb(n, packed); }
 
+// ---------------------------------------------------------------- the WHOLE scan in one launch, windows of 1 .. 3
+// The dim-1 tracking models (and the decoupled components of the dim-2 ones: lqg_amd/decouple.py) have windows of 2 x 2
+// (BoundedActor) or 3 x 3 (SubjectiveActor): one level of k_scan_level is then 4.5 us of launch, LDS staging and fences around
+// ~100 multiply-adds — 18 such launches are 40 % of a one-vector evaluation (profiles/r03_w_timeline_config2.txt has the
+// n = 4 / 6 picture).  Here ONE LANE owns one window: its element stays in registers through all log2(T) levels, the combine
+// is straight-line register code (the same formulas, the same partial pivoting — by compare-and-select, every lane its own
+// pivots), and only the partner window travels through LDS ([component][window]: conflict-free).  One workgroup per
+// (sequence, system); the sequence (T + 1 <= 1024 windows, 3 n^2 T doubles <= 150 KB) never leaves the CU between levels.
+template <int N>
+LQG_DEV void lane_combine(const D (&e1)[3 * N * N], const D (&e2)[3 * N * N], D (&eo)[3 * N * N]) {
+  constexpr int NN = N * N, W = 3 * N;
+  const D *A1 = e1, *C1 = e1 + NN, *J1 = e1 + 2 * NN, *A2 = e2, *C2 = e2 + NN, *J2 = e2 + 2 * NN;
+  D Wm[N * W];                                                       // [ I + C1 J2 | A1 | C1 ]
+  LQG_UNROLL for (int i = 0; i < N; ++i)
+    LQG_UNROLL for (int j = 0; j < N; ++j) {
+      D acc = (i == j) ? 1.0 : 0.0;
+      LQG_UNROLL for (int k = 0; k < N; ++k) acc = fma(C1[i * N + k], J2[k * N + j], acc);
+      Wm[i * W + j] = acc;
+      Wm[i * W + N + j] = A1[i * N + j];
+      Wm[i * W + 2 * N + j] = C1[i * N + j];
+    }
+  LQG_UNROLL for (int c = 0; c < N; ++c) {                           // Gauss-Jordan, partial pivoting (lowest row on ties)
+    LQG_UNROLL for (int r = c + 1; r < N; ++r) {
+      // (bring the larger of rows c, r to row c: after the loop row c holds the column's largest entry, as k_scan_level picks)
+      const bool sw = fabs(Wm[r * W + c]) > fabs(Wm[c * W + c]);
+      LQG_UNROLL for (int j = c; j < W; ++j) {
+        const D a = Wm[c * W + j], b = Wm[r * W + j];
+        Wm[c * W + j] = sw ? b : a;
+        Wm[r * W + j] = sw ? a : b;
+      }
+    }
+    const D pinv = 1.0 / Wm[c * W + c];
+    LQG_UNROLL for (int j = c + 1; j < W; ++j) Wm[c * W + j] *= pinv;
+    LQG_UNROLL for (int r = 0; r < N; ++r) {
+      if (r == c) continue;
+      const D f = Wm[r * W + c];
+      LQG_UNROLL for (int j = c + 1; j < W; ++j) Wm[r * W + j] = fma(-f, Wm[c * W + j], Wm[r * W + j]);
+    }
+  }
+  D T1[NN], U[NN];                                                   // X1 = Wm[:, N:2N], X2 = Wm[:, 2N:3N]
+  LQG_UNROLL for (int i = 0; i < N; ++i)
+    LQG_UNROLL for (int j = 0; j < N; ++j) {
+      D a = 0.0, t = 0.0, u = 0.0;
+      LQG_UNROLL for (int k = 0; k < N; ++k) {
+        a = fma(A2[i * N + k], Wm[k * W + N + j], a);
+        t = fma(A2[i * N + k], Wm[k * W + 2 * N + j], t);
+        u = fma(J2[i * N + k], Wm[k * W + N + j], u);
+      }
+      eo[i * N + j] = a;
+      T1[i * N + j] = t;
+      U[i * N + j] = u;
+    }
+  LQG_UNROLL for (int i = 0; i < N; ++i)
+    LQG_UNROLL for (int j = i; j < N; ++j) {
+      D c1 = C2[i * N + j], c2 = C2[j * N + i], j1 = J1[i * N + j], j2 = J1[j * N + i];
+      LQG_UNROLL for (int k = 0; k < N; ++k) {
+        c1 = fma(T1[i * N + k], A2[j * N + k], c1);
+        c2 = fma(T1[j * N + k], A2[i * N + k], c2);
+        j1 = fma(A1[k * N + i], U[k * N + j], j1);
+        j2 = fma(A1[k * N + j], U[k * N + i], j2);
+      }
+      eo[NN + i * N + j] = eo[NN + j * N + i] = 0.5 * (c1 + c2);
+      eo[2 * NN + i * N + j] = eo[2 * NN + j * N + i] = 0.5 * (j1 + j2);
+    }
+}
+
+// grid (sequences, systems), block >= the longest sequence.  Sequence i: `len` windows from s.in, result into s.out.
+template <int N, int MAXT>
+__global__ void __launch_bounds__(MAXT) k_scan_lane(const Seg s0, const Seg s1) {
+  constexpr int ES = 3 * N * N;
+  extern __shared__ double lqg_coop_smem[];
+  const bool second = blockIdx.x == 1;
+  const D* in = second ? s1.in : s0.in;
+  D* out = second ? s1.out : s0.out;
+  const int len = second ? s1.len : s0.len, left = second ? s1.left : s0.left;
+  const int k = (int)threadIdx.x;
+  const bool live = k < len;
+  const long base = ((long)blockIdx.y * len + (live ? k : 0)) * ES;
+  D own[ES];
+  LQG_UNROLL for (int e = 0; e < ES; ++e) own[e] = in[base + e];
+  for (int d = 1; d < len; d *= 2) {
+    if (live) {
+      LQG_UNROLL for (int e = 0; e < ES; ++e) lqg_coop_smem[e * len + k] = own[e];
+    }
+    __syncthreads();
+    if (live && k >= d) {
+      D other[ES], res[ES];
+      LQG_UNROLL for (int e = 0; e < ES; ++e) other[e] = lqg_coop_smem[e * len + k - d];
+      if (left) lane_combine<N>(own, other, res);                    // (the window that comes FIRST in time is the left operand)
+      else lane_combine<N>(other, own, res);
+      LQG_UNROLL for (int e = 0; e < ES; ++e) own[e] = res[e];
+    }
+    __syncthreads();                                                 // every partner read before the next level's writes
+  }
+  if (live) {
+    LQG_UNROLL for (int e = 0; e < ES; ++e) out[base + e] = own[e];
+  }
+}
+constexpr int kScanLaneMaxN = 3;
+// (3 x 3 windows need ~150 registers per lane: at most 512 lanes per workgroup, i.e. T <= 511)
+inline int scan_lane_max_len(int n) { return n <= 2 ? 1024 : 512; }
+inline size_t scan_lane_lds(int n, int len) { return (size_t)3 * n * n * len * sizeof(D); }
+
 // ---------------------------------------------------------------- one level of the scan, windows of 25 .. 64
 // The delay-augmented models (lqg/tracking/delay.py:9-51: b = 39, m - d = 64 for the reference's DelayedSubjectiveActor)
 // have windows whose 14 n^2 doubles do not fit LDS.  Same combine, same pivoting rule, other data placement — run-time n,

@@ -79,6 +79,24 @@ void run_scan(int n, int nseg, D* const in[2], D* const out[2], const int len[2]
   D* b[2] = {out[0], nseg > 1 ? out[1] : nullptr};
   const int l1 = nseg > 1 ? len[1] : 0;
   const int longest = len[0] > l1 ? len[0] : l1;
+  // windows of 1 .. 3 whose whole sequence fits one workgroup: every level in ONE launch (k_scan_lane)
+  static const bool lane_off = [] { const char* e = getenv("LQG_SCAN_LANE"); return e && atoi(e) == 0; }();
+  if (!lane_off && n <= scan::kScanLaneMaxN && longest <= scan::scan_lane_max_len(n) && scan::scan_lane_lds(n, longest) <= 150 * 1024) {
+    const scan::Seg s0{a[0], b[0], len[0], 0, left[0]};
+    const scan::Seg s1{a[1], b[1], l1, 0, nseg > 1 ? left[1] : 0};
+    const size_t lds = scan::scan_lane_lds(n, longest);
+    const dim3 grid((unsigned)nseg, (unsigned)n_sys), blk((unsigned)((longest + 63) / 64 * 64));
+    auto go = [&](auto kern) {
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kern, grid, blk, lds, st, s0, s1);
+    };
+    if (n == 1) go(scan::k_scan_lane<1, 1024>);
+    else if (n == 2) go(scan::k_scan_lane<2, 1024>);
+    else go(scan::k_scan_lane<3, 512>);
+    res[0] = b[0];
+    res[1] = b[1];
+    return;
+  }
   for (int d = 1; d < longest; d *= 2) {
     const scan::Seg s0{a[0], b[0], len[0], d, left[0]};
     const scan::Seg s1{a[1], b[1], l1, d, nseg > 1 ? left[1] : 0};
