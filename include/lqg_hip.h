@@ -235,6 +235,17 @@ int lqg_point_mass_setup(int64_t n, const double* damping, const double* mass, c
  * frozen decisions rest on these preconditions (lqg_amd/infer/graphed.py poisons its result with NaN when ok == 0). */
 int lqg_precondition_flags(const lqg_problem* p, double max_cond, int32_t check_cond, int32_t* ok, void* stream);
 
+/* Central differences around the candidate sweep, for callers that replay one evaluation as a hipGraph (the reference takes
+ * jax.grad of the summed log-likelihood: lqg/infer/models.py:34, lqg/optim.py:142-147).  All pointers are device memory.
+ * lqg_fd_candidates: z[K, P] (fp64 log-parameters) -> flat[K (2 P + 1), F] in `dtype` (LQG_F32 / LQG_F64), the flattened
+ *   specs of the centre and of the +-h perturbations of every point through the affine map theta -> base[F] + theta D[P, F]
+ *   (theta = exp(z)); candidate c = k (2 P + 1) + j with j = 0 the centre, 1 + p: +h on parameter p, 1 + P + p: -h.
+ * lqg_fd_combine: obj[K (2 P + 1)] (the summed log-likelihoods of those candidates) -> out[K, 1 + P] = value and the
+ *   central-difference gradient w.r.t. z; ok (NULL or the flag of lqg_precondition_flags): *ok == 0 turns out into NaN. */
+int lqg_fd_candidates(const double* z, const double* base, const double* D, void* flat, int32_t dtype, int64_t K, int32_t P,
+                      int64_t F, double h, void* stream);
+int lqg_fd_combine(const double* obj, const int32_t* ok, double* out, int64_t K, int32_t P, double h, void* stream);
+
 /* Replaces the per-trial scan of System.simulate [lqg/system.py:106-128] with the standard-normal
  * draws supplied by the caller (the reference draws them from jax.random, :102-105).
  * gains L[B,T,u,b], l[B,T,u] (l.ptr NULL = 0), K[B,T,b,y] as produced by the two calls above;

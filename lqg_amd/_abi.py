@@ -101,6 +101,11 @@ def _bind(path):
     if hasattr(lib, "lqg_precondition_flags"):
         lib.lqg_precondition_flags.argtypes = [C.POINTER(Problem), C.c_double, C.c_int32, C.c_void_p, C.c_void_p]
         lib.lqg_precondition_flags.restype = C.c_int
+    if hasattr(lib, "lqg_fd_candidates"):
+        lib.lqg_fd_candidates.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_int64, C.c_int32, C.c_int64, C.c_double, C.c_void_p]
+        lib.lqg_fd_candidates.restype = C.c_int
+        lib.lqg_fd_combine.argtypes = [C.c_void_p] * 3 + [C.c_int64, C.c_int32, C.c_double, C.c_void_p]
+        lib.lqg_fd_combine.restype = C.c_int
     if hasattr(lib, "lqg_point_mass_setup"):
         lib.lqg_point_mass_setup.argtypes = [C.c_int64] + [C.c_void_p] * 4 + [C.c_double, C.c_double] + [C.c_void_p] * 4
         lib.lqg_point_mass_setup.restype = C.c_int

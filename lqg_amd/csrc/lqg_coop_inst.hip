@@ -4,6 +4,8 @@
 // With -DLQG_INST_COOPF="x,b,u,y,d" / -DLQG_INST_COOPR="b,u" (+ -DLQG_INST_F32 / _F64) this file instead compiles ONE
 // fixed-dims instantiation of the forward / Riccati kernel (lqg_amd/build.py: one translation unit per shape of
 // lqg_dims.def, built in parallel); the base unit dispatches to them and keeps the run-time-dims kernels for the rest.
+#include <mutex>
+#include <unordered_map>
 #include "lqg_coop.hpp"
 #include "lqg_coop_launch.hpp"
 #include "lqg_launch.hpp"
@@ -33,10 +35,19 @@ inline long fwd_reals(const lqg_problem* p, bool kalman_only) {
 // largest product has at most two elements per lane; larger systems spread every product over the whole workgroup
 inline bool waves_for(int elems) { return elems <= 128; }
 
+// (a property of the kernel, not of a launch: raised once per kernel and size, never again from inside a stream capture)
 template <typename K>
 hipError_t raise_lds(K kernel, size_t bytes) {
   if (bytes <= kLdsDefault) return hipSuccess;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  static std::mutex mu;
+  static std::unordered_map<const void*, size_t> raised;
+  const void* key = reinterpret_cast<const void*>(kernel);
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = raised[key];
+  if (bytes <= have) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) have = bytes;
+  return e;
 }
 
 template <typename R>
@@ -67,9 +78,11 @@ namespace host {
 template <typename R, int CX, int CB, int CU, int CY, int CD>
 hipError_t coop_forward_fixed(const coop::Args<R>& k, size_t lds, hipStream_t st) {
   auto kern = coop::k_coop_forward<R, 256, false, true, CX, CB, CU, CY, CD>;
-  if (lds > 64 * 1024) {
+  static size_t raised = 0;             // (per instantiation: once per size, never again inside a stream capture)
+  if (lds > 64 * 1024 && lds > raised) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    raised = lds;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)k.n_sys), dim3(256), lds, st, k);
   return hipGetLastError();
@@ -77,9 +90,11 @@ hipError_t coop_forward_fixed(const coop::Args<R>& k, size_t lds, hipStream_t st
 template <typename R, int CB, int CU>
 hipError_t coop_riccati_fixed(const coop::Args<R>& k, size_t lds, hipStream_t st) {
   auto kern = coop::k_coop_riccati<R, 256, false, true, CB, CU>;
-  if (lds > 64 * 1024) {
+  static size_t raised = 0;             // (per instantiation: once per size, never again inside a stream capture)
+  if (lds > 64 * 1024 && lds > raised) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    raised = lds;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)k.n_sys), dim3(256), lds, st, k);
   return hipGetLastError();

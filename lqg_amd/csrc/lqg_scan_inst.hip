@@ -1,6 +1,8 @@
 // lqg_scan_inst.hip — host side of the time-parallel system sweeps (lqg_scan.hpp): workspace accounting and the launch
 // sequence  elements -> log2(T) scan levels -> per-step finalisers  for the Riccati, Kalman and moment recursions.
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
 
 #include "lqg_scan.hpp"
 #include "lqg_coop_launch.hpp"
@@ -11,6 +13,20 @@ namespace host {
 
 namespace {
 using scan::D;
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel, not of a launch: raised once per kernel and size —
+// never again from inside a stream capture, where the replays of the inference loops launch these kernels
+hipError_t raise_lds_once(const void* kern, size_t bytes) {
+  if (bytes <= 64 * 1024) return hipSuccess;
+  static std::mutex mu;
+  static std::unordered_map<const void*, size_t> raised;
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = raised[kern];
+  if (bytes <= have) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) have = bytes;
+  return e;
+}
 
 struct ScanPlan {
   size_t elems_off, elems_bytes, l_off, k_off, fg_off, ops_off, total;
@@ -56,11 +72,7 @@ template <int NW>
 void launch_level_rt_v(const scan::Seg& s0, const scan::Seg& s1, int n, long n_sys, hipStream_t st) {
   auto kern = scan::k_scan_level_rt<NW>;
   const size_t lds = scan::scan_level_rt_lds(n);
-  static size_t raised = 0;           // (an attribute of the kernel, not of the launch: raised once per size)
-  if (lds > 64 * 1024 && lds > raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
-      raised = lds;
-  }
+  (void)raise_lds_once(reinterpret_cast<const void*>(kern), lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)(s0.len + s1.len), (unsigned)n_sys), dim3(scan::scan_level_rt_threads(n, NW)), lds, st, s0, s1, n);
 }
 void launch_level_rt(const scan::Seg& s0, const scan::Seg& s1, int n, long n_sys, hipStream_t st) {
@@ -87,7 +99,7 @@ void run_scan(int n, int nseg, D* const in[2], D* const out[2], const int len[2]
     const size_t lds = scan::scan_lane_lds(n, longest);
     const dim3 grid((unsigned)nseg, (unsigned)n_sys), blk((unsigned)((longest + 63) / 64 * 64));
     auto go = [&](auto kern) {
-      if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)raise_lds_once(reinterpret_cast<const void*>(kern), lds);
       hipLaunchKernelGGL(kern, grid, blk, lds, st, s0, s1);
     };
     if (n == 1) go(scan::k_scan_lane<1, 1024>);
@@ -184,10 +196,8 @@ hipError_t scan_system_sweeps(const lqg_problem* p, lqg_view Sig, void* workspac
   auto launch = [&](auto kern, int count, long lds_doubles) {
     k.lds_elem = (int)lds_doubles;
     const size_t lds = (size_t)lds_doubles * blk.y * sizeof(D);
-    if (lds > 64 * 1024) {
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) attr = e;
-    }
+    const hipError_t e = raise_lds_once(reinterpret_cast<const void*>(kern), lds);
+    if (e != hipSuccess) attr = e;
     hipLaunchKernelGGL(kern, dim3((unsigned)((count + blk.y - 1) / blk.y), B), blk, lds, st, k);
   };
   // ---- Riccati (suffix scan over T + 1 elements, reversed storage) and Kalman (prefix scan over T elements) side by side

@@ -273,3 +273,66 @@ extern "C" int lqg_precondition_flags(const lqg_problem* p, double max_cond, int
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
+
+// ---------------------------------------------------------------- central differences around the candidate sweep
+// The one-vector value + gradient of the inference loops (lqg/infer/mle.py:17-23, lqg/optim.py:142-147 use jax.grad) is K
+// points x (2 P + 1) perturbed parameter vectors through ONE candidate sweep (lqg_amd/infer/graphed.py).  Inside the replayed
+// hipGraph every kernel costs ~4.7 us whatever it does, and the torch glue on either side of the sweep was 12 of its 26
+// kernels: these two replace it.
+namespace {
+// flat[c, f] = base[f] + sum_p exp(z[k, p] + s(c, p) h) D[p, f],  c = k (2 P + 1) + j:  j = 0 centre, 1 + p: +h on p, 1 + P + p: -h
+template <typename R>
+__global__ void __launch_bounds__(256) k_fd_candidates(const double* __restrict__ z, const double* __restrict__ base,
+                                                       const double* __restrict__ Dm, R* __restrict__ flat, long K, int P, long F,
+                                                       double h) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  const long C = K * (2 * P + 1);
+  if (e >= C * F) return;
+  const long c = e / F, f = e - c * F;
+  const long k = c / (2 * P + 1);
+  const int j = (int)(c - k * (2 * P + 1));
+  double acc = base[f];
+  for (int p = 0; p < P; ++p) {
+    const double s = (j == 1 + p) ? h : (j == 1 + P + p) ? -h : 0.0;
+    acc = fma(exp(z[k * P + p] + s), Dm[(long)p * F + f], acc);
+  }
+  flat[e] = (R)acc;
+}
+// out[k, 0] = obj[k, 0], out[k, 1 + p] = (obj[k, 1 + p] - obj[k, 1 + P + p]) / (2 h); NaN everywhere when *ok == 0
+__global__ void __launch_bounds__(256) k_fd_combine(const double* __restrict__ obj, const int32_t* __restrict__ ok, double* __restrict__ out,
+                                                    long K, int P, double h) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= K * (1 + P)) return;
+  const long k = e / (1 + P);
+  const int j = (int)(e - k * (1 + P));
+  const double* f = obj + k * (2 * P + 1);
+  double v = (j == 0) ? f[0] : (f[j] - f[P + j]) / (2.0 * h);
+  if (ok && *ok == 0) v = __builtin_nan("");
+  out[e] = v;
+}
+}  // namespace
+
+extern "C" int lqg_fd_candidates(const double* z, const double* base, const double* D, void* flat, int32_t dtype, int64_t K,
+                                 int32_t P, int64_t F, double h, void* stream) {
+  if (!z || !base || !D || !flat) return LQG_ERR_NULL;
+  if (K <= 0 || P <= 0 || F <= 0 || (dtype != LQG_F32 && dtype != LQG_F64)) return LQG_ERR_ARG;
+  const long n = K * (2 * P + 1) * F;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (dtype == LQG_F64)
+    hipLaunchKernelGGL(k_fd_candidates<double>, grid, block, 0, (hipStream_t)stream, z, base, D, static_cast<double*>(flat), (long)K,
+                       P, (long)F, h);
+  else
+    hipLaunchKernelGGL(k_fd_candidates<float>, grid, block, 0, (hipStream_t)stream, z, base, D, static_cast<float*>(flat), (long)K, P,
+                       (long)F, h);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int lqg_fd_combine(const double* obj, const int32_t* ok, double* out, int64_t K, int32_t P, double h, void* stream) {
+  if (!obj || !out) return LQG_ERR_NULL;
+  if (K <= 0 || P <= 0 || !(h > 0.0)) return LQG_ERR_ARG;
+  const long n = K * (1 + P);
+  hipLaunchKernelGGL(k_fd_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, obj, ok, out, (long)K, P, h);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}

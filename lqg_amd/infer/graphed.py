@@ -139,7 +139,7 @@ class GraphedLogLik:
         if not err < 1e-12:
             return None
         return dict(layout_a=fa[0], layout_d=fd[0], n_a=fa[1].shape[1], base=base.to(dt_).contiguous(), D=D.to(dt_).contiguous(),
-                    actor_cls=type(m.actor), dyn_cls=type(m.dynamics))
+                    base64=base.contiguous(), D64=D.contiguous(), actor_cls=type(m.actor), dyn_cls=type(m.dynamics))
 
     def _model(self, theta):
         af = self._affine
@@ -184,12 +184,7 @@ class GraphedLogLik:
         a = model.actor
         lib = _abi.load()
         if hasattr(lib, "lqg_precondition_flags"):
-            ln = _hip.Launch(model.actor, model.dynamics, d=self.d, n_trials=1, eps=self.eps)
-            flag = torch.empty(1, dtype=torch.int32, device=self.x.device)
-            _abi.check(lib.lqg_precondition_flags(C.byref(ln.p), float(plan.SCAN_MAX_COND), 1 if self.use_scan else 0,
-                                                  C.c_void_p(flag.data_ptr()), ln.stream()), "lqg_precondition_flags")
-            self._guard_keep = (ln, flag)
-            return flag[0] != 0
+            return self._guard_flag(model)[0] != 0
 
         def bounds(M):                               # [C, k, k] -> Gershgorin (lower, upper) per candidate
             M = 0.5 * (M + M.transpose(-1, -2))
@@ -204,6 +199,17 @@ class GraphedLogLik:
             lo, hi = bounds(V @ V.transpose(-1, -2))
             ok = ok & (lo > 0) & (hi <= plan.SCAN_MAX_COND * lo)
         return ok.all()
+
+    def _guard_flag(self, model):
+        """int32 [1] on the device: 1 when the preconditions of the frozen path hold (lqg_precondition_flags)."""
+        from lqg_amd import plan
+        lib = _abi.load()
+        ln = _hip.Launch(model.actor, model.dynamics, d=self.d, n_trials=1, eps=self.eps)
+        flag = torch.empty(1, dtype=torch.int32, device=self.x.device)
+        _abi.check(lib.lqg_precondition_flags(C.byref(ln.p), float(plan.SCAN_MAX_COND), 1 if self.use_scan else 0,
+                                              C.c_void_p(flag.data_ptr()), ln.stream()), "lqg_precondition_flags")
+        self._guard_keep = (ln, flag)
+        return flag
 
     def _decide(self):
         """Eager, once: everything that needs host values.  Structure (decoupling, sparsity pattern) is read off a model
@@ -253,7 +259,7 @@ class GraphedLogLik:
             return False                     # (decoupling inside the graph is only available through the measured affine map)
         return True
 
-    def _loglik(self, model):
+    def _loglik(self, model, poison=True):
         ln = _hip.Launch(model.actor, model.dynamics, d=self.d, n_trials=self.n, eps=self.eps)
         lib = ln.require_gpu()
         ll = ln.empty(self.n)
@@ -280,7 +286,7 @@ class GraphedLogLik:
         _abi.check(rc, "lqg_log_likelihood (graphed)")
         self._keep = (model, ln, ws, ll)
         obj = _hip.sum_trials(ll)                         # fp64 [C]
-        if self._guarded:                                 # a violated precondition of the frozen path poisons the result
+        if self._guarded and poison:                      # a violated precondition of the frozen path poisons the result
             obj = torch.where(self._guards(model), obj, torch.full_like(obj, float("nan")))
         return obj
 
@@ -343,6 +349,28 @@ class GraphedFiniteDifference(GraphedLogLik):
     def _forward(self):
         K, P = self.K, self.P
         z = self.z
+        lib = _abi.load()
+        if self._affine is not None and self.extra is None and hasattr(lib, "lqg_fd_candidates"):
+            # two kernels of the library around the sweep instead of a dozen of torch's (each ~4.7 us inside the graph):
+            # z -> the flattened specs of all K (2 P + 1) candidates; their objectives (+ the guard flag) -> value and gradient
+            af = self._affine
+            F = af["base"].shape[0]
+            flat = torch.empty(K * (2 * P + 1), F, dtype=self.x.dtype, device=self.x.device)
+            st = C.c_void_p(torch.cuda.current_stream(self.x.device).cuda_stream)
+            _abi.check(lib.lqg_fd_candidates(C.c_void_p(z.data_ptr()), C.c_void_p(af["base64"].data_ptr()),
+                                             C.c_void_p(af["D64"].data_ptr()), C.c_void_p(flat.data_ptr()),
+                                             _abi.F64 if self.x.dtype == torch.float64 else _abi.F32, K, P, F, self.h, st),
+                       "lqg_fd_candidates")
+            T = self.rows - 1
+            model = _Specs(_unflatten_spec(af["actor_cls"], af["layout_a"], flat[:, :af["n_a"]], T),
+                           _unflatten_spec(af["dyn_cls"], af["layout_d"], flat[:, af["n_a"]:], T))
+            obj = self._loglik(model, poison=False)
+            flag = self._guard_flag(model) if self._guarded else None
+            out = torch.empty(K, 1 + P, dtype=torch.float64, device=self.x.device)
+            _abi.check(lib.lqg_fd_combine(C.c_void_p(obj.data_ptr()), C.c_void_p(flag.data_ptr()) if flag is not None else None,
+                                          C.c_void_p(out.data_ptr()), K, P, self.h, st), "lqg_fd_combine")
+            self._fd_keep = (flat, obj, flag)
+            return out
         Z = torch.cat([z[:, None, :], z[:, None, :] + self._eye, z[:, None, :] - self._eye], dim=1).reshape(K * (2 * P + 1), P)
         f = self._loglik(self._model(torch.exp(Z).to(self.x.dtype))).reshape(K, 2 * P + 1)
         out = torch.cat([f[:, :1], (f[:, 1:P + 1] - f[:, P + 1:]) / (2 * self.h)], dim=1)

@@ -1,7 +1,2 @@
-python bench_grad.py 2>/dev/null | python -c "
-import sys, json
-for l in sys.stdin:
-    if l.startswith('{'):
-        j = json.loads(l); print(j.get('method'), j.get('ms_per_eval', j.get('ms_per_step')))
-"
-python scripts/small_batch.py f64 2>/dev/null | grep -v amdgpu | grep "systems   1 \|systems   9 " | head -12
+timeout 900 python -m pytest tests/test_infer.py -x -q -m gpu 2>&1 | tail -3
+export TMPDIR=/tmp; rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_fdg -o p -- python3 scripts/fd_graph_timeline.py run > /dev/null 2>&1; python3 scripts/fd_graph_timeline.py report | tee gpurun_out/fd_graph_timeline.txt; rm -rf gpurun_out/prof_fdg
