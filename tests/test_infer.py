@@ -410,3 +410,42 @@ def test_graph_survives_eviction_of_the_constructor_constant_caches():
     torch.cuda.synchronize()
     assert torch.equal(ev(z), before)
     del junk
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_finite_difference_kernels_against_their_torch_form(dtype):
+    """lqg_fd_candidates / lqg_fd_combine (include/lqg_hip.h; the two ends of the graphed central differences) against the
+    torch expressions they replace: perturbed exp(z) through an affine map, value and gradient with and without a tripped flag."""
+    import ctypes as C
+    from lqg_amd import _abi
+    lib = _abi.load()
+    g = torch.Generator().manual_seed(3)
+    K, P, F, h = 3, 5, 37, 1e-4
+    dev = torch.device("cuda")
+    z = torch.randn(K, P, generator=g, dtype=torch.float64).to(dev)
+    base = torch.randn(F, generator=g, dtype=torch.float64).to(dev)
+    D = torch.randn(P, F, generator=g, dtype=torch.float64).to(dev)
+    flat = torch.empty(K * (2 * P + 1), F, dtype=dtype, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    code = _abi.F64 if dtype == torch.float64 else _abi.F32
+    assert lib.lqg_fd_candidates(C.c_void_p(z.data_ptr()), C.c_void_p(base.data_ptr()), C.c_void_p(D.data_ptr()),
+                                 C.c_void_p(flat.data_ptr()), code, K, P, F, h, st) == 0
+    eye = h * torch.eye(P, dtype=torch.float64, device=dev)
+    Z = torch.cat([z[:, None, :], z[:, None, :] + eye, z[:, None, :] - eye], dim=1).reshape(K * (2 * P + 1), P)
+    want = base + torch.exp(Z) @ D
+    tol = 1e-13 if dtype == torch.float64 else 2e-6
+    assert float((flat.double() - want).abs().max() / want.abs().max()) < tol
+    obj = torch.randn(K * (2 * P + 1), generator=g, dtype=torch.float64).to(dev)
+    out = torch.empty(K, 1 + P, dtype=torch.float64, device=dev)
+    ok = torch.ones(1, dtype=torch.int32, device=dev)
+    f = obj.reshape(K, 2 * P + 1)
+    ref = torch.cat([f[:, :1], (f[:, 1:P + 1] - f[:, P + 1:]) / (2 * h)], dim=1)
+    for flag in (None, ok):
+        assert lib.lqg_fd_combine(C.c_void_p(obj.data_ptr()), C.c_void_p(flag.data_ptr()) if flag is not None else None,
+                                  C.c_void_p(out.data_ptr()), K, P, h, st) == 0
+        assert torch.allclose(out, ref, rtol=1e-14, atol=0.0)
+    ok.zero_()
+    assert lib.lqg_fd_combine(C.c_void_p(obj.data_ptr()), C.c_void_p(ok.data_ptr()), C.c_void_p(out.data_ptr()), K, P, h, st) == 0
+    assert bool(torch.isnan(out).all())
+    assert lib.lqg_fd_combine(None, None, C.c_void_p(out.data_ptr()), K, P, h, st) < 0          # (null argument: negative code)
