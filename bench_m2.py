@@ -38,15 +38,11 @@ def soa(base, T, B, gen, jitter, sym=False, positive_diag=False):
     return phys.permute(3, 0, 1, 2)
 
 
-def run(dev, dtype_name="f32", log2_batch=17, T=500, reps=5):
-    """One M2 measurement -> dict (the line main() prints; bench.py's `extra.m2_f32` leg)."""
-    from lqg_amd import _hipev
-    dtype = torch.float32 if dtype_name == "f32" else torch.float64
-    w = 4 if dtype_name == "f32" else 8
-    B = 1 << log2_batch
+def m2_system(dev, dtype, B, T):
+    """The headline model with every non-zero entry of every spec matrix moving in time and over the systems (multiplicative
+    jitter): genuinely time-varying [T, ...] stacks in the [T][element][system] layout.  -> (system, time-invariant base)."""
     gen = torch.Generator(device=dev)
     gen.manual_seed(4321)
-
     base, _ = workload.headline_system(B, T, seed=77, device=dev, dtype=dtype)
     a0, d0 = base.actor, base.dynamics
     first = lambda t: t[:, 0] if t.dim() == 4 else t[0].expand(B, *t.shape[1:])
@@ -60,7 +56,25 @@ def run(dev, dtype_name="f32", log2_batch=17, T=500, reps=5):
                           A=soa(first(d0.A), T, B, gen, jit), B=soa(first(d0.B), T, B, gen, jit),
                           F=soa(first(d0.F), T, B, gen, jit), V=soa(first(d0.V), T, B, gen, jit),
                           W=soa(first(d0.W), T, B, gen, jit))
-    system = lqg_amd.System(actor=actor, dynamics=dyn)
+    return lqg_amd.System(actor=actor, dynamics=dyn), base
+
+
+def m2_pattern():
+    """(dims, masks, key) of the sparsity pattern the M2 workload keeps through time (a small CPU instance of it: the pattern
+    does not depend on the batch) — __graft_entry__.build() compiles its library so that the bench does not."""
+    from lqg_amd import specialize
+    system, _ = m2_system(torch.device("cpu"), torch.float64, 4, 3)
+    dims, masks = specialize.pattern_of_time_varying(system, 4)
+    return dims, masks, specialize.pattern_key(dims, masks)
+
+
+def run(dev, dtype_name="f32", log2_batch=17, T=500, reps=5):
+    """One M2 measurement -> dict (the line main() prints; bench.py's `extra.m2_f32` leg)."""
+    from lqg_amd import _hipev
+    dtype = torch.float32 if dtype_name == "f32" else torch.float64
+    w = 4 if dtype_name == "f32" else 8
+    B = 1 << log2_batch
+    system, base = m2_system(dev, dtype, B, T)
     x = workload.pack_trials(workload.simulate_one_trial_each(base, seed=5))          # [B,1,T+1,4]
     dm = dict(x=4, b=6, u=2, y=4, m=10, d=4)
 
@@ -82,7 +96,18 @@ def run(dev, dtype_name="f32", log2_batch=17, T=500, reps=5):
     for i in range(4):
         lnm.p.phase_events[i] = evs[i].h
 
-    def one_pass():
+    # the structure-specialised library when the specs keep one sparsity pattern through time (they do: a zoo model with
+    # moving entries), else the dense kernels of the main library
+    sp_entry = _hip.materialised_entry(lnm, system, 4)
+
+    def one_pass(dense=False):
+        if sp_entry is not None and not dense:
+            # one ABI call, two kernels: k_riccati_tv_sp (L, H out + gain scratch) -> k_forward_tv_sp (K, mu, Sigma, ll out)
+            _abi.check(sp_entry(
+                C.byref(lnm.p), lnm.traj(xx, xb), lnm.view(L), _abi.NULL_VIEW, lnm.view(H), lnm.view(K), lnm.traj(mu),
+                lnm.view(Sig), C.c_void_p(ll.data_ptr()), 1, C.c_void_p(ws.data_ptr()), nbytes, lnm.stream()),
+                "lqg_solve_materialised_sp")
+            return
         # one ABI call, two kernels: k_riccati (L, H out + gain scratch) -> k_forward (K, mu, Sigma, ll out)
         _abi.check(lib.lqg_solve_materialised(
             C.byref(lnm.p), lnm.traj(xx, xb), lnm.view(L), _abi.NULL_VIEW, lnm.view(H), lnm.view(K), lnm.traj(mu),
@@ -102,6 +127,20 @@ def run(dev, dtype_name="f32", log2_batch=17, T=500, reps=5):
         ric.append(evs[0].elapsed_ms(evs[1]))
         fwd.append(evs[1].elapsed_ms(evs[2]))
     ms = float(np.median(ms))
+    dense_ms = None
+    if sp_entry is not None:                             # the same pass on the dense kernels, for the record
+        one_pass(dense=True)
+        torch.cuda.synchronize()
+        dm_ = []
+        for _ in range(2):
+            e0.record()
+            one_pass(dense=True)
+            e1.record()
+            e1.synchronize()
+            dm_.append(e0.elapsed_time(e1))
+        dense_ms = float(np.median(dm_))
+        one_pass()                                       # (the outputs checked below are the specialised path's)
+        torch.cuda.synchronize()
 
     b, u, y, xx_, m, d = dm["b"], dm["u"], dm["y"], dm["x"], dm["m"], dm["d"]
     in_per_step = (3 * b * b + b * u + y * b + y * y + u * u) + (b + u * b + u) + (2 * xx_ * xx_ + xx_ * u + y * xx_ + y * y)
@@ -129,10 +168,13 @@ def run(dev, dtype_name="f32", log2_batch=17, T=500, reps=5):
         "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                      "frac_of_measured_copy_rate": gbs / 6290.0,
                      "algorithmic_bytes_per_pass": bytes_solve * B, "traffic": None,
-                     "kernel": "k_riccati<TI=false> + k_forward<TI=false, FUSED, MAT> (one pass = both)",
+                     "kernel": ("k_riccati_tv_sp + k_forward_tv_sp (pattern library: structurally non-zero entries loaded per step; "
+                                "one pass = both)" if sp_entry is not None else
+                                "k_riccati<TI=false> + k_forward<TI=false, FUSED, MAT> (one pass = both)"),
+                     "dense_kernels_ms_per_pass": dense_ms,
                      "kernel_ms": float(np.median(ric)) + float(np.median(fwd)),
                      "riccati_kernel_ms": float(np.median(ric)), "forward_kernel_ms": float(np.median(fwd))},
-        "calls": "lqg_solve_materialised (1 ABI call, 2 kernels: k_riccati -> k_forward)",
+        "calls": ("lqg_solve_materialised_sp" if sp_entry is not None else "lqg_solve_materialised") + " (1 ABI call, 2 kernels)",
         "workspace_GB": nbytes / 1e9, "parity_rel_maxnorm_vs_fp64_oracle": parity}
 
 

@@ -248,6 +248,31 @@ def specialised_library(ln, system, d, check_strategy=True):
     return specialize.load_pattern(key, dims, masks)
 
 
+def materialised_entry(ln, system, d):
+    """`lqg_solve_materialised_sp` of the structure-specialised library for this launch — time-varying specs included, as
+    long as they keep one sparsity pattern (specialize.pattern_of_time_varying) — or None: then `lqg_solve_materialised` of
+    the main library serves the call (dense kernels).  One trial per system, no affine cost terms."""
+    import os
+    if system is None or os.environ.get("LQG_NO_SPECIALIZE") == "1" or ln.p.n_trials != 1 or ln.m > LANE_MAX_JOINT:
+        return None
+    if any(getattr(ln.p.actor, f).ptr for f in ("q", "qf", "P", "r")):
+        return None
+    from lqg_amd import specialize
+    cache = system.__dict__.setdefault("_lqg_materialised_pattern", {})
+    key = (int(d), specialize.spec_versions(system))
+    if key not in cache:
+        varying = any(getattr(spec, f).st != 0 for spec, fields in ((ln.p.actor, ("Q", "R", "A", "B", "V", "F", "W")),
+                                                                    (ln.p.dynamics, ("A", "B", "V", "F", "W"))) for f in fields)
+        if varying and ln.T > 1:
+            dims, masks = specialize.pattern_of_time_varying(system, d)
+            cache[key] = (dims, masks, specialize.pattern_key(dims, masks))
+        else:
+            cache[key] = specialize.system_pattern(system, d)
+    dims, masks, pkey = cache[key]
+    lib = specialize.load_pattern(pkey, dims, masks)
+    return getattr(lib, "lqg_solve_materialised_sp", None) if lib is not None else None
+
+
 def sum_trials(ll):
     """ll[(B,)n] -> fp64 sums [(B,)] with a fixed reduction tree (lqg_sum_trials)."""
     lib = _abi.load()

@@ -64,7 +64,7 @@ constexpr int sp_chunk() {
 // one backward step: S <- Q + A'SA + L'HL + L'G + G'L with L = -Ht^-1 G (lqr.py:22-34), L returned
 template <typename R, int NB, int NU, typename MA, typename MB, typename MQ, typename MR>
 LQG_DEV void riccati_step_sp(R (&S)[NB * NB], const MA& A, const MB& Bm, const MQ& Q, const MR& Rm, const R eps,
-                             R (&L)[NU * NB]) {
+                             R (&L)[NU * NB], R* Ht_out = nullptr) {
   const auto Sm = from_dense<R, NB, NB>(S);
   const auto SA = mul(Sm, A);
   const auto SB = mul(Sm, Bm);
@@ -77,6 +77,7 @@ LQG_DEV void riccati_step_sp(R (&S)[NB * NB], const MA& A, const MB& Bm, const M
   R Ht[NU * NU];
   LQG_UNROLL for (int i = 0; i < NU * NU; ++i) Ht[i] = H[i];
   LQG_UNROLL for (int i = 0; i < NU; ++i) Ht[i * NU + i] += shift;  // lqr.py:27-28
+  if (Ht_out) { LQG_UNROLL for (int i = 0; i < NU * NU; ++i) Ht_out[i] = Ht[i]; }
   R Lc[NU * NU], dinv[NU], Li[NU * NU], Hi[NU * NU];
   chol_lower<R, NU>(Ht, Lc, dinv);
   tri_inverse_lower<R, NU>(Lc, dinv, Li);
@@ -451,6 +452,183 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
       LQG_UNROLL for (int j = 0; j <= i; ++j) op[Ops::L_OFF + (e++)] = (OT)Li[i * O + j];
     op[Ops::H_OFF] = (OT)(hl + kLogNorm);
   }
+}
+
+// ---------------------------------------------------------------- TIME-VARYING specs, everything materialised (mode M2)
+// lqg_solve_materialised through the generic dense kernels is bound by its ~3700 instructions per step at one wave per SIMD
+// (DESIGN.md §6b).  When the time-varying specs keep ONE sparsity pattern (a zoo model whose entries move in time: the masks are
+// the union over systems and steps, lqg_amd/specialize.py), the same two sweeps run on the pattern's masks: only the
+// structurally non-zero entries are loaded per step, the step is the ~250 instructions of the headline path, and L, H, K,
+// mu, Sigma are stored dense (structural zeros as zeros).  One trial per system, swept in-lane.
+template <typename R, int NB, int NU, typename PAT>
+__global__ void __launch_bounds__(LQG_BLOCK, 2) k_riccati_tv_sp(const RiccatiArgs<R> a) {
+  const long s = blockIdx.x * (long)LQG_BLOCK + threadIdx.x;
+  if (s >= a.n_sys) return;
+  R S[NB * NB];
+  load_sym<R, NB>(a.Qf.p + s * a.Qf.sb, a.Qf.sr, a.Qf.sc, S);
+  for (int t = a.T - 1; t >= 0; --t) {
+    const auto A = load_masked<R, NB, NB, PAT::Aa>(a.A.p + s * a.A.sb + t * a.A.st, a.A.sr, a.A.sc);
+    const auto Bm = load_masked<R, NB, NU, PAT::Ba>(a.B.p + s * a.B.sb + t * a.B.st, a.B.sr, a.B.sc);
+    const auto Q = load_sym_masked<R, NB, PAT::Q>(a.Q.p + s * a.Q.sb + t * a.Q.st, a.Q.sr, a.Q.sc);
+    const auto Rm = load_sym_masked<R, NU, PAT::Rr>(a.Rm.p + s * a.Rm.sb + t * a.Rm.st, a.Rm.sr, a.Rm.sc);
+    R L[NU * NB], Ht[NU * NU];
+    riccati_step_sp<R, NB, NU>(S, A, Bm, Q, Rm, a.eps, L, Ht);
+    if (a.Ls) {                                    // (null when the caller's L output doubles as the forward sweep's gain stream)
+      R* dst = a.Ls + (long)t * (NU * NB) * a.ldb + s;
+      LQG_UNROLL for (int e = 0; e < NU * NB; ++e) dst[e * a.ldb] = L[e];
+    }
+    if (a.L.p) store_mat<R, NU, NB>(const_cast<R*>(a.L.p) + s * a.L.sb + t * a.L.st, a.L.sr, a.L.sc, L);
+    if (a.l.p) {
+      R* ld = const_cast<R*>(a.l.p) + s * a.l.sb + t * a.l.st;
+      LQG_UNROLL for (int i = 0; i < NU; ++i) ld[i * a.l.sr] = R(0);
+    }
+    if (a.H.p) store_mat<R, NU, NU>(const_cast<R*>(a.H.p) + s * a.H.sb + t * a.H.st, a.H.sr, a.H.sc, Ht);
+  }
+}
+
+template <typename R, int NX, int NB, int NU, int NY, int ND, typename PAT, bool DENSE_P>
+__global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? 2 : 1) k_forward_tv_sp(const ForwardArgs<R> a, const DView<R> Lv) {
+  constexpr int M = NX + NB, O = ND, RR = M - ND;
+  const long s = blockIdx.x * (long)LQG_BLOCK + threadIdx.x;
+  if (s >= a.n_sys) return;
+  constexpr auto PMASK = kalman_state_mask<PAT, NB, NY, DENSE_P>();
+  Mat<R, NB, NB, PMASK> Pm;
+  {
+    R P0[NB * NB];
+    if (DENSE_P && a.Sigma0.p) load_sym<R, NB>(a.Sigma0.p + s * a.Sigma0.sb, a.Sigma0.sr, a.Sigma0.sc, P0);
+    else load_gram<R, NB>(a.aV.p + s * a.aV.sb, a.aV.sr, a.aV.sc, a.nva, P0);               // V[0] V[0]'   system.py:160
+    LQG_UNROLL for (int i = 0; i < NB * NB; ++i)
+      if (PMASK.b[i]) Pm.v[i] = P0[i];
+  }
+  R Sg[M * M], xprev[O], dO[O], muR[RR];
+  double acc = 0.0;
+  const R* xp = a.x.p + s * a.x.sb;
+  LQG_UNROLL for (int i = 0; i < O; ++i) { xprev[i] = xp[i * a.x.sd]; dO[i] = R(0); }
+  LQG_UNROLL for (int i = 0; i < RR; ++i) muR[i] = R(0);
+  const R kLogNorm = R(0.5 * ND * 1.8378770664093453);
+  R Li[O * O], U2[RR * O], hl;
+  auto condition = [&]() {
+    R Soo[O * O], Lc[O * O], dinv[O];
+    LQG_UNROLL for (int i = 0; i < O; ++i)
+      LQG_UNROLL for (int j = 0; j < O; ++j) Soo[i * O + j] = Sg[i * M + j];
+    chol_lower<R, O>(Soo, Lc, dinv);
+    tri_inverse_lower<R, O>(Lc, dinv, Li);
+    R pd = dinv[0];
+    LQG_UNROLL for (int i = 1; i < O; ++i) pd *= dinv[i];
+    hl = -log_<R>(pd);
+    LQG_UNROLL for (int p = 0; p < RR; ++p)
+      LQG_UNROLL for (int j = 0; j < O; ++j) {
+        R v = R(0);
+        LQG_UNROLL for (int k = 0; k <= j; ++k) v += Sg[(O + p) * M + k] * Li[j * O + k];
+        U2[p * O + j] = v;
+      }
+  };
+  R w[O], xt[O];
+  auto innovate = [&](int row, bool score) {
+    const R* xr = xp + (long)row * a.x.st;
+    LQG_UNROLL for (int i = 0; i < O; ++i) xt[i] = xr[i * a.x.sd];
+    R zz = R(0);
+    LQG_UNROLL for (int i = 0; i < O; ++i) {
+      R v = R(0);
+      LQG_UNROLL for (int j = 0; j <= i; ++j) v += Li[i * O + j] * ((xt[j] - xprev[j]) - dO[j]);
+      w[i] = v;
+      zz += v * v;
+    }
+    if (score) acc -= (double)(R(0.5) * zz + hl + kLogNorm);
+  };
+  // this step's specs: structurally non-zero entries only
+  auto ldAa = [&](int t) { return load_masked<R, NB, NB, PAT::Aa>(a.aA.p + s * a.aA.sb + t * a.aA.st, a.aA.sr, a.aA.sc); };
+  auto ldBa = [&](int t) { return load_masked<R, NB, NU, PAT::Ba>(a.aB.p + s * a.aB.sb + t * a.aB.st, a.aB.sr, a.aB.sc); };
+  auto ldFa = [&](int t) { return load_masked<R, NY, NB, PAT::Fa>(a.aF.p + s * a.aF.sb + t * a.aF.st, a.aF.sr, a.aF.sc); };
+  auto ldVVa = [&](int t) { return load_gram_masked<R, NB, PAT::VVa>(a.aV.p + s * a.aV.sb + t * a.aV.st, a.aV.sr, a.aV.sc, a.nva); };
+  auto ldWWa = [&](int t) { return load_gram_masked<R, NY, PAT::WWa>(a.aW.p + s * a.aW.sb + t * a.aW.st, a.aW.sr, a.aW.sc, a.nwa); };
+  auto ldAd = [&](int t) { return load_masked<R, NX, NX, PAT::Ad>(a.dA.p + s * a.dA.sb + t * a.dA.st, a.dA.sr, a.dA.sc); };
+  auto ldBd = [&](int t) { return load_masked<R, NX, NU, PAT::Bd>(a.dB.p + s * a.dB.sb + t * a.dB.st, a.dB.sr, a.dB.sc); };
+  auto ldN1 = [&](int t) { return load_gram_masked<R, NX, PAT::N1>(a.dV.p + s * a.dV.sb + t * a.dV.st, a.dV.sr, a.dV.sc, a.nvd); };
+  auto ldFd = [&](int t) { return load_masked<R, NY, NX, PAT::Fd>(a.dF.p + s * a.dF.sb + t * a.dF.st, a.dF.sr, a.dF.sc); };
+  auto ldWWd = [&](int t) { return load_gram_masked<R, NY, PAT::WWd>(a.dW.p + s * a.dW.sb + t * a.dW.st, a.dW.sr, a.dW.sc, a.nwd); };
+  auto ldL = [&](int t) {
+    Mat<R, NU, NB> L;                             // gains of step t: the caller's L array or the gain scratch, as a strided view
+    const R* src = Lv.p + s * Lv.sb + (long)t * Lv.st;
+    LQG_UNROLL for (int i = 0; i < NU; ++i)
+      LQG_UNROLL for (int j = 0; j < NB; ++j) L.v[i * NB + j] = src[i * Lv.sr + j * Lv.sc];
+    return L;
+  };
+  // (measured on 2^17 systems — two waves per SIMD — and not kept: requesting the next step's rows one or four steps ahead
+  // (17.6 -> 19.0 ms forward, 5.4 -> 6.0 ms Riccati) and running the Kalman step of t + 1 inside iteration t as a second
+  // dependency chain (17.8 -> 18.9 ms))
+  auto step = [&]<bool FIRST>(int t) {
+    const auto Aa = ldAa(t);
+    const auto Ba = ldBa(t);
+    const auto Fa = ldFa(t);
+    const auto VVa = ldVVa(t);
+    const auto WWa = ldWWa(t);
+    const auto Ad = ldAd(t);
+    const auto Bd = ldBd(t);
+    const auto N1 = ldN1(t);
+    const auto Fd = ldFd(t);
+    const auto WWd = ldWWd(t);
+    const Mat<R, NU, NB> L = ldL(t);
+    const auto FAa = restrict_to<PAT::FAa>(mul(Fa, Aa));
+    const auto FAd = restrict_to<PAT::FAd>(mul(Fd, Ad));
+    const auto DB = restrict_to<PAT::DB>(sub(mul(Fd, Bd), mul(Fa, Ba)));
+    const auto N2 = restrict_to<PAT::N2>(mul(Fd, N1));
+    const auto N3 = restrict_to<PAT::N3>(mul_nt_sym_add(mul(Fd, N1), Fd, WWd));
+    // ---- Kalman step                                                   kf.py:10-14
+    const auto AP = mul(Aa, Pm);
+    const auto Pp = mul_nt_sym_add(AP, Aa, VVa);
+    const auto FP = mul(Fa, Pp);
+    const auto Gi = spd_inverse_masked(mul_nt_sym_add(FP, Fa, WWa));
+    const auto K = mul_tn(FP, Gi);
+    assign_state(Pm, sym_sub_mul(Pp, K, FP));
+    if (a.Kout.p) {
+      R Kd[NB * NY];
+      to_dense(K, Kd);
+      store_mat<R, NB, NY>(const_cast<R*>(a.Kout.p) + s * a.Kout.sb + t * a.Kout.st, a.Kout.sr, a.Kout.sc, Kd);
+    }
+    // ---- joint dynamics and noise covariance                           system.py:167-207
+    const auto BK = add(Ba, mul(K, DB));
+    const auto Fj = block2x2(Ad, mul(Bd, L), mul(K, FAd), add(sub(Aa, mul(K, FAa)), mul(BK, L)));
+    static_assert(mask_eq(decltype(Fj)::mask, joint_dynamics_mask<PAT, NX, NB, NU, NY, DENSE_P>()),
+                  "joint_dynamics_mask() must mirror the mask algebra of the joint system built here");
+    const auto KN2 = mul(K, N2);
+    const auto GG = block2x2(N1, transpose(KN2), KN2, mul_nt_sym_add(mul(K, N3), K, Mat<R, NB, NB, mask_none<NB, NB>()>{}));
+    if constexpr (FIRST) to_dense(GG, Sg);                               // Sigma0 := G[0] G[0]^T  system.py:212
+    // ---- condition on x_t, score it, propagate the mean                system.py:219-221, 244-248
+    condition();
+    innovate(t, !FIRST);
+    R cvec[M], mn[M];
+    LQG_UNROLL for (int j = 0; j < O; ++j) cvec[j] = xt[j];
+    LQG_UNROLL for (int p = 0; p < RR; ++p) {
+      R v = muR[p];
+      LQG_UNROLL for (int j = 0; j < O; ++j) v += U2[p * O + j] * w[j];
+      cvec[O + p] = v;
+    }
+    dev_matvec_row<O, 0>(Fj, cvec, mn);                                  // rows < O as deviation from x_t
+    LQG_UNROLL for (int i = 0; i < O; ++i) { dO[i] = mn[i]; xprev[i] = xt[i]; }
+    LQG_UNROLL for (int p = 0; p < RR; ++p) muR[p] = mn[O + p];
+    if (a.mu.p) {
+      R* dst = const_cast<R*>(a.mu.p) + s * a.mu.sb + (long)t * a.mu.st;
+      LQG_UNROLL for (int i = 0; i < M; ++i) dst[i * a.mu.sd] = (i < O) ? xt[i] + mn[i] : mn[i];
+    }
+    // ---- Sigma' = F2 C F2^T + GG,  C = Srr - U2 U2^T                    system.py:223-230
+    Mat<R, RR, RR> C;
+    LQG_UNROLL for (int p = 0; p < RR; ++p)
+      LQG_UNROLL for (int q = p; q < RR; ++q) {
+        R v = Sg[(O + p) * M + O + q];
+        LQG_UNROLL for (int j = 0; j < O; ++j) v -= U2[p * O + j] * U2[q * O + j];
+        C.v[p * RR + q] = v;
+        C.v[q * RR + p] = v;
+      }
+    const auto F2 = cols<O, RR>(Fj);
+    to_dense(mul_nt_sym_add(mul(F2, C), F2, GG), Sg);
+    if (a.Sig.p) store_mat<R, M, M>(const_cast<R*>(a.Sig.p) + s * a.Sig.sb + t * a.Sig.st, a.Sig.sr, a.Sig.sc, Sg);
+  };
+  step.template operator()<true>(0);
+  for (int t = 1; t < a.T; ++t) step.template operator()<false>(t);
+  condition();
+  innovate(a.T, true);
+  if (a.ll) a.ll[s * a.ll_sb] = (R)acc;
 }
 
 // ---------------------------------------------------------------- per-trial sweep with the operator's structure

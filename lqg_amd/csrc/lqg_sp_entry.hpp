@@ -192,6 +192,54 @@ int log_likelihood_sp(const lqg_problem* p, lqg_traj x, void* ll, int64_t ll_sb,
   return LQG_ERR_ARG;
 }
 
+// lqg_solve_materialised (include/lqg_hip.h) for specs that may vary in TIME under the pattern the library is compiled for:
+// one trial per system, no affine cost terms; every output view optional.  Refusals as log_likelihood_sp.
+template <typename PAT, int NX, int NB, int NU, int NY, int ND>
+int solve_materialised_sp(const lqg_problem* p, lqg_traj x, lqg_view L, lqg_view l, lqg_view H, lqg_view K, lqg_traj mu,
+                          lqg_view Sigma, void* ll, int64_t ll_sb, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!p || !x.ptr) return LQG_ERR_NULL;
+  const lqg_dims& dm = p->dims;
+  if (dm.x != NX || dm.b != NB || dm.u != NU || dm.y != NY || dm.d != ND) return LQG_ERR_DIMS;
+  if (p->n_trials != 1 || p->T < 1 || affine(p)) return LQG_ERR_ARG;
+  if (p->dtype != LQG_F32 && p->dtype != LQG_F64) return LQG_ERR_ARG;
+  if (p->n_sys == 0) return 0;
+  const Workspace w = carve(p, false);
+  if (!workspace || workspace_bytes < w.total) return LQG_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  auto mark = [&](int i) {
+    if (p->phase_events[i]) (void)hipEventRecord(static_cast<hipEvent_t>(p->phase_events[i]), st);
+  };
+  const lqg_spec& a = p->actor;
+  const lqg_spec& d = p->dynamics;
+  const dim3 grid(blocks_for(p->n_sys)), block(LQG_BLOCK);
+  auto go = [&](auto tag) {
+    using R = decltype(tag);
+    R* Ls = reinterpret_cast<R*>(static_cast<char*>(workspace) + w.ls_off);
+    mark(0);
+    // the materialised L doubles as the forward sweep's gain stream (no second copy in the workspace) when it is requested
+    const bool own_l = L.ptr != nullptr;
+    lqg::RiccatiArgs<R> rk{dv<R>(a.Q), dv<R>(a.q), dv<R>(a.Qf), dv<R>(a.qf), dv<R>(a.P), dv<R>(a.R), dv<R>(a.r),
+                           dv<R>(a.A), dv<R>(a.B), dv<R>(L), dv<R>(l), dv<R>(H), own_l ? nullptr : Ls, w.ldb, (long)p->n_sys,
+                           p->T, (R)p->eps};
+    const lqg::DView<R> Lv = own_l ? dv<R>(L)
+                                   : lqg::DView<R>{Ls, 1, (long)(NU * NB) * w.ldb, (long)NB * w.ldb, w.ldb};
+    hipLaunchKernelGGL((lqg::k_riccati_tv_sp<R, NB, NU, PAT>), grid, block, 0, st, rk);
+    mark(1);
+    lqg::ForwardArgs<R> fk{dv<R>(a.A), dv<R>(a.B), dv<R>(a.F), dv<R>(a.V), dv<R>(a.W),
+                           dv<R>(d.A), dv<R>(d.B), dv<R>(d.F), dv<R>(d.V), dv<R>(d.W),
+                           dv<R>(p->Sigma0), Ls, w.ldb, dt<R>(x), static_cast<R*>(ll), (long)ll_sb, nullptr, dv<R>(Sigma),
+                           dt<R>(mu), dv<R>(K), (long)p->n_sys, p->T, p->dims.nva, p->dims.nwa, p->dims.nvd, p->dims.nwd};
+    if (p->Sigma0.ptr) hipLaunchKernelGGL((lqg::k_forward_tv_sp<R, NX, NB, NU, NY, ND, PAT, true>), grid, block, 0, st, fk, Lv);
+    else hipLaunchKernelGGL((lqg::k_forward_tv_sp<R, NX, NB, NU, NY, ND, PAT, false>), grid, block, 0, st, fk, Lv);
+    mark(2);
+    mark(3);
+  };
+  if (p->dtype == LQG_F64) go(double{});
+  else go(float{});
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
 // lqg_trial_sweep_fn (include/lqg_hip.h): the sweep alone, over an operator stream some other library produced (the
 // time-parallel system sweeps of the main library).  Same refusals as log_likelihood_sp.
 template <typename PAT, int NX, int NB, int NU, int NY, int ND>

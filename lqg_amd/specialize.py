@@ -76,6 +76,39 @@ def pattern_of(system, d, grad_full=False):
     return dims, out
 
 
+def pattern_of_time_varying(system, d):
+    """Masks for specs that vary in TIME (and over the systems) under one sparsity pattern: the raw fields' masks are the
+    union over every system and step (a reduction, no temporary of the fields' size — 2^17 systems x 500 steps are 65 M
+    matrices per field); the masks of the hoisted products follow from those by the boolean algebra of the products, i.e.
+    they are CONSERVATIVE (a numerical cancellation such as Fd Bd - Fa Ba = 0 of the tracking models is not assumed: it does
+    not survive independent variation of the entries in time)."""
+    a, dy = system.actor, system.dynamics
+
+    def nz(t):
+        lead = tuple(range(t.dim() - 2))
+        return (torch.count_nonzero(t.detach(), dim=lead) != 0).cpu().numpy() if lead else (t.detach() != 0).cpu().numpy()
+
+    def diag_differs_from_one(t):
+        dg = torch.diagonal(t.detach(), dim1=-2, dim2=-1)
+        lead = tuple(range(dg.dim() - 1))
+        return (torch.count_nonzero(dg - 1, dim=lead) != 0).cpu().numpy() if lead else (dg != 1).cpu().numpy()
+
+    bm = lambda p, q: (p.astype(np.int64) @ q.astype(np.int64)) > 0           # boolean matrix product
+    Aa, Ba, Fa, Va, Wa = (nz(getattr(a, f)) for f in ("A", "B", "F", "V", "W"))
+    Q, Rr = nz(a.Q) | nz(a.Qf), nz(a.R)
+    Ad, Bd, Fd, Vd, Wd = (nz(getattr(dy, f)) for f in ("A", "B", "F", "V", "W"))
+    N1 = bm(Vd, Vd.T)
+    AdmI = Ad.copy()
+    np.fill_diagonal(AdmI, diag_differs_from_one(dy.A))
+    masks = dict(Aa=Aa, Ba=Ba, Fa=Fa, VVa=bm(Va, Va.T), WWa=bm(Wa, Wa.T), Q=Q | Q.T, Rr=Rr | Rr.T, Ad=Ad, AdmI=AdmI, Bd=Bd,
+                 Fd=Fd, N1=N1, WWd=bm(Wd, Wd.T), FAa=bm(Fa, Aa), FAd=bm(Fd, Ad), DB=bm(Fd, Bd) | bm(Fa, Ba), N2=bm(Fd, N1),
+                 N3=bm(bm(Fd, N1), Fd.T) | bm(Wd, Wd.T))
+    for k in ("VVa", "WWa", "N1", "WWd", "N3"):
+        masks[k] = masks[k] | masks[k].T
+    dims = dict(x=Ad.shape[-1], b=Aa.shape[-1], u=Ba.shape[-1], y=Fa.shape[-2], d=int(d))
+    return dims, masks
+
+
 def pattern_key(dims, masks):
     h = hashlib.sha1(repr(sorted(dims.items())).encode())
     for k in _FIELDS:
@@ -106,6 +139,11 @@ def generate_source(key, dims, masks):
               "                                  const void* ops, void* stream) {",
               f"  return lqg::host::trial_sweep_entry<Pat, {dims['x']}, {dims['b']}, {dims['u']}, {dims['y']}, {dims['d']}>(",
               "      p, x, ll, ll_sb, ll_sn, ops, stream);", "}",
+              'extern "C" int lqg_solve_materialised_sp(const lqg_problem* p, lqg_traj x, lqg_view L, lqg_view l, lqg_view H, lqg_view K,',
+              "                                         lqg_traj mu, lqg_view Sigma, void* ll, int64_t ll_sb, void* workspace,",
+              "                                         size_t workspace_bytes, void* stream) {",
+              f"  return lqg::host::solve_materialised_sp<Pat, {dims['x']}, {dims['b']}, {dims['u']}, {dims['y']}, {dims['d']}>(",
+              "      p, x, L, l, H, K, mu, Sigma, ll, ll_sb, workspace, workspace_bytes, stream);", "}",
               f'extern "C" const char* lqg_sp_pattern_key(void) {{ return "{key}"; }}', ""]
     return "\n".join(lines)
 
@@ -180,6 +218,10 @@ def load_pattern(key, dims, masks, verbose=False):
             lib.lqg_trial_sweep_sp.argtypes = [C.POINTER(_abi.Problem), _abi.Traj, C.c_void_p, C.c_int64, C.c_int64,
                                                C.c_void_p, C.c_void_p]
             lib.lqg_trial_sweep_sp.restype = C.c_int
+            if hasattr(lib, "lqg_solve_materialised_sp"):
+                lib.lqg_solve_materialised_sp.argtypes = ([C.POINTER(_abi.Problem), _abi.Traj] + [_abi.View] * 4 + [_abi.Traj, _abi.View]
+                                                          + [C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p])
+                lib.lqg_solve_materialised_sp.restype = C.c_int
     except (OSError, RuntimeError) as e:
         import warnings
         warnings.warn(f"lqg_amd: no specialised library for pattern {key} ({e!s:.200}); using the generic dense kernels")

@@ -21,7 +21,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(f"{g}/prof_{tag}m2_{c}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            name = "k_riccati" if "k_riccati" in k else "k_forward" if "k_forward" in k else None
+            name = ("k_riccati_tv_sp" if "k_riccati_tv_sp" in k else "k_forward_tv_sp" if "k_forward_tv_sp" in k else
+                    "k_riccati (dense, for comparison)" if "k_riccati<" in k else
+                    "k_forward (dense, for comparison)" if "k_forward<" in k else None)
             if name and r["Counter_Name"] == c:
                 acc[name][c].append(float(r["Counter_Value"]))
 m2 = json.loads(open(f"{g}/m2_{tag}m2.json").read().strip().splitlines()[-1])
@@ -35,7 +37,8 @@ for name, d in acc.items():
     out["launches_averaged"][name] = len(F)
     out["kernels"][name] = {"fetch_size_kib_raw": fs, "write_size_kib_raw": ws, "hbm_bytes_per_launch": (2 * fs + ws) * 1024}
 rf = m2["roofline"]
-out["hbm_bytes_per_pass"] = sum(v["hbm_bytes_per_launch"] for v in out["kernels"].values())
+timed = [n for n in out["kernels"] if "comparison" not in n] if any("tv_sp" in n for n in out["kernels"]) else list(out["kernels"])
+out["hbm_bytes_per_pass"] = sum(out["kernels"][n]["hbm_bytes_per_launch"] for n in timed)
 out["bench_m2"] = {"ms_per_pass": m2["ms_per_pass"], "frac": rf["frac"], "achieved_GBs": rf["achieved"]}
 out["algorithmic_bytes_per_pass"] = rf["achieved"] * 1e9 * m2["ms_per_pass"] * 1e-3
 out["traffic_over_algorithmic"] = out["hbm_bytes_per_pass"] / out["algorithmic_bytes_per_pass"]

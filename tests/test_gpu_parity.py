@@ -339,3 +339,69 @@ def test_joint_m20_kernels_still_agree_with_the_decoupled_path(monkeypatch):
     assert s.decoupled(4) is None
     for xs in (x, x[:1]):
         assert np.abs(np_(s.log_likelihood(xs)) / g["ll"][:len(xs)] - 1).max() < 1e-10
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 2e-5)], ids=["f64", "f32"])
+def test_time_varying_structured_specs_materialise_through_the_pattern_library(oracle_lib, dtype, tol):
+    """lqg_solve_materialised_sp (csrc/lqg_kernels_sp.hpp: k_riccati_tv_sp / k_forward_tv_sp): a zoo model whose entries move in
+    time keeps one sparsity pattern; L, H, K, mu, Sigma and ll from the pattern library against the dense kernels of the main
+    library on the same inputs and against the fp64 C oracle."""
+    import ctypes as C
+    import lqg_amd
+    from lqg_amd import _abi, _hip
+    dev = torch.device("cuda")
+    B, T = 48, 37
+    g = torch.Generator(device=dev).manual_seed(11)
+    sig = torch.linspace(4.0, 12.0, B, dtype=dtype, device=dev)
+    base = lqg_amd.SubjectiveActor(dim=2, T=T, sigma_target=sig, device=dev, dtype=dtype)
+
+    def vary(t):                                   # [B, T, r, c]: every non-zero entry moves by 0.1 % in time and over systems
+        full = t.expand(B, T, *t.shape[-2:]) if t.dim() == 4 else t.expand(B, *t.shape[-3:])
+        return (full * (1.0 + 1e-3 * torch.randn(full.shape, generator=g, dtype=dtype, device=dev))).contiguous()
+
+    a0, d0 = base.actor, base.dynamics
+    Qv, Rv = vary(a0.Q), vary(a0.R)
+    actor = a0._replace(A=vary(a0.A), B=vary(a0.B), F=vary(a0.F), V=vary(a0.V), W=vary(a0.W),
+                        Q=0.5 * (Qv + Qv.transpose(-1, -2)), R=0.5 * (Rv + Rv.transpose(-1, -2)))
+    dyn = d0._replace(A=vary(d0.A), B=vary(d0.B), F=vary(d0.F), V=vary(d0.V), W=vary(d0.W))
+    system = lqg_amd.System(actor=actor, dynamics=dyn)
+    with torch.no_grad():
+        x = base.simulate(3, n=1).contiguous()                                     # [B, 1, T+1, 4]
+    ln = _hip.Launch(system.actor, system.dynamics, d=4, n_trials=1)
+    lib = _abi.load()
+    entry = _hip.materialised_entry(ln, system, 4)
+    assert entry is not None
+    xx, xb = _hip._prep_x(ln, x)
+    nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_CONDITIONAL_MOMENTS)
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+
+    def outputs():
+        e = lambda *sh: torch.full((B, T) + sh, float("nan"), dtype=dtype, device=dev)
+        return dict(L=e(2, 6), H=e(2, 2), K=e(6, 4), Sig=e(10, 10), mu=torch.full((B, 1, T, 10), float("nan"), dtype=dtype, device=dev),
+                    ll=torch.empty(B, 1, dtype=dtype, device=dev))
+
+    o_sp, o_ge = outputs(), outputs()
+    _abi.check(entry(C.byref(ln.p), ln.traj(xx, xb), ln.view(o_sp["L"]), _abi.NULL_VIEW, ln.view(o_sp["H"]), ln.view(o_sp["K"]),
+                     ln.traj(o_sp["mu"]), ln.view(o_sp["Sig"]), C.c_void_p(o_sp["ll"].data_ptr()), 1, C.c_void_p(ws.data_ptr()),
+                     nbytes, ln.stream()), "lqg_solve_materialised_sp")
+    _abi.check(lib.lqg_solve_materialised(C.byref(ln.p), ln.traj(xx, xb), ln.view(o_ge["L"]), _abi.NULL_VIEW, ln.view(o_ge["H"]),
+                                          ln.view(o_ge["K"]), ln.traj(o_ge["mu"]), ln.view(o_ge["Sig"]),
+                                          C.c_void_p(o_ge["ll"].data_ptr()), 1, 1, C.c_void_p(ws.data_ptr()), nbytes, ln.stream()),
+               "lqg_solve_materialised")
+    for k in o_sp:
+        a_, b_ = o_sp[k].double(), o_ge[k].double()
+        assert bool(torch.isfinite(a_).all()), k
+        assert float((a_ - b_).abs().max() / b_.abs().max()) < tol, k
+    # against the fp64 C oracle (three systems)
+    from lqg_amd import workload
+    sel = [0, B // 2, B - 1]
+    one_of = lambda spec, j: {f: (getattr(spec, f)[j] if getattr(spec, f).dim() == workload._batched_ndim(f)
+                                  else getattr(spec, f)).double().cpu().numpy() for f in spec._fields}
+    for j in sel:
+        one = lambda dct: dct
+        a64, d64 = one_of(system.actor, j), one_of(system.dynamics, j)
+        mur, Sr = oracle_lib.conditional_moments(one(a64), one(d64), x[j].double().cpu().numpy())
+        llr = oracle_lib.log_likelihood(one(a64), one(d64), x[j].double().cpu().numpy(), None)
+        assert np.abs(o_sp["Sig"][j].double().cpu().numpy() - Sr).max() / np.abs(Sr).max() < tol
+        assert np.abs(o_sp["mu"][j].double().cpu().numpy() - mur).max() / np.abs(mur).max() < tol
+        assert abs(float(o_sp["ll"][j, 0]) / float(llr[0]) - 1) < max(tol * 0.1, 1e-10)
