@@ -198,7 +198,12 @@ int lqg_log_likelihood_scan_with(const lqg_problem* p, lqg_traj x, void* ll, int
  *     int lqg_log_likelihood_sp(<exactly the argument list of lqg_log_likelihood>);
  * with the same contract, restricted to time-invariant specs without affine terms and to the dims / pattern
  * they were compiled for (anything else returns LQG_ERR_ARG / LQG_ERR_DIMS without launching).  They are an
- * optimisation layer: results are identical to lqg_log_likelihood's up to rounding, and every caller falls back to it. */
+ * optimisation layer: results are identical to lqg_log_likelihood's up to rounding, and every caller falls back to it.
+ * The same libraries export the materialising pass for specs that may vary in TIME as long as they keep the pattern (a model
+ * whose entries move: the masks are then the union over systems and steps, specialize.pattern_of_time_varying):
+ *     int lqg_solve_materialised_sp(<the argument list of lqg_solve_materialised without ll_sn>);
+ * one trial per system, no affine cost terms; every output view optional; the materialised L doubles as the forward sweep's
+ * gain stream.  Mode M2 of bench_m2.py runs on it (csrc/lqg_kernels_sp.hpp: k_riccati_tv_sp, k_forward_tv_sp). */
 
 /* Everything the reference's path materialises, in ONE pass (two or three kernels instead of the seven that separate
  * lqr.backward + kf.forward + conditional_moments + log_likelihood calls launch — each of which recomputes the gains
