@@ -161,3 +161,44 @@ def test_trial_chunk_scratch_grows_with_the_chunk_count(monkeypatch):
     monkeypatch.setenv("LQG_TRIAL_CHUNKS", "0")
     b = lib.lqg_workspace_bytes(C.byref(_hip.Launch(short.actor, short.dynamics, d=2, n_trials=64).p), _abi.OP_LOG_LIKELIHOOD)
     assert a == b
+
+
+def test_time_varying_pattern_is_the_union_over_time_and_conservative():
+    """specialize.pattern_of_time_varying (the masks mode M2's pattern library is compiled for): raw-field masks are the union
+    over systems and steps, derived masks are boolean products — supersets of the numerically observed ones — and the pattern
+    does not depend on the batch size or on the values of the moving entries."""
+    import numpy as np
+    import lqg_amd
+    from lqg_amd import specialize
+    torch.manual_seed(0)
+
+    def moving(B, T, scale):
+        base = lqg_amd.SubjectiveActor(dim=2, T=T, sigma_target=torch.linspace(4.0, 9.0, B, dtype=torch.float64),
+                                       device="cpu", dtype=torch.float64)
+        vary = lambda t: (t.expand(B, T, *t.shape[-2:]) * (1.0 + scale * torch.randn(B, T, *t.shape[-2:], dtype=torch.float64))).contiguous()
+        a0, d0 = base.actor, base.dynamics
+        actor = a0._replace(A=vary(a0.A), B=vary(a0.B), F=vary(a0.F), V=vary(a0.V), W=vary(a0.W), Q=vary(a0.Q), R=vary(a0.R))
+        dyn = d0._replace(A=vary(d0.A), B=vary(d0.B), F=vary(d0.F), V=vary(d0.V), W=vary(d0.W))
+        return lqg_amd.System(actor=actor, dynamics=dyn), base
+
+    sys_a, base = moving(3, 5, 1e-3)
+    sys_b, _ = moving(7, 4, 5e-2)
+    dims_a, masks_a = specialize.pattern_of_time_varying(sys_a, 4)
+    dims_b, masks_b = specialize.pattern_of_time_varying(sys_b, 4)
+    assert dims_a == dims_b == dict(x=4, b=6, u=2, y=4, d=4)
+    assert specialize.pattern_key(dims_a, masks_a) == specialize.pattern_key(dims_b, masks_b)
+    # raw fields: exactly the base model's non-zeros (multiplicative motion keeps zeros zero)
+    _, base_masks = specialize.pattern_of(base, 4)
+    for k in ("Aa", "Ba", "Fa", "Ad", "Bd", "Fd"):
+        assert np.array_equal(masks_a[k], base_masks[k]), k
+    # derived masks: supersets of the numeric ones of the time-varying system itself (which may cancel by accident) and of the
+    # base model's (whose F_d B_d - F_a B_a cancels exactly)
+    _, numeric = specialize.pattern_of(sys_a, 4)
+    for k in masks_a:
+        assert not np.any(numeric[k] & ~masks_a[k]), k
+        assert not np.any(base_masks[k] & ~masks_a[k]), k
+    assert masks_a["DB"].sum() > base_masks["DB"].sum()            # (the cancellation is not assumed)
+    # a structural zero that becomes non-zero at ONE (system, step) enters the union
+    sys_a.actor.A[2, 3, 0, 5] = 0.25
+    _, masks_c = specialize.pattern_of_time_varying(sys_a, 4)
+    assert masks_c["Aa"][0, 5] and not masks_a["Aa"][0, 5]
