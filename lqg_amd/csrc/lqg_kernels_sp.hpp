@@ -540,13 +540,13 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? 2 : 1) k_forward_t
   auto ldAa = [&](int t) { return load_masked<R, NB, NB, PAT::Aa>(a.aA.p + s * a.aA.sb + t * a.aA.st, a.aA.sr, a.aA.sc); };
   auto ldBa = [&](int t) { return load_masked<R, NB, NU, PAT::Ba>(a.aB.p + s * a.aB.sb + t * a.aB.st, a.aB.sr, a.aB.sc); };
   auto ldFa = [&](int t) { return load_masked<R, NY, NB, PAT::Fa>(a.aF.p + s * a.aF.sb + t * a.aF.st, a.aF.sr, a.aF.sc); };
-  auto ldVVa = [&](int t) { return load_gram_masked<R, NB, PAT::VVa>(a.aV.p + s * a.aV.sb + t * a.aV.st, a.aV.sr, a.aV.sc, a.nva); };
-  auto ldWWa = [&](int t) { return load_gram_masked<R, NY, PAT::WWa>(a.aW.p + s * a.aW.sb + t * a.aW.st, a.aW.sr, a.aW.sc, a.nwa); };
+  auto ldVVa = [&](int t) { return load_gram_masked_raw<R, NB, PAT::VVa, PAT::Va>(a.aV.p + s * a.aV.sb + t * a.aV.st, a.aV.sr, a.aV.sc, a.nva); };
+  auto ldWWa = [&](int t) { return load_gram_masked_raw<R, NY, PAT::WWa, PAT::Wa>(a.aW.p + s * a.aW.sb + t * a.aW.st, a.aW.sr, a.aW.sc, a.nwa); };
   auto ldAd = [&](int t) { return load_masked<R, NX, NX, PAT::Ad>(a.dA.p + s * a.dA.sb + t * a.dA.st, a.dA.sr, a.dA.sc); };
   auto ldBd = [&](int t) { return load_masked<R, NX, NU, PAT::Bd>(a.dB.p + s * a.dB.sb + t * a.dB.st, a.dB.sr, a.dB.sc); };
-  auto ldN1 = [&](int t) { return load_gram_masked<R, NX, PAT::N1>(a.dV.p + s * a.dV.sb + t * a.dV.st, a.dV.sr, a.dV.sc, a.nvd); };
+  auto ldN1 = [&](int t) { return load_gram_masked_raw<R, NX, PAT::N1, PAT::Vd>(a.dV.p + s * a.dV.sb + t * a.dV.st, a.dV.sr, a.dV.sc, a.nvd); };
   auto ldFd = [&](int t) { return load_masked<R, NY, NX, PAT::Fd>(a.dF.p + s * a.dF.sb + t * a.dF.st, a.dF.sr, a.dF.sc); };
-  auto ldWWd = [&](int t) { return load_gram_masked<R, NY, PAT::WWd>(a.dW.p + s * a.dW.sb + t * a.dW.st, a.dW.sr, a.dW.sc, a.nwd); };
+  auto ldWWd = [&](int t) { return load_gram_masked_raw<R, NY, PAT::WWd, PAT::Wd>(a.dW.p + s * a.dW.sb + t * a.dW.st, a.dW.sr, a.dW.sc, a.nwd); };
   auto ldL = [&](int t) {
     Mat<R, NU, NB> L;                             // gains of step t: the caller's L array or the gain scratch, as a strided view
     const R* src = Lv.p + s * Lv.sb + (long)t * Lv.st;

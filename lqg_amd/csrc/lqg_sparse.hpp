@@ -155,6 +155,33 @@ LQG_DEV Mat<R, N, N, MK> load_gram_masked(const R* __restrict__ p, long sr, long
     LQG_UNROLL for (int j = 0; j < i; ++j) r.v[i * N + j] = r.v[j * N + i];
   return r;
 }
+// the same with the structural zeros of the stored factor itself: MV(i, k) for its first N columns (further columns, if
+// nv > N, are loaded in full).  The time-varying sweeps load the factor every step, and a zoo model's noise factors are
+// (block-)diagonal: 84 of the 192 memory instructions of a step of k_forward_tv_sp were zeros of V and W.
+template <typename R, int N, Mask<N, N> MK, Mask<N, N> MV>
+LQG_DEV Mat<R, N, N, MK> load_gram_masked_raw(const R* __restrict__ p, long sr, long sc, int nv) {
+  Mat<R, N, N, MK> r;
+  LQG_UNROLL for (int i = 0; i < N * N; ++i) r.v[i] = R(0);
+  LQG_UNROLL for (int k = 0; k < N; ++k) {
+    if (k < nv) {
+      R col[N];
+      LQG_UNROLL for (int i = 0; i < N; ++i) col[i] = MV(i, k) ? p[i * sr + k * sc] : R(0);
+      LQG_UNROLL for (int i = 0; i < N; ++i)
+        LQG_UNROLL for (int j = i; j < N; ++j)
+          if (MK(i, j) && MV(i, k) && MV(j, k)) r.v[i * N + j] += col[i] * col[j];
+    }
+  }
+  for (int k = N; k < nv; ++k) {
+    R col[N];
+    LQG_UNROLL for (int i = 0; i < N; ++i) col[i] = p[i * sr + k * sc];
+    LQG_UNROLL for (int i = 0; i < N; ++i)
+      LQG_UNROLL for (int j = i; j < N; ++j)
+        if (MK(i, j)) r.v[i * N + j] += col[i] * col[j];
+  }
+  LQG_UNROLL for (int i = 0; i < N; ++i)
+    LQG_UNROLL for (int j = 0; j < i; ++j) r.v[i * N + j] = r.v[j * N + i];
+  return r;
+}
 // dense image (structural zeros written out) — for loop-carried state and for the dense Cholesky kernels
 template <typename R, int M, int N, Mask<M, N> MK>
 LQG_DEV void to_dense(const Mat<R, M, N, MK>& a, R (&out)[M * N]) {

@@ -25,7 +25,8 @@ from lqg_amd import _abi
 from lqg_amd import build as _build
 
 PAT_DIR = os.environ.get("LQG_PAT_DIR") or os.path.join(_build.CSRC, "pat")
-_FIELDS = ("Aa", "Ba", "Fa", "VVa", "WWa", "Q", "Rr", "Ad", "AdmI", "Bd", "Fd", "N1", "WWd", "FAa", "FAd", "DB", "N2", "N3")
+_FIELDS = ("Aa", "Ba", "Fa", "VVa", "WWa", "Q", "Rr", "Ad", "AdmI", "Bd", "Fd", "N1", "WWd", "FAa", "FAd", "DB", "N2", "N3",
+           "Va", "Wa", "Vd", "Wd")            # (the last four: the stored noise factors themselves, first n columns)
 _libs = {}
 _class_patterns = {}
 
@@ -37,6 +38,15 @@ def _any_nz(t):
     while nz.dim() > 2:
         nz = nz.any(dim=0)
     return nz.cpu().numpy()
+
+
+def _square(mask, n):
+    """[n, nv] mask of a stored noise factor -> [n, n]: its first n columns (absent columns False; the kernels load columns
+    beyond n in full)."""
+    out = np.zeros((n, n), dtype=bool)
+    c = min(n, mask.shape[1])
+    out[:, :c] = mask[:, :c]
+    return out
 
 
 def _first(t):
@@ -72,6 +82,8 @@ def pattern_of(system, d, grad_full=False):
     out = {k: _any_nz(v) for k, v in masks.items()}
     for k in ("VVa", "WWa", "Q", "Rr", "N1", "WWd", "N3"):      # symmetric quantities: keep the mask symmetric
         out[k] = out[k] | out[k].T
+    for k, v in (("Va", Va), ("Wa", Wa), ("Vd", Vd), ("Wd", Wd)):
+        out[k] = _square(_any_nz(v), v.shape[-2])
     dims = dict(x=Ad.shape[-1], b=Aa.shape[-1], u=Ba.shape[-1], y=Fa.shape[-2], d=int(d))
     return dims, out
 
@@ -105,6 +117,8 @@ def pattern_of_time_varying(system, d):
                  N3=bm(bm(Fd, N1), Fd.T) | bm(Wd, Wd.T))
     for k in ("VVa", "WWa", "N1", "WWd", "N3"):
         masks[k] = masks[k] | masks[k].T
+    for k, v in (("Va", Va), ("Wa", Wa), ("Vd", Vd), ("Wd", Wd)):
+        masks[k] = _square(v, v.shape[0])
     dims = dict(x=Ad.shape[-1], b=Aa.shape[-1], u=Ba.shape[-1], y=Fa.shape[-2], d=int(d))
     return dims, masks
 
