@@ -99,6 +99,11 @@ def run(dev, dtype_name="f32", log2_batch=17, T=500, reps=5):
     # the structure-specialised library when the specs keep one sparsity pattern through time (they do: a zoo model with
     # moving entries), else the dense kernels of the main library
     sp_entry = _hip.materialised_entry(lnm, system, 4)
+    if sp_entry is not None:                             # (a library that refuses the problem leaves it to the dense kernels)
+        rc = sp_entry(C.byref(lnm.p), lnm.traj(xx, xb), lnm.view(L), _abi.NULL_VIEW, lnm.view(H), lnm.view(K), lnm.traj(mu),
+                      lnm.view(Sig), C.c_void_p(ll.data_ptr()), 1, C.c_void_p(ws.data_ptr()), nbytes, lnm.stream())
+        if rc != 0:
+            sp_entry = None
 
     def one_pass(dense=False):
         if sp_entry is not None and not dense:
