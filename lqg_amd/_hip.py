@@ -188,10 +188,12 @@ def conditional_moments(actor, dynamics, x, Sigma0=None, eps=1e-8, want_mu=True,
     return mu, Sig
 
 
-def solve_materialised(actor, dynamics, x, Sigma0=None, eps=1e-8, out=None):
+def solve_materialised(actor, dynamics, x, Sigma0=None, eps=1e-8, out=None, system=None):
     """One pass producing everything the reference materialises: dict(L, l, H, K, mu, Sigma, ll).
 
-    `out` may pre-supply any of those tensors (any strides, e.g. [T][element][system] storage)."""
+    `out` may pre-supply any of those tensors (any strides, e.g. [T][element][system] storage).  system: the System that owns
+    the two specs — with it (one trial per system, no affine cost terms) the pass runs on the structure-specialised library
+    of the specs' sparsity pattern, time-varying specs included (materialised_entry); the pattern is cached on the system."""
     d, n = x.shape[-1], x.shape[-3]
     ln = Launch(actor, dynamics, d=d, n_trials=n, Sigma0=Sigma0, eps=eps)
     lib = ln.require_gpu()
@@ -207,6 +209,14 @@ def solve_materialised(actor, dynamics, x, Sigma0=None, eps=1e-8, out=None):
     o.setdefault("ll", ln.empty(n))
     with torch.cuda.device(ln.device):
         ws, nbytes = ln.workspace(lib, _abi.OP_CONDITIONAL_MOMENTS)
+        sp = materialised_entry(ln, system, d) if (system is not None and n == 1 and lib is _abi.load()) else None
+        if sp is not None:
+            o["l"].zero_()
+            rc = sp(C.byref(ln.p), ln.traj(x, xb), ln.view(o["L"]), _abi.NULL_VIEW, ln.view(o["H"]), ln.view(o["K"]),
+                    ln.traj(o["mu"]), ln.view(o["Sigma"]), C.c_void_p(o["ll"].data_ptr()),
+                    o["ll"].stride(0) if ln.batched else 0, C.c_void_p(ws.data_ptr()), nbytes, ln.stream())
+            if rc == 0:
+                return o
         _abi.check(lib.lqg_solve_materialised(
             C.byref(ln.p), ln.traj(x, xb), ln.view(o["L"]), ln.view(o["l"], vector=True), ln.view(o["H"]),
             ln.view(o["K"]), ln.traj(o["mu"]), ln.view(o["Sigma"]), C.c_void_p(o["ll"].data_ptr()),

@@ -392,6 +392,11 @@ def test_time_varying_structured_specs_materialise_through_the_pattern_library(o
         a_, b_ = o_sp[k].double(), o_ge[k].double()
         assert bool(torch.isfinite(a_).all()), k
         assert float((a_ - b_).abs().max() / b_.abs().max()) < tol, k
+    # the Python route: _hip.solve_materialised(..., system=...) takes the same library by itself
+    o_py = _hip.solve_materialised(system.actor, system.dynamics, x, system=system)
+    for k_py, k_sp in (("L", "L"), ("H", "H"), ("K", "K"), ("mu", "mu"), ("Sigma", "Sig"), ("ll", "ll")):
+        assert torch.equal(o_py[k_py].reshape(o_sp[k_sp].shape), o_sp[k_sp]), k_py
+    assert float(o_py["l"].abs().max()) == 0.0
     # against the fp64 C oracle (three systems)
     from lqg_amd import workload
     sel = [0, B // 2, B - 1]
