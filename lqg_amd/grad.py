@@ -57,6 +57,17 @@ def _layout(dm):
     return out, off
 
 
+def _promote64(spec):
+    """fp64 image of a spec that keeps stride-0 time axes stride-0 (a time-invariant field stays ONE matrix)."""
+    def up(t):
+        if not isinstance(t, torch.Tensor) or t.dtype != torch.float32:
+            return t
+        if t.dim() >= 3 and t.shape[-3] > 1 and t.stride(-3) == 0:
+            return t.narrow(-3, 0, 1).double().expand_as(t)
+        return t.double()
+    return spec._replace(**{f: up(getattr(spec, f)) for f in spec._fields})
+
+
 class Sweep:
     """One adjoint evaluation in two phases sharing the kept forward state: `forward()` (Riccati + forward sweep, returns
     the log-likelihood) and `reverse(g)` (the two adjoint sweeps with upstream weights g, returns the bars).  The
@@ -64,6 +75,14 @@ class Sweep:
 
     def __init__(self, actor, dynamics, x, Sigma0=None, eps=1e-8):
         d = x.shape[-1]
+        # fp32 with EVERY state observed (the point-mass model seen in full: cond(Sigma_oo) ~ 5e8): the reverse sweep
+        # conditions through the explicit S_oo^-1, which fp32 cannot carry -- same policy as the mixed forward problem
+        # LQG_F32_SYS64 (include/lqg_hip.h): the sweeps run over an fp64 image, value and bars are rounded to fp32 once
+        self.out_dtype = None
+        if actor.A.dtype == torch.float32 and d == dynamics.A.shape[-1]:
+            self.out_dtype = torch.float32
+            actor, dynamics, x = _promote64(actor), _promote64(dynamics), x.double()
+            Sigma0 = Sigma0.double() if Sigma0 is not None else None
         ln = _hip.Launch(actor, dynamics, d=d, n_trials=x.shape[-3], Sigma0=Sigma0, eps=eps)
         self.lib = ln.require_gpu(_abi.FAM_ADJOINT)     # lane kernels only: an unlisted shape is compiled on first use
         if not self.lib.lqg_grad_supported(ln.p.dtype, C.byref(ln.p.dims)):
@@ -94,7 +113,7 @@ class Sweep:
         ll = self.ln.empty(self.N)
         self._call(1, None, ll, None)
         self.fresh = True
-        return ll
+        return ll if self.out_dtype is None else ll.to(self.out_dtype)
 
     def reverse(self, g=None):
         """-> {name: [B, N, r, c]} per-(system, trial) bars (lqg_hip.h: order of the gradient elements); with
@@ -110,7 +129,8 @@ class Sweep:
         bars = {}
         for k, (o, r, c) in self.lay.items():
             v = out[:, o:o + r * c, :self.lanes].reshape(self.slabs, r, c, ln.B, self.N).permute(3, 4, 0, 1, 2)
-            bars[k] = v[:, :, 0] if (self.slabs == 1 or k in ("aQf", "aS0")) else v
+            v = v[:, :, 0] if (self.slabs == 1 or k in ("aQf", "aS0")) else v
+            bars[k] = v if self.out_dtype is None else v.to(self.out_dtype)
         return bars
 
 

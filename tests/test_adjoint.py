@@ -83,15 +83,19 @@ def _ti(spec):
 def test_hip_adjoint_matches_the_restatement(name, dtype, tol):
     from gpu_common import system_from_golden
     from lqg_amd import grad as G
-    if name == "pointmass_d4_T50" and dtype == torch.float32:
-        pytest.skip("full point-mass state observed: cond(Sigma_oo) ~ 5e8.  The adjoint conditions through the explicit "
-                    "S_oo^-1 (W = S_ro S_oo^-1), which fp32 cannot carry at that conditioning even with the deviation-form "
-                    "innovation (value off by 1 %); it would need the adjoint of the Cholesky/Schur form the forward kernels "
-                    "use.  Gradients of this model are fp64-only (DESIGN.md §10); the d=2 observation of the same model is fine")
+    # (pointmass_d4 in fp32 -- every state observed, cond(Sigma_oo) ~ 5e8 -- runs its sweeps over an fp64 image and rounds
+    # value and bars once: grad.Sweep; the bars still arrive as fp32 tensors)
     g, actor, dyn = load_golden(name)
     x = g["x"]
     w = np.linspace(0.5, 1.5, x.shape[0])
-    ll_ref, ga, gd, _ = ADJ.loglik_grad(actor, dyn, x, w)
+    if name == "pointmass_d4_T50" and dtype == torch.float32:
+        # at this conditioning the ROUNDING OF THE INPUTS to fp32 alone moves the gradient by 7e-4 (measured): the reference
+        # is the restatement on the problem the fp32 caller actually poses
+        r32 = lambda d_: {k: (v.astype(np.float32).astype(np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float64
+                              else v) for k, v in d_.items()}
+        ll_ref, ga, gd, _ = ADJ.loglik_grad(r32(actor), r32(dyn), x.astype(np.float32).astype(np.float64), w)
+    else:
+        ll_ref, ga, gd, _ = ADJ.loglik_grad(actor, dyn, x, w)
     s = system_from_golden(actor, dyn, dtype)
     ll, bars, _ = G.raw_grad(_ti(s.actor), _ti(s.dynamics), torch.as_tensor(x, dtype=dtype, device="cuda"),
                              g=torch.as_tensor(w, dtype=dtype, device="cuda"))
