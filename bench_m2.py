@@ -34,8 +34,13 @@ def soa(base, T, B, gen, jitter, sym=False, positive_diag=False):
     xi = torch.randn((T, r, c, B), dtype=base.dtype, device=base.device, generator=gen)
     if sym:
         xi = 0.5 * (xi + xi.transpose(1, 2))
-    phys = base.permute(1, 2, 0).unsqueeze(0) * (1.0 + jitter * xi)
-    return phys.permute(3, 0, 1, 2)
+    # (.contiguous(): the product of a permuted [B, r, c] view and a dense [T, r, c, B] tensor comes out in the PERMUTED
+    # operand's memory order, [T][B][r][c] -- 64 lanes of a wave 64 cache lines apart -- which is what this function
+    # returned until the end of round 3: see DESIGN.md 6b)
+    phys = (base.permute(1, 2, 0).unsqueeze(0) * (1.0 + jitter * xi)).contiguous()
+    out = phys.permute(3, 0, 1, 2)
+    assert out.stride(0) == 1 and out.stride(1) == r * c * B, out.stride()
+    return out
 
 
 def m2_system(dev, dtype, B, T):
@@ -150,7 +155,16 @@ def run(dev, dtype_name="f32", log2_batch=17, T=500, reps=5):
     b, u, y, xx_, m, d = dm["b"], dm["u"], dm["y"], dm["x"], dm["m"], dm["d"]
     in_per_step = (3 * b * b + b * u + y * b + y * y + u * u) + (b + u * b + u) + (2 * xx_ * xx_ + xx_ * u + y * xx_ + y * y)
     out_per_step = u * b + u + u * u + b * y + m + m * m
-    bytes_solve = w * (T * in_per_step + (T + 1) * d) + w * T * out_per_step          # SURVEY.md §8(d) M2 formula
+    bytes_dense = w * (T * in_per_step + (T + 1) * d) + w * T * out_per_step          # SURVEY.md §8(d) M2 formula
+    if sp_entry is not None:
+        # the pattern kernels request only the structurally non-zero entries of the specs (a zero of the pattern is never
+        # read): the bytes the pass MUST move are those rows, the trajectory and every output it writes (l is not requested)
+        _, masks, _ = m2_pattern()
+        in_rows = sum(int(np.asarray(masks[k]).sum()) for k in ("Aa", "Ba", "Fa", "Va", "Wa", "Q", "Rr", "Ad", "Bd", "Fd", "Vd", "Wd"))
+        bytes_solve = w * (T * in_rows + (T + 1) * d) + w * T * (out_per_step - u)
+    else:
+        in_rows = in_per_step
+        bytes_solve = bytes_dense
     gbs = bytes_solve * B / (ms * 1e-3) / 1e9
     # parity spot check of the time-varying path against the fp64 oracle
     import oracle as OC
@@ -169,9 +183,13 @@ def run(dev, dtype_name="f32", log2_batch=17, T=500, reps=5):
     return {
         "mode": "M2 (time-varying [T,...] specs in; L,H,K,mu,Sigma materialised out)", "dtype": dtype_name,
         "systems": B, "T": T, "ms_per_pass": ms, "solves_per_s": B / (ms * 1e-3),
-        "algorithmic_bytes_per_solve": bytes_solve,
+        "algorithmic_bytes_per_solve": bytes_solve, "spec_rows_read_per_step": in_rows,
+        "dense_format_bytes_per_solve": bytes_dense,
+        "input_layout": "[T][row][col][system] (system stride 1), asserted in soa()",
         "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                      "frac_of_measured_copy_rate": gbs / 6290.0,
+                     "dense_format_bytes_over_time_GBps": bytes_dense * B / (ms * 1e-3) / 1e9,
+                     "dense_kernels_frac": (bytes_dense * B / (dense_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if dense_ms else None,
                      "algorithmic_bytes_per_pass": bytes_solve * B, "traffic": None,
                      "kernel": ("k_riccati_tv_sp + k_forward_tv_sp (pattern library: structurally non-zero entries loaded per step; "
                                 "one pass = both)" if sp_entry is not None else

@@ -7,7 +7,7 @@ import sys, json
 for line in sys.stdin:
     if line.startswith('{'):
         j = json.loads(line); r = j['roofline']
-        print('$dt ms %.2f frac %.3f riccati %.2f forward %.2f parity %.2e %s' % (j['ms_per_pass'], r['frac'], r['riccati_kernel_ms'], r['forward_kernel_ms'], max(j['parity_rel_maxnorm_vs_fp64_oracle'].values()), j['calls']))
+        print('$dt ms %.2f frac %.3f riccati %.2f forward %.2f dense %s parity %.2e %s' % (j['ms_per_pass'], r['frac'], r['riccati_kernel_ms'], r['forward_kernel_ms'], r['dense_kernels_ms_per_pass'], max(j['parity_rel_maxnorm_vs_fp64_oracle'].values()), j['calls']))
     else: print(line.rstrip()[-300:])
 "
 done
