@@ -202,3 +202,16 @@ def test_time_varying_pattern_is_the_union_over_time_and_conservative():
     sys_a.actor.A[2, 3, 0, 5] = 0.25
     _, masks_c = specialize.pattern_of_time_varying(sys_a, 4)
     assert masks_c["Aa"][0, 5] and not masks_a["Aa"][0, 5]
+
+
+def test_m2_benchmark_inputs_are_lane_contiguous():
+    """Mode M2's time-varying specs must reach the kernels in [T][row][col][system] order (system stride 1): an elementwise
+    product with a permuted operand silently produced [T][system][row][col] until the end of round 3."""
+    import bench_m2
+    B, T = 64, 5
+    system, _ = bench_m2.m2_system(torch.device("cpu"), torch.float32, B, T)
+    for spec, fields in ((system.actor, "ABFVWQR"), (system.dynamics, "ABFVW")):
+        for f in fields:
+            t = getattr(spec, f)
+            r, c = t.shape[-2:]
+            assert t.shape[:2] == (B, T) and t.stride() == (1, r * c * B, c * B, B), (f, t.shape, t.stride())
