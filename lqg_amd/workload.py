@@ -76,3 +76,14 @@ def pack_trials(x):
     if x.dim() == 3:
         return x.permute(1, 2, 0).contiguous().permute(2, 0, 1)
     return x.permute(2, 3, 0, 1).contiguous().permute(2, 3, 0, 1)
+
+
+def pack_systems(t):
+    """Re-lay a batched time-varying spec field t[B, T, r, c] so that the SYSTEM index is the fastest-varying one in HBM
+    ([T][r][c][B] storage) while keeping the logical shape — the layout the lane-per-system sweeps want for arrays they
+    read at every step (one wave-load = 256 contiguous bytes instead of 64 cache lines; mode M2 runs 1.6x faster on it,
+    DESIGN.md 6b).  Note that `a.permute(...) * b` does NOT produce it: an elementwise result takes the memory order of its
+    permuted operand.  Returns a strided VIEW; every API of this package accepts it unchanged."""
+    if t.dim() != 4:
+        raise ValueError(f"pack_systems expects [B, T, r, c], got {tuple(t.shape)}")
+    return t.permute(1, 2, 3, 0).contiguous().permute(3, 0, 1, 2)

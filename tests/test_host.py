@@ -215,3 +215,23 @@ def test_m2_benchmark_inputs_are_lane_contiguous():
             t = getattr(spec, f)
             r, c = t.shape[-2:]
             assert t.shape[:2] == (B, T) and t.stride() == (1, r * c * B, c * B, B), (f, t.shape, t.stride())
+
+
+def test_system_major_time_varying_specs_get_one_layout_hint_and_pack_systems_fixes_it():
+    import warnings
+    import bench_m2
+    from lqg_amd import _hip, workload
+    system, _ = bench_m2.m2_system(torch.device("cpu"), torch.float32, 4096, 3)
+    _hip._layout_warned = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        _hip.Launch(system.actor, system.dynamics, d=4)                     # [T][r][c][B]: nothing to say
+        assert not [x for x in w if issubclass(x.category, _hip.LqgLayoutWarning)]
+        major = system.actor._replace(A=system.actor.A.contiguous())        # [B][T][r][c]
+        _hip.Launch(major, system.dynamics, d=4)
+        _hip.Launch(major, system.dynamics, d=4)                            # (once per process)
+        hints = [x for x in w if issubclass(x.category, _hip.LqgLayoutWarning)]
+        assert len(hints) == 1 and "pack_systems" in str(hints[0].message)
+    packed = workload.pack_systems(major.A)
+    assert packed.stride(0) == 1 and torch.equal(packed, major.A)
+    _hip._layout_warned = False
