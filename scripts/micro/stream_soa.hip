@@ -35,13 +35,25 @@ __global__ void k_stream(const float* __restrict__ in, float* __restrict__ out, 
       for (int e = 0; e < EI; ++e) nx[e] = in[iaddr(tn, e)];
     } else {
 #pragma unroll
-      for (int e = 0; e < EI; ++e) v[e] = in[iaddr(t, e)];
+      for (int e = 0; e < EI; ++e) {
+#if defined(NT_LOAD)
+        v[e] = __builtin_nontemporal_load(&in[iaddr(t, e)]);
+#else
+        v[e] = in[iaddr(t, e)];
+#endif
+      }
     }
     // a dependent chain over the step's inputs (stands for the recursion: outputs need every input)
 #pragma unroll
     for (int e = 0; e < EI; ++e) acc = acc * 0.999f + v[e];
 #pragma unroll
-    for (int e = 0; e < EO; ++e) out[oaddr(t, e)] = acc + (float)e;
+    for (int e = 0; e < EO; ++e) {
+#if defined(NT_STORE)
+      __builtin_nontemporal_store(acc + (float)e, &out[oaddr(t, e)]);     // -DNT_STORE: do streaming hints raise the ceiling?
+#else
+      out[oaddr(t, e)] = acc + (float)e;
+#endif
+    }
   }
 }
 
