@@ -257,6 +257,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
   const R kLogNorm = R(0.5 * ND * 1.8378770664093453);
 
   R Li[O * O], U2[RR * O], hl;
+  unsigned pois = 0u;                             // largest pos_finite_key of the pivot products (lqg_small.hpp)
   auto condition = [&]() {
     R Soo[O * O], Lc[O * O], dinv[O];
     LQG_UNROLL for (int i = 0; i < O; ++i)
@@ -265,6 +266,10 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
     tri_inverse_lower<R, O>(Lc, dinv, Li);
     R pd = dinv[0];
     LQG_UNROLL for (int i = 1; i < O; ++i) pd *= dinv[i];
+    {
+      const unsigned key = pos_finite_key(pd);
+      pois = key > pois ? key : pois;
+    }
     hl = -log_<R>(pd);
     LQG_UNROLL for (int p = 0; p < RR; ++p)
       LQG_UNROLL for (int j = 0; j < O; ++j) {
@@ -394,7 +399,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
         LQG_UNROLL for (int i = 0; i < O; ++i)
           LQG_UNROLL for (int j = 0; j <= i; ++j) op[Ops::L_OFF + (e++)] = (OT)Li[i * O + j];
       }
-      op[Ops::H_OFF] = (OT)(hl + kLogNorm);
+      store_or_nan(&op[Ops::H_OFF], (OT)(hl + kLogNorm), pois >= kPosFiniteLimit<R>);
     }
     // ---- Sigma' = F2 C F2^T + GG,  C = Srr - U2 U2^T                    system.py:223-230
     Mat<R, RR, RR> C;
@@ -443,14 +448,14 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
   if (FUSED) {
     LQG_UNROLL for (int n = 0; n < NT; ++n) {
       innovate(n, a.T, true);
-      a.ll[s * a.ll_sb + n * ll_sn] = (R)acc[n];
+      store_or_nan(&a.ll[s * a.ll_sb + n * ll_sn], (R)acc[n], pois >= kPosFiniteLimit<R>);
     }
   } else {
     OT* op = reinterpret_cast<OT*>(a.ops) + ((long)s * (a.T + 1) + a.T) * Ops::N;
     int e = 0;
     LQG_UNROLL for (int i = 0; i < O; ++i)
       LQG_UNROLL for (int j = 0; j <= i; ++j) op[Ops::L_OFF + (e++)] = (OT)Li[i * O + j];
-    op[Ops::H_OFF] = (OT)(hl + kLogNorm);
+    store_or_nan(&op[Ops::H_OFF], (OT)(hl + kLogNorm), pois >= kPosFiniteLimit<R>);
   }
 }
 
@@ -507,6 +512,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? 2 : 1) k_forward_t
   LQG_UNROLL for (int i = 0; i < RR; ++i) muR[i] = R(0);
   const R kLogNorm = R(0.5 * ND * 1.8378770664093453);
   R Li[O * O], U2[RR * O], hl;
+  unsigned pois = 0u;                             // largest pos_finite_key of the pivot products (lqg_small.hpp)
   auto condition = [&]() {
     R Soo[O * O], Lc[O * O], dinv[O];
     LQG_UNROLL for (int i = 0; i < O; ++i)
@@ -515,6 +521,10 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? 2 : 1) k_forward_t
     tri_inverse_lower<R, O>(Lc, dinv, Li);
     R pd = dinv[0];
     LQG_UNROLL for (int i = 1; i < O; ++i) pd *= dinv[i];
+    {
+      const unsigned key = pos_finite_key(pd);
+      pois = key > pois ? key : pois;
+    }
     hl = -log_<R>(pd);
     LQG_UNROLL for (int p = 0; p < RR; ++p)
       LQG_UNROLL for (int j = 0; j < O; ++j) {
@@ -628,7 +638,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? 2 : 1) k_forward_t
   for (int t = 1; t < a.T; ++t) step.template operator()<false>(t);
   condition();
   innovate(a.T, true);
-  if (a.ll) a.ll[s * a.ll_sb] = (R)acc;
+  if (a.ll) store_or_nan(&a.ll[s * a.ll_sb], (R)acc, pois >= kPosFiniteLimit<R>);
 }
 
 // ---------------------------------------------------------------- per-trial sweep with the operator's structure

@@ -46,6 +46,22 @@ template <> LQG_DEV float log_<float>(float v) { return logf(v); }
 template <> LQG_DEV double log_<double>(double v) { return log(v); }
 template <typename R> LQG_DEV R abs_(R v) { return v < R(0) ? -v : v; }
 
+// "positive, finite, non-zero" as INTEGER arithmetic on the bit pattern: key(v) < kPosFiniteLimit<R> iff 0 < v < inf (fp64:
+// iff the high word is in [1, 0x7FEFFFFF], i.e. v >= 2^-1022 * 2^-20 as well).  The pattern libraries are compiled with
+// -fno-honor-nans -fno-honor-infinities (lqg_amd/specialize.py), under which the compiler may assume that no floating-point
+// operation yields NaN / inf and fold comparisons, selects and 0 * x accordingly; it may not touch integer operations on the
+// bits.  The specialised sweeps track the largest key of the products of their Cholesky pivots' reciprocal square roots
+// and overwrite a log-likelihood whose factorisation ever left the positive finite range with NaN, through an integer store.
+LQG_DEV unsigned pos_finite_key(float v) { return __float_as_uint(v) - 1u; }
+LQG_DEV unsigned pos_finite_key(double v) { return (unsigned)((unsigned long long)__double_as_longlong(v) >> 32) - 1u; }
+template <typename R> inline constexpr unsigned kPosFiniteLimit = sizeof(R) == 4 ? 0x7F7FFFFFu : 0x7FEFFFFFu;
+LQG_DEV void store_or_nan(float* dst, float v, bool poison) {
+  *reinterpret_cast<unsigned*>(dst) = poison ? 0x7FC00000u : __float_as_uint(v);
+}
+LQG_DEV void store_or_nan(double* dst, double v, bool poison) {
+  *reinterpret_cast<unsigned long long*>(dst) = poison ? 0x7FF8000000000000ull : (unsigned long long)__double_as_longlong(v);
+}
+
 // ---- strided loads (per-lane base pointer already includes the system offset) -------------------------------
 template <typename R, int ROWS, int COLS>
 LQG_DEV void load_mat(const R* __restrict__ p, long sr, long sc, R (&out)[ROWS * COLS]) {

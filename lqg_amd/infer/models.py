@@ -40,6 +40,27 @@ def log_likelihood_objective(x, model_type, params, process_noise=1.0, dt=1.0 / 
     return ld.log_likelihood_sum(model, x, group=group)
 
 
+def lqg_model(x, model_type, process_noise=1.0, dt=1.0 / 60, **fixed_params):
+    """The name and signature of lqg/infer/models.py:20-34.  In the reference this is a NumPyro model function (it
+    registers `numpyro.param`s and one `numpyro.sample("x", ..., obs=x)` site) handed to `max_likelihood` / `infer` as their
+    third / fifth positional argument.  There is no NumPyro param store here: called directly it returns what that sample
+    site contributes at the initial point — sum_n log p(x_n | constructor defaults, fixed_params), fp64 — and the drivers of
+    this package recognise the function itself as "the built-in objective" (`max_likelihood(x, Model, lqg_model, 1.0)`)."""
+    return log_likelihood_objective(x, model_type, {}, process_noise=process_noise, dt=dt, **fixed_params)
+
+
+def lifted_model(x, model_type, process_noise=1.0, dt=1.0 / 60, **fixed_params):
+    """What lqg/infer/utils.py:9 imports as the default model of `infer` (parameters lifted to their priors,
+    lqg/infer/prior.py): the log joint at the initial point — `lqg_model` plus the log prior of the non-fixed parameters at
+    their constructor defaults.  `infer` samples this posterior (lqg_amd/infer/mcmc.py: Potential)."""
+    import torch
+    from lqg_amd.infer import prior as _prior
+    from lqg_amd.infer.mcmc import log_prior
+    lp = sum(float(log_prior(k, torch.tensor(float(v), dtype=torch.float64), _prior.default_prior))
+             for k, v in get_model_params(model_type).items() if k not in fixed_params and k in _prior.default_prior)
+    return lqg_model(x, model_type, process_noise, dt, **fixed_params) + lp
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # (Nc, N, T, d) data: several CONDITIONS, each with its own trials, some parameters shared across conditions and some
 # per condition — lqg/infer/models.py:37-61 (`common_lqg_model`: everything shared except sigma_target) and :67-130

@@ -47,6 +47,14 @@ SCAN_MAX_COND = float(os.environ.get("LQG_SCAN_MAX_COND", "1e7"))
 MIXED_MIN_TRIALS = int(os.environ.get("LQG_MIXED_MIN_TRIALS", "3"))
 MIXED_LONG_HORIZON = 600        # steps beyond which an fp32 problem leaves the in-lane sweeps for the stream path, any n
 FUSE_F32_MAX_STEPS = 256        # steps up to which small fp32 (system, trial) batches run as all-fp32 fused pairs
+# WIDE: an fp32 problem whose observed process-noise block (V V')[:d, :d] has a condition number above this runs — for ANY
+# number of trials — every sweep, the per-trial one included, in fp64 over an fp64 image of the specs and of the data; the
+# log-likelihoods are rounded to fp32 once.  The whitening of an ill-conditioned innovation (Li ~ sqrt(cond)) amplifies
+# the fp32 rounding of the recursions and of the mean state: the golden `pointmass_d4_T50` (cond 5.6e8: every state of the
+# point mass observed, velocity / activation noise 1e-3) gives 1.5e-3 or NaN on the all-fp32 in-lane sweeps and 7e-6 MIXED,
+# 1e-7 on this route.  Threshold = SCAN_MAX_COND: BASELINE config 2 (the same model observed through target and cursor, cond
+# 1e6) holds 6e-8 in fp32 and keeps its fp32 per-trial sweep.  LQG_F32_WIDE=0 disables (A/B, tests of the fp32 kernels).
+F32_MAX_COND = float(os.environ.get("LQG_F32_MAX_COND", "1e7"))
 
 
 def scan_min_steps(m):
@@ -74,20 +82,40 @@ def scan_max_systems(m, fp64=False):
 
 
 def _observed_noise_cond(sub, d):
-    """Largest condition number of (V V')[:d, :d] of the dynamics over systems and steps.  One small device-to-host copy;
-    the eigenvalues are taken on the host (a batched eigvalsh of 2x2..4x4 blocks costs ~0.3 ms on the GPU, more than the
-    evaluation it guards)."""
+    """Largest condition number of (V V')[:d, :d] of the dynamics over systems and steps (cached on the system).  Few
+    blocks: one small device-to-host copy and the eigenvalues on the host (a batched eigvalsh of 2x2..4x4 blocks costs
+    ~0.3 ms on the GPU, more than the evaluation it guards).  Many blocks (a batch of candidates): reduced on the device —
+    closed form for d <= 2, batched eigvalsh beyond — and ONE scalar comes back."""
     import numpy as np
     cache = sub.__dict__.setdefault("_lqg_noise_cond", {})
     key = (int(d), specialize.spec_versions(sub))
     if key in cache:
         return cache[key]
     V = specialize._first(sub.dynamics.V.detach())[..., :d, :]       # (one time slice when the spec is time-invariant)
-    VV = (V @ V.transpose(-1, -2)).double().cpu().numpy()
-    ev = np.linalg.eigvalsh(VV)
-    lo, hi = np.maximum(ev[..., 0], 0.0), ev[..., -1]
-    cache[key] = float(np.max(hi / np.maximum(lo, 1e-300)))
+    VV = (V @ V.transpose(-1, -2)).double()
+    if VV.numel() <= d * d * 4096:
+        ev = np.linalg.eigvalsh(VV.cpu().numpy())
+        lo, hi = np.maximum(ev[..., 0], 0.0), ev[..., -1]
+        cache[key] = float(np.max(hi / np.maximum(lo, 1e-300)))
+    else:
+        if d == 1:
+            lo = hi = VV[..., 0, 0]
+        elif d == 2:
+            a, b, c = VV[..., 0, 0], VV[..., 0, 1], VV[..., 1, 1]
+            h, r = 0.5 * (a + c), torch.sqrt(0.25 * (a - c) ** 2 + b * b)
+            hi = h + r
+            lo = (a * c - b * b) / hi                                 # (the small root without cancellation)
+        else:
+            ev = torch.linalg.eigvalsh(VV)
+            lo, hi = ev[..., 0], ev[..., -1]
+        cache[key] = float((hi / lo.clamp_min(1e-300)).max())
     return cache[key]
+
+
+def f32_needs_wide(sub, d):
+    """True when an fp32 problem is evaluated over an fp64 image of its specs and data (F32_MAX_COND above)."""
+    return (sub.actor.A.dtype == torch.float32 and sub.actor.A.is_cuda and os.environ.get("LQG_F32_WIDE", "1") != "0"
+            and _observed_noise_cond(sub, d) > F32_MAX_COND)
 
 
 def scan_eligible(lib, ln, sub, eps, systems_scale=1):
@@ -115,6 +143,7 @@ class LogLikelihoodPlan:
         flight per SIMD at the headline shape); costs a one-time re-packing copy of x, so it is off for the throw-away
         plan of System.log_likelihood."""
         self.system = system
+        self.out_dtype = None                    # set when a component runs WIDE (fp64 image of an fp32 problem)
         d = x.shape[-1]
         lib = _abi.load()
         parts = system.decoupled(d, Sigma0, eps=eps) or [(system, list(range(d)), None)]
@@ -139,6 +168,8 @@ class LogLikelihoodPlan:
                 self.n_stacked = len(parts)
                 parts, x = [(stacked[0], list(range(stacked[1].shape[-1])), None)], stacked[1]
         self.work = []
+        # (one ill-conditioned component takes the whole evaluation WIDE: the components' results are added)
+        wide_any = any(f32_needs_wide(sub, len(cols)) for sub, cols, _ in parts)
         for ip, (sub, cols, bs) in enumerate(parts):
             contiguous = cols == list(range(cols[0], cols[-1] + 1))
             xs = x[..., cols[0]:cols[-1] + 1] if contiguous else x[..., cols]
@@ -148,6 +179,12 @@ class LogLikelihoodPlan:
             n = xs.shape[-3]
             n_sys0 = sub.n_systems or 1
             sub0 = sub                           # (keeps the zoo class: its sparsity pattern is cached per class)
+            wide = wide_any
+            if wide:                             # ill-conditioned fp32 problem: fp64 image of specs AND data, any n
+                sub = sub.to(torch.float64)
+                xs = xs.to(torch.float64)
+                S0 = None if S0 is None else S0.to(torch.float64)
+                self.out_dtype = torch.float32
             use_scan = scan_eligible(_abi.load(), _hip.Launch(sub.actor, sub.dynamics, d=len(cols), n_trials=n, Sigma0=S0,
                                                                eps=eps), sub, eps) if sub.actor.A.is_cuda else False
             # (an fp32 problem over a long horizon keeps the operator-stream path: its system sweeps then run in fp64 —
@@ -222,7 +259,7 @@ class LogLikelihoodPlan:
                                   entry=(scan_entry if use_scan else (sp or lib.lqg_log_likelihood)),
                                   scan_sp=bool(use_scan and scan_sp),
                                   generic=lib.lqg_log_likelihood, scan=use_scan,
-                                  specialised=sp is not None, n=n, fused_pairs=fuse_pairs, mixed=mixed,
+                                  specialised=sp is not None, n=n, fused_pairs=fuse_pairs, mixed=mixed, wide=wide,
                                   coop=bool(not use_scan and sp is None
                                             and lib.lqg_strategy(C.byref(ln.p)) == _abi.STRATEGY_COOP),
                                   pattern_key=(specialize.system_pattern(sub0, len(cols))[2] if sp is not None else None),
@@ -272,6 +309,8 @@ class LogLikelihoodPlan:
                 "generic dense (k_riccati + k_forward") + tail
         if all(k.get("mixed") for k in w):
             kind += " [system sweeps in fp64, operators rounded to fp32 once, per-trial sweep fp32]"
+        if any(k.get("wide") for k in w):
+            kind += " [ill-conditioned fp32 problem: every sweep over an fp64 image of specs and data, results rounded to fp32 once]"
         if len(w) > 1:
             kind += f", {len(w)} decoupled components of dims (x,b,u,y,d)={w[0]['dims']}"
         if self.n_stacked > 1:
@@ -284,7 +323,7 @@ class LogLikelihoodPlan:
     def run(self):
         """Launch the whole evaluation on the current stream; returns ll[(B,) n] (a buffer owned by the plan)."""
         if self.work[0]["n"] == 0:
-            return self.ll                     # no trials: nothing to launch
+            return self._result()              # no trials: nothing to launch
         with torch.cuda.device(self.device):
             main = torch.cuda.current_stream(self.device)
             if self.side:
@@ -329,7 +368,10 @@ class LogLikelihoodPlan:
                     self.ll.add_(wk["ll"])     # log p(x) = sum over independent components
             if self.n_stacked > 1:
                 torch.sum(self._ll_stacked.view(self.n_stacked, *self.ll.shape), dim=0, out=self.ll)
-        return self.ll
+        return self._result()
+
+    def _result(self):
+        return self.ll if self.out_dtype is None else self.ll.to(self.out_dtype)       # WIDE: rounded to fp32 once
 
     def use_events(self, sets):
         """Point the library's phase-event hook of every component at its own event set for the NEXT run:

@@ -21,23 +21,28 @@ class TrajectoryNormal:
     `.sample`, `.to_event`.  `Sigma` is stored once per system ([T,k,k]); `covariance_matrix` broadcasts it
     over trials without copying (under vmap the reference holds n identical copies)."""
 
-    def __init__(self, loc, Sigma, lo, hi, event_dims=0):
+    def __init__(self, loc, Sigma, lo, hi, event_dims=0, dtype=None):
+        """dtype: the caller's dtype when the moments are held wider (System.conditional_distribution keeps the moments
+        of an fp32 problem in fp64: a mean of magnitude ~50 rounded to fp32 loses the digits of an innovation of ~0.1, and
+        log_prob(x[:, 1:]) — the reference's log_likelihood, lqg/system.py:246-248 — would miss 1e-6).  `.loc`,
+        `.covariance_matrix`, `.sample` and the result of `.log_prob` are of that dtype."""
         self._mu, self._Sigma, self._lo, self._hi = loc, Sigma, lo, hi
         self._event_dims = event_dims
+        self._dtype = loc.dtype if dtype is None else dtype
 
     @property
     def loc(self):
-        return self._mu[..., self._lo:self._hi]
+        return self._mu[..., self._lo:self._hi].to(self._dtype)
 
     mean = loc
 
     @property
     def covariance_matrix(self):
-        S = self._Sigma[..., self._lo:self._hi, self._lo:self._hi]
+        S = self._Sigma[..., self._lo:self._hi, self._lo:self._hi].to(self._dtype)
         return S.unsqueeze(-4).expand(*self._mu.shape[:-1], S.shape[-2], S.shape[-1])
 
     def to_event(self, n=1):
-        return TrajectoryNormal(self._mu, self._Sigma, self._lo, self._hi, self._event_dims + n)
+        return TrajectoryNormal(self._mu, self._Sigma, self._lo, self._hi, self._event_dims + n, self._dtype)
 
     def shape(self, sample_shape=()):
         return tuple(sample_shape) + tuple(self.loc.shape)
@@ -59,18 +64,18 @@ class TrajectoryNormal:
             raise NotImplementedError("per-step log_prob: use .to_event(1) (the only form the reference uses)")
         k = self._hi - self._lo
         if self._lo == 0:
-            return _hip.gaussian_logprob(value, self._mu, self._Sigma, k)
-        mu = self.loc.contiguous()
+            return _hip.gaussian_logprob(value, self._mu, self._Sigma, k).to(self._dtype)
+        mu = self._mu[..., self._lo:self._hi].contiguous()
         S = self._Sigma[..., self._lo:self._hi, self._lo:self._hi].contiguous()
-        return _hip.gaussian_logprob(value, mu, S, k)
+        return _hip.gaussian_logprob(value, mu, S, k).to(self._dtype)
 
     def sample(self, key=None, sample_shape=()):
         """Draw from the per-step Gaussians (torch RNG; `key` = int seed or torch.Generator)."""
         gen = _generator(key, self._mu.device)
-        S = self._Sigma[..., self._lo:self._hi, self._lo:self._hi]
+        S = self._Sigma[..., self._lo:self._hi, self._lo:self._hi].to(self._dtype)
         Lc = torch.linalg.cholesky(S)
         shape = tuple(sample_shape) + tuple(self.loc.shape)
-        z = torch.randn(shape, dtype=self._mu.dtype, device=self._mu.device, generator=gen)
+        z = torch.randn(shape, dtype=self._dtype, device=self._mu.device, generator=gen)
         return self.loc + torch.einsum("...tij,...ntj->...nti", Lc, z)
 
 
@@ -188,18 +193,28 @@ class System:
     def conditional_moments(self, x, Sigma0=None):
         """p(x_{t+1}, xhat_{t+1} | x_{1:t}) for ONE trajectory x[T+1, d] -> mu[T, m], Sigma[T, m, m]
         (lqg/system.py:142-235).  With B systems: x[B, T+1, d] -> mu[B, T, m], Sigma[B, T, m, m]."""
-        xx = x.unsqueeze(-3)
-        mu, Sig = _hip.conditional_moments(self.actor, self.dynamics, xx, Sigma0=Sigma0, system=self)
+        mu, Sig = self._moments(x.unsqueeze(-3), Sigma0)
         return mu.squeeze(-3), Sig
 
-    def _moments(self, x, Sigma0):
+    def _moments(self, x, Sigma0, keep_wide=False):
+        """mu[(B,) n, T, m], Sigma[(B,) T, m, m].  An fp32 problem is evaluated over an fp64 image of its specs and data when
+        its observed noise block is ill-conditioned (plan.F32_MAX_COND) or when the caller keeps the moments wide
+        (keep_wide: conditional_distribution); the moments are rounded to fp32 unless keep_wide."""
+        if self.actor.A.dtype == torch.float32 and self.actor.A.is_cuda:
+            from lqg_amd import plan
+            if keep_wide or plan.f32_needs_wide(self, x.shape[-1]):
+                wide = self.to(torch.float64)
+                S0 = None if Sigma0 is None else Sigma0.to(torch.float64)
+                mu, Sig = _hip.conditional_moments(wide.actor, wide.dynamics, x.to(torch.float64), Sigma0=S0, system=wide)
+                return (mu, Sig) if keep_wide else (mu.to(torch.float32), Sig.to(torch.float32))
         return _hip.conditional_moments(self.actor, self.dynamics, x, Sigma0=Sigma0, system=self)
 
     def conditional_distribution(self, x, Sigma0=None):
-        """x[n, T+1, d] -> Gaussian over x[:, 1:] with event shape (T, d) (lqg/system.py:237-244)."""
+        """x[n, T+1, d] -> Gaussian over x[:, 1:] with event shape (T, d) (lqg/system.py:237-244).  (fp32: the moments are
+        held in fp64 inside the distribution, TrajectoryNormal.__init__.)"""
         d = x.shape[-1]
-        mu, Sig = self._moments(x, Sigma0)
-        return TrajectoryNormal(mu, Sig, 0, d).to_event(1)
+        mu, Sig = self._moments(x, Sigma0, keep_wide=True)
+        return TrajectoryNormal(mu, Sig, 0, d, dtype=self.actor.A.dtype).to_event(1)
 
     def log_likelihood(self, x, Sigma0=None):
         """log p(x_{1:T} | x_0) per trial: x[n, T+1, d] -> [n] (lqg/system.py:246-248).  Fused HIP path."""

@@ -19,14 +19,15 @@ if ROOT not in sys.path:
 
 from lqg_amd import _abi  # noqa: E402  (struct definitions only; no HIP library is loaded)
 
-LIB = os.path.join(HERE, "liblqg_oracle.so")
+# LQG_ORACLE_LIB: another build of the same sources (the sanitizer build `make -C oracle asan`, tests/test_oracle.py)
+LIB = os.environ.get("LQG_ORACLE_LIB") or os.path.join(HERE, "liblqg_oracle.so")
 _lib = None
 
 
 def build(force=False):
     src_m = max(os.path.getmtime(os.path.join(HERE, f)) for f in ("lqg_oracle.c", "lqg_oracle_body.inc"))
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < src_m:
-        subprocess.check_call(["make", "-C", HERE, "-s", "-B"])
+        subprocess.check_call(["make", "-C", HERE, "-s", "-B", os.path.basename(LIB)])
     return LIB
 
 

@@ -45,9 +45,9 @@ def random_system(rng, x, b, u, y, T, time_varying, affine):
     return actor, dyn
 
 
-# fp32 log-likelihood: measured worst case over the ten systems 8.1e-7 of the largest |ll| (scripts/rand_err.py) — inside the
-# north star's 1e-6; asserted at 2e-6 (short horizons: |ll| is only 20-200, so one ulp of a term weighs more than at T = 500)
-@pytest.mark.parametrize("dtype,tol_ll,tol_m", [(torch.float64, 1e-9, 1e-8), (torch.float32, 2e-6, 5e-4)], ids=["f64", "f32"])
+# fp32 log-likelihood: the north star's 1e-6 of the largest |ll| (measured worst case over the ten systems 8.1e-7,
+# scripts/rand_err.py; short horizons: |ll| is only 20-200, so one ulp of a term weighs more than at T = 500)
+@pytest.mark.parametrize("dtype,tol_ll,tol_m", [(torch.float64, 1e-9, 1e-8), (torch.float32, 1e-6, 5e-4)], ids=["f64", "f32"])
 @pytest.mark.parametrize("case", range(10))
 def test_random_systems_match_the_oracle(oracle_lib, case, dtype, tol_ll, tol_m):
     rng = np.random.default_rng(1000 + case)

@@ -25,6 +25,26 @@ def test_infer_rejects_unknown_method_like_the_reference():
         infer(None, 10, 10, method="neutra")
 
 
+def test_reference_positional_order_of_the_model_function_slot():
+    """lqg/infer/mle.py:14 `max_likelihood(x, model, numpyro_fn, process_noise, dt, steps, step_size)` and
+    lqg/infer/utils.py:14 `infer(x, num_samples, num_warmup, model, numpyro_fn, process_noise, dt, method)`: a
+    reference-style positional call must bind the model function to ITS slot (round 3 bound it to process_noise); a foreign
+    NumPyro function is refused before anything runs."""
+    import inspect
+    from lqg_amd.infer import lifted_model, lqg_model
+    assert list(inspect.signature(max_likelihood).parameters)[:7] == ["x", "model", "numpyro_fn", "process_noise", "dt", "steps",
+                                                                      "step_size"]
+    assert list(inspect.signature(infer).parameters)[:8] == ["x", "num_samples", "num_warmup", "model", "numpyro_fn",
+                                                             "process_noise", "dt", "method"]
+    assert list(inspect.signature(lqg_model).parameters) == ["x", "model_type", "process_noise", "dt", "fixed_params"]
+    foreign = lambda x, model_type, process_noise=1.0, dt=1.0 / 60, **fixed: None
+    with pytest.raises(NotImplementedError, match="numpyro_fn"):
+        max_likelihood(None, lqg_amd.BoundedActor, foreign, 1.0)
+    with pytest.raises(NotImplementedError, match="numpyro_fn"):
+        infer(None, 10, 10, lqg_amd.BoundedActor, foreign, 1.0)
+    assert lifted_model is not lqg_model
+
+
 def test_nuts_driver_samples_a_known_gaussian():
     """The sampler itself (lqg_amd/infer/mcmc.py), with the log-density injected: four chains driven in lock step —
     one batched evaluation per round — recover mean and covariance of a correlated Gaussian."""
@@ -106,6 +126,58 @@ def test_max_likelihood_improves_and_approaches_truth():
     nll_true = -float(m.log_likelihood(x).sum())
     assert float(losses[-1]) < nll_true + 5.0                              # at least as good as the truth (+slack)
     assert abs(params["sigma_target"] - 12.0) < 4.0 and abs(params["action_variability"] - 0.4) < 0.15
+
+
+@pytest.mark.gpu
+def test_reference_style_positional_calls_run():
+    """The reference's own call shapes: `max_likelihood(x, Model, lqg_model, 1.0, 1 / 60, steps, step_size, **fixed)` and
+    `infer(x, n, n_warm, Model, lifted_model, 1.0, 1 / 60, "nuts")`; steps = 0 returns the initial values (advisor, round 3)."""
+    from lqg_amd.infer import lifted_model, lqg_model
+    m = lqg_amd.BoundedActor(T=80, device="cuda", dtype=torch.float64, sigma_target=10.0)
+    x = m.simulate(5, n=10)
+    kw = dict(action_cost=0.5, sigma_cursor=1.0)
+    p1, l1 = max_likelihood(x, lqg_amd.BoundedActor, lqg_model, 1.0, 1.0 / 60, 12, 0.05, **kw)
+    p2, l2 = max_likelihood(x, lqg_amd.BoundedActor, process_noise=1.0, steps=12, step_size=0.05, **kw)
+    assert p1 == p2 and torch.equal(l1, l2) and l1.shape == (12,)
+    assert abs(float(l1[0]) + float(lqg_model(x, lqg_amd.BoundedActor, 1.0, 1.0 / 60, **kw))) < 1e-9 * abs(float(l1[0]))
+    p0, l0 = max_likelihood(x, lqg_amd.BoundedActor, lqg_model, 1.0, steps=0, **kw)
+    assert l0.numel() == 0 and p0 == {k: float(v) for k, v in get_model_params(lqg_amd.BoundedActor).items() if k not in kw}
+    mc = infer(x, 8, 8, lqg_amd.BoundedActor, lifted_model, 1.0, 1.0 / 60, "nuts", **kw)
+    assert set(mc.get_samples()) == set(p1)
+
+
+@pytest.mark.gpu
+def test_max_likelihood_resumes_eagerly_from_the_last_verified_state(monkeypatch):
+    """A replay poisoned by the graph's device-side guard (NaN) sends the loop back to the last verified state and on from
+    there on the eager path (advisor, round 3: it used to refit every step from scratch)."""
+    from lqg_amd.infer import mle
+    from lqg_amd.infer import gradient
+    m = lqg_amd.BoundedActor(T=60, device="cuda", dtype=torch.float64, sigma_target=10.0)
+    x = m.simulate(5, n=10)
+    kw = dict(action_cost=0.5, sigma_cursor=1.0)
+    monkeypatch.setattr(mle, "GUARD_EVERY", 4)
+    real = gradient._graphed_fd
+    calls = {"n": 0}
+
+    def poisoning(*a, **k):
+        ev = real(*a, **k)
+        if ev is None:
+            return None
+
+        def wrapped(z):
+            calls["n"] += 1
+            out = ev(z)
+            return out * float("nan") if calls["n"] == 7 else out       # the 7th replay trips the guard
+        return wrapped
+    monkeypatch.setattr(gradient, "_graphed_fd", poisoning)
+    monkeypatch.setenv("LQG_GRAPH", "1")
+    p1, l1 = max_likelihood(x, lqg_amd.BoundedActor, steps=12, step_size=0.05, **kw)
+    assert calls["n"] == 8                                               # replays 1..8, NaN seen at the check after step 8
+    monkeypatch.setattr(gradient, "_graphed_fd", real)
+    monkeypatch.setenv("LQG_GRAPH", "0")
+    p0, l0 = max_likelihood(x, lqg_amd.BoundedActor, steps=12, step_size=0.05, **kw)
+    assert torch.isfinite(l1).all() and torch.allclose(l1, l0, rtol=1e-9, atol=0)
+    assert all(abs(p1[k] / p0[k] - 1) < 1e-8 for k in p0)
 
 
 @pytest.mark.gpu

@@ -171,3 +171,54 @@ def test_nan_propagates_for_singular_observed_noise(oracle_lib):
     spec = bounded(10, action_variability=0.0)
     x = np.zeros((1, 11, 2))
     assert not np.isfinite(oracle_lib.log_likelihood(spec, spec, x)).all()
+
+
+_ASAN_CHILD = r'''
+import sys
+import numpy as np
+sys.path[:0] = [ROOT + "/tests", ROOT + "/oracle", ROOT]
+from conftest import golden_names, load_golden
+import oracle as OC
+assert OC.LIB.endswith("liblqg_oracle_asan.so"), OC.LIB
+n = 0
+for name in golden_names():
+    g, actor, dyn = load_golden(name)
+    S0 = g.get("Sigma0")
+    for dtype in (np.float64, np.float32):
+        OC.riccati_backward(actor, dtype=dtype)
+        OC.kalman_forward(actor, S0, dtype=dtype)
+        OC.simulate(actor, dyn, g["sim_eps"], g["sim_eta"], x0=g.get("x0"), Sigma0=S0, dtype=dtype)
+        OC.conditional_moments(actor, dyn, g["x"], S0, dtype=dtype)
+        ll = OC.log_likelihood(actor, dyn, g["x"], S0, dtype=dtype)
+        n += 1
+    assert abs(ll / g["ll"] - 1).max() < 1e-3 or name == "pointmass_d4_T50"
+# a batch of systems across OpenMP threads (the cpu_baseline leg's shape of call)
+g, actor, dyn = load_golden("subjective2d_T60")
+rep = lambda d: {k: np.repeat(v[None], 24, axis=0) for k, v in d.items()}
+OC.lib().lqg_oracle_set_threads(4)
+llb = OC.log_likelihood(rep(actor), rep(dyn), np.repeat(g["x"][None], 24, axis=0))
+assert np.allclose(llb, g["ll"][None], rtol=1e-9)
+print("ASAN_OK", n)
+'''
+
+
+def test_c_oracle_under_address_and_undefined_behaviour_sanitizers():
+    """`make -C oracle asan` (-fsanitize=address,undefined, no recovery): every golden case, both dtypes, every entry point,
+    plus a batch across OpenMP threads, in a child process with libasan preloaded.  A heap / stack overrun, a use after free
+    or undefined behaviour in the restatement aborts the child.  (CPU only: no GPU sanitizers exist on this pool.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    odir = os.path.join(root, "oracle")
+    subprocess.check_call(["make", "-C", odir, "-s", "liblqg_oracle_asan.so"])
+    libasan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    if not os.path.isabs(libasan):
+        pytest.skip("gcc has no libasan.so")
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=86",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1", LQG_ORACLE_LIB=os.path.join(odir, "liblqg_oracle_asan.so"),
+               OMP_NUM_THREADS="4")
+    r = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}\n" + _ASAN_CHILD], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "ASAN_OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
