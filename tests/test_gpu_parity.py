@@ -26,11 +26,21 @@ ILL = {"pointmass_d4_T50"}
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("name", golden_names())
-def test_golden(name, dtype):
+def test_golden(name, dtype, oracle_lib):
     from lqg_amd.belief import kf
     from lqg_amd.control import lqr
 
     g, actor, dyn = load_golden(name)
+    if name in ILL and dtype == torch.float32:
+        # Rounding the INPUTS of this model to fp32 already moves its exact log-likelihood by 4e-6 (cond 5.6e8: the whitened
+        # innovation amplifies a 6e-8 relative change of x and of the noise factors), which no arithmetic downstream can undo:
+        # the moments and the log-likelihood are compared with the fp64 oracle evaluated ON THE SAME (fp32-rounded) inputs
+        r32 = lambda d_: {k: np.asarray(v, dtype=np.float32).astype(np.float64) for k, v in d_.items()}
+        a32, d32, x32 = r32(actor), r32(dyn), np.asarray(g["x"], dtype=np.float32).astype(np.float64)
+        g = dict(g)
+        g["ll"] = oracle_lib.log_likelihood(a32, d32, x32)
+        mu32, Sig32 = oracle_lib.conditional_moments(a32, d32, x32)
+        g["mu"], g["Sigma"] = mu32, np.broadcast_to(Sig32, (x32.shape[0],) + Sig32.shape)
     sys_ = system_from_golden(actor, dyn, dtype)
     tol = dict(TOL[dtype])
     if name in ILL:
