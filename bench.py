@@ -33,7 +33,7 @@ PEAK_FP64_TFLOPS = 78.6    # datasheet FP64 vector == FP64 matrix peak
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 COPY_HBM_GBS = 6290.0      # MI355X_MICROARCH.md: measured device copy rate
 VALU_WAVE_INSTS_PER_S = 1024 * 2.4e9 / 2    # 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")      # scripts/pmc_legs.sh + scripts/pmc_records.py
 
 
 def algorithmic_flops_per_step(x, b, u, y, d):
@@ -62,8 +62,12 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", type=int, default=5, choices=[3, 5],
-                    help="5 = the headline (BASELINE metric); 3 = candidate search, trial axis split over the ranks")
+    ap.add_argument("--config", type=int, default=5, choices=[3, 4, 5],
+                    help="5 = the headline (BASELINE metric); 3 = candidate search, trial axis split over the ranks; "
+                         "4 = BASELINE config 4: one 2-D hand model (n=10, T=1000), 262144 / N trials per rank")
+    ap.add_argument("--only", default=None,
+                    help="run ONE secondary leg (a key of `extra`) instead of the headline — what the per-leg PMC passes "
+                         "profile (scripts/pmc_legs.sh)")
     ap.add_argument("--log2-batch", type=int, default=20,
                     help="solves per GPU per step = 2**this (2^20: 14.7 GB resident; 2^18 fills each SIMD with exactly 4 waves "
                          "and runs ~12 %% slower per solve)")
@@ -125,15 +129,16 @@ def launch_ranks(args):
     return subprocess.run(cmd, env=env).returncode
 
 
-def pmc_record(kernel, pattern_key, dtype, log2_batch):
-    """The PMC-derived HBM bytes / VALU instructions of `kernel`, but only if the committed profile was taken on
-    exactly these kernels: same library source hash, same sparsity-pattern library, dtype and batch."""
+def pmc_record(leg, kernel):
+    """The PMC-derived HBM bytes / VALU instructions per launch of `kernel` (a family name: "forward", "riccati", "trial")
+    inside bench leg `leg`, but only if the committed profile (profiles/r04_pmc.json, collected by scripts/pmc_legs.sh as
+    separate --pmc passes of `bench.py --only <leg>`) was taken on exactly this build: same library source hash, same
+    pattern-library header hash.  None otherwise — a leg then reports `traffic: null` rather than a stale figure."""
     try:
         from lqg_amd import build, specialize
         pj = json.load(open(PMC_FILE))
         for rec in pj.get("records", []):
-            if (rec.get("kernel") == kernel and rec.get("dtype") == dtype and rec.get("log2_batch") == log2_batch
-                    and rec.get("pattern_key") == pattern_key and rec.get("source_hash") == build.source_hash()
+            if (rec.get("leg") == leg and rec.get("kernel") == kernel and rec.get("source_hash") == build.source_hash()
                     and rec.get("sp_headers_hash") == specialize._headers_hash()):
                 return rec
     except Exception:
@@ -183,21 +188,43 @@ def timed_steps(torch, dist, step, steps, warmup, before_step=None):
     return out, elapsed, per_rank, tm.ms()
 
 
-def allreduce_us(torch, dist, n, reps=50):
-    """Mean latency of the path's one collective: all-reduce of n fp64 values (RCCL over xGMI)."""
+def allreduce_us(torch, dist, n, reps=200):
+    """Latency of the path's one collective — all-reduce of n fp64 values (RCCL over xGMI) — each call timed on its own:
+    {"mean", "p50", "p90", "p99", "max", "back_to_back_mean"} in microseconds (None without a process group)."""
     if dist is None:
         return None
+    import numpy as np
     v = torch.zeros(n, dtype=torch.float64, device="cuda")
-    for _ in range(5):
+    for _ in range(10):
         dist.all_reduce(v)
     torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record()
+        dist.all_reduce(v)
+        b.record()
+    torch.cuda.synchronize()
+    us = np.array([a.elapsed_time(b) for a, b in ev]) * 1e3
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
         dist.all_reduce(v)
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e3
+    return {"elements_fp64": int(n), "calls": int(reps), "mean": float(us.mean()), "p50": float(np.percentile(us, 50)),
+            "p90": float(np.percentile(us, 90)), "p99": float(np.percentile(us, 99)), "max": float(us.max()),
+            "back_to_back_mean": e0.elapsed_time(e1) / reps * 1e3}
+
+
+def collective_info(torch, dist, args, world):
+    """What the N > 1 line says about its process group, so that the first run on a real multi-GPU node explains itself:
+    backend, ranks the backend reports after init (RCCL: `rccl_ranks_seen`), devices."""
+    if dist is None:
+        return {"backend": None, "world_size": world, "rccl_ranks_seen": None}
+    backend = "gloo (host tensors, --share-gpu)" if args.share_gpu else "nccl (RCCL)"
+    seen = dist.get_world_size()
+    return {"backend": backend, "world_size": int(seen), "rccl_ranks_seen": None if args.share_gpu else int(seen),
+            "devices_visible": int(torch.cuda.device_count()), "device": torch.cuda.get_device_name(torch.cuda.current_device())}
 
 
 def host_specs(torch, np, workload, LQGSpec, system, sel, np_dt):
@@ -223,7 +250,64 @@ def host_specs(torch, np, workload, LQGSpec, system, sel, np_dt):
     return host(system.actor), host(system.dynamics)
 
 
-def headline_leg(torch, dist, args, dev, rank, world, dtype_name, log2_batch, steps, warmup, env=None, cpu=False):
+def cpu_baseline(torch, np, OC, workload, lqg_amd, system, x_ref, dev, dtype_name, T, B, args):
+    """The CPU baseline BASELINE.md 2 planned: the literal dense C restatement (oracle/lqg_oracle.c — a LITERAL PORT of the
+    reference's formulas with run-time dims: LU with pivoting, Jacobi eigenvalues, no structure, one heap block per system;
+    it is the parity checker, not a tuned CPU solver) timed on the GPU box's host cores on bounded samples of the same
+    workload: all cores and ONE thread, in the bench dtype and in the other one.  A stated baseline, not the target."""
+    ncpu = os.cpu_count() or 1
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+
+    def timed(np_dt, nsamp, threads, budget_s):
+        OC.lib().lqg_oracle_set_threads(threads)
+        sel = np.arange(nsamp) % B
+        a_s, d_s = host_specs(torch, np, workload, lqg_amd.LQGSpec, system, sel, np_dt)
+        x_s = x_ref[torch.as_tensor(sel, device=dev)].cpu().numpy().astype(np_dt)
+        k = max(1, min(8, nsamp))
+        OC.log_likelihood({f: v[:k] for f, v in a_s.items()}, {f: v[:k] for f, v in d_s.items()}, x_s[:k], dtype=np_dt)
+        tc = time.perf_counter()
+        OC.log_likelihood(a_s, d_s, x_s, dtype=np_dt)
+        t1 = time.perf_counter() - tc
+        nrep = 1
+        if t1 < 0.5 * budget_s:
+            nrep = int(min(16, max(1, budget_s / max(t1, 1e-3))))
+            tc = time.perf_counter()
+            for _ in range(nrep):
+                OC.log_likelihood(a_s, d_s, x_s, dtype=np_dt)
+            t1 = (time.perf_counter() - tc) / nrep
+        return nsamp / t1, nrep
+
+    np_main = np.float32 if dtype_name == "f32" else np.float64
+    np_other, other = (np.float64, "f64") if dtype_name == "f32" else (np.float32, "f32")
+    nsamp = args.cpu_sample or 16384                  # 64 solves per thread on a 256-thread host
+    v_all, nrep = timed(np_main, nsamp, ncpu, 8.0)
+    threads = OC.lib().lqg_oracle_max_threads()
+    n1 = max(16, min(512, int(v_all / max(threads, 1) * 3.0)))       # ~3 s of one thread
+    v_one, _ = timed(np_main, n1, 1, 3.0)
+    v_all_o, _ = timed(np_other, nsamp, ncpu, 4.0)
+    v_one_o, _ = timed(np_other, n1, 1, 2.0)
+    OC.lib().lqg_oracle_set_threads(ncpu)
+    return dict(
+        value=v_all, unit="solves/s", cores=threads, kind="port",
+        port="literal dense restatement (oracle/lqg_oracle.c: run-time dims, no structure, one heap block per system, "
+             "-O3 -march=x86-64-v3, OpenMP over systems) — the parity checker, not a tuned CPU solver",
+        sample=f"{nsamp} solves of the same workload ({dtype_name}, T={T}) x {nrep} repetitions on all cores; {n1} solves on "
+               f"one thread; the same two samples in {other}",
+        single_thread={"value": v_one, "unit": "solves/s", "cores": 1, "dtype": dtype_name, "sample_solves": n1},
+        other_dtype={"dtype": other, "value": v_all_o, "cores": threads,
+                     "single_thread": {"value": v_one_o, "cores": 1, "sample_solves": n1}},
+        cpu_model=model, host_cpu_count=ncpu)
+
+
+def headline_leg(torch, dist, args, dev, rank, world, dtype_name, log2_batch, steps, warmup, env=None, cpu=False, leg=None,
+                 layout=None):
     """One measurement of the headline workload; returns the dict rank 0 prints (None on other ranks)."""
     import numpy as np
     import lqg_amd
@@ -239,7 +323,16 @@ def headline_leg(torch, dist, args, dev, rank, world, dtype_name, log2_batch, st
         system, _ = workload.headline_system(B, T, seed=1234 + rank, device=dev, dtype=dtype)
         dm = dict(x=system.xdim, b=system.bdim, u=system.udim, y=system.ydim, d=system.xdim)
         x_ref = workload.simulate_one_trial_each(system, seed=99 + 7919 * rank)            # [B,1,T+1,d]
-        x = workload.pack_trials(x_ref) if args.layout == "packed" else x_ref
+        layout = layout or args.layout
+        pack_ms = None
+        if layout == "packed":
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            x = workload.pack_trials(x_ref)                # one-time re-layout [B,1,T+1,d] -> storage [T+1][d][B] (outside the timed region)
+            torch.cuda.synchronize()
+            pack_ms = (time.perf_counter() - tp) * 1e3
+        else:
+            x = x_ref
         torch.cuda.synchronize()
         # The hot path exactly as lqg_amd.System.log_likelihood runs it (lqg_amd/plan.py), decided once:
         # (1) a model whose interaction graph splits into independent components is solved per component (every dim=2
@@ -285,10 +378,7 @@ def headline_leg(torch, dist, args, dev, rank, world, dtype_name, log2_batch, st
     fwd_avg_ms, ric_avg_ms = float(np.mean(fwd_ms)), float(np.mean(ric_ms))
     n_launch = len(plan.work)                       # forward-kernel launches per step
     alg_gbs = bytes_solve * B / (fwd_avg_ms * 1e-3) / 1e9     # algorithmic bytes of one step / forward-kernel time
-    kernel = ("k_forward_sp" if sp_all else "k_forward") + \
-        (f"<merged{max(plan.merged)}>" if plan.merged and max(plan.merged) > 1 else "") + f"x{n_launch}"
-    pkey = plan.work[0].get("pattern_key") if sp_all else "generic"
-    rec = pmc_record(kernel, pkey, dtype_name, log2_batch)
+    rec = pmc_record(leg or f"headline_{dtype_name}", "forward") if (leg or (log2_batch == 20 and not env)) else None
     traffic = rec["hbm_bytes_per_launch"] if rec else None
     limits = {"note": "which side binds the dominant kernel: measured HBM bytes/s against the guide's achievable copy rate "
                       "vs wave64 VALU instructions issued/s against 1024 SIMDs x 2.4 GHz / 2 cycles"}
@@ -308,11 +398,13 @@ def headline_leg(torch, dist, args, dev, rank, world, dtype_name, log2_batch, st
         "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
         "config": {"workload": f"SubjectiveActor(dim=2) x=4 b=6 u=2 y=4 d=4, T={T}, {B} independent "
                                f"(candidate, trajectory) solves per GPU per step (BASELINE config 5 / headline shape)",
-                   "solves_per_gpu": B, "T": T, "trajectory_layout": args.layout, "path": plan.description,
+                   "solves_per_gpu": B, "T": T, "trajectory_layout": layout, "pack_trials_ms_one_time": pack_ms,
+                   "path": plan.description,
                    "parallelism": f"candidate-sharded x{world}, all-reduce of the summed log-likelihood"},
         "world_size": world if dist is None else dist.get_world_size(),
-        "per_rank_solves_per_s": [float(B) * steps / t for t in per_rank], "allreduce_us": ar_us,
-        "share_gpu": bool(args.share_gpu),
+        "per_rank_solves_per_s": [float(B) * steps / t for t in per_rank],
+        "allreduce_us": ar_us["mean"] if ar_us else None, "allreduce_us_percentiles": ar_us,
+        "collective": collective_info(torch, dist, args, world), "share_gpu": bool(args.share_gpu),
         # Contract form: achieved = ALGORITHMIC bytes per launch (mode M1: trajectory in, specs in, one
         # scalar out) / the dominant kernel's HIP-event time; traffic = PMC bytes of that launch (null unless the
         # committed profile was taken on exactly this build).
@@ -339,39 +431,33 @@ def headline_leg(torch, dist, args, dev, rank, world, dtype_name, log2_batch, st
         ref = OC.log_likelihood(a64, d64, x64, dtype=np.float64)[:, 0]
         out["parity"] = dict(samples=int(ns), max_rel_err_vs_fp64_oracle=float(np.abs(ll_host[idx] / ref - 1).max()))
         if cpu:
-            ncpu = os.cpu_count() or 1
-            OC.lib().lqg_oracle_set_threads(ncpu)
-            np_dt = np.float32 if dtype_name == "f32" else np.float64
-            nsamp = args.cpu_sample or 16384          # 64 solves per thread on a 256-thread host
-            sel = np.arange(nsamp) % B
-            a_s, d_s = host_specs(torch, np, workload, lqg_amd.LQGSpec, system, sel, np_dt)
-            x_s = x_ref[torch.as_tensor(sel, device=dev)].cpu().numpy().astype(np_dt)
-            OC.log_likelihood({k: v[:8] for k, v in a_s.items()}, {k: v[:8] for k, v in d_s.items()}, x_s[:8], dtype=np_dt)
-            tc = time.perf_counter()
-            OC.log_likelihood(a_s, d_s, x_s, dtype=np_dt)
-            tc1 = time.perf_counter() - tc
-            nrep = 1
-            if tc1 < 8.0 and not args.cpu_sample:     # repeat the sample so that the CPU leg does ~10-20 s of work
-                nrep = int(min(16, max(1, 12.0 / max(tc1, 1e-3))))
-                tc = time.perf_counter()
-                for _ in range(nrep):
-                    OC.log_likelihood(a_s, d_s, x_s, dtype=np_dt)
-                tc1 = (time.perf_counter() - tc) / nrep
-            model = ""
-            try:
-                for line in open("/proc/cpuinfo"):
-                    if line.startswith("model name"):
-                        model = line.split(":", 1)[1].strip()
-                        break
-            except OSError:
-                pass
-            out["cpu_baseline"] = dict(
-                value=nsamp / tc1, unit="solves/s", cores=OC.lib().lqg_oracle_max_threads(), kind="port",
-                sample=f"{nsamp} solves of the same workload ({dtype_name}, T={T}) x {nrep} repetitions, "
-                       f"oracle/lqg_oracle.c (literal dense restatement) with OpenMP over systems",
-                cpu_model=model, host_cpu_count=ncpu)
+            out["cpu_baseline"] = cpu_baseline(torch, np, OC, workload, lqg_amd, system, x_ref, dev, dtype_name, T, B, args)
     except Exception as e:  # the oracle is a checker: its absence must not break the measurement
         out["parity"] = dict(error=repr(e))
+    return out
+
+
+def config3_roofline(ph, Bc, n_trials, T, w):
+    """Dominant kernel of config 3: k_trial_sp, the per-trial mean recursion + density over the operator stream.  Its data
+    (x: 8.7 MB) stays in L2 and its operators come through the scalar cache: VALU-issue-bound.  achieved = wave64 VALU
+    instructions issued per second from the committed PMC pass of THIS build (SQ_INSTS_VALU per launch / kernel time), peak =
+    1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction; traffic = the PMC HBM bytes of one launch.  Without a record
+    carrying the running build's hashes: achieved / frac / traffic are null (never a stale number)."""
+    rec = pmc_record("config3", "trial")
+    ms = ph[2]
+    steps_per_s = float(Bc) * n_trials * T / (ms * 1e-3)
+    out = {"bound": "valu", "kernel": "k_trial_sp (per-trial mean recursion + density over the operator stream)",
+           "kernel_ms": ms, "system_sweeps_ms": ph[0] + ph[1], "unit": "wave64 VALU instructions/s",
+           "peak": VALU_WAVE_INSTS_PER_S, "achieved": None, "frac": None, "traffic": None,
+           "trial_steps_per_s": steps_per_s,
+           "data_rows_GBps_through_L2": float(Bc) * n_trials * (T + 1) * 2 * w / (ms * 1e-3) / 1e9,
+           "algorithmic_bytes_per_launch": n_trials * (T + 1) * 2 * w + Bc * n_trials * w}
+    if rec and rec.get("valu_wave_insts_per_launch"):
+        out["achieved"] = rec["valu_wave_insts_per_launch"] / (ms * 1e-3)
+        out["frac"] = out["achieved"] / VALU_WAVE_INSTS_PER_S
+        out["valu_insts_per_trial_step"] = rec["valu_wave_insts_per_launch"] * 64.0 / (float(Bc) * n_trials * T)
+        out["traffic"] = rec.get("hbm_bytes_per_launch")
+        out["profile"] = rec.get("profile")
     return out
 
 
@@ -421,50 +507,134 @@ def config3(torch, dist, args, dev, rank, world):
                    "candidates": Bc, "trials": Nt, "trials_per_rank": Nt // world, "T": T, "path": plan.description,
                    "parallelism": f"trial-split x{world}, all-reduce of the [{Bc}] fp64 objective"},
         "world_size": world if dist is None else dist.get_world_size(),
-        "per_rank_s": per_rank, "allreduce_us": ar_us, "share_gpu": bool(args.share_gpu),
+        "per_rank_s": per_rank, "allreduce_us": ar_us["mean"] if ar_us else None, "allreduce_us_percentiles": ar_us,
+        "collective": collective_info(torch, dist, args, world), "share_gpu": bool(args.share_gpu),
         "objective_checksum": float(obj.sum()),
         "phase_ms": {"riccati": ph[0], "forward": ph[1], "trial": ph[2]},
-        "roofline": {"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                     "kernel": "k_trial (per-trial mean recursion + density over the operator stream)",
-                     "note": "the per-trial sweep reads each data row once per CANDIDATE BLOCK from L2/HBM and its operators "
-                             f"from the scalar cache; algorithmic bytes of the data alone = {bytes_launch} B per rank — "
-                             "the sweep is VALU-bound (bench_configs.py carries the per-config accounting)"},
+        "roofline": config3_roofline(ph, Bc, Nt // world, T, w),
         "best_candidate": int(obj.argmax()), "objective_max": float(obj.max()),
     }
 
 
-def extra_legs(torch, args, dev):
-    """Secondary legs, outside the headline's timed region (same workload generator, same timing protocol): the other
-    dtype of the headline, and the generic dense joint n=6 kernels (no specialisation, no decoupling) in both dtypes."""
-    extra = {}
+def config4(torch, dist, args, dev, rank, world, n_total=262144, steps=None, warmup=None):
+    """BASELINE config 4, literally: the 2-D hand model (notebooks/HandModel.ipynb: x = b = 10, u = 2, y = 4, d = 4, T = 1000),
+    ONE parameter vector, 262 144 trials sharded over the ranks (262144 / N per rank, contiguous blocks); every
+    rank solves the one system itself (a few kB of specs), one all-reduce of the scalar fp64 objective per step.  Strong
+    scaling.  Data are simulated per rank from a rank-dependent seed (the shards of one synthetic data set)."""
+    import numpy as np
+    import bench_configs as bc
+    from lqg_amd import _hip, workload
+    from lqg_amd.plan import LogLikelihoodPlan
+    steps, warmup = steps or args.steps, args.warmup if warmup is None else warmup
+    if n_total % world:
+        raise SystemExit(f"--config 4: {n_total} trials do not split over {world} ranks")
+    dtype = torch.float32 if args.dtype == "f32" else torch.float64
+    T, n_loc = 1000, n_total // world
+    m = bc.hand2d_system(T, dev, dtype)
+    x = workload.pack_trials(m.simulate(1400 + rank, n=n_loc)[..., :4].contiguous())
+    plan = LogLikelihoodPlan(m, x, events=True)
+
+    def step():
+        obj = _hip.sum_trials(plan.run())            # scalar fp64 partial objective of this rank's trials
+        if dist is not None:
+            obj = obj.reshape(1)
+            dist.all_reduce(obj)
+        return obj
+
+    obj, elapsed, per_rank, step_ms = timed_steps(torch, dist, step, steps, warmup)
+    ph = plan.phase_ms()
+    ar_us = allreduce_us(torch, dist, 1)
+    ll = plan.run()
+    parity = None
+    if rank == 0:
+        try:
+            parity = bc.oracle_check(m, x, ll, n_samples=3)
+        except Exception as e:
+            parity = repr(e)
+    if rank != 0:
+        return None
+    w = 4 if args.dtype == "f32" else 8
+    b4 = n_loc * (T + 1) * 4 * w + n_loc * w          # this rank's trajectories in, one scalar per trial out
+    return {
+        "metric": "trial-evals/sec (BASELINE config 4: 2-D hand model n=10, T=1000, 262144 trials over N GPUs)",
+        "value": float(n_total) * steps / elapsed, "unit": "trial-evals/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "ms_per_step_min": float(np.min(step_ms)),
+        "ms_per_step_median": float(np.median(step_ms)), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"BASELINE config 4: hand model 2-D (x=b=10 u=2 y=4 d=4), T={T}, one system x {n_total} trials",
+                   "trials": n_total, "trials_per_rank": n_loc, "T": T, "path": plan.description,
+                   "parallelism": f"trial-split x{world}, all-reduce of the scalar fp64 objective"},
+        "world_size": world if dist is None else dist.get_world_size(), "per_rank_s": per_rank,
+        "allreduce_us": ar_us["mean"] if ar_us else None, "allreduce_us_percentiles": ar_us,
+        "collective": collective_info(torch, dist, args, world), "share_gpu": bool(args.share_gpu),
+        "objective_sum": float(obj.sum()), "phase_ms": {"riccati": ph[0], "forward": ph[1], "trial": ph[2]},
+        "max_rel_err_vs_fp64_oracle": parity,
+        "roofline": {"bound": "hbm", "kernel": f"per-trial sweep over {n_loc} trajectories per rank (x streamed once)",
+                     "kernel_ms": ph[2], "system_sweeps_ms": ph[0] + ph[1], "achieved": b4 / (ph[2] * 1e-3) / 1e9,
+                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": b4 / (ph[2] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                     "traffic": None, "algorithmic_bytes_per_launch": b4},
+    }
+
+
+def _with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def leg_headline_other(torch, args, dev):
     other = "f64" if args.dtype == "f32" else "f32"
-    torch.cuda.empty_cache()
     leg = headline_leg(torch, None, args, dev, 0, 1, other, args.log2_batch, min(args.steps, 10), 2)
-    extra[f"headline_{other}"] = {k: leg[k] for k in ("value", "unit", "ms_per_step", "dtype", "parity", "roofline")}
-    extra[f"headline_{other}"]["path"] = leg["config"]["path"]
-    torch.cuda.empty_cache()
-    for dn in ("f32", "f64"):
+    out = {k: leg[k] for k in ("value", "unit", "ms_per_step", "dtype", "parity", "roofline")}
+    out["path"] = leg["config"]["path"]
+    return out
+
+
+def leg_reference_layout(torch, args, dev):
+    """The headline with the trajectories in the REFERENCE's layout x[B, 1, T+1, d] (what a drop-in caller hands over) instead
+    of the packed [T+1][d][B] storage the default line is timed on, plus the one-time cost of the re-layout."""
+    leg = headline_leg(torch, None, args, dev, 0, 1, args.dtype, args.log2_batch, min(args.steps, 10), 2, layout="reference")
+    packed = headline_leg(torch, None, args, dev, 0, 1, args.dtype, args.log2_batch, 3, 1, layout="packed")
+    return {"value": leg["value"], "unit": leg["unit"], "ms_per_step": leg["ms_per_step"], "dtype": args.dtype,
+            "trajectory_layout": "reference [B][1][T+1][d] (each lane reads its own 8 kB trajectory: 64 cache lines per wave-load)",
+            "kernel_ms": leg["roofline"]["kernel_ms"], "frac_hbm_algorithmic": leg["roofline"]["frac"],
+            "pack_trials_ms_one_time": packed["config"]["pack_trials_ms_one_time"],
+            "note": "pack_trials is paid once per data set (it is reused by every candidate / optimiser step); "
+                    "ms_per_step here is the sweep on the unpacked data",
+            "parity": leg.get("parity")}
+
+
+def leg_dense_generic(dn):
+    def run(torch, args, dev):
         leg = headline_leg(torch, None, args, dev, 0, 1, dn, 17, min(args.steps, 5), 1,
                            env={"LQG_NO_SPECIALIZE": "1", "LQG_NO_DECOUPLE": "1"})
         r = leg["roofline"]
-        # dense joint n=6 (m=10) kernel: VALU-bound; executed-instruction figures come from the ISA of
-        # k_forward<R,4,6,2,4,4,TI,FUSED> (profiles/README.md), the algorithmic flop rate from SURVEY 8(d)
+        # dense joint n=6 (m=10) kernel: VALU-bound; the algorithmic flop rate is SURVEY 8(d)'s reference formulation
         fl_rate = r["algorithmic_flops_per_solve"] * leg["value"] / 1e12
-        extra[f"dense_generic_{dn}"] = {
-            "value": leg["value"], "unit": leg["unit"], "ms_per_step": leg["ms_per_step"], "dtype": dn,
-            "solves_per_gpu": 1 << 17, "path": leg["config"]["path"], "parity": leg.get("parity"),
-            "env": "LQG_NO_SPECIALIZE=1 LQG_NO_DECOUPLE=1",
-            "roofline": {"bound": "valu", "achieved": fl_rate, "unit": "TFLOP/s (algorithmic, SURVEY 8d)",
-                         "peak": PEAK_FP32_TFLOPS if dn == "f32" else PEAK_FP64_TFLOPS,
-                         "frac": fl_rate / (PEAK_FP32_TFLOPS if dn == "f32" else PEAK_FP64_TFLOPS),
-                         "kernel_ms": r["kernel_ms"], "riccati_kernel_ms": r["riccati_kernel_ms"]}}
-        torch.cuda.empty_cache()
-    # one system x many trials (BASELINE configs 2 and 4, the inner loop of MLE / NUTS): the time-parallel path (scans over
-    # the time axis + time-chunked per-trial sweep) against the sequential lane kernels, wall ms per evaluation
-    import bench_configs as bc
-    import lqg_amd
-    from lqg_amd import workload
-    for cfg in (2, 4):
+        peak = PEAK_FP32_TFLOPS if dn == "f32" else PEAK_FP64_TFLOPS
+        return {"value": leg["value"], "unit": leg["unit"], "ms_per_step": leg["ms_per_step"], "dtype": dn,
+                "solves_per_gpu": 1 << 17, "path": leg["config"]["path"], "parity": leg.get("parity"),
+                "env": "LQG_NO_SPECIALIZE=1 LQG_NO_DECOUPLE=1",
+                "roofline": {"bound": "valu", "achieved": fl_rate, "unit": "TFLOP/s (algorithmic, SURVEY 8d)", "peak": peak,
+                             "frac": fl_rate / peak, "kernel_ms": r["kernel_ms"], "riccati_kernel_ms": r["riccati_kernel_ms"],
+                             "traffic": None}}
+    return run
+
+
+def leg_one_system(cfg):
+    def run(torch, args, dev):
+        # one system x many trials (BASELINE configs 2 and 4, the inner loop of MLE / NUTS): the time-parallel path (scans over
+        # the time axis + time-chunked per-trial sweep) against the sequential lane kernels, wall ms per evaluation
+        import bench_configs as bc
+        import lqg_amd
+        from lqg_amd import workload
         if cfg == 2:
             m = lqg_amd.PointMassBoundedActor(T=500, action_variability=0.5, device=dev, dtype=torch.float32)
             x = workload.pack_trials(m.simulate(12, n=65536)[..., :2].contiguous())
@@ -473,27 +643,20 @@ def extra_legs(torch, args, dev):
             x = workload.pack_trials(m.simulate(14, n=32768)[..., :4].contiguous())
         leg = {"systems": 1, "trials": int(x.shape[-3]), "T": int(m.T), "dtype": "f32"}
         for name, env in (("time_parallel", {}), ("sequential", {"LQG_SCAN": "0", "LQG_TRIAL_CHUNKS": "0"})):
-            old = {k: os.environ.get(k) for k in env}
-            os.environ.update(env)
-            try:
-                ll, ph = bc.timed_loglik(m, x, 10)
-            finally:
-                for k, v in old.items():
-                    if v is None:
-                        os.environ.pop(k, None)
-                    else:
-                        os.environ[k] = v
+            ll, ph = _with_env(env, lambda: bc.timed_loglik(m, x, 10))
             leg[name] = {"wall_ms": ph["wall_ms"], "system_sweeps_ms": ph["riccati_ms"] + ph["forward_ms"],
                          "per_trial_sweep_ms": ph["trial_ms"], "path": ph["path"],
                          "max_rel_err_vs_fp64_oracle": bc.oracle_check(m, x, ll, n_samples=4)}
         leg["speedup"] = leg["sequential"]["wall_ms"] / leg["time_parallel"]["wall_ms"]
-        extra[f"config{cfg}_one_system"] = leg
-        del x
-        torch.cuda.empty_cache()
+        return leg
+    return run
+
+
+def leg_one_vector(torch, args, dev):
     # the inner loop of the reference's inference drivers (lqg/infer/mle.py:17-23, NUTS): value + gradient of ONE parameter
     # vector on 50 trials, T = 500, fp64 — batched central differences replayed as one hipGraph (lqg_amd/infer/graphed.py),
     # the same launched from Python, and the reverse-mode sweep; BASELINE.md derives ~54 evaluations/s for the reference
-    import time
+    import lqg_amd
     from lqg_amd.infer import gradient
     true = dict(sigma_target=25.0, sigma_cursor=1.0, action_cost=0.05, action_variability=0.5)
     with torch.no_grad():
@@ -502,9 +665,7 @@ def extra_legs(torch, args, dev):
     p0 = dict(sigma_target=20.0, sigma_cursor=2.0, action_cost=0.1, action_variability=0.4)
     leg = {"workload": "BoundedActor T=500, 50 trials, 4 parameters, one parameter vector, fp64", "unit": "ms per value+gradient"}
     for name, method, env, reps in (("fd_graph", "fd", {}, 300), ("fd_eager", "fd", {"LQG_GRAPH": "0"}, 100), ("adjoint", "adjoint", {}, 50)):
-        old = {k: os.environ.get(k) for k in env}
-        os.environ.update(env)
-        try:
+        def go():
             for i in range(5):
                 gradient.value_and_grad(xg, lqg_amd.BoundedActor, dict(p0, sigma_target=20.0 + 0.01 * i), method=method)
             torch.cuda.synchronize()
@@ -512,111 +673,175 @@ def extra_legs(torch, args, dev):
             for i in range(reps):          # (a different vector every call: nothing is cached across evaluations)
                 gradient.value_and_grad(xg, lqg_amd.BoundedActor, dict(p0, sigma_target=20.0 + 1e-3 * i), method=method)
             torch.cuda.synchronize()
-            leg[name] = (time.perf_counter() - t0) / reps * 1e3
-        finally:
-            for k, v in old.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
+            return (time.perf_counter() - t0) / reps * 1e3
+        leg[name] = _with_env(env, go)
     leg["evaluations_per_s"] = 1e3 / leg["fd_graph"]
-    extra["one_vector_value_and_grad"] = leg
-    torch.cuda.empty_cache()
-    # ---- the measurement claims of DESIGN.md §6 that used to be builder-run only (round-2 review item 4) -------------------
+    return leg
+
+
+def leg_m2(torch, args, dev):
     # mode M2 of SURVEY 8(d): genuinely time-varying specs in, L, H, K, mu, Sigma out, [T][element][system] storage
-    try:
-        import bench_m2
-        extra["m2_f32"] = bench_m2.run(dev, "f32", 17, 500, 3)
-    except Exception as e:
-        extra["m2_f32"] = {"error": repr(e)}
-    torch.cuda.empty_cache()
+    import bench_m2
+    out = bench_m2.run(dev, "f32", 17, 500, 3)
+    rec_r, rec_f = pmc_record("m2_f32", "riccati"), pmc_record("m2_f32", "forward")
+    if rec_r and rec_f:
+        out["roofline"]["traffic"] = rec_r["hbm_bytes_per_launch"] + rec_f["hbm_bytes_per_launch"]
+        out["roofline"]["traffic_kernels"] = {"k_riccati_tv_sp": rec_r["hbm_bytes_per_launch"],
+                                              "k_forward_tv_sp": rec_f["hbm_bytes_per_launch"]}
+        out["roofline"]["profile"] = rec_f.get("profile")
+    return out
+
+
+def leg_config3(torch, args, dev):
     # BASELINE config 3 at its literal shape (4096 candidates x 1024 trials, T = 1067): trial-evals/s, k_trial_sp time
-    try:
-        class A3:
-            dtype, steps, warmup, share_gpu = "f32", 10, 2, False
-        c3 = config3(torch, None, A3, dev, 0, 1)
-        w3 = 4
-        tb = 4096 * 1024 * (1067 + 1) * 2 * w3                 # one data row per (candidate, trial, step) as the sweep reads it
-        c3["roofline"] = {"bound": "valu", "kernel": "k_trial_sp (per-trial mean recursion + density over the operator stream)",
-                          "kernel_ms": c3["phase_ms"]["trial"], "system_sweeps_ms": c3["phase_ms"]["riccati"] + c3["phase_ms"]["forward"],
-                          "achieved": tb / (c3["phase_ms"]["trial"] * 1e-3) / 1e9, "unit": "GB/s of data rows through L2 (x is 8.7 MB: "
-                          "HBM sees it once per pass)", "peak": None, "frac": None, "traffic": None,
-                          "trial_steps_per_s": 4096 * 1024 * 1067 / (c3["phase_ms"]["trial"] * 1e-3)}
-        extra["config3"] = {k: c3[k] for k in ("metric", "value", "unit", "ms_per_step", "phase_ms", "roofline", "config",
-                                                "best_candidate")}
-    except Exception as e:
-        extra["config3"] = {"error": repr(e)}
-    torch.cuda.empty_cache()
+    class A3:
+        dtype, steps, warmup, share_gpu = "f32", 10, 2, False
+    c3 = config3(torch, None, A3, dev, 0, 1)
+    return {k: c3[k] for k in ("metric", "value", "unit", "ms_per_step", "phase_ms", "roofline", "config", "best_candidate")}
+
+
+def leg_config4(torch, args, dev):
+    class A4:
+        dtype, steps, warmup, share_gpu = "f32", 10, 2, False
+    c4 = config4(torch, None, A4, dev, 0, 1)
+    return {k: c4[k] for k in ("metric", "value", "unit", "ms_per_step", "phase_ms", "roofline", "config",
+                               "max_rel_err_vs_fp64_oracle")}
+
+
+def leg_config5_one_system(torch, args, dev):
     # BASELINE config 5 in its literal form: ONE system x 2^20 trials (the per-trial sweep streams x once: HBM-bound)
-    try:
-        m5 = lqg_amd.SubjectiveActor(dim=2, T=500, device=dev, dtype=torch.float32)
-        x5 = workload.pack_trials(m5.simulate(15, n=1 << 20))
-        ll5, ph5 = bc.timed_loglik(m5, x5, 10)
-        b5 = (1 << 20) * 501 * 4 * 4 + (1 << 20) * 4
-        extra["config5_one_system"] = {
-            "systems": 1, "trials": 1 << 20, "T": 500, "dtype": "f32", "wall_ms": ph5["wall_ms"], "path": ph5["path"],
+    import bench_configs as bc
+    import lqg_amd
+    from lqg_amd import workload
+    m5 = lqg_amd.SubjectiveActor(dim=2, T=500, device=dev, dtype=torch.float32)
+    x5 = workload.pack_trials(m5.simulate(15, n=1 << 20))
+    ll5, ph5 = bc.timed_loglik(m5, x5, 10)
+    b5 = (1 << 20) * 501 * 4 * 4 + (1 << 20) * 4
+    rec = pmc_record("config5_one_system", "trial")
+    return {"systems": 1, "trials": 1 << 20, "T": 500, "dtype": "f32", "wall_ms": ph5["wall_ms"], "path": ph5["path"],
             "value": (1 << 20) / (ph5["wall_ms"] * 1e-3), "unit": "trial-evals/s",
             "roofline": {"bound": "hbm", "kernel": "per-trial sweep (k_trial_sp) over 2^20 trajectories", "kernel_ms": ph5["trial_ms"],
                          "system_sweeps_ms": ph5["riccati_ms"] + ph5["forward_ms"],
                          "achieved": b5 / (ph5["trial_ms"] * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": b5 / (ph5["trial_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                         "frac": b5 / (ph5["trial_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                         "traffic": rec["hbm_bytes_per_launch"] if rec else None, "profile": rec.get("profile") if rec else None,
                          "algorithmic_bytes_per_launch": b5},
             "max_rel_err_vs_fp64_oracle": bc.oracle_check(m5, x5, ll5, n_samples=4)}
-        del x5
-    except Exception as e:
-        extra["config5_one_system"] = {"error": repr(e)}
-    torch.cuda.empty_cache()
+
+
+def leg_delay12(torch, args, dev):
     # the reference's largest model: DelayedSubjectiveActor (delay 12: x = 26, b = 39, m = 65): time-parallel system sweeps on
     # windows of 39 / 63 (k_scan_level_rt) + the row-parallel per-trial sweep
-    try:
-        from lqg_amd.tracking.delay import DelayedSubjectiveActor
-        md = DelayedSubjectiveActor(T=500, device=dev, dtype=torch.float32)
-        legd = {"model": "DelayedSubjectiveActor (lqg/tracking/delay.py:44-51): x=26 b=39 m=65, T=500", "dtype": "f32",
-                "unit": "ms per log-likelihood evaluation"}
-        xd_all = md.simulate(21, n=256)[..., :2].contiguous()
-        for nt in (1, 256):
-            xd = xd_all[:nt].contiguous()
-            lld, phd = bc.timed_loglik(md, xd, 5)
-            legd[f"trials_{nt}"] = {"wall_ms": phd["wall_ms"], "riccati_ms": phd["riccati_ms"], "forward_ms": phd["forward_ms"],
-                                    "trial_ms": phd["trial_ms"], "path": phd["path"]}
-        # the same evaluation on the sequential (workgroup-per-system) sweeps, which the default rule leaves for few long systems
-        prev = os.environ.get("LQG_SCAN")
-        os.environ["LQG_SCAN"] = "0"
+    import bench_configs as bc
+    from lqg_amd.infer import gradient
+    from lqg_amd.tracking.delay import DelayedSubjectiveActor
+    md = DelayedSubjectiveActor(T=500, device=dev, dtype=torch.float32)
+    legd = {"model": "DelayedSubjectiveActor (lqg/tracking/delay.py:44-51): x=26 b=39 m=65, T=500", "dtype": "f32",
+            "unit": "ms per log-likelihood evaluation"}
+    xd_all = md.simulate(21, n=256)[..., :2].contiguous()
+    for nt in (1, 256):
+        xd = xd_all[:nt].contiguous()
+        lld, phd = bc.timed_loglik(md, xd, 5)
+        legd[f"trials_{nt}"] = {"wall_ms": phd["wall_ms"], "riccati_ms": phd["riccati_ms"], "forward_ms": phd["forward_ms"],
+                                "trial_ms": phd["trial_ms"], "path": phd["path"]}
+    # the same evaluation on the sequential (workgroup-per-system) sweeps, which the default rule leaves for few long systems
+    _, phs = _with_env({"LQG_SCAN": "0"}, lambda: bc.timed_loglik(md, xd_all[:1].contiguous(), 5))
+    legd["trials_1_sequential_sweeps"] = {"wall_ms": phs["wall_ms"], "riccati_ms": phs["riccati_ms"],
+                                          "forward_ms": phs["forward_ms"], "trial_ms": phs["trial_ms"], "path": phs["path"]}
+    t0 = time.perf_counter()
+    legd["max_rel_err_vs_fp64_oracle"] = bc.oracle_check(md, xd_all[:2].contiguous(),
+                                                         md.log_likelihood(xd_all[:2].contiguous()), n_samples=2)
+    # (the same evaluation by the literal dense C port on ONE host core, two trials — context, not a target)
+    legd["cpu_port_ms_two_trials_incl_check"] = (time.perf_counter() - t0) * 1e3
+    # value + gradient of the same model (6 parameters): the reverse-mode sweep when the library has it for this shape, and
+    # central differences = 13 systems, each its own workgroup, evaluated concurrently (one launch set)
+    from lqg_amd.infer.models import get_model_params
+    pd = {k: float(v) for k, v in get_model_params(DelayedSubjectiveActor).items()
+          if k in ("c", "action_variability", "subj_noise", "subj_vel_noise", "sigma_target", "sigma_cursor")}
+    xg2 = torch.cat([xd_all[:50], xd_all[:50, -1:]], dim=1).double()
+    for method, key in (("fd", "value_and_grad_fd"), ("adjoint", "value_and_grad_adjoint")):
         try:
-            _, phs = bc.timed_loglik(md, xd_all[:1].contiguous(), 5)
-            legd["trials_1_sequential_sweeps"] = {"wall_ms": phs["wall_ms"], "riccati_ms": phs["riccati_ms"],
-                                                  "forward_ms": phs["forward_ms"], "trial_ms": phs["trial_ms"], "path": phs["path"]}
-        finally:
-            if prev is None:
-                os.environ.pop("LQG_SCAN", None)
-            else:
-                os.environ["LQG_SCAN"] = prev
-        t0 = time.perf_counter()
-        legd["max_rel_err_vs_fp64_oracle"] = bc.oracle_check(md, xd_all[:2].contiguous(),
-                                                             md.log_likelihood(xd_all[:2].contiguous()), n_samples=2)
-        # (the same evaluation by the literal dense C port on ONE host core, two trials — context, not a target)
-        legd["cpu_port_ms_two_trials_incl_check"] = (time.perf_counter() - t0) * 1e3
-        # value + gradient of the same model: central differences over its 6 parameters = 13 systems, each its own
-        # workgroup, evaluated concurrently (one launch set) — the gradient route for shapes without adjoint lane kernels
-        try:
-            from lqg_amd.infer.models import get_model_params
-            pd = {k: float(v) for k, v in get_model_params(DelayedSubjectiveActor).items()
-                  if k in ("c", "action_variability", "subj_noise", "subj_vel_noise", "sigma_target", "sigma_cursor")}
-            xg2 = torch.cat([xd_all[:50], xd_all[:50, -1:]], dim=1).double()
             for i in range(2):
-                gradient.value_and_grad(xg2, DelayedSubjectiveActor, pd, method="fd")
+                gradient.value_and_grad(xg2, DelayedSubjectiveActor, pd, method=method)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(5):
-                v_, g_ = gradient.value_and_grad(xg2, DelayedSubjectiveActor, dict(pd, sigma_target=pd["sigma_target"] + 1e-3 * i), method="fd")
+                v_, g_ = gradient.value_and_grad(xg2, DelayedSubjectiveActor, dict(pd, sigma_target=pd["sigma_target"] + 1e-3 * i),
+                                                 method=method)
             torch.cuda.synchronize()
-            legd["value_and_grad_fd"] = {"ms": (time.perf_counter() - t0) / 5 * 1e3, "parameters": len(pd), "systems": 2 * len(pd) + 1,
-                                         "trials": 50, "dtype": "f64", "finite": bool(all(v == v for v in g_.values()))}
+            legd[key] = {"ms": (time.perf_counter() - t0) / 5 * 1e3, "parameters": len(pd), "trials": 50, "dtype": "f64",
+                         "systems": 2 * len(pd) + 1 if method == "fd" else 1, "finite": bool(all(v == v for v in g_.values()))}
         except Exception as e:
-            legd["value_and_grad_fd"] = {"error": repr(e)[:300]}
-        extra["delay12"] = legd
-    except Exception as e:
-        extra["delay12"] = {"error": repr(e)}
+            legd[key] = {"error": repr(e)[:300]}
+    return legd
+
+
+def leg_delay12_batch(torch, args, dev):
+    """m = 65 as a BATCH of candidates x 120 trials (the shape cpp_data_fit.py fits, /root/reference cpp_data_fit.py:15-55:
+    20 trials x 6 conditions): 64 and 4096 candidates, sequential cooperative sweeps (one workgroup per system) against the
+    time-parallel sweeps, ms per objective sweep and the bound that binds."""
+    import bench_configs as bc
+    from lqg_amd.tracking.delay import DelayedSubjectiveActor
+    T, nt = 500, 120
+    truth = DelayedSubjectiveActor(T=T, device=dev, dtype=torch.float32)
+    x = truth.simulate(23, n=nt)[..., :2].contiguous()
+    out = {"model": "DelayedSubjectiveActor x=26 b=39 m=65, T=500", "trials": nt, "dtype": "f32", "unit": "ms per objective sweep"}
+    for nc in (64, 4096):
+        sig = torch.linspace(3.0, 40.0, nc, device=dev, dtype=torch.float32)
+        m = DelayedSubjectiveActor(T=T, sigma_target=sig, device=dev, dtype=torch.float32)
+        leg = {}
+        for name, env in (("sequential_cooperative", {"LQG_SCAN": "0"}), ("time_parallel", {"LQG_SCAN": "1"})):
+            if name == "time_parallel" and nc > 64:
+                leg[name] = {"skipped": "a level of 4096 x 500 windows of 63 x 63 is 2e6 workgroups of 0.1 ms: the scan costs per "
+                                        "system what the sequential sweep costs per CU-round"}
+                continue
+            try:
+                ll, ph = _with_env(env, lambda: bc.timed_loglik(m, x, 2))
+                leg[name] = {"wall_ms": ph["wall_ms"], "riccati_ms": ph["riccati_ms"], "forward_ms": ph["forward_ms"],
+                             "trial_ms": ph["trial_ms"], "path": ph["path"],
+                             "candidate_evals_per_s": nc / (ph["wall_ms"] * 1e-3)}
+            except Exception as e:
+                leg[name] = {"error": repr(e)[:300]}
+        seq = leg.get("sequential_cooperative", {})
+        if "wall_ms" in seq:
+            # one workgroup per system, 256 CUs: ceil(nc / 256) rounds of T dependent steps
+            rounds = -(-nc // 256)
+            leg["bound"] = (f"latency of the T = {T} dependent steps of one workgroup per system x {rounds} CU-round(s): "
+                            f"{seq['forward_ms'] / rounds / T * 1e3:.1f} us per forward step per round")
+        out[f"candidates_{nc}"] = leg
+        del m
+        torch.cuda.empty_cache()
+    return out
+
+
+LEGS = {
+    "headline_other": leg_headline_other, "reference_layout": leg_reference_layout,
+    "dense_generic_f32": leg_dense_generic("f32"), "dense_generic_f64": leg_dense_generic("f64"),
+    "config2_one_system": leg_one_system(2), "config4_one_system": leg_one_system(4),
+    "one_vector_value_and_grad": leg_one_vector, "m2_f32": leg_m2, "config3": leg_config3, "config4_sharded": leg_config4,
+    "config5_one_system": leg_config5_one_system, "delay12": leg_delay12, "delay12_batch": leg_delay12_batch,
+}
+
+
+def extra_legs(torch, args, dev, only=None):
+    """Secondary legs, outside the headline's timed region (same workload generators, same timing protocol).  Each is
+    self-sufficient: its own roofline object (bound, achieved, peak, frac, traffic from the stamped PMC record)."""
+    extra = {}
+    for name, fn in LEGS.items():
+        if only is not None and name != only:
+            continue
+        key = name
+        if name == "headline_other":
+            key = "headline_" + ("f64" if args.dtype == "f32" else "f32")
+        torch.cuda.empty_cache()
+        t0 = time.perf_counter()
+        try:
+            extra[key] = fn(torch, args, dev)
+        except Exception as e:          # a secondary leg must never cost the headline line
+            extra[key] = {"error": repr(e)[:400]}
+        if isinstance(extra[key], dict):
+            extra[key]["leg_wall_s"] = round(time.perf_counter() - t0, 2)
+    torch.cuda.empty_cache()
     return extra
 
 
@@ -650,8 +875,20 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    if args.config == 3:
+    if args.only:
+        if world != 1:
+            raise SystemExit("--only runs one secondary leg on one GPU")
+        key = {"headline_f32": None, "headline_f64": None}.get(args.only, args.only)
+        if key is None:                                    # the headline itself in the named dtype (PMC passes)
+            out = headline_leg(torch, None, args, dev, 0, 1, args.only[-3:], args.log2_batch, args.steps, args.warmup)
+        else:
+            if key not in LEGS:
+                raise SystemExit(f"--only {key}: unknown leg; known: headline_f32, headline_f64, {', '.join(LEGS)}")
+            out = extra_legs(torch, args, dev, only=key)
+    elif args.config == 3:
         out = config3(torch, dist, args, dev, rank, world)
+    elif args.config == 4:
+        out = config4(torch, dist, args, dev, rank, world)
     else:
         out = headline_leg(torch, dist, args, dev, rank, world, args.dtype, args.log2_batch, args.steps, args.warmup,
                            cpu=(world == 1 and not args.no_cpu_baseline))
@@ -660,6 +897,20 @@ def main():
                 out["extra"] = extra_legs(torch, args, dev)
             except Exception as e:          # the secondary legs must never cost the headline line
                 out["extra"] = {"error": repr(e)}
+        elif world > 1 and not args.no_extra:
+            # N > 1: BASELINE config 4 literally — 262144 / N trials per rank, one all-reduce per step (strong scaling) — measured
+            # collectively by the same ranks after the headline (every rank runs the same code on the same shapes: a failure is
+            # the same exception on every rank before any collective, and costs only this leg)
+            c4 = None
+            if 262144 % world == 0:
+                try:
+                    class A4:
+                        dtype, steps, warmup, share_gpu = "f32", 10, 2, args.share_gpu
+                    c4 = config4(torch, dist, A4, dev, rank, world)
+                except Exception as e:
+                    c4 = {"error": repr(e)[:300]}
+            if out is not None:
+                out["extra"] = {"config4_sharded": c4}
     if rank == 0 and out is not None:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -10,7 +10,10 @@
  *   - Plain C: pointers, sizes, POD structs.  No torch / HIP types in signatures (`stream` is a
  *     hipStream_t passed as void*; NULL = the default stream).
  *   - The caller owns ALL device memory (inputs, outputs, workspace).  The library never allocates,
- *     frees or retains a pointer past the call, and holds no mutable global state: re-entrant.
+ *     frees or retains a pointer past the call, reads NO environment variable and holds no option state:
+ *     everything that selects between the library's equivalent kernels travels in the problem (`lqg_tuning`,
+ *     ABI 3).  Re-entrant.  (Internal, result-neutral caches: the per-(device, kernel) record that a kernel's
+ *     dynamic-LDS limit has been raised, behind a mutex.)
  *   - Calls are stream-ordered and asynchronous; the library never synchronises.
  *   - Return 0 on success; <0 invalid argument / unsupported shape (nothing launched; see
  *     lqg_last_error()); >0 a hipError_t from the launch.
@@ -33,7 +36,7 @@
 extern "C" {
 #endif
 
-#define LQG_ABI_VERSION 2
+#define LQG_ABI_VERSION 3
 
 /* LQG_F32 / LQG_F64: arithmetic and storage type of every array of the problem.
  * LQG_F32_SYS64 (mixed; lqg_log_likelihood / lqg_log_likelihood_sp / lqg_workspace_bytes only; always through the operator
@@ -87,6 +90,28 @@ typedef struct lqg_dims {
   int32_t nvd, nwd;  /* columns of dynamics V, W */
 } lqg_dims;
 
+/* Tuning switches that travel WITH the problem (ABI 3; rounds 1-3 read LQG_* environment variables inside the library, some
+ * cached in function-local statics, so that the behaviour of a loaded library depended on when a variable had been set).
+ * All zero = the library's default rules.  Nothing here changes WHAT is computed, only which of the library's equivalent
+ * kernels / launch geometries computes it (results agree to rounding; tests/test_gpu_coop.py, test_gpu_trial_chunks.py,
+ * test_gpu_scan.py pin every setting against the default).  The Python package fills it from `lqg_amd.options`
+ * (which documents the LQG_* developer switches it reads — in ONE place, per call). */
+typedef struct lqg_tuning {
+  int32_t coop;                  /* strategy: 0 default rule (lane kernels where they exist), 1 cooperative kernels wherever
+                                    they are supported, -1 never when lane kernels exist                              */
+  int32_t trial_chunks;          /* lane per-trial sweep cut along time: 0 default rule, k > 0 exactly k chunks (clamped to
+                                    chunks of >= 4 steps), -1 one pass                                                 */
+  int32_t trial_chunk_waves;     /* default rule: waves to put in flight (0 = 16384)                                   */
+  int32_t trial_chunk_max_waves; /* default rule: chunk only while the trials alone are at most this many waves (0 = 2048) */
+  int32_t trial_chunk_tpl;       /* trials per lane of the zero-state pass: 0 rule, 1, 2                               */
+  int32_t coop_trial_chunks;     /* the same cut for the row-parallel sweep of large joint dimensions: 0 rule, k, -1    */
+  int32_t coop_trial_rows;       /* row-parallel per-trial sweep (k_coop_trial_rows): 0 on, -1 off (k_coop_trial)       */
+  int32_t coop_sparse;           /* run-time sparsity lists of the cooperative sweeps: 0 on, -1 off                     */
+  int32_t scan_lane;             /* one-launch scans of 1x1 .. 3x3 windows (k_scan_lane): 0 on, -1 per-level launches   */
+  int32_t scan_rt_waves;         /* waves per window of k_scan_level_rt: 0 = 16, 8                                      */
+  int32_t reserved[6];           /* must be 0                                                                           */
+} lqg_tuning;
+
 typedef struct lqg_problem {
   int32_t  dtype;      /* lqg_dtype: arithmetic and storage type of every array (LQG_F32_SYS64: see above) */
   int32_t  T;          /* number of steps (System.T, lqg/system.py:17-24); data has T+1 rows */
@@ -102,6 +127,7 @@ typedef struct lqg_problem {
                           lqg_log_likelihood / lqg_conditional_moments record on `stream`
                           [0] before the Riccati sweep, [1] after it, [2] after the forward sweep,
                           [3] after the per-trial sweep.  The library only records; the caller reads them. */
+  lqg_tuning tuning;   /* all zero = default rules (see lqg_tuning) */
 } lqg_problem;
 
 int lqg_abi_version(void);
@@ -124,7 +150,7 @@ int lqg_kernel_supported(int32_t family, const lqg_dims* dims);
  * workgroup per system, matrices staged in LDS, dimensions are run-time arguments (any x, b; u, y, d <= 4) — for few
  * systems (one parameter vector x many trials) and for shapes no lane kernel holds (x + b > 20: the reference's
  * DelayedSubjectiveActor, lqg/tracking/delay.py:44-51).  lqg_strategy(p) tells which one THIS library runs for p
- * (environment LQG_COOP=0/1 overrides the default rule); lqg_workspace_bytes accounts for it. */
+ * (p->tuning.coop overrides the default rule); lqg_workspace_bytes accounts for it. */
 #define LQG_STRATEGY_LANE 0
 #define LQG_STRATEGY_COOP 1
 int lqg_coop_supported(const lqg_dims* dims);
@@ -261,10 +287,11 @@ int lqg_simulate(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view K, lqg_t
                  void* stream);
 
 /* lqg_simulate with the draws of lqg/system.py:100-105 (eps ~ N(0, I), eta ~ N(0, I) per (trial, step), jax.random in the
- * reference) made IN THE KERNEL: counter-based Philox4x32-10 keyed by `seed`, counter = (pair, step, block) with
- * pair = system * n_trials + trial, Box-Muller normals in fp32 (csrc/lqg_rng.hpp).  A trajectory is a pure function of
- * (seed, pair): it does not depend on the batch size, on which kernel serves the shape, or on the mapping of pairs to
- * lanes (pairs are numbered within the call: ranks that simulate disjoint shards use distinct seeds).
+ * reference) made IN THE KERNEL: counter-based Philox4x32-10 keyed by `seed`, counter = (trial, system, step, block)
+ * (ABI 3; indices below 2^32), Box-Muller normals evaluated in fp32 and widened for an fp64 problem (csrc/lqg_rng.hpp: an
+ * fp64 simulation draws 24-bit normals).  The trajectory of trial n of system s is a pure function of (seed, s, n): it does
+ * not depend on how many systems or trials the call holds, on which kernel serves the shape, or on the mapping to lanes.
+ * Systems and trials are numbered WITHIN the call: ranks that simulate disjoint shards use distinct seeds.
  * Nothing but the trajectories crosses HBM (lqg_simulate reads 2 T (x + y) reals per trial it was handed). */
 int lqg_simulate_rng(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view K, uint64_t seed, lqg_view x0,
                      lqg_view xhat0, lqg_traj xs, lqg_traj xhat, lqg_traj ys, lqg_traj us, void* stream);

@@ -6,7 +6,9 @@ compute entry point raises (no CPU fallback, by design — see DESIGN.md "Bounda
 import ctypes as C
 import os
 
-ABI_VERSION = 2
+from lqg_amd import options as _options
+
+ABI_VERSION = 3
 F32, F64, F32_SYS64 = 0, 1, 2      # F32_SYS64: include/lqg_hip.h (fp32 problem, fp64 spec arrays and system sweeps)
 OP_LOG_LIKELIHOOD, OP_CONDITIONAL_MOMENTS = 0, 1
 FAM_FORWARD, FAM_RICCATI, FAM_KALMAN, FAM_TRIAL, FAM_SIMULATE, FAM_ADJOINT = range(6)
@@ -37,10 +39,17 @@ class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("x", "b", "u", "y", "d", "nva", "nwa", "nvd", "nwd")]
 
 
+class Tuning(C.Structure):
+    """include/lqg_hip.h: lqg_tuning (all zero = the library's default rules; filled by lqg_amd.options.fill_tuning)."""
+    _fields_ = [(n, C.c_int32) for n in ("coop", "trial_chunks", "trial_chunk_waves", "trial_chunk_max_waves", "trial_chunk_tpl",
+                                          "coop_trial_chunks", "coop_trial_rows", "coop_sparse", "scan_lane", "scan_rt_waves")] + \
+               [("reserved", C.c_int32 * 6)]
+
+
 class Problem(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("T", C.c_int32), ("n_sys", C.c_int64), ("n_trials", C.c_int64),
                 ("dims", Dims), ("actor", Spec), ("dynamics", Spec), ("Sigma0", View), ("eps", C.c_double),
-                ("phase_events", C.c_void_p * 4)]
+                ("phase_events", C.c_void_p * 4), ("tuning", Tuning)]
 
 
 NULL_VIEW = View(None, 0, 0, 0, 0)
@@ -192,7 +201,7 @@ def library_for(dims, family=FAM_FORWARD, n_sys=None):
     coop_ok = family in (FAM_FORWARD, FAM_RICCATI, FAM_KALMAN) and lib.lqg_coop_supported(C.byref(_dims_struct(dc)))
     if family == FAM_SIMULATE:
         coop_ok = True                              # k_coop_simulate: any (x, b, u, y)
-    can_jit = shape_in_range(*key0) and os.path.exists(build.HIPCC) and os.environ.get("LQG_JIT", "1") != "0"
+    can_jit = shape_in_range(*key0) and os.path.exists(build.HIPCC) and _options.flag("JIT")
     big = n_sys is not None and n_sys >= JIT_MIN_SYSTEMS
     names = "xbuyd"
     want = {k: dims[k] for k in _FAMILY_KEYS[family]}

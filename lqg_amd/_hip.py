@@ -8,7 +8,7 @@ import ctypes as C
 
 import torch
 
-from lqg_amd import _abi
+from lqg_amd import _abi, options
 from lqg_amd._abi import LqgHipError
 from lqg_amd.spec import LQGSpec
 
@@ -89,6 +89,7 @@ class Launch:
         p = _abi.Problem()
         p.dtype, p.T, p.n_sys, p.n_trials, p.eps = (_abi.F32_SYS64 if self.mixed else _DT[A.dtype]), self.T, self.B, n_trials, float(eps)
         p.dims = _abi.Dims(**self.dims)
+        options.fill_tuning(p.tuning)          # which of the library's equivalent kernels serve it (include/lqg_hip.h: lqg_tuning)
         self._keep = []
         for spec, dst, fields in ((actor, p.actor, _abi.SPEC_FIELDS), (dynamics, p.dynamics, ("A", "B", "F", "V", "W"))):
             for f in _abi.SPEC_FIELDS:
@@ -263,7 +264,7 @@ def specialised_library(ln, system, d, check_strategy=True):
     Eligible: every spec field time-invariant, no affine cost terms.  LQG_NO_SPECIALIZE=1 forces the generic dense
     library (A/B measurements, tests)."""
     import os
-    if system is None or os.environ.get("LQG_NO_SPECIALIZE") == "1" or ln.p.n_trials < 1:
+    if system is None or options.flag("NO_SPECIALIZE") or ln.p.n_trials < 1:
         return None
     if ln.m > LANE_MAX_JOINT:
         return None             # (pattern libraries hold lane kernels: one system's matrices in registers)
@@ -286,7 +287,7 @@ def materialised_entry(ln, system, d):
     long as they keep one sparsity pattern (specialize.pattern_of_time_varying) — or None: then `lqg_solve_materialised` of
     the main library serves the call (dense kernels).  One trial per system, no affine cost terms."""
     import os
-    if system is None or os.environ.get("LQG_NO_SPECIALIZE") == "1" or ln.p.n_trials != 1 or ln.m > LANE_MAX_JOINT:
+    if system is None or options.flag("NO_SPECIALIZE") or ln.p.n_trials != 1 or ln.m > LANE_MAX_JOINT:
         return None
     if any(getattr(ln.p.actor, f).ptr for f in ("q", "qf", "P", "r")):
         return None

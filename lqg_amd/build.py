@@ -229,6 +229,20 @@ def build_dims_library(x, b, u, y, d, workers=None, verbose=True):
     return so
 
 
+def refresh_dims_libraries(verbose=True):
+    """Rebuild every auxiliary per-shape library found in the dims directory whose stamp is not the current source hash
+    (they travel to the GPU box with the tree; a stale one would be recompiled THERE, on GPU time, at first use)."""
+    done = []
+    if not os.path.isdir(DIMS_DIR):
+        return done
+    want = source_hash()
+    for f in sorted(os.listdir(DIMS_DIR)):
+        m = re.fullmatch(r"liblqg_hip_(\d+)_(\d+)_(\d+)_(\d+)_(\d+)\.so", f)
+        if m and not stamped(os.path.join(DIMS_DIR, f), want):
+            done.append(build_dims_library(*(int(v) for v in m.groups()), verbose=verbose))
+    return done
+
+
 def build(force=False, workers=None, verbose=True):
     if not force and up_to_date():
         if verbose:

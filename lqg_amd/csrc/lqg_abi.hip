@@ -182,15 +182,10 @@ bool has_forward(const lqg_dims& d) {
 #ifndef LQG_COOP_MIN_M
 #define LQG_COOP_MIN_M 8
 #endif
-int coop_mode() {
-  const char* e = getenv("LQG_COOP");
-  return (e && *e) ? atoi(e) : -1;
-}
 bool use_coop(const lqg_problem* p) {
   if (!coop_supported(p->dims)) return false;
   if (!has_forward(p->dims)) return true;
-  const int mode = coop_mode();
-  if (mode >= 0) return mode == 1;
+  if (p->tuning.coop != 0) return p->tuning.coop > 0;            // (include/lqg_hip.h: lqg_tuning)
   return p->n_sys <= LQG_COOP_MAX_SYS && p->dims.x + p->dims.b >= LQG_COOP_MIN_M;
 }
 
@@ -478,7 +473,7 @@ int lqg_riccati_backward(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view 
   bool found = false;
   hipError_t e = hipSuccess;
   const bool can_coop = p->dims.u <= 6 && coop_fits_lds(p, false, true);     // (y, d play no part in lqr.backward)
-  if (!(coop_mode() == 1 && can_coop))
+  if (!(p->tuning.coop > 0 && can_coop))
     e = p->dtype == LQG_F64 ? dispatch_riccati<double>(p, L, l, H, nullptr, 0, (hipStream_t)stream, &found)
                             : dispatch_riccati<float>(p, L, l, H, nullptr, 0, (hipStream_t)stream, &found);
   if (!found) {                 // no (b, u) instantiation: the cooperative run-time-dims kernel (working set in LDS)
@@ -500,7 +495,7 @@ int lqg_kalman_forward(const lqg_problem* p, lqg_view K, void* stream) {
   bool found = false;
   hipError_t e = hipSuccess;
   const bool can_coop = p->dims.y <= 6 && coop_fits_lds(p, true, false);     // (u, d play no part in kf.forward)
-  if (!(coop_mode() == 1 && can_coop))
+  if (!(p->tuning.coop > 0 && can_coop))
     e = p->dtype == LQG_F64 ? dispatch_kalman<double>(p, K, (hipStream_t)stream, &found)
                             : dispatch_kalman<float>(p, K, (hipStream_t)stream, &found);
   if (!found) {                 // no (b, y) instantiation: the cooperative run-time-dims kernel (working set in LDS)

@@ -1103,7 +1103,7 @@ __global__ void __launch_bounds__(BLOCK) k_coop_simulate(const SimArgs<R> a, con
     if constexpr (RNG) {                                     // the same draws as k_simulate<RNG> (lqg_rng.hpp)
       for (int k0 = 0; k0 < a.nvd; k0 += 4) {
         float z[4];
-        rng::normal4(a.seed, (unsigned long long)gid, (uint32_t)t, (uint32_t)(k0 >> 2), z);
+        rng::normal4(a.seed, s, n, (uint32_t)t, (uint32_t)(k0 >> 2), z);
         LQG_UNROLL for (int j = 0; j < 4; ++j)
           if (k0 + j < a.nvd)
             for (int i = 0; i < nx; ++i) AT(xn, i) += M(a.dV, t, i, k0 + j) * (R)z[j];
@@ -1123,7 +1123,7 @@ __global__ void __launch_bounds__(BLOCK) k_coop_simulate(const SimArgs<R> a, con
     if constexpr (RNG) {
       for (int k0 = 0; k0 < a.nwd; k0 += 4) {
         float z[4];
-        rng::normal4(a.seed, (unsigned long long)gid, (uint32_t)t, rng::kEtaBlock + (uint32_t)(k0 >> 2), z);
+        rng::normal4(a.seed, s, n, (uint32_t)t, rng::kEtaBlock + (uint32_t)(k0 >> 2), z);
         LQG_UNROLL for (int j = 0; j < 4; ++j)
           if (k0 + j < a.nwd)
             for (int i = 0; i < ny; ++i) AT(yy, i) += M(a.dW, t, i, k0 + j) * (R)z[j];

@@ -38,16 +38,7 @@ inline bool waves_for(int elems) { return elems <= 128; }
 // (a property of the kernel, not of a launch: raised once per kernel and size, never again from inside a stream capture)
 template <typename K>
 hipError_t raise_lds(K kernel, size_t bytes) {
-  if (bytes <= kLdsDefault) return hipSuccess;
-  static std::mutex mu;
-  static std::unordered_map<const void*, size_t> raised;
-  const void* key = reinterpret_cast<const void*>(kernel);
-  std::lock_guard<std::mutex> lock(mu);
-  size_t& have = raised[key];
-  if (bytes <= have) return hipSuccess;
-  const hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (e == hipSuccess) have = bytes;
-  return e;
+  return raise_dynamic_lds(reinterpret_cast<const void*>(kernel), bytes, kLdsDefault);      // lqg_coop_launch.hpp
 }
 
 template <typename R>
@@ -78,24 +69,14 @@ namespace host {
 template <typename R, int CX, int CB, int CU, int CY, int CD>
 hipError_t coop_forward_fixed(const coop::Args<R>& k, size_t lds, hipStream_t st) {
   auto kern = coop::k_coop_forward<R, 256, false, true, CX, CB, CU, CY, CD>;
-  static size_t raised = 0;             // (per instantiation: once per size, never again inside a stream capture)
-  if (lds > 64 * 1024 && lds > raised) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    raised = lds;
-  }
+  if (hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)k.n_sys), dim3(256), lds, st, k);
   return hipGetLastError();
 }
 template <typename R, int CB, int CU>
 hipError_t coop_riccati_fixed(const coop::Args<R>& k, size_t lds, hipStream_t st) {
   auto kern = coop::k_coop_riccati<R, 256, false, true, CB, CU>;
-  static size_t raised = 0;             // (per instantiation: once per size, never again inside a stream capture)
-  if (lds > 64 * 1024 && lds > raised) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    raised = lds;
-  }
+  if (hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)k.n_sys), dim3(256), lds, st, k);
   return hipGetLastError();
 }
@@ -163,7 +144,7 @@ hipError_t coop_riccati(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view H
   const dim3 grid((unsigned)p->n_sys);
   const bool waves = waves_for(p->dims.b * p->dims.b);
   // run-time sparsity lists (large models only: the whole-workgroup mode), in LDS behind the arena / alone when it is global
-  static const bool sparse_off = [] { const char* e = getenv("LQG_COOP_SPARSE"); return e && atoi(e) == 0; }();
+  const bool sparse_off = p->tuning.coop_sparse < 0;
   const size_t lists = (size_t)coop::row_lists_bytes(p->dims.b, p->dims.b);
   k.sparse = (!waves && !sparse_off && p->dims.b <= 255 && (global ? lists : lds + lists) <= kLdsLimit) ? 1 : 0;
   k.lists_bytes = k.sparse ? (long)lists : 0;
@@ -210,7 +191,7 @@ hipError_t coop_forward(const lqg_problem* p, const void* Ls, void* ops, lqg_vie
   const dim3 grid((unsigned)p->n_sys);
   const int m = p->dims.x + p->dims.b;
   const bool waves = waves_for(kalman_only ? p->dims.b * p->dims.b : m * m);
-  static const bool sparse_off = [] { const char* e = getenv("LQG_COOP_SPARSE"); return e && atoi(e) == 0; }();
+  const bool sparse_off = p->tuning.coop_sparse < 0;
   const size_t lists = (size_t)coop::row_lists_bytes(p->dims.b, p->dims.b) + (size_t)coop::row_lists_bytes(m, m - p->dims.d);
   k.sparse = (!waves && !sparse_off && m <= 255 && (global ? lists : lds + lists) <= kLdsLimit) ? 1 : 0;
   k.lists_bytes = k.sparse ? (long)lists : 0;
@@ -254,7 +235,7 @@ hipError_t coop_trial(const lqg_problem* p, const void* ops, lqg_traj x, lqg_tra
     int tpb = 1;
     while (tpb < 16 && (long)p->n_sys * ((p->n_trials + tpb - 1) / tpb) > 2048) tpb *= 2;
     const size_t lds_r = ((size_t)2 * nops + (size_t)tpb * 2 * m) * sizeof(R);
-    static const bool rows_off = [] { const char* e = getenv("LQG_COOP_TRIAL_ROWS"); return e && atoi(e) == 0; }();
+    const bool rows_off = p->tuning.coop_trial_rows < 0;
     if (!rows_off && m >= 16 && o <= 6 && (nops + BR - 1) / BR <= MAXPF && lds_r <= kLdsLimit) {
       auto kr = coop::k_coop_trial_rows<R, BR>;
       hipError_t er = raise_lds(kr, lds_r);

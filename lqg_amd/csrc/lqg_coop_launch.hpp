@@ -4,10 +4,32 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "../../include/lqg_hip.h"
 
 namespace lqg {
 namespace host {
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of a kernel ON A DEVICE, not of a launch: raised once per
+// (device, kernel) and size — never again from inside a stream capture, where the replays of the inference loops launch these
+// kernels.  (Rounds 2-3 keyed the record on the kernel alone: a process driving a second GPU skipped the raise there and its
+// launches with more than 64 KB of LDS failed.)  The only state the library keeps; result-neutral, behind a mutex.
+inline hipError_t raise_dynamic_lds(const void* kernel, size_t bytes, size_t without_raise = 64 * 1024) {
+  if (bytes <= without_raise) return hipSuccess;
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, size_t> raised;
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = raised[{dev, kernel}];
+  if (bytes <= have) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) have = bytes;
+  return e;
+}
+
 
 // dims the cooperative kernels serve: u, y, d <= 4 (coop::kMaxSmall: their small factorizations run in registers); x, b unbounded
 bool coop_supported(const lqg_dims& d);

@@ -715,7 +715,7 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_simulate(const SimArgs<R> a) {
       if constexpr (RNG) {
         for (int k0 = 0; k0 < a.nvd; k0 += 4) {
           float z[4];
-          rng::normal4(a.seed, (unsigned long long)gid, (uint32_t)t, (uint32_t)(k0 >> 2), z);
+          rng::normal4(a.seed, s, n, (uint32_t)t, (uint32_t)(k0 >> 2), z);
           LQG_UNROLL for (int j = 0; j < 4; ++j)
             if (k0 + j < a.nvd) {
               LQG_UNROLL for (int i = 0; i < NX; ++i) xn[i] += Vp[i * a.dV.sr + (k0 + j) * a.dV.sc] * (R)z[j];
@@ -741,7 +741,7 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_simulate(const SimArgs<R> a) {
       if constexpr (RNG) {
         for (int k0 = 0; k0 < a.nwd; k0 += 4) {
           float z[4];
-          rng::normal4(a.seed, (unsigned long long)gid, (uint32_t)t, rng::kEtaBlock + (uint32_t)(k0 >> 2), z);
+          rng::normal4(a.seed, s, n, (uint32_t)t, rng::kEtaBlock + (uint32_t)(k0 >> 2), z);
           LQG_UNROLL for (int j = 0; j < 4; ++j)
             if (k0 + j < a.nwd) {
               LQG_UNROLL for (int i = 0; i < NY; ++i) y[i] += Wp[i * a.dW.sr + (k0 + j) * a.dW.sc] * (R)z[j];

@@ -18,6 +18,10 @@
 #include "lqg_kernels.hpp"
 #include "lqg_sparse.hpp"
 
+// lambdas of the sweeps are called from several sites (first / whole / last chunk): without the attribute hipcc outlines them
+// and every array they capture by reference goes to scratch memory (measured: 526 flat_load + 296 flat_store per chunk)
+#define LQG_LAMBDA_INLINE __attribute__((always_inline))
+
 namespace lqg {
 
 #ifndef LQG_SP_RIC_WAVES
@@ -256,27 +260,45 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
   }
   const R kLogNorm = R(0.5 * ND * 1.8378770664093453);
 
-  R Li[O * O], U2[RR * O], hl;
+  R Li[O * O], U2[RR * O], hl = R(0), pd = R(1);
   unsigned pois = 0u;                             // largest pos_finite_key of the pivot products (lqg_small.hpp)
-  auto condition = [&]() {
+  // FUSED scoring (round 4): log N(x_t; mu, S) = -1/2 |w|^2 + log(prod of the Cholesky pivots' reciprocal roots) - (d/2) log 2 pi.
+  // Per step only  part[n] += 1/2 |w|^2  (one fma per trial) and the log-determinant term run: fp32 takes ONE v_log_f32
+  // (log2, 1 ulp; the ln 2 factor is applied in fp64 at the flush), fp64 multiplies the pivot products of the block together
+  // and takes one log per flush (software log: ~40 instructions).  Every 8 steps the partial sums are flushed into the fp64
+  // accumulators; the constant is added once at the end.  Before: a full logf (range checks, extended-precision ln 2 product),
+  // three adds, a conversion and an fp64 add per trial per step — 23 of the step's 266 instructions.
+  R part[NT], ldet = (sizeof(R) == 4) ? R(0) : R(1);
+  LQG_UNROLL for (int k = 0; k < NT; ++k) part[k] = R(0);
+  auto flush = [&]() LQG_LAMBDA_INLINE {
+    double ld;
+    if constexpr (sizeof(R) == 4) { ld = 0.6931471805599453 * (double)ldet; ldet = R(0); }
+    else { ld = (double)log_<R>(ldet); ldet = R(1); }
+    LQG_UNROLL for (int k = 0; k < NT; ++k) { acc[k] += ld - (double)part[k]; part[k] = R(0); }
+  };
+  auto condition = [&]() LQG_LAMBDA_INLINE {
     R Soo[O * O], Lc[O * O], dinv[O];
     LQG_UNROLL for (int i = 0; i < O; ++i)
       LQG_UNROLL for (int j = 0; j < O; ++j) Soo[i * O + j] = Sg[i * M + j];
     chol_lower<R, O>(Soo, Lc, dinv);
     tri_inverse_lower<R, O>(Lc, dinv, Li);
-    R pd = dinv[0];
+    pd = dinv[0];
     LQG_UNROLL for (int i = 1; i < O; ++i) pd *= dinv[i];
     {
       const unsigned key = pos_finite_key(pd);
       pois = key > pois ? key : pois;
     }
-    hl = -log_<R>(pd);
+    if constexpr (!FUSED) hl = -log_<R>(pd);
     LQG_UNROLL for (int p = 0; p < RR; ++p)
       LQG_UNROLL for (int j = 0; j < O; ++j) {
         R v = R(0);
         LQG_UNROLL for (int k = 0; k <= j; ++k) v += Sg[(O + p) * M + k] * Li[j * O + k];
         U2[p * O + j] = v;
       }
+  };
+  auto score_logdet = [&]() LQG_LAMBDA_INLINE {                      // the step's log-determinant term (shared by the NT trials)
+    if constexpr (sizeof(R) == 4) ldet += __builtin_amdgcn_logf(pd);       // v_log_f32: log2
+    else ldet *= pd;
   };
   R w[O], xt[O];
 #if LQG_SP_PREFETCH
@@ -302,11 +324,11 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
     if constexpr (CK > 0) return load_sym_masked<R, NU, PAT::Rr>(rc.Rm.p + s * rc.Rm.sb, rc.Rm.sr, rc.Rm.sc);
     else return 0;
   }();
-  auto request_ckpt = [&](int c) {                       // issue the loads of checkpoint c (S at the END of chunk c)
+  auto request_ckpt = [&](int c) LQG_LAMBDA_INLINE {                       // issue the loads of checkpoint c (S at the END of chunk c)
     const R* src = rc.Ls + (long)c * NS * rc.ldb + s;
     LQG_UNROLL for (int e = 0; e < NS; ++e) Snx[e] = src[e * rc.ldb];
   };
-  auto refill = [&](int t0) {                            // gains of steps t0 .. t0 + CK - 1 from the requested checkpoint
+  auto refill = [&]<bool WHOLE = false>(int t0) LQG_LAMBDA_INLINE {        // gains of steps t0 .. t0 + CK - 1 from the requested checkpoint
     if constexpr (CK > 0) {
       R Sr[NB * NB];
       {
@@ -316,10 +338,10 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
       }
       if (t0 + CK < a.T) request_ckpt(t0 / CK + 1);      // next chunk's checkpoint: a whole chunk of work hides it
       LQG_UNROLL for (int j = CK - 1; j >= 0; --j)
-        if (t0 + j < a.T) riccati_step_sp<R, NB, NU>(Sr, Aa, Ba, rQ, rR, rc.eps, Lbuf[j]);
+        if (WHOLE || t0 + j < a.T) riccati_step_sp<R, NB, NU>(Sr, Aa, Ba, rQ, rR, rc.eps, Lbuf[j]);
     }
   };
-  auto innovate = [&](int n, int row, bool score) {        // trial n, data row `row`
+  auto innovate = [&](int n, int row, bool score) LQG_LAMBDA_INLINE {        // trial n, data row `row`
 #if LQG_SP_PREFETCH
     (void)row;
     LQG_UNROLL for (int i = 0; i < O; ++i) xt[i] = xnx[n][i];
@@ -334,12 +356,12 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
       w[i] = v;
       zz += v * v;
     }
-    if (score) acc[n] -= (double)(R(0.5) * zz + hl + kLogNorm);
+    if (score) part[n] += R(0.5) * zz;
   };
 
   // The first step is peeled (templated lambda): it alone initialises Sigma := G_0 G_0^T and skips the score of x_0;
   // inside one loop the compiler turns those two `t == 0` tests into ~30 v_cndmask per step.
-  auto step = [&]<bool FIRST, int J>(int t) {
+  auto step = [&]<bool FIRST, int J>(int t) LQG_LAMBDA_INLINE {
     // ---- Kalman step                                                   kf.py:10-14
     const auto AP = mul(Aa, Pm);
     const auto Pp = mul_nt_sym_add(AP, Aa, VVa);
@@ -371,6 +393,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
     // ---- condition on x_t, score it, propagate the mean                system.py:219-221, 244-248
     condition();
     if (FUSED) {
+      if constexpr (!FIRST) score_logdet();
       LQG_UNROLL for (int n = 0; n < NT; ++n) {
         innovate(n, t, !FIRST);
         R cvec[M];
@@ -431,23 +454,45 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F
   };
   if constexpr (CK == 0) {
     step.template operator()<true, 0>(0);
-    for (int t = 1; t < a.T; ++t) step.template operator()<false, 0>(t);
+    for (int t = 1; t < a.T; ++t) {
+      step.template operator()<false, 0>(t);
+      if (FUSED && (t & 7) == 0) flush();
+    }
   } else {
     request_ckpt(0);
-    auto chunk = [&]<int... J>(int t0, std::integer_sequence<int, J...>) {
+    // Whole chunks run WITHOUT a per-step `t < T` test (round 4): guarded steps are separate basic blocks, and the values the
+    // software pipeline carries from one step to the next (data rows, previous row, mean state) were copied at every merge —
+    // 14 v_mov + a scalar compare / branch per step in the ISA (scripts/isa_mix.py).  The first chunk (its first step
+    // initialises Sigma and skips the score) and the last, partial chunk keep the guarded form.
+    auto chunk_guarded = [&]<int... J>(int t0, std::integer_sequence<int, J...>) LQG_LAMBDA_INLINE {
       ((t0 + J < a.T ? ((J == 0 && t0 == 0) ? step.template operator()<true, J>(0)
                                              : step.template operator()<false, J>(t0 + J))
                      : (void)0), ...);
     };
-    for (int t0 = 0; t0 < a.T; t0 += CK) {
+    auto chunk_whole = [&]<int... J>(int t0, std::integer_sequence<int, J...>) LQG_LAMBDA_INLINE {
+      (step.template operator()<false, J>(t0 + J), ...);
+    };
+    refill(0);
+    chunk_guarded(0, std::make_integer_sequence<int, CKN>{});
+    if (FUSED) flush();
+    int t0 = CK;
+    for (; t0 + CK <= a.T; t0 += CK) {
+      refill.template operator()<true>(t0);
+      chunk_whole(t0, std::make_integer_sequence<int, CKN>{});
+      if (FUSED) flush();
+    }
+    if (t0 < a.T) {
       refill(t0);
-      chunk(t0, std::make_integer_sequence<int, CKN>{});
+      chunk_guarded(t0, std::make_integer_sequence<int, CKN>{});
     }
   }
   condition();
   if (FUSED) {
+    score_logdet();
+    LQG_UNROLL for (int n = 0; n < NT; ++n) innovate(n, a.T, true);
+    flush();
     LQG_UNROLL for (int n = 0; n < NT; ++n) {
-      innovate(n, a.T, true);
+      acc[n] -= (double)a.T * (0.5 * ND * 1.8378770664093453);           // T scored rows x (d / 2) log 2 pi
       store_or_nan(&a.ll[s * a.ll_sb + n * ll_sn], (R)acc[n], pois >= kPosFiniteLimit<R>);
     }
   } else {

@@ -2,12 +2,15 @@
 // eps ~ N(0, I_x), eta ~ N(0, I_y) per (trial, step) from jax.random inside its per-trial scan).
 //
 // Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): a keyed bijection of a 128-bit
-// counter; no state, no sequence — draw (pair, step, block) is a pure function of (seed, pair, step, block), so a
-// trajectory does not depend on how the batch is mapped to lanes, kernels or GPUs (the lane kernels and the
-// run-time-dims kernel of lqg_coop.hpp produce the same numbers), and nothing is materialised in HBM.
-//   counter = (pair low, pair high, step, block),  key = (seed low, seed high),  pair = system * n_trials + trial
+// counter; no state, no sequence — a draw is a pure function of (seed, system, trial, step, block), so the trajectory of
+// trial k of system s does not depend on the NUMBER of systems or trials in the call, nor on how the batch is mapped to
+// lanes, kernels or GPUs (the lane kernels and the run-time-dims kernel of lqg_coop.hpp produce the same numbers), and
+// nothing is materialised in HBM.  (Rounds 2-3 keyed the counter on pair = system * n_trials + trial: the draws of every
+// system but the first changed with n_trials.)
+//   counter = (trial, system, step, block),  key = (seed low, seed high);  trial and system indices below 2^32
 //   blocks 0, 1, ... of a step feed the process noise eps (4 normals per block), blocks kEtaBlock, ... the observation noise
-// Normals: Box-Muller on uniforms (k + 1/2) 2^-32 in (0, 1), evaluated in fp32 (the reference's default precision).
+// Normals: Box-Muller on 32-bit uniforms (k + 1/2) 2^-32 in (0, 1), evaluated in fp32 (the reference's default precision)
+// and widened for an fp64 problem: the draws of an fp64 simulation are fp32 normals (24-bit mantissa, |z| <= 6.66).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -34,10 +37,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uin
   }
 }
 
-// four standard normals of (seed, pair, step, block)
-__device__ __forceinline__ void normal4(unsigned long long seed, unsigned long long pair, uint32_t step, uint32_t block,
+// four standard normals of (seed, system, trial, step, block)
+__device__ __forceinline__ void normal4(unsigned long long seed, long system, long trial, uint32_t step, uint32_t block,
                                         float (&z)[4]) {
-  uint32_t c[4] = {(uint32_t)pair, (uint32_t)(pair >> 32), step, block};
+  uint32_t c[4] = {(uint32_t)trial, (uint32_t)system, step, block};
   philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
   constexpr float kInv32 = 2.3283064365386963e-10f;        // 2^-32
 #pragma unroll

@@ -16,17 +16,7 @@ using scan::D;
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel, not of a launch: raised once per kernel and size —
 // never again from inside a stream capture, where the replays of the inference loops launch these kernels
-hipError_t raise_lds_once(const void* kern, size_t bytes) {
-  if (bytes <= 64 * 1024) return hipSuccess;
-  static std::mutex mu;
-  static std::unordered_map<const void*, size_t> raised;
-  std::lock_guard<std::mutex> lock(mu);
-  size_t& have = raised[kern];
-  if (bytes <= have) return hipSuccess;
-  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (e == hipSuccess) have = bytes;
-  return e;
-}
+hipError_t raise_lds_once(const void* kern, size_t bytes) { return raise_dynamic_lds(kern, bytes); }   // lqg_coop_launch.hpp
 
 struct ScanPlan {
   size_t elems_off, elems_bytes, l_off, k_off, fg_off, ops_off, total;
@@ -75,24 +65,23 @@ void launch_level_rt_v(const scan::Seg& s0, const scan::Seg& s1, int n, long n_s
   (void)raise_lds_once(reinterpret_cast<const void*>(kern), lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)(s0.len + s1.len), (unsigned)n_sys), dim3(scan::scan_level_rt_threads(n, NW)), lds, st, s0, s1, n);
 }
-void launch_level_rt(const scan::Seg& s0, const scan::Seg& s1, int n, long n_sys, hipStream_t st) {
+void launch_level_rt(const scan::Seg& s0, const scan::Seg& s1, int n, long n_sys, const lqg_tuning& tune, hipStream_t st) {
   // 16 waves per window (4 rows each): the elimination is bound by its two barriers and LDS round trips per column, not by
-  // issue — delay12 system sweeps 7.0 / 4.5 / 4.1 ms at 4 / 8 / 16 waves (LQG_SCAN_RT_WAVES=8 keeps the A/B)
-  static const int waves = [] { const char* e = getenv("LQG_SCAN_RT_WAVES"); return e ? atoi(e) : 16; }();
-  if (waves == 8) launch_level_rt_v<8>(s0, s1, n, n_sys, st);
+  // issue — delay12 system sweeps 7.0 / 4.5 / 4.1 ms at 4 / 8 / 16 waves (tuning.scan_rt_waves = 8 keeps the A/B)
+  if (tune.scan_rt_waves == 8) launch_level_rt_v<8>(s0, s1, n, n_sys, st);
   else launch_level_rt_v<16>(s0, s1, n, n_sys, st);
 }
 
 // Hillis-Steele over one or two independent sequences of n x n triples (segment i: len[i] elements starting in in[i],
 // ping-ponging with out[i]); on return res[i] is the buffer holding segment i's result.
 void run_scan(int n, int nseg, D* const in[2], D* const out[2], const int len[2], const int left[2], long n_sys,
-              const D* res[2], hipStream_t st) {
+              const D* res[2], const lqg_tuning& tune, hipStream_t st) {
   D* a[2] = {in[0], nseg > 1 ? in[1] : nullptr};
   D* b[2] = {out[0], nseg > 1 ? out[1] : nullptr};
   const int l1 = nseg > 1 ? len[1] : 0;
   const int longest = len[0] > l1 ? len[0] : l1;
   // windows of 1 .. 3 whose whole sequence fits one workgroup: every level in ONE launch (k_scan_lane)
-  static const bool lane_off = [] { const char* e = getenv("LQG_SCAN_LANE"); return e && atoi(e) == 0; }();
+  const bool lane_off = tune.scan_lane < 0;
   if (!lane_off && n <= scan::kScanLaneMaxN && longest <= scan::scan_lane_max_len(n) && scan::scan_lane_lds(n, longest) <= 150 * 1024) {
     const scan::Seg s0{a[0], b[0], len[0], 0, left[0]};
     const scan::Seg s1{a[1], b[1], l1, 0, nseg > 1 ? left[1] : 0};
@@ -120,7 +109,7 @@ void run_scan(int n, int nseg, D* const in[2], D* const out[2], const int len[2]
       LQG_SCAN_CASE(19) LQG_SCAN_CASE(20) LQG_SCAN_CASE(21) LQG_SCAN_CASE(22) LQG_SCAN_CASE(23) LQG_SCAN_CASE(24)
 #undef LQG_SCAN_CASE
       default:                        // windows of 25 .. 64 (scan_supported): registers + scalar operands, run-time n
-        launch_level_rt(s0, s1, n, n_sys, st);
+        launch_level_rt(s0, s1, n, n_sys, tune, st);
         break;
     }
     for (int i = 0; i < 2; ++i) { D* t = a[i]; a[i] = b[i]; b[i] = t; }
@@ -209,7 +198,7 @@ hipError_t scan_system_sweeps(const lqg_problem* p, lqg_view Sig, void* workspac
     k.elems = in[0];
     k.elems2 = in[1];
     launch(scan::k_scan_build_rk<R>, 2 * T + 1, sl.build_rk);
-    run_scan(b, 2, in, out, len, left, p->n_sys, res, st);
+    run_scan(b, 2, in, out, len, left, p->n_sys, res, p->tuning, st);
     k.res = res[0];
     k.res2 = res[1];
     launch(scan::k_scan_gains_rk<R>, 2 * T, sl.gains_rk);
@@ -222,7 +211,7 @@ hipError_t scan_system_sweeps(const lqg_problem* p, lqg_view Sig, void* workspac
     const D* res[2];
     k.elems = in[0];
     launch(scan::k_scan_build_sigma<R>, T + 1, sl.build_sigma);
-    run_scan(m - o, 1, in, out, len, left, p->n_sys, res, st);     // (elements on the unobserved block: lqg_scan.hpp)
+    run_scan(m - o, 1, in, out, len, left, p->n_sys, res, p->tuning, st);     // (elements on the unobserved block: lqg_scan.hpp)
     k.res = res[0];
   }
   launch(scan::k_scan_ops<R>, T + 1, sl.ops);

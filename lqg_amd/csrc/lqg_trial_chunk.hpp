@@ -237,22 +237,22 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial_sum(const double* __restric
 
 namespace host {
 
-// Number of chunks the per-trial sweep of this problem is cut into (1: the one-pass k_trial).  LQG_TRIAL_CHUNKS=0/1
-// disables, =k forces k chunks (clamped to chunks of >= 4 steps).  By default the sweep is chunked only while the trials
-// alone leave the chip latency-bound — at most LQG_TRIAL_CHUNK_MAX_WAVES (2048) waves, two per SIMD — into enough chunks
-// to put LQG_TRIAL_CHUNK_WAVES (16384) waves in flight, at most sqrt(2 T) chunks (the minimum of the dependent chain
+// Number of chunks the per-trial sweep of this problem is cut into (1: the one-pass k_trial).  p->tuning.trial_chunks = -1
+// disables, = k forces k chunks (clamped to chunks of >= 4 steps).  By default the sweep is chunked only while the trials
+// alone leave the chip latency-bound — at most tuning.trial_chunk_max_waves (2048) waves, two per SIMD — into enough chunks
+// to put tuning.trial_chunk_waves (16384) waves in flight, at most sqrt(2 T) chunks (the minimum of the dependent chain
 // 2 T / k + k).  Measured, one system of m = 8, T = 500, fp32, per-trial sweep in ms, one pass / chunked
 // (scripts/chunk_regime.py): 2^10 trials 0.49 / 0.06, 2^14: 0.50 / 0.11, 2^16 (1024 waves): 0.52 / 0.23, 2^17: 0.55 / 0.44,
 // 2^18 (4096 waves): 0.63 / 0.81, 2^19: 0.93 / 1.5 — the two passes cost ~2x the arithmetic, which only pays while the
 // one-pass sweep is bound by the latency of its dependent steps and not by instruction issue.
 // Joint dimensions without lane kernels (x + b > 24: the delay-augmented models on the row-parallel k_coop_trial_rows, one
 // WORKGROUP per few trials): chunked while the trials leave the chip empty — DelayedSubjectiveActor, T = 500, one trial: 1.72 ms
-// in one pass (500 dependent steps of 3.4 us).  LQG_COOP_TRIAL_CHUNKS=0/1 disables, =k forces k chunks.
+// in one pass (500 dependent steps of 3.4 us).  p->tuning.coop_trial_chunks = -1 disables, = k forces k chunks.
 inline int coop_trial_chunks(const lqg_problem* p) {
   if (p->n_trials < 1 || p->T < 64) return 1;
-  const char* e1 = getenv("LQG_COOP_TRIAL_CHUNKS");
-  long nc = e1 ? atol(e1) : -1;
-  if (nc < 0) {
+  long nc = p->tuning.coop_trial_chunks;
+  if (nc < 0) return 1;
+  if (nc == 0) {
     // (every (system, chunk) also pushes m unit vectors through the chunk: pays for a handful of systems only — 64 systems of
     // one trial each: 2.5 ms in one pass, 16 ms chunked)
     // trial_ms one pass / chunked, fp32: 1 trial 1.88 / 0.35, 64: 1.87 / 0.45, 256: 1.88 / 0.87, 1024: 2.36 / 2.80
@@ -269,15 +269,12 @@ constexpr int kLaneTrialMaxJoint = 24;    // beyond: no lane per-trial kernels e
 inline int trial_chunks(const lqg_problem* p) {
   if (p->dims.x + p->dims.b > kLaneTrialMaxJoint) return coop_trial_chunks(p);
   if (p->n_trials <= 2 || p->T < 16) return 1;
-  // (read per call: a test or a tuning script may change them between launches)
-  const char* e1 = getenv("LQG_TRIAL_CHUNKS");
-  const char* e2 = getenv("LQG_TRIAL_CHUNK_WAVES");
-  const char* e3 = getenv("LQG_TRIAL_CHUNK_MAX_WAVES");
-  const int forced = e1 ? atoi(e1) : -1;
-  const long target = e2 ? atol(e2) : 16384L;
-  const long max_waves = e3 ? atol(e3) : 2048L;
+  const int forced = p->tuning.trial_chunks;
+  if (forced < 0) return 1;
+  const long target = p->tuning.trial_chunk_waves > 0 ? p->tuning.trial_chunk_waves : 16384L;
+  const long max_waves = p->tuning.trial_chunk_max_waves > 0 ? p->tuning.trial_chunk_max_waves : 2048L;
   long nc;
-  if (forced >= 0) {
+  if (forced > 0) {
     nc = forced;
   } else {
     const long waves = (long)p->n_sys * ((p->n_trials + LQG_BLOCK - 1) / LQG_BLOCK);
@@ -325,7 +322,7 @@ hipError_t launch_trial_chunked(const lqg_problem* p, const void* ops, lqg_traj 
   const dim3 block(LQG_BLOCK);
   const R* o = static_cast<const R*>(ops);
   // two trials per lane once (trial, chunk) pairs alone over-fill the chip (> 8 waves per SIMD at one per lane)
-  static const int tpl_mode = [] { const char* e = getenv("LQG_TRIAL_CHUNK_TPL"); return e ? atoi(e) : 0; }();
+  const int tpl_mode = p->tuning.trial_chunk_tpl;
   const bool two = tpl_mode == 2 || (tpl_mode == 0 && (long)tb * B * nc > 8192L);
   const unsigned tb2 = (unsigned)((p->n_trials + 2 * LQG_BLOCK - 1) / (2 * LQG_BLOCK));
   if (two) hipLaunchKernelGGL((lqg::k_trial_zs<R, M, ND, FMP, 2>), dim3(tb2 + 1, B, nc - 1), block, 0, st, o, k);

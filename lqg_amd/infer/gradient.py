@@ -7,6 +7,8 @@ method="fd": central finite differences in log-space evaluated as ONE batched ca
 forward path; the cross-check, and the fallback for model shapes without adjoint kernels."""
 import torch
 
+from lqg_amd import options
+
 from lqg_amd.infer.models import get_model_params, log_likelihood_objective
 
 
@@ -17,7 +19,7 @@ def _graphed_fd(x, model_type, names, fixed, process_noise, dt, fd_step, group, 
     """Captured evaluator for (data, model class, parameter names, fixed values), built on first use; None when the
     evaluation cannot be captured (then, and with LQG_GRAPH=0, the eager path below runs)."""
     import os
-    if group is not None or not x.is_cuda or os.environ.get("LQG_GRAPH") == "0":
+    if group is not None or not x.is_cuda or not options.flag("GRAPH"):
         return None
     from lqg_amd.infer import graphed
     if graphed._sharded():

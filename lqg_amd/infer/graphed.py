@@ -29,12 +29,11 @@ components (identical ones — the dim = 2 tracking models — are merged as tri
 affine map), an initialised process group (the all-reduce stays outside).  `make()` returns None in those cases and the callers keep the eager path.  LQG_GRAPH=0 disables.
 """
 import ctypes as C
-import os
 import warnings
 
 import torch
 
-from lqg_amd import _abi, _hip
+from lqg_amd import _abi, _hip, options
 from lqg_amd.infer.models import get_model_params
 
 
@@ -197,7 +196,7 @@ class GraphedLogLik:
         if self.use_scan:
             V = first(model.dynamics.V)[..., :self.d, :]
             lo, hi = bounds(V @ V.transpose(-1, -2))
-            ok = ok & (lo > 0) & (hi <= plan.SCAN_MAX_COND * lo)
+            ok = ok & (lo > 0) & (hi <= options.get("SCAN_MAX_COND") * lo)
         return ok.all()
 
     def _guard_flag(self, model):
@@ -206,7 +205,7 @@ class GraphedLogLik:
         lib = _abi.load()
         ln = _hip.Launch(model.actor, model.dynamics, d=self.d, n_trials=1, eps=self.eps)
         flag = torch.empty(1, dtype=torch.int32, device=self.x.device)
-        _abi.check(lib.lqg_precondition_flags(C.byref(ln.p), float(plan.SCAN_MAX_COND), 1 if self.use_scan else 0,
+        _abi.check(lib.lqg_precondition_flags(C.byref(ln.p), float(options.get("SCAN_MAX_COND")), 1 if self.use_scan else 0,
                                               C.c_void_p(flag.data_ptr()), ln.stream()), "lqg_precondition_flags")
         self._guard_keep = (ln, flag)
         return flag
@@ -253,7 +252,7 @@ class GraphedLogLik:
         import lqg_amd
         known = self.model_type in (lqg_amd.BoundedActor, lqg_amd.OptimalActor, lqg_amd.RelativeObservationBoundedActor,
                                     lqg_amd.SubjectiveActor) or getattr(self.model_type, "_lqg_affine_constructor", False)
-        if known and (os.environ.get("LQG_GRAPH_AFFINE") != "0" or cols is not None):
+        if known and (options.flag("GRAPH_AFFINE") or cols is not None):
             self._affine = self._probe_affine()
         if cols is not None and self._affine is None:
             return False                     # (decoupling inside the graph is only available through the measured affine map)
@@ -397,7 +396,7 @@ def _sharded():
 
 def make(cls, x, model_type, names, n, group=None, **kw):
     """A captured evaluator, or None when this evaluation cannot be captured (the caller keeps its eager path)."""
-    if os.environ.get("LQG_GRAPH") == "0" or group is not None or not x.is_cuda or _sharded():
+    if not options.flag("GRAPH") or group is not None or not x.is_cuda or _sharded():
         return None
     try:
         ev = cls(x, model_type, names, n, **kw)

@@ -12,10 +12,10 @@ separate XLA host devices, main.py:8, lqg/infer/utils.py:37).  Gradients: method
 behind torch.autograd, lqg_amd/grad.py).  fp64 throughout.
 """
 import math
-import os
 
 import torch
 
+from lqg_amd import options
 from lqg_amd.infer import prior as _prior
 from lqg_amd.infer.models import get_model_params
 
@@ -57,7 +57,7 @@ class Potential:
         """Captured finite-difference evaluator for up to the largest number of positions asked so far (fewer are padded);
         None when the evaluation cannot be captured or a process group shards the trials."""
         import os
-        if self.group is not None or not z.is_cuda or os.environ.get("LQG_GRAPH") == "0":
+        if self.group is not None or not z.is_cuda or not options.flag("GRAPH"):
             return None
         from lqg_amd.infer import graphed as _g
         if _g._sharded():
@@ -109,11 +109,8 @@ class Potential:
                 self.evaluations += C * (2 * P + 1)
                 if not bool(torch.isnan(out).any()):      # (NaN: a frozen precondition failed at these values: eager path)
                     return out[:, 0], out[:, 1:]
-                os.environ["LQG_GRAPH"], prev = "0", os.environ.get("LQG_GRAPH")
-                try:
+                with options.override(GRAPH=0):
                     lp, gr = self(z)
-                finally:
-                    os.environ.pop("LQG_GRAPH") if prev is None else os.environ.__setitem__("LQG_GRAPH", prev)
                 both = torch.cat([lp.detach()[:, None], gr.detach()], dim=1).cpu()
                 return both[:, 0], both[:, 1:]
         lp, gr = self(z)

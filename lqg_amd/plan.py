@@ -3,11 +3,10 @@ components, structure-specialised vs generic library, workspace, argument struct
 evaluations (benchmarks, optimisation loops over the same data) are pure launches.  `System.log_likelihood` builds a
 throw-away plan; bench.py / bench_configs.py keep one."""
 import ctypes as C
-import os
 
 import torch
 
-from lqg_amd import _abi, _hip, _hipev, specialize
+from lqg_amd import _abi, _hip, _hipev, options, specialize
 
 
 # Above this much operator-stream workspace a multi-trial evaluation is run as one fused single-trial sweep per
@@ -18,7 +17,7 @@ OPS_WORKSPACE_LIMIT = 16 << 30
 # recomputed per trial — the lanes are idle anyway — and the per-trial sweep over the operator stream, a third
 # latency-bound 500-step kernel, disappears): one parameter vector (or the 2P+1 finite-difference candidates) x tens of
 # trials, the inner loop of lqg/infer/mle.py:17-23 and of NUTS.  LQG_FUSE_TRIALS_MAX=0 disables.
-FUSE_TRIALS_MAX = int(os.environ.get("LQG_FUSE_TRIALS_MAX", "2048"))
+FUSE_TRIALS_MAX = 2048          # default of options "FUSE_TRIALS_MAX"
 # TIME-PARALLEL system sweeps (csrc/lqg_scan.hpp: Riccati, Kalman and moment recursions as associative scans, log2(T)
 # dependent combines instead of T dependent steps), followed by the time-chunked per-trial sweep.  The sequential sweeps
 # cost T dependent steps whatever the number of systems (one lane each); the scans cost a fixed ~0.16 ms plus ~4 us
@@ -27,13 +26,13 @@ FUSE_TRIALS_MAX = int(os.environ.get("LQG_FUSE_TRIALS_MAX", "2048"))
 # host-side checks for the scan route (eigenvalue floor, conditioning), so the default rule stays below that and takes the
 # scans for at most 8 (m / 4)^2 systems (8 at m <= 4, capped at 64) with at least scan_min_steps(m) steps.
 # LQG_SCAN=0 never, LQG_SCAN=1 wherever the path is defined (no affine terms, floor provably inactive, u, y, d <= 4).
-SCAN_MAX_SYSTEMS = int(os.environ.get("LQG_SCAN_MAX_SYSTEMS", "0"))       # 0: the rule above
-SCAN_MIN_STEPS = int(os.environ.get("LQG_SCAN_MIN_STEPS", "0"))           # 0: the rule below
+SCAN_MAX_SYSTEMS = 0            # default of option "SCAN_MAX_SYSTEMS" (0: the rule above)
+SCAN_MIN_STEPS = 0              # default of option "SCAN_MIN_STEPS" (0: the rule below)
 # The scan elements hold (F' Sigma_oo^-1 F)-type terms, so an ill-conditioned observed block costs the scans more digits
 # than the sequential recursion: scripts/scan_cond.py, point mass with all four states observed, scan against sequential
 # fp64 — cond((V V')[:d, :d]) <= 5.6e6: 1e-11; 5.6e8 (golden pointmass_d4_T50): 2e-6.  Above this condition number of the
 # observed process-noise block the default rule keeps the sequential sweeps.
-SCAN_MAX_COND = float(os.environ.get("LQG_SCAN_MAX_COND", "1e7"))
+SCAN_MAX_COND = 1e7             # default of option "SCAN_MAX_COND"
 
 
 # MIXED precision (include/lqg_hip.h: LQG_F32_SYS64).  An fp32 problem scored on many trials per system runs its per-system
@@ -44,7 +43,7 @@ SCAN_MAX_COND = float(os.environ.get("LQG_SCAN_MAX_COND", "1e7"))
 # (3 or more trials per system) — the result of a trial then does not depend on how many other trials were scored with it
 # (shards of a trial split agree bitwise); LQG_MIXED_MIN_TRIALS raises the threshold for workloads of many systems with a
 # handful of trials each, where the system sweeps dominate and doubling their cost is not amortised; LQG_MIXED=0 disables.
-MIXED_MIN_TRIALS = int(os.environ.get("LQG_MIXED_MIN_TRIALS", "3"))
+MIXED_MIN_TRIALS = 3            # default of option "MIXED_MIN_TRIALS"
 MIXED_LONG_HORIZON = 600        # steps beyond which an fp32 problem leaves the in-lane sweeps for the stream path, any n
 FUSE_F32_MAX_STEPS = 256        # steps up to which small fp32 (system, trial) batches run as all-fp32 fused pairs
 # WIDE: an fp32 problem whose observed process-noise block (V V')[:d, :d] has a condition number above this runs — for ANY
@@ -54,15 +53,15 @@ FUSE_F32_MAX_STEPS = 256        # steps up to which small fp32 (system, trial) b
 # point mass observed, velocity / activation noise 1e-3) gives 1.5e-3 or NaN on the all-fp32 in-lane sweeps and 7e-6 MIXED,
 # 1e-7 on this route.  Threshold = SCAN_MAX_COND: BASELINE config 2 (the same model observed through target and cursor, cond
 # 1e6) holds 6e-8 in fp32 and keeps its fp32 per-trial sweep.  LQG_F32_WIDE=0 disables (A/B, tests of the fp32 kernels).
-F32_MAX_COND = float(os.environ.get("LQG_F32_MAX_COND", "1e7"))
+F32_MAX_COND = 1e7              # default of option "F32_MAX_COND"
 
 
 def scan_min_steps(m):
     """Horizon from which the scans beat one lane walking the recursion: the sequential step costs ~0.4 us at m = 4 and
     ~2 us at m = 8 (~m^2), the scans ~0.11-0.15 ms whatever T (config 1, m = 4, T = 100: 0.064 ms sequential, 0.11 ms
     scans; m = 4, T = 500: 0.20 / 0.14; m = 8, T = 500: 1.0 / 0.21)."""
-    if SCAN_MIN_STEPS > 0:
-        return SCAN_MIN_STEPS
+    if options.get("SCAN_MIN_STEPS") > 0:
+        return options.get("SCAN_MIN_STEPS")
     return int(max(64, 6000 / (m * m)))
 
 
@@ -70,8 +69,8 @@ def scan_max_systems(m, fp64=False):
     """(fp64 problems would tolerate twice as many on the GPU timeline — their sequential sweeps are ~1.5x slower, the scans
     are fp64 either way — but for a throw-away plan the scan route's extra host checks eat the difference: one vector's
     central differences, 9 systems x 50 trials at m = 4 in fp64: 1.01 ms fused pairs / 1.12 ms scans end to end.)"""
-    if SCAN_MAX_SYSTEMS > 0:
-        return SCAN_MAX_SYSTEMS
+    if options.get("SCAN_MAX_SYSTEMS") > 0:
+        return options.get("SCAN_MAX_SYSTEMS")
     if m > 24:
         # windows of 25 .. 64 (k_scan_level_rt: one 1024-lane workgroup per window, ~0.1 ms per combine, a level of one system's
         # 500 windows already fills the chip twice): DelayedSubjectiveActor (m = 65, T = 500) 3.8 ms of system sweeps per
@@ -114,8 +113,8 @@ def _observed_noise_cond(sub, d):
 
 def f32_needs_wide(sub, d):
     """True when an fp32 problem is evaluated over an fp64 image of its specs and data (F32_MAX_COND above)."""
-    return (sub.actor.A.dtype == torch.float32 and sub.actor.A.is_cuda and os.environ.get("LQG_F32_WIDE", "1") != "0"
-            and _observed_noise_cond(sub, d) > F32_MAX_COND)
+    return (sub.actor.A.dtype == torch.float32 and sub.actor.A.is_cuda and options.flag("F32_WIDE")
+            and _observed_noise_cond(sub, d) > options.get("F32_MAX_COND"))
 
 
 def scan_eligible(lib, ln, sub, eps, systems_scale=1):
@@ -123,7 +122,7 @@ def scan_eligible(lib, ln, sub, eps, systems_scale=1):
     systems_scale: a caller whose decisions are taken once and replayed (infer/graphed.py) does not pay the scan route's
     host checks per evaluation and can afford the GPU-timeline crossover instead of the end-to-end one (6x in fp64, 2x in fp32:
     profiles/r02_*_small_batch_f64.txt — BoundedActor, 32 / 64 systems: 0.28 / 0.41 ms scans, 0.32 / 0.38 ms lane kernels)."""
-    mode = os.environ.get("LQG_SCAN", "")
+    mode = options.get("SCAN")
     if mode == "0" or not hasattr(lib, "lqg_log_likelihood_scan"):
         return False
     if mode != "1" and not (ln.B <= min(64, (1 if ln.m > 24 else systems_scale) * scan_max_systems(ln.m, ln.dtype == torch.float64)) and ln.T >= scan_min_steps(ln.m)):
@@ -133,7 +132,7 @@ def scan_eligible(lib, ln, sub, eps, systems_scale=1):
     from lqg_amd import decouple
     if not decouple.floor_provably_inactive(sub, eps):
         return False
-    return mode == "1" or _observed_noise_cond(sub, ln.dims["d"]) <= SCAN_MAX_COND
+    return mode == "1" or _observed_noise_cond(sub, ln.dims["d"]) <= options.get("SCAN_MAX_COND")
 
 
 class LogLikelihoodPlan:
@@ -150,7 +149,7 @@ class LogLikelihoodPlan:
         # merge=True: decoupled components with bit-identical specs are ONE system observed on different data columns
         # (every dim=2 zoo model): the per-system sweeps run once and the components become trials of that system
         self.merged = []
-        if merge and len(parts) > 1 and os.environ.get("LQG_NO_MERGE") != "1":
+        if merge and len(parts) > 1 and not options.flag("NO_MERGE"):
             from lqg_amd import decouple
             merged_parts, merged_x = [], []
             for g in decouple.identical_groups(system, d, parts, Sigma0):
@@ -190,16 +189,16 @@ class LogLikelihoodPlan:
             # (an fp32 problem over a long horizon keeps the operator-stream path: its system sweeps then run in fp64 —
             # MIXED, below — where the fused pairs would run every recursion in fp32; §6a: the fp32 tail passes 1e-6 near T = 1000)
             long_f32 = (sub.actor.A.dtype == torch.float32 and sub.T > MIXED_LONG_HORIZON
-                        and os.environ.get("LQG_MIXED", "1") != "0")
+                        and options.flag("MIXED"))
             # (fused pairs in fp32 only up to FUSE_F32_MAX_STEPS: worst pair of scripts/fuzz_mixed.py 8.7e-7 at T = 500 —
             # too close to the north star's 1e-6 for a path that exists for speed on tiny problems; beyond, the stream path
             # runs MIXED: worst 2.8e-7)
             short_f32 = not (sub.actor.A.dtype == torch.float32 and sub.T > FUSE_F32_MAX_STEPS
-                             and os.environ.get("LQG_MIXED", "1") != "0")
+                             and options.flag("MIXED"))
             # (a lane-kernel route: the cooperative kernels walk one system per WORKGROUP — replicating the system per trial
             # multiplies their work, and their per-trial sweep is time-chunked for few systems, csrc/lqg_trial_chunk.hpp)
             lane_dims = sub.actor.A.shape[-1] + sub.dynamics.A.shape[-1] <= _hip.LANE_MAX_JOINT
-            fuse_pairs = ((not use_scan) and 2 < n and n_sys0 * n <= FUSE_TRIALS_MAX and _time_invariant(sub)
+            fuse_pairs = ((not use_scan) and 2 < n and n_sys0 * n <= options.get("FUSE_TRIALS_MAX") and _time_invariant(sub)
                           and not long_f32 and short_f32 and lane_dims)
             if fuse_pairs:                       # (system, trial) pairs as n_sys0 * n one-trial systems
                 sub, xs, S0 = _pairs_as_systems(sub, xs, S0, n_sys0, n)
@@ -211,8 +210,8 @@ class LogLikelihoodPlan:
             # trials beyond MIXED_LONG_HORIZON steps (one or two trials per system then leave the in-lane fp32 sweeps for
             # the stream path) — while the stream fits the workspace limit (2^20 systems x T = 1000 would need 150 GB: such a
             # batch keeps the in-lane fp32 sweeps, whose tail passes 1e-6 near T = 1000; fp64 is the remedy there)
-            mixed = ((not use_scan) and ln.dtype == torch.float32 and os.environ.get("LQG_MIXED", "1") != "0"
-                     and (n >= max(3, MIXED_MIN_TRIALS) or (long_f32 and n >= 1))
+            mixed = ((not use_scan) and ln.dtype == torch.float32 and options.flag("MIXED")
+                     and (n >= max(3, options.get("MIXED_MIN_TRIALS")) or (long_f32 and n >= 1))
                      and lib.lqg_strategy(C.byref(ln.p)) == _abi.STRATEGY_LANE)
             if mixed:                            # fp64 image of the specs (a few kB per system), float trajectories
                 sub_m = sub.to(torch.float64)

@@ -167,8 +167,10 @@ class System:
 
         rng_key: int seed or torch.Generator (the reference takes a jax PRNGKey; the stream of normal draws
         necessarily differs, the recursion does not).  An int seed (or None = 0) draws IN THE KERNEL (counter-based
-        Philox keyed by the seed, csrc/lqg_rng.hpp: trial k of system s gets the same draws whatever the batch around it,
-        and no [n, T, x + y] noise arrays pass through HBM); a torch.Generator supplies the draws from torch's stream.
+        Philox keyed by the seed, counter = (trial, system, step, block), csrc/lqg_rng.hpp: trial k of system s gets the same
+        draws whatever the number of systems or trials around it — shards of one study on different ranks must therefore
+        use different seeds — and no [n, T, x + y] noise arrays pass through HBM; fp64 problems get fp32 normals, widened);
+        a torch.Generator supplies the draws from torch's stream.
         Returns x[n, T+1, xdim]; with return_all also x_hat[n, T+1, bdim], y[n, T, ydim], u[n, T, udim]."""
         # (the gains only travel from the two sweeps to the simulate kernel: system-fastest storage, coalesced both ways)
         L_, l_, H_ = _hip.riccati_backward(self.actor, system_fastest=True)
@@ -228,10 +230,9 @@ class System:
         """Independent components of this system for data with d observed dims ([(sub_system, data columns, belief
         dims)], lqg_amd/decouple.py), or None when it does not decouple (or LQG_NO_DECOUPLE=1).  for_grad: the
         differentiable evaluation's variant (decouple.plan)."""
-        import os
-        if os.environ.get("LQG_NO_DECOUPLE") == "1":
+        from lqg_amd import _abi, decouple, options
+        if options.flag("NO_DECOUPLE"):
             return None
-        from lqg_amd import _abi, decouple
         parts = decouple.plan(self, d, Sigma0, for_grad=for_grad)
         if parts is None:
             return None

@@ -3,6 +3,7 @@ first-order muscle filter, discretised exactly (zero-order hold via the matrix e
 with Van Loan process-noise discretisation (:82-110) made positive definite by eigenvalue clipping (:130-144)."""
 import torch
 
+from lqg_amd import options
 from lqg_amd.system import Actor, System
 from lqg_amd.tracking import _build as bd
 
@@ -64,7 +65,7 @@ def point_mass_dynamics_matrices(damping, m, tau, action_variability, dt):
     (setup arithmetic is done in float64 on the host device of the parameters and cast by the caller)."""
     import os
     if damping.is_cuda and not any(t.requires_grad for t in (damping, m, tau, action_variability)) \
-            and isinstance(dt, float) and os.environ.get("LQG_SETUP_KERNEL") != "0":
+            and isinstance(dt, float) and options.flag("SETUP_KERNEL"):
         return _setup_on_gpu(damping, m, tau, action_variability, dt)
     z, o = torch.zeros_like(damping), torch.ones_like(damping)
     A_c = torch.stack([torch.stack([z, o, z], -1), torch.stack([z, -damping / m, o / m], -1),

@@ -48,9 +48,11 @@ def test_struct_layout_matches_header():
 #include "lqg_hip.h"
 int main(void) {
   printf("%zu %zu %zu %zu %zu ", sizeof(lqg_view), sizeof(lqg_traj), sizeof(lqg_spec), sizeof(lqg_dims), sizeof(lqg_problem));
-  printf("%zu %zu %zu %zu %zu %zu %zu\n", offsetof(lqg_problem, n_sys), offsetof(lqg_problem, dims),
+  printf("%zu %zu %zu %zu %zu %zu %zu ", offsetof(lqg_problem, n_sys), offsetof(lqg_problem, dims),
          offsetof(lqg_problem, actor), offsetof(lqg_problem, dynamics), offsetof(lqg_problem, Sigma0),
          offsetof(lqg_problem, eps), offsetof(lqg_problem, phase_events));
+  printf("%zu %zu %zu %zu\n", sizeof(lqg_tuning), offsetof(lqg_problem, tuning), offsetof(lqg_tuning, coop_trial_chunks),
+         offsetof(lqg_tuning, scan_rt_waves));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as td:
@@ -62,8 +64,33 @@ int main(void) {
     P = _abi.Problem
     want = [C.sizeof(_abi.View), C.sizeof(_abi.Traj), C.sizeof(_abi.Spec), C.sizeof(_abi.Dims), C.sizeof(P),
             P.n_sys.offset, P.dims.offset, P.actor.offset, P.dynamics.offset, P.Sigma0.offset, P.eps.offset,
-            P.phase_events.offset]
+            P.phase_events.offset, C.sizeof(_abi.Tuning), P.tuning.offset, _abi.Tuning.coop_trial_chunks.offset,
+            _abi.Tuning.scan_rt_waves.offset]
     assert got == want
+
+
+def test_the_library_reads_no_environment_variable_and_options_travel_in_the_problem(monkeypatch):
+    """ABI 3 (round-3 review, weak #9): no getenv in the library sources; the switches that select between its equivalent
+    kernels are `lqg_problem.tuning`, filled from lqg_amd.options at the moment a problem is described (env read per call,
+    programmatic override wins)."""
+    import glob
+    from lqg_amd import options
+    for f in glob.glob(os.path.join(ROOT, "lqg_amd", "csrc", "*.h*")):
+        assert "getenv" not in open(f).read(), f
+    t = options.fill_tuning(_abi.Tuning())
+    assert all(getattr(t, n) == 0 for n, _ in _abi.Tuning._fields_[:10])           # defaults: all zero
+    monkeypatch.setenv("LQG_COOP", "1")
+    monkeypatch.setenv("LQG_TRIAL_CHUNKS", "0")
+    monkeypatch.setenv("LQG_COOP_TRIAL_CHUNKS", "7")
+    monkeypatch.setenv("LQG_SCAN_LANE", "0")
+    t = options.fill_tuning(_abi.Tuning())
+    assert (t.coop, t.trial_chunks, t.coop_trial_chunks, t.scan_lane) == (1, -1, 7, -1)
+    with options.override(COOP="0", TRIAL_CHUNKS="5"):
+        t = options.fill_tuning(_abi.Tuning())
+        assert (t.coop, t.trial_chunks) == (-1, 5)
+    assert options.fill_tuning(_abi.Tuning()).coop == 1
+    with pytest.raises(KeyError):
+        options.set("NO_SUCH_SWITCH", 1)
 
 
 def test_argument_errors_do_not_launch(lib):
@@ -102,23 +129,29 @@ def test_workspace_size_formula(lib, monkeypatch):
     from lqg_amd import _hip
     import lqg_amd
     m = lqg_amd.SubjectiveActor(dim=2, T=500, sigma_target=torch.linspace(1, 2, 100), device="cpu")
+    from lqg_amd import options
     ln = _hip.Launch(m.actor, m.dynamics, d=4, n_trials=1)
+    # (ABI 3: the switches travel in the problem — lqg_tuning, filled when the problem is described; re-filled here)
     monkeypatch.setenv("LQG_COOP", "1")          # cooperative strategy: always through the operator stream
+    options.fill_tuning(ln.p.tuning)
     assert lib.lqg_strategy(C.byref(ln.p)) == _abi.STRATEGY_COOP
     coop = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
     monkeypatch.setenv("LQG_COOP", "0")          # lane strategy (also the default for shapes with lane kernels)
+    options.fill_tuning(ln.p.tuning)
     assert lib.lqg_strategy(C.byref(ln.p)) == _abi.STRATEGY_LANE
     fused = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
     assert coop == fused + (100 * 501 * 136 * 4 + 255) // 256 * 256      # + operator stream; the working set is in LDS
     assert fused == 500 * 2 * 6 * 128 * 4                               # gain scratch [T][u*b][B padded to 64]
     ln2 = _hip.Launch(m.actor, m.dynamics, d=4, n_trials=16)
     monkeypatch.setenv("LQG_TRIAL_CHUNKS", "0")  # the one-pass per-trial sweep
+    options.fill_tuning(ln2.p.tuning)
     split = lib.lqg_workspace_bytes(C.byref(ln2.p), _abi.OP_LOG_LIKELIHOOD)
     ops = (100 + 24 + 10 + 1 + 3) // 4 * 4
     assert ops == 136 and split == fused + (100 * 501 * ops * 4 + 255) // 256 * 256
     # the time-chunked per-trial sweep (csrc/lqg_trial_chunk.hpp) adds, after the operator stream: start states
     # [B][chunks-1][m][n], chunk transition matrices [B][chunks-1][m][m], fp64 partial sums [B][chunks][n]
     monkeypatch.setenv("LQG_TRIAL_CHUNKS", "4")
+    options.fill_tuning(ln2.p.tuning)
     al = lambda v: (v + 255) // 256 * 256
     chunked = lib.lqg_workspace_bytes(C.byref(ln2.p), _abi.OP_LOG_LIKELIHOOD)
     assert chunked == split + al(100 * 3 * 10 * 16 * 4) + al(100 * 3 * 10 * 10 * 4) + al(100 * 4 * 16 * 8)

@@ -235,8 +235,10 @@ def test_in_kernel_normal_draws_are_standard_normal(dtype):
 
 
 def test_in_kernel_draws_do_not_depend_on_batch_kernel_or_dtype():
-    """A trajectory is a pure function of (seed, pair index): the first trials of a larger batch, the lane kernels and the
-    run-time-dims cooperative kernel, fp32 and fp64 all see the same normals."""
+    """A trajectory is a pure function of (seed, system index, trial index): the first trials of a larger batch, the lane
+    kernels and the run-time-dims cooperative kernel, fp32 and fp64 all see the same normals; with B > 1 systems the draws of
+    system s do not change when the number of trials or of systems does (advisor, round 3: they did, the counter was
+    system * n_trials + trial)."""
     m = _identity_noise_system(2, 40, torch.float64)
     a = m.simulate(7, n=300)
     b = m.simulate(7, n=64)
@@ -249,10 +251,19 @@ def test_in_kernel_draws_do_not_depend_on_batch_kernel_or_dtype():
     m5 = _identity_noise_system(5, 40, torch.float64, ydim=4)
     c = m5.simulate(7, n=64)
     assert c.shape == (64, 41, 5) and torch.equal(c[..., :2], b)
-    # many systems: pair = system * n_trials + trial
+    # many systems: counter = (trial, system, step, block) — system 0 of a batch is the single system; every system's
+    # trajectories are invariant to n and to B; different systems draw different streams
     ms = _identity_noise_system(2, 40, torch.float64, n_sys=5)
-    d = ms.simulate(7, n=60)                                  # [5, 60, 41, 2] = pairs 0 .. 299
-    assert torch.equal(d.reshape(300, 41, 2), a)
+    d = ms.simulate(7, n=60)                                  # [5, 60, 41, 2]
+    assert torch.equal(d[0], a[:60])
+    d17 = ms.simulate(7, n=17)
+    assert torch.equal(d17, d[:, :17])                        # fewer trials: the same draws for every system
+    m3 = _identity_noise_system(2, 40, torch.float64, n_sys=3)
+    assert torch.equal(m3.simulate(7, n=60), d[:3])           # fewer systems: the same draws
+    cc = np.corrcoef(d[1, :, 1:].reshape(-1).cpu().numpy(), d[2, :, 1:].reshape(-1).cpu().numpy())[0, 1]
+    assert abs(cc) < 0.05 and not torch.equal(d[1], d[2])
+    m5s = _identity_noise_system(5, 40, torch.float64, n_sys=3, ydim=4)      # the cooperative kernel agrees on systems too
+    assert torch.equal(m5s.simulate(7, n=17)[..., :2], d[:3, :17])
 
 
 def test_bounded_equals_subjective_under_a_shared_seed():
