@@ -250,12 +250,42 @@ def host_specs(torch, np, workload, LQGSpec, system, sel, np_dt):
     return host(system.actor), host(system.dynamics)
 
 
+def usable_cpus():
+    """(threads worth starting, what limits them): the scheduler affinity of this process and the cgroup CPU quota of the
+    container — on a pod with a quota of a few CPUs, 256 OpenMP threads time-slice a handful of cores (round 3 reported
+    `cores: 256` for what were ~6 cores' worth of throughput: the one-thread figure gave it away)."""
+    n = os.cpu_count() or 1
+    why = {"os_cpu_count": n}
+    try:
+        aff = len(os.sched_getaffinity(0))
+        why["sched_affinity"] = aff
+        n = min(n, aff)
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                q = max(1, int(float(quota) / period + 0.5))
+                why["cgroup_cpu_quota"] = float(quota) / period
+                n = min(n, q)
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n), why
+
+
 def cpu_baseline(torch, np, OC, workload, lqg_amd, system, x_ref, dev, dtype_name, T, B, args):
     """The CPU baseline BASELINE.md 2 planned: the literal dense C restatement (oracle/lqg_oracle.c — a LITERAL PORT of the
     reference's formulas with run-time dims: LU with pivoting, Jacobi eigenvalues, no structure, one heap block per system;
     it is the parity checker, not a tuned CPU solver) timed on the GPU box's host cores on bounded samples of the same
     workload: all cores and ONE thread, in the bench dtype and in the other one.  A stated baseline, not the target."""
-    ncpu = os.cpu_count() or 1
+    host_cpus = os.cpu_count() or 1
+    ncpu, cpu_limit = usable_cpus()
     model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -303,7 +333,7 @@ def cpu_baseline(torch, np, OC, workload, lqg_amd, system, x_ref, dev, dtype_nam
         single_thread={"value": v_one, "unit": "solves/s", "cores": 1, "dtype": dtype_name, "sample_solves": n1},
         other_dtype={"dtype": other, "value": v_all_o, "cores": threads,
                      "single_thread": {"value": v_one_o, "cores": 1, "sample_solves": n1}},
-        cpu_model=model, host_cpu_count=ncpu)
+        cpu_model=model, host_cpu_count=host_cpus, cpu_limit=cpu_limit)
 
 
 def headline_leg(torch, dist, args, dev, rank, world, dtype_name, log2_batch, steps, warmup, env=None, cpu=False, leg=None,

@@ -194,10 +194,12 @@ def conditional_moments(actor, dynamics, x, Sigma0=None, eps=1e-8, want_mu=True,
     mu = ln.empty(n, ln.T, ln.m) if want_mu else None
     Sig = ln.empty(ln.T, ln.m, ln.m) if want_sigma else None
     use_scan = False
-    if lib is _abi.load() and hasattr(lib, "lqg_conditional_moments_scan"):
+    if hasattr(_abi.load(), "lqg_conditional_moments_scan"):
         from lqg_amd import plan as _plan          # (same rule as the log-likelihood: few systems, long horizon)
         from lqg_amd.system import System
-        use_scan = _plan.scan_eligible(lib, ln, system if system is not None else System(actor=actor, dynamics=dynamics), eps)
+        use_scan = _plan.scan_eligible(_abi.load(), ln, system if system is not None else System(actor=actor, dynamics=dynamics), eps)
+        if use_scan:
+            lib = _abi.load()                      # (the scans live in the main library, whatever serves the shape's lane kernels)
     with torch.cuda.device(ln.device):
         if use_scan:                     # time-parallel system sweeps (csrc/lqg_scan.hpp)
             nbytes = lib.lqg_scan_workspace_bytes(C.byref(ln.p))

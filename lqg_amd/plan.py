@@ -12,7 +12,21 @@ from lqg_amd import _abi, _hip, _hipev, options, specialize
 # Above this much operator-stream workspace a multi-trial evaluation is run as one fused single-trial sweep per
 # trial instead (N x the per-system work, no [system][step][operator] stream): e.g. 2^18 systems x 2 trials at
 # n=6, T=500 would need 71 GB of stream for 2 trials' worth of work.
-OPS_WORKSPACE_LIMIT = 16 << 30
+# (16 GiB through round 3, whatever the device held.  288 GB of HBM leave room for more: the limit is the smaller of 64 GiB
+# and 40 % of the device memory that is free when the plan is built — 4096 candidates of the reference's delay-12 model
+# (m = 65: 4.4 k reals per step) x 120 trials need a 36 GB stream; looping over the trials instead re-ran the 4096 system
+# sweeps 120 times: 34 s against 0.3 s.)
+OPS_WORKSPACE_LIMIT = None          # None: ops_workspace_limit(device); an int pins it (tests)
+
+
+def ops_workspace_limit(device):
+    if OPS_WORKSPACE_LIMIT is not None:
+        return OPS_WORKSPACE_LIMIT
+    try:
+        free, _ = torch.cuda.mem_get_info(device)
+    except Exception:
+        return 16 << 30
+    return int(min(64 << 30, 0.4 * free))
 # Up to this many (system, trial) pairs a multi-trial evaluation is run as ONE fused sweep per PAIR (the system part is
 # recomputed per trial — the lanes are idle anyway — and the per-trial sweep over the operator stream, a third
 # latency-bound 500-step kernel, disappears): one parameter vector (or the 2P+1 finite-difference candidates) x tens of
@@ -204,7 +218,10 @@ class LogLikelihoodPlan:
                 sub, xs, S0 = _pairs_as_systems(sub, xs, S0, n_sys0, n)
                 n_pairs, n = n, 1
             ln = _hip.Launch(sub.actor, sub.dynamics, d=len(cols), n_trials=n, Sigma0=S0, eps=eps)
-            lib = ln.require_gpu()               # liblqg_hip.so, or the auxiliary library of an unlisted shape
+            # liblqg_hip.so, or the auxiliary library of an unlisted shape; the time-parallel sweeps live in the main library
+            # only — once they are chosen (few systems, long horizon) a cached auxiliary lane-kernel library must not take the
+            # launch back
+            lib = ln.require_gpu() if not use_scan else (ln.require_gpu() and _abi.load())
             nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
             # MIXED: from MIXED_MIN_TRIALS trials per system on (the operator stream is used anyway), and for ANY number of
             # trials beyond MIXED_LONG_HORIZON steps (one or two trials per system then leave the in-lane fp32 sweeps for
@@ -218,7 +235,7 @@ class LogLikelihoodPlan:
                 ln_m = _hip.Launch(sub_m.actor, sub_m.dynamics, d=len(cols), n_trials=n, Sigma0=S0, eps=eps,
                                    traj_dtype=torch.float32)
                 nbytes_m = lib.lqg_workspace_bytes(C.byref(ln_m.p), _abi.OP_LOG_LIKELIHOOD)
-                if nbytes_m <= OPS_WORKSPACE_LIMIT:
+                if nbytes_m <= ops_workspace_limit(ln.device):
                     sub, ln, nbytes = sub_m, ln_m, nbytes_m
                 else:
                     mixed = False
@@ -239,7 +256,7 @@ class LogLikelihoodPlan:
                 ln.p.n_trials = 1
                 nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
                 ln.p.n_trials = 2
-            loop_trials = (not use_scan) and n > 1 and nbytes > OPS_WORKSPACE_LIMIT
+            loop_trials = (not use_scan) and n > 1 and nbytes > ops_workspace_limit(ln.device)
             if loop_trials:                      # one fused sweep per trial: the problem describes ONE trial
                 ln.p.n_trials = 1
                 nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)

@@ -347,7 +347,7 @@ def test_per_trial_fallback_when_the_operator_stream_would_be_huge(monkeypatch):
     x = torch.cat([workload.simulate_one_trial_each(sys_, seed=s) for s in (1, 2, 3)], dim=1)     # [300, 3, 61, 4]
     ref = sys_.log_likelihood(x).clone()
     monkeypatch.setattr(plan_mod, "OPS_WORKSPACE_LIMIT", 1024)
-    monkeypatch.setattr(plan_mod, "FUSE_TRIALS_MAX", 0)              # (1800 pairs would otherwise run as fused pairs)
+    monkeypatch.setenv("LQG_FUSE_TRIALS_MAX", "0")                   # (1800 pairs would otherwise run as fused pairs)
     p = plan_mod.LogLikelihoodPlan(sys_, x)
     assert all(wk["loop_trials"] for wk in p.work)
     got = p.run()
@@ -371,7 +371,7 @@ def test_small_problems_run_as_fused_system_trial_pairs(monkeypatch, dtype, tol)
         p = plan_mod.LogLikelihoodPlan(m, x)
         assert all(wk["fused_pairs"] for wk in p.work)
         got = p.run().clone()
-        monkeypatch.setattr(plan_mod, "FUSE_TRIALS_MAX", 0)
+        monkeypatch.setenv("LQG_FUSE_TRIALS_MAX", "0")
         q = plan_mod.LogLikelihoodPlan(m, x)
         assert not any(wk["fused_pairs"] for wk in q.work)
         ref = q.run().clone()
