@@ -27,14 +27,23 @@ namespace lqg {
 #ifndef LQG_SP_RIC_WAVES
 #define LQG_SP_RIC_WAVES 2
 #endif
-// waves per SIMD the forward kernel is allocated for: 2 in fp32 (256 registers per lane, measured 13 % faster than 1),
-// 1 in fp64 (the working set needs the full 512-register file; at 2 it spills and runs 5x slower)
+// waves per SIMD the forward kernel is allocated for: 2 in fp32 (256 registers per lane, measured 13 % faster than 1); in fp64
+// 2 for the smallest joint dimensions (m = x + b <= 5: the 1-D tracking components — 255 registers with 4 spilled at the
+// headline shape, round 4: 134.6 -> 160.5 M solves/s together with the checkpointed gains below), else 1 (the working set of
+// m >= 8 needs the full 512-register file; at 2 it spills and runs 5x slower)
 #ifndef LQG_SP_FWD_WAVES_F32
 #define LQG_SP_FWD_WAVES_F32 2
+#endif
+#ifndef LQG_SP_FWD_WAVES_F64_SMALL
+#define LQG_SP_FWD_WAVES_F64_SMALL 2
 #endif
 #ifndef LQG_SP_FWD_WAVES_F64
 #define LQG_SP_FWD_WAVES_F64 1
 #endif
+template <typename R, int M>
+constexpr int sp_fwd_waves() {
+  return sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F32 : (M <= 5 ? LQG_SP_FWD_WAVES_F64_SMALL : LQG_SP_FWD_WAVES_F64);
+}
 
 // ---------------------------------------------------------------- Riccati backward, TI, no affine terms
 // LQG_SP_CHUNK = CK > 0: CHECKPOINTED gains.  The backward sweep keeps only the packed cost-to-go S every CK steps
@@ -45,7 +54,10 @@ namespace lqg {
 // 241 / 246 / 253 / 230 M solves/s (the Riccati kernel stops being HBM-write-bound: 1.02 -> 0.69 ms; the forward kernel
 // pays 3.28 -> 3.41 ms for the recompute and drops from 4 to 3 waves per SIMD; at 16 the 48 gain registers cost more);
 // fp64 CK = 0 / 8 -> 113 / 111 M (fp64 VALU runs at half rate: the recompute costs more than the traffic it saves).
-// Hence: 8 in fp32, 0 in fp64, and only for gains of at most 4 reals per step (u b <= 4: every 1-D tracking model).
+// Round 4: with whole chunks run without per-step guards (k_forward_sp) the chunked fp64 sweep issues 249 instead of 305
+// instructions per step (the per-step loop of CK = 0 carries 26 v_mov_b64 and is not unrolled) and moves half the bytes:
+// CK = 0 / 4 / 8 (1 wave) / 8 (2 waves per SIMD) -> 134.6 / 151.2 / 142.0 / 160.5 M solves/s.
+// Hence: 8 in both precisions, and only for gains of at most 4 reals per step (u b <= 4: every 1-D tracking model).
 // LQG_SP_CHUNK overrides both (A/B builds: scripts/exp_chunk.sh).
 #ifdef LQG_SP_CHUNK
 #define LQG_SP_CHUNK_F32 LQG_SP_CHUNK
@@ -55,7 +67,7 @@ namespace lqg {
 #define LQG_SP_CHUNK_F32 8
 #endif
 #ifndef LQG_SP_CHUNK_F64
-#define LQG_SP_CHUNK_F64 0
+#define LQG_SP_CHUNK_F64 8
 #endif
 #ifndef LQG_SP_CHUNK_MAX_GAIN
 #define LQG_SP_CHUNK_MAX_GAIN 4
@@ -206,7 +218,7 @@ constexpr Mask<NX + NB, NX + NB> trial_operator_mask() {
 // CK > 0: checkpointed gains (see k_riccati_sp): `rc` carries the actor's cost matrices and the checkpoint stream.
 // OT: element type of the operator stream (NTR == 0), see k_forward.
 template <typename R, int NX, int NB, int NU, int NY, int ND, typename PAT, int NTR, bool DENSE_P, int CK, typename OT = R>
-__global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? LQG_SP_FWD_WAVES_F32 : LQG_SP_FWD_WAVES_F64)
+__global__ void __launch_bounds__(LQG_BLOCK, sp_fwd_waves<R, NX + NB>())
     k_forward_sp(const ForwardArgs<R> a, const long ll_sn, const RiccatiArgs<R> rc) {
   constexpr bool FUSED = NTR > 0;
   constexpr int NT = FUSED ? NTR : 1;

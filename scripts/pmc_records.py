@@ -22,8 +22,8 @@ KERNELS = {
     "headline_f32": {"forward": r"k_forward_sp<float", "riccati": r"k_riccati_sp<float"},
     "headline_f64": {"forward": r"k_forward_sp<double", "riccati": r"k_riccati_sp<double"},
     "m2_f32": {"forward": r"k_forward_tv_sp<", "riccati": r"k_riccati_tv_sp<"},
-    "config3": {"trial": r"k_trial_sp<", "forward": r"k_forward_sp<", "riccati": r"k_riccati_sp<"},
-    "config5_one_system": {"trial": r"k_trial_sp<"},
+    "config3": {"trial": r"k_trial_sp", "forward": r"k_forward_sp<", "riccati": r"k_riccati_sp<"},
+    "config5_one_system": {"trial": r"k_trial_sp"},
 }
 
 
