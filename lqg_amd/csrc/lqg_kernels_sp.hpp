@@ -218,7 +218,7 @@ constexpr Mask<NX + NB, NX + NB> trial_operator_mask() {
 // CK > 0: checkpointed gains (see k_riccati_sp): `rc` carries the actor's cost matrices and the checkpoint stream.
 // OT: element type of the operator stream (NTR == 0), see k_forward.
 template <typename R, int NX, int NB, int NU, int NY, int ND, typename PAT, int NTR, bool DENSE_P, int CK, typename OT = R>
-__global__ void __launch_bounds__(LQG_BLOCK, sp_fwd_waves<R, NX + NB>())
+__global__ void __launch_bounds__(LQG_BLOCK, (sp_fwd_waves<R, NX + NB>()))
     k_forward_sp(const ForwardArgs<R> a, const long ll_sn, const RiccatiArgs<R> rc) {
   constexpr bool FUSED = NTR > 0;
   constexpr int NT = FUSED ? NTR : 1;
