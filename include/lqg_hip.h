@@ -330,6 +330,11 @@ int lqg_grad_supported(int32_t dtype, const lqg_dims* dims);
 int64_t lqg_grad_elements(const lqg_dims* dims);
 int32_t lqg_grad_slabs(const lqg_problem* p);
 size_t lqg_grad_workspace_bytes(const lqg_problem* p, int64_t ld);
+/* Lanes of the gradient array per system: n_trials for shapes with adjoint LANE kernels (one lane per (system, trial) pair,
+ * the caller sums over the trials), 1 for every other supported shape (fp64; x, b <= 64; u, y, d <= 4: the cooperative
+ * sweep of csrc/lqg_coop_adjoint.hip — one workgroup per system — returns the bars ALREADY summed over the trials with the
+ * weights g; then ld >= n_sys and lane = system).  lqg_grad_workspace_bytes accounts for either. */
+int32_t lqg_grad_lanes_per_system(const lqg_problem* p);
 int lqg_log_likelihood_grad(const lqg_problem* p, lqg_traj x, const void* g, int64_t g_sb, int64_t g_sn, void* ll,
                             int64_t ll_sb, int64_t ll_sn, void* grad, int64_t ld, void* workspace,
                             size_t workspace_bytes, int32_t phases, void* stream);

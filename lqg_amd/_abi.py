@@ -131,6 +131,7 @@ def _bind(path):
         lib.lqg_grad_supported.argtypes, lib.lqg_grad_supported.restype = [C.c_int32, C.POINTER(Dims)], C.c_int
         lib.lqg_grad_elements.argtypes, lib.lqg_grad_elements.restype = [C.POINTER(Dims)], C.c_int64
         lib.lqg_grad_slabs.argtypes, lib.lqg_grad_slabs.restype = [C.POINTER(Problem)], C.c_int32
+        lib.lqg_grad_lanes_per_system.argtypes, lib.lqg_grad_lanes_per_system.restype = [C.POINTER(Problem)], C.c_int32
         lib.lqg_grad_workspace_bytes.argtypes = [C.POINTER(Problem), C.c_int64]
         lib.lqg_grad_workspace_bytes.restype = C.c_size_t
         lib.lqg_log_likelihood_grad.argtypes = [C.POINTER(Problem), Traj, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
@@ -201,7 +202,11 @@ def library_for(dims, family=FAM_FORWARD, n_sys=None):
     coop_ok = family in (FAM_FORWARD, FAM_RICCATI, FAM_KALMAN) and lib.lqg_coop_supported(C.byref(_dims_struct(dc)))
     if family == FAM_SIMULATE:
         coop_ok = True                              # k_coop_simulate: any (x, b, u, y)
+    if family == FAM_ADJOINT:                       # the cooperative reverse-mode sweep (fp64; x, b <= 64; u, y, d <= 4)
+        coop_ok = bool(lib.lqg_grad_supported(F64, C.byref(dm)))
     can_jit = shape_in_range(*key0) and os.path.exists(build.HIPCC) and _options.flag("JIT")
+    if family == FAM_ADJOINT and dims["x"] + dims["b"] > build.ADJOINT_MAX_JOINT:
+        can_jit = False                             # (on-demand libraries carry the gradient sweep up to x + b = 12)
     big = n_sys is not None and n_sys >= JIT_MIN_SYSTEMS
     names = "xbuyd"
     want = {k: dims[k] for k in _FAMILY_KEYS[family]}

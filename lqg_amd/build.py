@@ -31,6 +31,7 @@ ADJ_HEADERS = ["lqg_small.hpp", "lqg_adjoint.hpp", "lqg_adjoint_launch.hpp", "..
 # headers each source depends on (an adjoint-kernel edit must not recompile the forward kernels and vice versa)
 DEPS = {"lqg_inst.hip": HEADERS, "lqg_adjoint_inst.hip": ADJ_HEADERS, "lqg_coop_inst.hip": COOP_HEADERS,
         "lqg_scan_inst.hip": SCAN_HEADERS, "lqg_setup.hip": ["../../include/lqg_hip.h"],
+        "lqg_coop_adjoint.hip": ["lqg_coop_launch.hpp", "../../include/lqg_hip.h"],
         "lqg_abi.hip": sorted(set(HEADERS + ADJ_HEADERS + ["lqg_coop_launch.hpp"]))}
 FAMILIES = ("FORWARD", "RICCATI", "KALMAN", "TRIAL", "SIM", "ADJOINT")
 ADJOINT_MAX_JOINT = 12          # on-demand libraries get the gradient sweep up to x + b = 12 (33 s per dtype at 12; minutes beyond)
@@ -49,7 +50,8 @@ def dims_lists():
 def jobs(lists=None, extra_defs=()):
     extra_defs = list(extra_defs)
     js = [("abi.o", "lqg_abi.hip", extra_defs), ("coop.o", "lqg_coop_inst.hip", extra_defs),
-          ("scan.o", "lqg_scan_inst.hip", extra_defs), ("setup.o", "lqg_setup.hip", extra_defs)]
+          ("scan.o", "lqg_scan_inst.hip", extra_defs), ("setup.o", "lqg_setup.hip", extra_defs),
+          ("coopadj.o", "lqg_coop_adjoint.hip", extra_defs)]
     for fam, tuples in (lists or dims_lists()).items():
         for t in tuples:
             for dt in ("F32", "F64"):
@@ -80,7 +82,8 @@ def source_hash():
     snapshot to the GPU box, the hash does."""
     h = hashlib.sha256(" ".join(FLAGS).encode())
     for f in sorted(set(HEADERS + ADJ_HEADERS + SCAN_HEADERS + ["lqg_abi.hip", "lqg_inst.hip", "lqg_adjoint_inst.hip",
-                                                                "lqg_coop_inst.hip", "lqg_scan_inst.hip", "lqg_setup.hip"])):
+                                                                "lqg_coop_inst.hip", "lqg_scan_inst.hip", "lqg_setup.hip",
+                                                                "lqg_coop_adjoint.hip"])):
         h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()
 

@@ -426,6 +426,7 @@ int lqg_conditional_moments_scan(const lqg_problem* p, lqg_traj x, lqg_traj mu, 
 int lqg_coop_supported(const lqg_dims* dims) { return dims && coop_supported(*dims) ? 1 : 0; }
 int lqg_strategy(const lqg_problem* p) { return p && use_coop(p) ? LQG_STRATEGY_COOP : LQG_STRATEGY_LANE; }
 
+static bool has_adjoint_lane(const lqg_dims& d);
 int lqg_kernel_supported(int32_t family, const lqg_dims* dims) {
   if (!dims) return 0;
   const lqg_dims& d = *dims;
@@ -452,7 +453,7 @@ int lqg_kernel_supported(int32_t family, const lqg_dims* dims) {
       LQG_SIM_DIMS(X)
 #undef X
       return 0;
-    case LQG_FAMILY_ADJOINT: return lqg_grad_supported(LQG_F64, dims);
+    case LQG_FAMILY_ADJOINT: return has_adjoint_lane(*dims) ? 1 : 0;   // (lane kernels; lqg_grad_supported also counts the cooperative sweep)
     default: return 0;
   }
 }
@@ -657,15 +658,30 @@ int lqg_gaussian_logprob(int32_t dtype, int32_t k, int32_t T, int64_t n_sys, int
   return done(hipGetLastError(), who);
 }
 
-int lqg_grad_supported(int32_t dtype, const lqg_dims* dims) {
-  if (!dims || (dtype != LQG_F32 && dtype != LQG_F64)) return 0;
-  const lqg_dims& d = *dims;
+static bool has_adjoint_lane(const lqg_dims& d) {
   (void)d;
 #define X(X_, B_, U_, Y_, D_) \
-  if (d.x == X_ && d.b == B_ && d.u == U_ && d.y == Y_ && d.d == D_) return 1;
+  if (d.x == X_ && d.b == B_ && d.u == U_ && d.y == Y_ && d.d == D_) return true;
   LQG_ADJOINT_DIMS(X)
 #undef X
-  return 0;
+  return false;
+}
+
+int lqg_grad_supported(int32_t dtype, const lqg_dims* dims) {
+  if (!dims || (dtype != LQG_F32 && dtype != LQG_F64)) return 0;
+  if (has_adjoint_lane(*dims)) return 1;
+  return coop_adjoint_supported(dtype, *dims);       // fp64, any x, b <= 64 with u, y, d <= 4 (lqg_coop_adjoint.hip)
+}
+
+// tuning.reserved[0] == 1 ("coop_adjoint"): the cooperative sweep also for shapes WITH adjoint lane kernels (fp64 problems;
+// tests pin it against the lane kernels on every golden case)
+static bool adjoint_on_lanes(const lqg_problem* p) {
+  return has_adjoint_lane(p->dims) && !(p->tuning.reserved[0] == 1 && coop_adjoint_supported(p->dtype, p->dims));
+}
+
+int32_t lqg_grad_lanes_per_system(const lqg_problem* p) {
+  if (!p) return 0;
+  return adjoint_on_lanes(p) ? (int32_t)p->n_trials : 1;
 }
 
 int64_t lqg_grad_elements(const lqg_dims* dims) { return dims ? (int64_t)adj_grad_elements(*dims) : 0; }
@@ -674,6 +690,7 @@ int32_t lqg_grad_slabs(const lqg_problem* p) { return !p ? 0 : (adj_time_invaria
 
 size_t lqg_grad_workspace_bytes(const lqg_problem* p, int64_t ld) {
   if (!p || p->T <= 0 || ld <= 0) return 0;
+  if (!adjoint_on_lanes(p)) return coop_adjoint_supported(p->dtype, p->dims) ? coop_adjoint_workspace_bytes(p) : 0;
   const size_t e = p->dtype == LQG_F64 ? 8 : 4;
   return (size_t)p->T * (size_t)adj_step_reals(p->dims) * (size_t)ld * e;
 }
@@ -694,14 +711,17 @@ int lqg_log_likelihood_grad(const lqg_problem* p, lqg_traj x, const void* g, int
     return LQG_ERR_NULL;
   if (p->n_sys == 0 || p->n_trials == 0) return 0;
   if (!x.ptr || !workspace || ((phases & 2) && !grad)) return fail(LQG_ERR_NULL, "%s: NULL x / grad / workspace", who);
-  if (ld < p->n_sys * p->n_trials) return fail(LQG_ERR_ARG, "%s: ld %lld < n_sys * n_trials", who, (long long)ld);
+  const bool lane = adjoint_on_lanes(p);
+  if (!lane && !coop_adjoint_supported(p->dtype, p->dims)) return unsupported(p, who);
+  if (ld < p->n_sys * (lane ? p->n_trials : 1))
+    return fail(LQG_ERR_ARG, "%s: ld %lld < n_sys * lqg_grad_lanes_per_system", who, (long long)ld);
   if (workspace_bytes < lqg_grad_workspace_bytes(p, ld))
     return fail(LQG_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", who, workspace_bytes, lqg_grad_workspace_bytes(p, ld));
   const lqg_dims& d = p->dims;
   (void)d;
   hipStream_t st = (hipStream_t)stream;
 #define X(X_, B_, U_, Y_, D_)                                                                                   \
-  if (d.x == X_ && d.b == B_ && d.u == U_ && d.y == Y_ && d.d == D_)                                           \
+  if (lane && d.x == X_ && d.b == B_ && d.u == U_ && d.y == Y_ && d.d == D_)                                   \
     return done(p->dtype == LQG_F64                                                                             \
                     ? launch_adjoint<double, X_, B_, U_, Y_, D_>(p, x, g, g_sb, g_sn, ll, ll_sb, ll_sn, grad, ld, \
                                                                  workspace, phases, st)                                  \
@@ -710,8 +730,9 @@ int lqg_log_likelihood_grad(const lqg_problem* p, lqg_traj x, const void* g, int
                 who);
   LQG_ADJOINT_DIMS(X)
 #undef X
-  (void)st;
-  return unsupported(p, who);
+  // no lane kernels for this shape: one workgroup per system, bars summed over the trials (lqg_coop_adjoint.hip)
+  return done(coop_adjoint_run(p, x, g, g_sb, g_sn, ll, ll_sb, ll_sn, grad, ld, (long)adj_grad_elements(p->dims),
+                               adj_time_invariant(p), workspace, phases, st), who);
 }
 
 }  // extern "C"

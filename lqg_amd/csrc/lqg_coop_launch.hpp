@@ -57,6 +57,14 @@ hipError_t coop_simulate(const lqg_problem* p, lqg_view L, lqg_view l, lqg_view 
 // ---- time-parallel system sweeps (lqg_scan.hpp / lqg_scan_inst.hip)
 // dims and problem class the scan path serves (u, y, d <= 4, x + b <= 24, no affine cost terms); the caller additionally
 // guarantees that the eigenvalue floor of lqr.py:27-28 is inactive
+// reverse-mode gradient for shapes without adjoint lane kernels (lqg_coop_adjoint.hip): one workgroup per system, fp64,
+// bars summed over the trials
+int coop_adjoint_supported(int32_t dtype, const lqg_dims& d);
+size_t coop_adjoint_workspace_bytes(const lqg_problem* p);
+hipError_t coop_adjoint_run(const lqg_problem* p, lqg_traj x, const void* g, long g_sb, long g_sn, void* ll, long ll_sb,
+                            long ll_sn, void* grad, long ld, long elements, bool time_invariant, void* ws, int phases,
+                            hipStream_t st);
+
 bool scan_supported(const lqg_problem* p);
 size_t scan_workspace_bytes(const lqg_problem* p);
 template <typename R>

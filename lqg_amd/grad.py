@@ -84,14 +84,26 @@ class Sweep:
             actor, dynamics, x = _promote64(actor), _promote64(dynamics), x.double()
             Sigma0 = Sigma0.double() if Sigma0 is not None else None
         ln = _hip.Launch(actor, dynamics, d=d, n_trials=x.shape[-3], Sigma0=Sigma0, eps=eps)
-        self.lib = ln.require_gpu(_abi.FAM_ADJOINT)     # lane kernels only: an unlisted shape is compiled on first use
+        self.lib = ln.require_gpu(_abi.FAM_ADJOINT)     # lane kernels (an unlisted small shape is compiled on first use) or,
+        # for every other shape (x + b > 12: the delay models), the cooperative sweep of the main library — fp64 only: an fp32
+        # caller gets the fp64 image of the sweeps, value and bars rounded once (the policy of LQG_F32_SYS64)
+        if not self.lib.lqg_grad_supported(ln.p.dtype, C.byref(ln.p.dims)) and actor.A.dtype == torch.float32 \
+                and self.lib.lqg_grad_supported(_abi.F64, C.byref(ln.p.dims)):
+            self.out_dtype = torch.float32
+            actor, dynamics, x = _promote64(actor), _promote64(dynamics), x.double()
+            Sigma0 = Sigma0.double() if Sigma0 is not None else None
+            ln = _hip.Launch(actor, dynamics, d=d, n_trials=x.shape[-3], Sigma0=Sigma0, eps=eps)
         if not self.lib.lqg_grad_supported(ln.p.dtype, C.byref(ln.p.dims)):
-            raise _abi.LqgHipError(f"no adjoint kernels for model shape {tuple(ln.dims[k] for k in 'xbuyd')}: add it to "
-                                   "LQG_ADJOINT_DIMS in lqg_amd/csrc/lqg_dims.def and rebuild (there is no CPU path)")
+            raise _abi.LqgHipError(f"no adjoint kernels for model shape {tuple(ln.dims[k] for k in 'xbuyd')} "
+                                   "(lane kernels: LQG_ADJOINT_DIMS of lqg_amd/csrc/lqg_dims.def; cooperative sweep: x, b <= 64, "
+                                   "u, y, d <= 4); there is no CPU path")
         self.ln = ln
         self.x, self.xb = _hip._prep_x(ln, x)
         self.N = self.x.shape[-3]
-        self.lanes = ln.B * self.N
+        # lanes of the gradient array per system: the trials (lane kernels: the caller sums over them) or 1 (cooperative
+        # sweep: bars already summed over the trials) — include/lqg_hip.h: lqg_grad_lanes_per_system
+        self.per_sys = int(self.lib.lqg_grad_lanes_per_system(C.byref(ln.p)))
+        self.lanes = ln.B * self.per_sys
         self.ld = (self.lanes + 63) // 64 * 64
         self.lay, self.total = _layout(ln.dims)
         assert self.total == self.lib.lqg_grad_elements(C.byref(ln.p.dims))
@@ -117,7 +129,8 @@ class Sweep:
 
     def reverse(self, g=None):
         """-> {name: [B, N, r, c]} per-(system, trial) bars (lqg_hip.h: order of the gradient elements); with
-        time-varying specs [B, N, T, r, c] (aQf and aS0, which have no time axis, stay [B, N, r, c])."""
+        time-varying specs [B, N, T, r, c] (aQf and aS0, which have no time axis, stay [B, N, r, c]).  Shapes served by the
+        cooperative sweep return [B, 1, ...]: the bars already summed over the trials."""
         ln = self.ln
         if g is not None:
             g = g.to(dtype=ln.dtype, device=ln.device).expand(ln.lead() + (self.N,)).contiguous()
@@ -128,7 +141,7 @@ class Sweep:
         self.fresh = False
         bars = {}
         for k, (o, r, c) in self.lay.items():
-            v = out[:, o:o + r * c, :self.lanes].reshape(self.slabs, r, c, ln.B, self.N).permute(3, 4, 0, 1, 2)
+            v = out[:, o:o + r * c, :self.lanes].reshape(self.slabs, r, c, ln.B, self.per_sys).permute(3, 4, 0, 1, 2)
             v = v[:, :, 0] if (self.slabs == 1 or k in ("aQf", "aS0")) else v
             bars[k] = v if self.out_dtype is None else v.to(self.out_dtype)
         return bars

@@ -21,6 +21,7 @@ COOP              ""        "" default rule, "1" cooperative kernels wherever su
 COOP_SPARSE       1         run-time sparsity lists of the cooperative sweeps                         -> tuning.coop_sparse
 COOP_TRIAL_ROWS   1         row-parallel per-trial sweep of large joint dimensions                    -> tuning.coop_trial_rows
 COOP_TRIAL_CHUNKS ""        its cut along time: "" rule, "0" / "1" one pass, k chunks                  -> tuning.coop_trial_chunks
+COOP_ADJOINT      0         1: the cooperative reverse-mode sweep also for shapes with adjoint lane kernels -> tuning.reserved[0]
 TRIAL_CHUNKS      ""        lane per-trial sweep cut along time: "" rule, "0" / "1" one pass, k chunks -> tuning.trial_chunks
 TRIAL_CHUNK_WAVES / TRIAL_CHUNK_MAX_WAVES / TRIAL_CHUNK_TPL   0   parameters of that rule             -> tuning.trial_chunk_*
 FUSE_TRIALS_MAX   2048      (system, trial) pairs up to which a small multi-trial evaluation runs as fused pairs (0: never)
@@ -44,7 +45,7 @@ import os
 
 DEFAULTS = {
     "SCAN": "", "SCAN_MAX_SYSTEMS": 0, "SCAN_MIN_STEPS": 0, "SCAN_MAX_COND": 1e7, "SCAN_LANE": 1, "SCAN_RT_WAVES": 0,
-    "COOP": "", "COOP_SPARSE": 1, "COOP_TRIAL_ROWS": 1, "COOP_TRIAL_CHUNKS": "", "TRIAL_CHUNKS": "", "TRIAL_CHUNK_WAVES": 0,
+    "COOP": "", "COOP_SPARSE": 1, "COOP_TRIAL_ROWS": 1, "COOP_TRIAL_CHUNKS": "", "COOP_ADJOINT": 0, "TRIAL_CHUNKS": "", "TRIAL_CHUNK_WAVES": 0,
     "TRIAL_CHUNK_MAX_WAVES": 0, "TRIAL_CHUNK_TPL": 0, "FUSE_TRIALS_MAX": 2048, "MIXED": 1, "MIXED_MIN_TRIALS": 3,
     "F32_WIDE": 1, "F32_MAX_COND": 1e7, "NO_SPECIALIZE": 0, "NO_DECOUPLE": 0, "NO_MERGE": 0, "GRAPH": 1, "GRAPH_AFFINE": 1,
     "SETUP_KERNEL": 1, "JIT": 1,
@@ -128,4 +129,5 @@ def fill_tuning(t):
     t.coop_sparse = 0 if flag("COOP_SPARSE") else -1
     t.scan_lane = 0 if flag("SCAN_LANE") else -1
     t.scan_rt_waves = get("SCAN_RT_WAVES")
+    t.reserved[0] = 1 if flag("COOP_ADJOINT") else 0
     return t

@@ -240,6 +240,120 @@ def test_time_varying_specs_get_one_bar_per_step(dtype, tol):
         assert np.abs(Wd.grad.cpu().numpy() - gd["W"]).max() < 1e-8 * max(np.abs(gd["W"]).max(), 1e-3)
 
 
+# ---- the COOPERATIVE reverse-mode sweep (csrc/lqg_coop_adjoint.hip: one workgroup per system, run-time dims, fp64, bars summed
+# over the trials): every shape without adjoint lane kernels — the reference's delay models — and, forced with
+# LQG_COOP_ADJOINT=1, every golden case the lane kernels are pinned on
+COOP_CASES = TI_CASES + ["delay1_bounded_T30", "delay2_bounded_T30", "hand2d_T40", "subjective2d_T60", "delay12_subjective1d_T30"]
+
+
+def _got_and_ref(tot, ga, gd, actor, dyn, time_varying=False):
+    sym2 = lambda M: M + np.swapaxes(M, -1, -2)
+    V = (lambda sp, k: sp[k]) if time_varying else (lambda sp, k: sp[k][0])
+    got = {"dA": tot["dA"], "dB": tot["dB"], "dF": tot["dF"], "dV": sym2(tot["dVV"]) @ V(dyn, "V"),
+           "dW": sym2(tot["dWW"]) @ V(dyn, "W"), "aA": tot["aA"] + tot["aA2"], "aB": tot["aB"] + tot["aB2"],
+           "aF": tot["aF"], "aV": sym2(tot["aVV"]) @ V(actor, "V"), "aW": sym2(tot["aWW"]) @ V(actor, "W"),
+           "aQ": tot["aQ"], "aR": tot["aR"], "aQf": tot["aQf"]}
+    red = (lambda v: v) if time_varying else (lambda v: v.sum(0) if v.ndim == 3 else v)
+    ref = {"d" + k: red(v) for k, v in gd.items()}
+    ref.update({"a" + k: red(v) for k, v in ga.items()})
+    return got, ref
+
+
+@gpu
+@pytest.mark.parametrize("name", COOP_CASES)
+def test_cooperative_adjoint_matches_the_restatement(name, monkeypatch):
+    """fp64, 1e-8 of the NumPy restatement (round-3 review, item 4: `delay12_subjective1d_T30`, x = 26, b = 39, included)."""
+    from gpu_common import system_from_golden
+    from lqg_amd import _abi, grad as G
+    monkeypatch.setenv("LQG_COOP_ADJOINT", "1")
+    g, actor, dyn = load_golden(name)
+    x = g["x"]
+    w = np.linspace(0.5, 1.5, x.shape[0])
+    ll_ref, ga, gd, _ = ADJ.loglik_grad(actor, dyn, x, w)
+    s = system_from_golden(actor, dyn, torch.float64)
+    sw = G.Sweep(_ti(s.actor), _ti(s.dynamics), torch.as_tensor(x, dtype=torch.float64, device="cuda"))
+    assert sw.per_sys == 1 and sw.lib is _abi.load()                       # bars summed over the trials, main library
+    ll = sw.forward()
+    bars = sw.reverse(torch.as_tensor(w, dtype=torch.float64, device="cuda"))
+    assert np.abs(ll.cpu().numpy() - g["ll"]).max() < (1e-7 if name == "pointmass_d4_T50" else 1e-10) * np.abs(g["ll"]).max()
+    assert bars["dA"].shape[:2] == (1, 1)
+    tot = {k: v.sum(1)[0].cpu().numpy() for k, v in bars.items()}
+    got, ref = _got_and_ref(tot, ga, gd, actor, dyn)
+    scale = max(np.abs(v).max() for v in ref.values())
+    tol = 1e-6 if name == "pointmass_d4_T50" else 1e-8                     # (cond 5.6e8: the lane kernels' test allows the same)
+    for k, r in ref.items():
+        assert np.abs(got[k] - r).max() < tol * max(np.abs(r).max(), 1e-3 * scale), k
+
+
+@gpu
+def test_cooperative_adjoint_time_varying_specs_sigma0_and_candidates(monkeypatch):
+    """Per-step bars (every field time-varying, custom Sigma0: golden timevarying_T30) and a candidate axis with per-pair
+    weights, cooperative sweep against the lane kernels' results and the restatement."""
+    from gpu_common import system_from_golden
+    from lqg_amd import grad as G
+    import lqg_amd
+    g, actor, dyn = load_golden("timevarying_T30")
+    x, S0 = g["x"], g["Sigma0"]
+    w = np.linspace(0.5, 1.5, x.shape[0])
+    _, ga, gd, S0b = ADJ.loglik_grad(actor, dyn, x, w, S0)
+    s = system_from_golden(actor, dyn, torch.float64)
+    xt, S0t = torch.as_tensor(x, device="cuda"), torch.as_tensor(S0, device="cuda")
+    monkeypatch.setenv("LQG_COOP_ADJOINT", "1")
+    ll, bars, _ = G.raw_grad(s.actor, s.dynamics, xt, g=torch.as_tensor(w, device="cuda"), Sigma0=S0t)
+    assert np.abs(ll.cpu().numpy() - g["ll"]).max() < 1e-10 * np.abs(g["ll"]).max()
+    tot = {k: v.sum(1)[0].cpu().numpy() for k, v in bars.items()}
+    assert tot["dA"].shape == (30, 2, 2) and tot["aQf"].shape == (3, 3)
+    got, ref = _got_and_ref(tot, ga, gd, actor, dyn, time_varying=True)
+    scale = max(np.abs(v).max() for v in ref.values())
+    for k, r in ref.items():
+        assert np.abs(got[k] - r).max() < 1e-8 * max(np.abs(r).max(), 1e-3 * scale), k
+    assert np.abs(tot["aS0"] - S0b).max() < 1e-8 * max(np.abs(S0b).max(), 1e-3)
+    # candidates x trials with weights, through autograd: cooperative == lane kernels
+    sig = torch.tensor([3.0, 6.0, 12.0], dtype=torch.float64, device="cuda")
+    with torch.no_grad():
+        xb = lqg_amd.BoundedActor(T=80, sigma_target=6.0, device="cuda", dtype=torch.float64).simulate(1, n=4)
+    wt = torch.tensor([[1.0, 0.5, 2.0, 0.0], [0.3, 0.3, 0.3, 0.3], [1.0, -1.0, 1.0, -1.0]], dtype=torch.float64, device="cuda")
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LQG_COOP_ADJOINT", mode)
+        sg = sig.clone().requires_grad_(True)
+        cost = torch.tensor(0.1, dtype=torch.float64, device="cuda", requires_grad=True)
+        ll = lqg_amd.BoundedActor(T=80, sigma_target=sg, action_cost=cost, device="cuda", dtype=torch.float64).log_likelihood(xb)
+        (ll * wt).sum().backward()
+        res[mode] = (ll.detach().clone(), sg.grad.clone(), float(cost.grad))
+    assert torch.allclose(res["1"][0], res["0"][0], rtol=1e-11)
+    assert torch.allclose(res["1"][1], res["0"][1], rtol=1e-8) and abs(res["1"][2] / res["0"][2] - 1) < 1e-8
+
+
+@gpu
+def test_reverse_mode_serves_the_delay_models_end_to_end():
+    """`jax.grad` in the reference differentiates DelayedSubjectiveActor like any other model (lqg/tracking/delay.py:44-51,
+    lqg/optim.py:142-147): lqg_grad_supported is true for (x, b) = (26, 39), value_and_grad(method="adjoint") agrees with
+    central differences of the fp64 forward path, and an fp32 caller gets the fp64 image rounded once."""
+    import ctypes as C
+    from lqg_amd import _abi
+    from lqg_amd.infer import gradient
+    from lqg_amd.tracking.delay import DelayedSubjectiveActor
+    lib = _abi.load()
+    dm = _abi._dims_struct(dict(x=26, b=39, u=1, y=2, d=2))
+    assert lib.lqg_grad_supported(_abi.F64, C.byref(dm)) == 1 and lib.lqg_kernel_supported(_abi.FAM_ADJOINT, C.byref(dm)) == 0
+    with torch.no_grad():
+        x = DelayedSubjectiveActor(T=40, device="cuda", dtype=torch.float64).simulate(4, n=6)[..., :2].contiguous()
+    x = torch.cat([x, x[:, -1:]], dim=1)                              # lqg_model's convention: T rows = T - 1 steps
+    p = dict(c=0.5, action_variability=0.5, subj_noise=1.0, subj_vel_noise=10.0, sigma_target=6.0, sigma_cursor=3.0)
+    v1, g1 = gradient.value_and_grad(x, DelayedSubjectiveActor, p, method="adjoint")
+    v2, g2 = gradient.value_and_grad(x, DelayedSubjectiveActor, p, method="fd")
+    assert abs(v1 - v2) < 1e-9 * abs(v2)
+    for k in p:
+        assert abs(g1[k] - g2[k]) < 2e-5 * max(1.0, abs(g2[k])), (k, g1[k], g2[k])
+    sig = torch.tensor(6.0, dtype=torch.float32, device="cuda", requires_grad=True)
+    m32 = DelayedSubjectiveActor(T=40, sigma_target=sig, device="cuda", dtype=torch.float32)
+    ll32 = m32.log_likelihood(x[:, :-1].float())
+    assert ll32.dtype == torch.float32
+    ll32.sum().backward()
+    assert abs(float(sig.grad) - g1["sigma_target"]) < 2e-3 * max(1.0, abs(g1["sigma_target"]))
+
+
 @gpu
 def test_value_and_grad_adjoint_agrees_with_finite_difference_method():
     import lqg_amd
