@@ -17,6 +17,6 @@ for leg in $LEGS; do
     find $d -type f ! -name "*counter_collection.csv" ! -name "*kernel_trace.csv" -delete 2>/dev/null
   done
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_kt -o p -- python3 bench.py --no-extra --no-cpu-baseline --steps 10 --warmup 2 > gpurun_out/prof_${TAG}_kt.json 2> gpurun_out/prof_${TAG}_kt.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_kt -o p -- python3 bench.py --no-extra --no-cpu-baseline --steps 50 --warmup 10 > gpurun_out/prof_${TAG}_kt.json 2> gpurun_out/prof_${TAG}_kt.err
 find gpurun_out/prof_${TAG}_kt -type f ! -name "*stats*.csv" -delete 2>/dev/null
 python3 scripts/pmc_records.py $TAG $LEGS

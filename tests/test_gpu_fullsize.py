@@ -147,11 +147,23 @@ def test_unlisted_model_shape(oracle_lib, monkeypatch, big_batch):
     mu_r, Sig_r = oracle_lib.conditional_moments(spec, spec, xn[:1])
     assert np.abs(np_(mu) - mu_r[0]).max() < 1e-10 and np.abs(np_(Sig) - Sig_r).max() < 1e-10
     assert (set(_abi._dims_libs) != before) == big_batch                  # compiled only in the big-batch mode
-    # the gradient sweep has lane kernels only: an unknown shape without a compiler fails loudly, never a fallback
+    # without a compiler: the likelihood AND (round 4: cooperative reverse-mode sweep) the gradient of an unknown shape are
+    # served by the main library; a shape beyond every kernel family fails loudly, never a fallback
     monkeypatch.setattr(build, "HIPCC", "/nonexistent/hipcc")
-    with pytest.raises(_abi.LqgHipError, match="no hipcc"):
-        _abi.library_for(dict(x=3, b=4, u=1, y=2, d=3), family=_abi.FAM_ADJOINT)
-    assert _abi.library_for(dict(x=3, b=4, u=1, y=2, d=3)) is _abi.load()  # the likelihood itself needs no compiler
+    assert _abi.library_for(dict(x=3, b=4, u=1, y=2, d=3), family=_abi.FAM_ADJOINT) is _abi.load()
+    assert _abi.library_for(dict(x=3, b=4, u=1, y=2, d=3)) is _abi.load()
+    with pytest.raises(_abi.LqgHipError):
+        _abi.library_for(dict(x=3, b=4, u=5, y=2, d=3), family=_abi.FAM_ADJOINT)
+    sig = torch.tensor(2.0, dtype=torch.float64, device=DEV, requires_grad=True)          # ... and the gradient is right
+    Wg = torch.diag(torch.stack([sig, torch.tensor(3.0, dtype=torch.float64, device=DEV)]))
+    mg = lqg_amd.LQG(t64(A), t64(B), t64(F), t64(V), Wg, t64(Q), t64(R), T=T)
+    mg.log_likelihood(x).sum().backward()
+    h = 1e-6
+    with torch.no_grad():
+        f = lambda v: float(lqg_amd.LQG(t64(A), t64(B), t64(F), t64(V), t64(np.diag([v, 3.0])), t64(Q), t64(R), T=T)
+                            .log_likelihood(x).sum())
+        fd = (f(2.0 + h) - f(2.0 - h)) / (2 * h)
+    assert abs(float(sig.grad) - fd) < 1e-6 * max(1.0, abs(fd))
 
 
 def _run_bench(*flags):
