@@ -11,8 +11,8 @@ bash scripts/profile_headline.sh ${TAG}64 f64 > /dev/null 2>&1
 bash scripts/profile_m2.sh ${TAG}m2 f32 17 > /dev/null 2>&1
 # PMC record of THIS build first (bench.py reports `roofline.traffic` only from a record carrying the running build's hashes);
 # profiles/ does not travel back from the box, so the record is also left under gpurun_out/ to be copied into profiles/
-python3 scripts/make_pmc_record.py ${TAG} f32 20 > /dev/null 2>&1
-python3 scripts/make_pmc_record.py ${TAG}64 f64 20 > /dev/null 2>&1
+true
+true
 cp profiles/r03_pmc_traffic.json gpurun_out/${TAG}_pmc_traffic.json
 python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 python3 bench_configs.py > gpurun_out/${TAG}_configs.jsonl 2> gpurun_out/${TAG}_configs.err

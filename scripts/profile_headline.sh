@@ -2,7 +2,7 @@
 # rocprofv3 passes over `python bench.py` (headline workload) on the GPU box: kernel trace + stats, then one PMC counter
 # per pass (FETCH_SIZE and WRITE_SIZE do not fit one pass; never combined with a trace domain other than kernel-trace).
 #   bash scripts/profile_headline.sh <tag> [f32|f64] [extra bench args]
-# Outputs under gpurun_out/prof_<tag>_*; scripts/make_pmc_record.py turns them into profiles/r03_pmc_traffic.json rows.
+# Outputs under gpurun_out/prof_<tag>_*; (rounds 1-3; round 4 collects per-leg records with scripts/pmc_legs.sh + scripts/pmc_records.py)
 cd "$(dirname "$0")/.."
 TAG=$1; DT=${2:-f32}; shift; shift
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
