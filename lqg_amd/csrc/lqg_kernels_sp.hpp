@@ -763,67 +763,156 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial_sp(const R* __restrict__ op
     LQG_UNROLL for (int i = 0; i < O; ++i) xq[k][i] = xprev[k][i];
   constexpr bool PF = LQG_TRIAL_OPS_PREFETCH && (Ops::N * (int)(sizeof(R) / 4) <= LQG_TRIAL_OPS_PREFETCH_MAX);
   constexpr int NPF = PF ? Ops::N : 1;
-  // one step of the sweep; `cur` holds the step's operator block when it is prefetched into SGPRs (PF), else the block is
-  // read through `opt`
-  auto body = [&](int t, const R (&cur)[NPF], const R* __restrict__ opt) {
+  // Two loop structures (round 4).  Small joint dimensions (M < 8: the 1-D tracking models of configs 3 and 5) keep the
+  // two-step loop with run-time first / last tests below: the sweep lives on latency hiding at ~60 VGPRs, and blocks of 8
+  // unguarded steps — 30 instead of 36 VALU instructions per trial-step — let the compiler hoist the block's data loads to
+  // 117 VGPRs: config 3 3.54 -> 4.59 ms (measured).  Larger ones (M >= 8: the 2-D hand model of config 4,
+  // m = 10) are arithmetic-heavy and already register-bound: first / last step peeled, blocks of 8 unguarded steps, one
+  // flush of the fp32 partial sums per block: config 4 (262 144 trials) per-trial sweep 1.92 -> 1.35 ms.
+  constexpr bool BLOCK8 = M >= 8;
+  if constexpr (BLOCK8) {
+    auto body8 = [&]<bool FIRST, bool LAST>(int t, const R (&cur)[NPF], const R* __restrict__ opt) LQG_LAMBDA_INLINE {
 #define LQG_OP(i_) (PF ? cur[PF ? (i_) : 0] : opt[i_])
-    R Li[O * (O + 1) / 2];
-    LQG_UNROLL for (int i = 0; i < O * (O + 1) / 2; ++i) Li[i] = LQG_OP(Ops::L_OFF + i);
-    const R hlc = LQG_OP(Ops::H_OFF);
-    const bool flush = ((t & (kAccChunk - 1)) == 0) || t == a.T;
-    LQG_UNROLL for (int k = 0; k < TPL; ++k) {
-      R cv[M], w[O];                                      // cv = [x_t ; c]
-      LQG_UNROLL for (int i = 0; i < O; ++i) cv[i] = xq[k][i];
-      {
-        const long row = (t + 1 < a.T) ? (long)(t + 1) : (long)a.T;
-        LQG_UNROLL for (int i = 0; i < O; ++i) xq[k][i] = xr[k][row * a.x.st + i * a.x.sd];
-      }
-      R zz = R(0);
-      {
-        int e = 0;
-        LQG_UNROLL for (int i = 0; i < O; ++i) {
-          R v = R(0);
-          LQG_UNROLL for (int j = 0; j <= i; ++j) v += Li[e++] * ((cv[j] - xprev[k][j]) - dO[k][j]);
-          w[i] = v;
-          zz += v * v;
+      R Li[O * (O + 1) / 2];
+      LQG_UNROLL for (int i = 0; i < O * (O + 1) / 2; ++i) Li[i] = LQG_OP(Ops::L_OFF + i);
+      const R hlc = LQG_OP(Ops::H_OFF);
+      LQG_UNROLL for (int k = 0; k < TPL; ++k) {
+        R cv[M], w[O];                                      // cv = [x_t ; c]
+        LQG_UNROLL for (int i = 0; i < O; ++i) cv[i] = xq[k][i];
+        if constexpr (!LAST) {
+          LQG_UNROLL for (int i = 0; i < O; ++i) xq[k][i] = xr[k][(long)(t + 1) * a.x.st + i * a.x.sd];
+        }
+        R zz = R(0);
+        {
+          int e = 0;
+          LQG_UNROLL for (int i = 0; i < O; ++i) {
+            R v = R(0);
+            LQG_UNROLL for (int j = 0; j <= i; ++j) v += Li[e++] * ((cv[j] - xprev[k][j]) - dO[k][j]);
+            w[i] = v;
+            zz += v * v;
+          }
+        }
+        if constexpr (!FIRST) part[k] += R(0.5) * zz + hlc;
+        if constexpr (!LAST) {
+          LQG_UNROLL for (int p = 0; p < RR; ++p) {
+            R v = muR[k][p];
+            LQG_UNROLL for (int j = 0; j < O; ++j) v += LQG_OP(Ops::U_OFF + p * O + j) * w[j];
+            cv[O + p] = v;
+          }
+          R mn[M];
+          trial_mean_rows<R, M, ND, FM, PF, NPF, 0>(cur, opt, cv, mn);
+          LQG_UNROLL for (int i = 0; i < O; ++i) { dO[k][i] = mn[i]; xprev[k][i] = cv[i]; }
+          LQG_UNROLL for (int p = 0; p < RR; ++p) muR[k][p] = cv[O + p] + mn[O + p];   // (the stream holds Fj - I)
         }
       }
-      if (t > 0) part[k] += R(0.5) * zz + hlc;
-      if (flush) { acc[k] -= (double)part[k]; part[k] = R(0); }
-      if (t < a.T) {
-        LQG_UNROLL for (int p = 0; p < RR; ++p) {
-          R v = muR[k][p];
-          LQG_UNROLL for (int j = 0; j < O; ++j) v += LQG_OP(Ops::U_OFF + p * O + j) * w[j];
-          cv[O + p] = v;
-        }
-        R mn[M];
-        trial_mean_rows<R, M, ND, FM, PF, NPF, 0>(cur, opt, cv, mn);
-        LQG_UNROLL for (int i = 0; i < O; ++i) { dO[k][i] = mn[i]; xprev[k][i] = cv[i]; }
-        LQG_UNROLL for (int p = 0; p < RR; ++p) muR[k][p] = cv[O + p] + mn[O + p];   // (the stream holds Fj - I)
-      }
-    }
 #undef LQG_OP
-  };
-  if constexpr (PF) {
-    // Double-buffered operator blocks in SGPRs, the loop unrolled by two so that the buffers trade places instead of being
-    // copied (the copy was Ops::N s_mov per step: 44 scalar instructions per step against 68 vector ones on config 3)
-    R bufA[NPF], bufB[NPF];
-    auto fetch = [&](R (&dst)[NPF], int row) {
-      const R* __restrict__ src = op + (long)(row <= a.T ? row : a.T) * Ops::N;
-      LQG_UNROLL for (int i = 0; i < NPF; ++i) dst[i] = src[i];
     };
-    fetch(bufA, 0);
-    int t = 0;
-    for (; t + 1 <= a.T; t += 2) {
-      fetch(bufB, t + 1);
-      body(t, bufA, op);
-      fetch(bufA, t + 2);
-      body(t + 1, bufB, op);
+    auto flush = [&]() LQG_LAMBDA_INLINE {
+      LQG_UNROLL for (int k = 0; k < TPL; ++k) { acc[k] -= (double)part[k]; part[k] = R(0); }
+    };
+    static_assert(kAccChunk == 8, "the unguarded block is eight steps");
+    if constexpr (PF) {
+      // step t reads bufA when t is even, bufB when odd, and requests the block of step t + 1 into the other buffer first;
+      // blocks start at odd t, so the eight steps of a block have fixed buffers
+      R bufA[NPF], bufB[NPF];
+      auto fetch = [&](R (&dst)[NPF], int row) LQG_LAMBDA_INLINE {
+        const R* __restrict__ src = op + (long)(row <= a.T ? row : a.T) * Ops::N;
+        LQG_UNROLL for (int i = 0; i < NPF; ++i) dst[i] = src[i];
+      };
+      fetch(bufA, 0);
+      fetch(bufB, 1);
+      body8.template operator()<true, false>(0, bufA, op);
+      int t = 1;
+      for (; t + 8 <= a.T; t += 8) {
+        LQG_UNROLL for (int j = 0; j < 8; j += 2) {
+          fetch(bufA, t + j + 1);
+          body8.template operator()<false, false>(t + j, bufB, op);
+          fetch(bufB, t + j + 2);
+          body8.template operator()<false, false>(t + j + 1, bufA, op);
+        }
+        flush();
+      }
+      for (; t < a.T; ++t) {                                 // guarded tail (< 8 steps)
+        if (t & 1) { fetch(bufA, t + 1); body8.template operator()<false, false>(t, bufB, op); }
+        else { fetch(bufB, t + 1); body8.template operator()<false, false>(t, bufA, op); }
+      }
+      if (a.T & 1) body8.template operator()<false, true>(a.T, bufB, op);
+      else body8.template operator()<false, true>(a.T, bufA, op);
+    } else {
+      const R none[1] = {R(0)};
+      body8.template operator()<true, false>(0, none, op);
+      int t = 1;
+      for (; t + 8 <= a.T; t += 8) {
+        LQG_UNROLL for (int j = 0; j < 8; ++j) body8.template operator()<false, false>(t + j, none, op + (long)(t + j) * Ops::N);
+        flush();
+      }
+      for (; t < a.T; ++t) body8.template operator()<false, false>(t, none, op + (long)t * Ops::N);
+      body8.template operator()<false, true>(a.T, none, op + (long)a.T * Ops::N);
     }
-    if (t <= a.T) body(t, bufA, op);
+    flush();
   } else {
-    const R none[1] = {R(0)};
-    for (int t = 0; t <= a.T; ++t) body(t, none, op + (long)t * Ops::N);
+    // one step of the sweep; `cur` holds the step's operator block when it is prefetched into SGPRs (PF), else the block is
+    // read through `opt`
+    auto body = [&](int t, const R (&cur)[NPF], const R* __restrict__ opt) {
+  #define LQG_OP(i_) (PF ? cur[PF ? (i_) : 0] : opt[i_])
+      R Li[O * (O + 1) / 2];
+      LQG_UNROLL for (int i = 0; i < O * (O + 1) / 2; ++i) Li[i] = LQG_OP(Ops::L_OFF + i);
+      const R hlc = LQG_OP(Ops::H_OFF);
+      const bool flush = ((t & (kAccChunk - 1)) == 0) || t == a.T;
+      LQG_UNROLL for (int k = 0; k < TPL; ++k) {
+        R cv[M], w[O];                                      // cv = [x_t ; c]
+        LQG_UNROLL for (int i = 0; i < O; ++i) cv[i] = xq[k][i];
+        {
+          const long row = (t + 1 < a.T) ? (long)(t + 1) : (long)a.T;
+          LQG_UNROLL for (int i = 0; i < O; ++i) xq[k][i] = xr[k][row * a.x.st + i * a.x.sd];
+        }
+        R zz = R(0);
+        {
+          int e = 0;
+          LQG_UNROLL for (int i = 0; i < O; ++i) {
+            R v = R(0);
+            LQG_UNROLL for (int j = 0; j <= i; ++j) v += Li[e++] * ((cv[j] - xprev[k][j]) - dO[k][j]);
+            w[i] = v;
+            zz += v * v;
+          }
+        }
+        if (t > 0) part[k] += R(0.5) * zz + hlc;
+        if (flush) { acc[k] -= (double)part[k]; part[k] = R(0); }
+        if (t < a.T) {
+          LQG_UNROLL for (int p = 0; p < RR; ++p) {
+            R v = muR[k][p];
+            LQG_UNROLL for (int j = 0; j < O; ++j) v += LQG_OP(Ops::U_OFF + p * O + j) * w[j];
+            cv[O + p] = v;
+          }
+          R mn[M];
+          trial_mean_rows<R, M, ND, FM, PF, NPF, 0>(cur, opt, cv, mn);
+          LQG_UNROLL for (int i = 0; i < O; ++i) { dO[k][i] = mn[i]; xprev[k][i] = cv[i]; }
+          LQG_UNROLL for (int p = 0; p < RR; ++p) muR[k][p] = cv[O + p] + mn[O + p];   // (the stream holds Fj - I)
+        }
+      }
+  #undef LQG_OP
+    };
+    if constexpr (PF) {
+      // Double-buffered operator blocks in SGPRs, the loop unrolled by two so that the buffers trade places instead of being
+      // copied (the copy was Ops::N s_mov per step: 44 scalar instructions per step against 68 vector ones on config 3)
+      R bufA[NPF], bufB[NPF];
+      auto fetch = [&](R (&dst)[NPF], int row) {
+        const R* __restrict__ src = op + (long)(row <= a.T ? row : a.T) * Ops::N;
+        LQG_UNROLL for (int i = 0; i < NPF; ++i) dst[i] = src[i];
+      };
+      fetch(bufA, 0);
+      int t = 0;
+      for (; t + 1 <= a.T; t += 2) {
+        fetch(bufB, t + 1);
+        body(t, bufA, op);
+        fetch(bufA, t + 2);
+        body(t + 1, bufB, op);
+      }
+      if (t <= a.T) body(t, bufA, op);
+    } else {
+      const R none[1] = {R(0)};
+      for (int t = 0; t <= a.T; ++t) body(t, none, op + (long)t * Ops::N);
+    }
   }
   if (a.ll) {
     LQG_UNROLL for (int k = 0; k < TPL; ++k)
