@@ -29,3 +29,14 @@ for lo, hi in ((0, 1e3), (1e3, 1e4), (1e4, 1e5), (1e5, 1e6), (1e6, 1e7), (1e7, 1
 av = kw["action_variability"].cpu().numpy()
 bad = err > 1e-6
 print("bad candidates:", bad.sum(), "of", B, "| action_variability of bad: min %.2f max %.2f; of good: min %.2f max %.2f" % (av[bad].min() if bad.any() else 0, av[bad].max() if bad.any() else 0, av[~bad].min(), av[~bad].max()))
+
+# ---- the predictor the whitening suggests: max_t max diag(chol(Sigma_oo,t)^-1) from the fp64 moments
+xs = x[:1].double()
+_, Sig = m64._moments(xs.expand(B, *xs.shape) if False else xs, None)            # Sigma[B, T, m, m]
+Soo = Sig[..., :2, :2]
+Lc = torch.linalg.cholesky(Soo)
+gain = (1.0 / torch.diagonal(Lc, dim1=-2, dim2=-1)).amax((-1, -2)).cpu().numpy()   # max over steps and components
+for lo, hi in ((0, 10), (10, 30), (30, 100), (100, 300), (300, 1000), (1000, 3000), (3000, 1e4), (1e4, 1e5), (1e5, 1e9)):
+    sel = (gain >= lo) & (gain < hi)
+    if sel.any():
+        print("max whitening gain in [%g, %g): %3d candidates, fp32 rel err max %.1e median %.1e" % (lo, hi, sel.sum(), err[sel].max(), np.median(err[sel])))
