@@ -464,3 +464,32 @@ def test_time_varying_structured_specs_materialise_through_the_pattern_library(o
         assert np.abs(o_sp["Sig"][j].double().cpu().numpy() - Sr).max() / np.abs(Sr).max() < tol
         assert np.abs(o_sp["mu"][j].double().cpu().numpy() - mur).max() / np.abs(mur).max() < tol
         assert abs(float(o_sp["ll"][j, 0]) / float(llr[0]) - 1) < max(tol * 0.1, 1e-10)
+
+
+def test_fp32_candidate_ranges_point_mass():
+    """PointMassBoundedActor over the bench's candidate ranges, fp32 default routes against the fp64 path on the fp64 image of the SAME
+    fp32 inputs.  A log-likelihood is a sum of T d per-step terms of either sign; for candidates with a small action variability they nearly
+    cancel on these data (|ll| down to 0.1 against ~1e3 for the rest), and an error relative to |ll| then measures the zero crossing, not
+    the arithmetic (scripts/pointmass_f32_cond.py).  Stated tolerance: 1e-6 of max(|ll|, T d) — the plain relative 1e-6
+    wherever |ll| >= T d — and the absolute error of the cancelling candidates must not exceed that of the others."""
+    import lqg_amd
+    from lqg_amd import options, workload
+    dev = torch.device("cuda")
+    B, T, n, d = 256, 500, 8, 2
+    gen = torch.Generator(device=dev); gen.manual_seed(5)
+    names = ("action_variability", "sigma_target", "sigma_cursor", "action_cost")
+    kw = {k: workload.log_uniform(B, *workload.RANGES[k], gen, dev, torch.float32) for k in names}
+    m32 = lqg_amd.PointMassBoundedActor(T=T, device=dev, dtype=torch.float32, **kw)
+    x = lqg_amd.PointMassBoundedActor(T=T, device=dev, dtype=torch.float32).simulate(3, n=n)[..., :d].contiguous()
+    ref = m32.to(torch.float64).log_likelihood(x.double())
+    scale = ref.abs().clamp_min(float(T * d))
+    for ov in ({}, dict(F32_WIDE=0), dict(F32_WIDE=0, MIXED=0)):
+        with options.override(**ov):
+            ll = m32.log_likelihood(x).double()
+        err = (ll - ref).abs()
+        assert float((err / scale).max()) < 1e-6, ov
+        big = ref.abs() >= T * d
+        assert bool(big.any()) and float((err[big] / ref[big].abs()).max()) < 1e-6, ov        # plain relative where the sum does not cancel
+        small = ref.abs() < 0.1 * T * d
+        if bool(small.any()):
+            assert float(err[small].max()) <= 2.0 * float(err[~small].max()), ov
