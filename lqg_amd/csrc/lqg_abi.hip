@@ -673,10 +673,10 @@ int lqg_grad_supported(int32_t dtype, const lqg_dims* dims) {
   return coop_adjoint_supported(dtype, *dims);       // fp64, any x, b <= 64 with u, y, d <= 4 (lqg_coop_adjoint.hip)
 }
 
-// tuning.reserved[0] == 1 ("coop_adjoint"): the cooperative sweep also for shapes WITH adjoint lane kernels (fp64 problems;
+// tuning.coop_adjoint == 1: the cooperative sweep also for shapes WITH adjoint lane kernels (fp64 problems;
 // tests pin it against the lane kernels on every golden case)
 static bool adjoint_on_lanes(const lqg_problem* p) {
-  return has_adjoint_lane(p->dims) && !(p->tuning.reserved[0] == 1 && coop_adjoint_supported(p->dtype, p->dims));
+  return has_adjoint_lane(p->dims) && !(p->tuning.coop_adjoint == 1 && coop_adjoint_supported(p->dtype, p->dims));
 }
 
 int32_t lqg_grad_lanes_per_system(const lqg_problem* p) {

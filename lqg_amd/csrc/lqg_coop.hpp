@@ -892,9 +892,49 @@ struct TrialChunkRT {
   double* part;      // [sys][n_chunks][n_trials]
 };
 
+// Row lists of the mean-update block (Fj - I) of a system's operator stream: column k of row i is listed when the entry is
+// non-zero at ANY step (the union over the horizon: the walk below stays exact for gains whose entries vanish at some steps).
+// The delay augmentations' joint dynamics are shift-structured — DelayedSubjectiveActor (m = 65): 9 % of the 4225 entries —
+// and the dense update was the bulk of a candidate batch (4096 candidates x 120 trials: 582 of 784 ms).  Layout per
+// system: count[m] | columns[m][m] | flag (1: lists pay, i.e. fewer than half of the entries are listed).
+// Two kernels: k_coop_trial_flags (grid: systems x slices of the horizon; flag = 1 where an entry is non-zero at a step of the
+// slice, plain stores of the same value into the ZEROED columns area) and k_coop_trial_lists (one workgroup per system: every
+// row's flags compacted in place into its column list).
+template <typename R, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_coop_trial_flags(const R* __restrict__ ops_all, unsigned char* lists_all, long lists_stride,
+                                                            int T, int m, int nops, int steps_per_slice) {
+  const long sys = blockIdx.x;
+  const int t_lo = (int)blockIdx.y * steps_per_slice, t_hi = t_lo + steps_per_slice < T ? t_lo + steps_per_slice : T;
+  const R* __restrict__ op = ops_all + sys * (long)(T + 1) * nops;
+  unsigned char* flags = lists_all + sys * lists_stride + m;
+  for (int e = threadIdx.x; e < m * m; e += BLOCK) {
+    bool nz = false;
+    for (int t = t_lo; t < t_hi; ++t) nz |= op[(long)t * nops + e] != R(0);          // (a NaN entry counts as non-zero)
+    if (nz) flags[e] = 1;
+  }
+}
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_coop_trial_lists(unsigned char* lists_all, long lists_stride, int m) {
+  __shared__ int total;
+  unsigned char* out = lists_all + (long)blockIdx.x * lists_stride;
+  if (threadIdx.x == 0) total = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < m; i += BLOCK) {
+    unsigned char* ix = out + m + (long)i * m;                                        // flags in, columns out (n <= k: in place)
+    int n = 0;
+    for (int k = 0; k < m; ++k)
+      if (ix[k]) ix[n++] = (unsigned char)k;
+    out[i] = (unsigned char)n;
+    atomicAdd(&total, n);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) out[m + (long)m * m] = (2 * total < m * m) ? 1 : 0;
+}
+
 template <typename R, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) k_coop_trial_rows(const R* __restrict__ ops_all, const TrialArgsRT<R> a, const int tpb,
-                                                           const TrialChunkRT<R> ch) {
+                                                           const TrialChunkRT<R> ch, const unsigned char* __restrict__ lists_all,
+                                                           const long lists_stride) {
   extern __shared__ double lqg_coop_smem[];
   constexpr int MAXO = 6, MAXPF = 24;                        // d <= 6 (coop_supported); operator reals per thread per step
   const int m = a.m, o = a.d, rr = m - a.d, tid = threadIdx.x, nops = a.nops;
@@ -914,6 +954,16 @@ __global__ void __launch_bounds__(BLOCK) k_coop_trial_rows(const R* __restrict__
   R* opb[2] = {sm, sm + nops};
   R* cv = sm + 2 * nops + (long)g * 2 * m;                   // [x_t ; c] of this group's trial
   R* st = cv + m;                                            // state: dO (o) | muR (rr)
+  // row lists of the mean-update block (k_coop_trial_lists), behind the trials' vectors; absent or not worth it: dense rows
+  unsigned char* lcnt = reinterpret_cast<unsigned char*>(sm + 2 * nops + (long)tpb * 2 * m);
+  unsigned char* lidx = lcnt + m;
+  bool listed = false;
+  if (lists_all) {
+    const unsigned char* __restrict__ ls = lists_all + sys * lists_stride;
+    listed = ls[m + (long)m * m] != 0;                       // (workgroup-uniform)
+    if (listed)
+      for (int e = tid; e < m + m * m; e += BLOCK) lcnt[e] = ls[e];
+  }
   const int U_OFF = m * m, L_OFF = U_OFF + rr * o, H_OFF = L_OFF + o * (o + 1) / 2;
   const R* op = ops_all + (sys * (long)(a.T + 1) + t0) * nops;
   const R* xr = a.x.p + sys * a.x.sb + n * a.x.sn;
@@ -982,14 +1032,28 @@ __global__ void __launch_bounds__(BLOCK) k_coop_trial_rows(const R* __restrict__
       for (int i = r; i < m; i += RT) {
         const R* __restrict__ fr = ob + (long)i * m;
         R v0 = R(0), v1 = R(0), v2 = R(0), v3 = R(0);
-        int j = 0;
-        for (; j + 3 < m; j += 4) {
-          v0 += fr[j] * cv[j];
-          v1 += fr[j + 1] * cv[j + 1];
-          v2 += fr[j + 2] * cv[j + 2];
-          v3 += fr[j + 3] * cv[j + 3];
+        if (listed) {
+          const unsigned char* __restrict__ ix = lidx + i * m;
+          const int nn = lcnt[i];
+          int q = 0;
+          for (; q + 3 < nn; q += 4) {
+            const int k0 = ix[q], k1 = ix[q + 1], k2 = ix[q + 2], k3 = ix[q + 3];
+            v0 += fr[k0] * cv[k0];
+            v1 += fr[k1] * cv[k1];
+            v2 += fr[k2] * cv[k2];
+            v3 += fr[k3] * cv[k3];
+          }
+          for (; q < nn; ++q) { const int k = ix[q]; v0 += fr[k] * cv[k]; }
+        } else {
+          int j = 0;
+          for (; j + 3 < m; j += 4) {
+            v0 += fr[j] * cv[j];
+            v1 += fr[j + 1] * cv[j + 1];
+            v2 += fr[j + 2] * cv[j + 2];
+            v3 += fr[j + 3] * cv[j + 3];
+          }
+          for (; j < m; ++j) v0 += fr[j] * cv[j];
         }
-        for (; j < m; ++j) v0 += fr[j] * cv[j];
         const R mn = (v0 + v1) + (v2 + v3);
         const R ns = i < o ? mn : cv[i] + mn;
         st[i] = ns;

@@ -228,47 +228,78 @@ hipError_t coop_trial(const lqg_problem* p, const void* ops, lqg_traj x, lqg_tra
   coop::TrialArgsRT<R> k{dt<R>(x), dt<R>(mu), static_cast<R*>(ll), ll_sb, ll_sn, (long)p->n_trials, p->T, m, o,
                          (int)ops_reals(p->dims)};
   // large joint dimension: a group of threads per trial splits the rows of the mean update (k_coop_trial_rows); trials
-  // per block: the smallest power of two that keeps the grid within ~2048 workgroups, at most 16 (>= 16 threads per trial)
+  // per block: the smallest power of two that keeps the grid within ~2048 workgroups, at most 64 and what LDS holds —
+  // and, while a trial's group would have more threads than the update has rows, twice as many again: every workgroup streams
+  // the whole operator block of every step (m^2 reals: 35 KB at m = 65 in fp64), so trials that share a block share that
+  // traffic (13 delay-12 systems x 50 trials: 650 workgroups of one trial, 65 of 256 threads busy, 5.0 ms -> 325 of two)
   {
     constexpr int BR = 256, MAXPF = 24;
     const int nops = (int)ops_reals(p->dims);
-    int tpb = 1;
-    while (tpb < 16 && (long)p->n_sys * ((p->n_trials + tpb - 1) / tpb) > 2048) tpb *= 2;
-    const size_t lds_r = ((size_t)2 * nops + (size_t)tpb * 2 * m) * sizeof(R);
+    const size_t lists_lds = ((size_t)m + (size_t)m * m + 7) / 8 * 8;
+    auto rows_lds = [&](int t) { return ((size_t)2 * nops + (size_t)t * 2 * m) * sizeof(R) + lists_lds; };
+    // most trials per workgroup: 64 (measured, delay-12 model, per-trial sweep in ms at a cap of 16 / 32 / 64 / 128 — 4096 candidates x
+    // 120 trials fp32: 135 / 135 / 108 / 172; 512 x 120 fp64: 47.5 / 33 / 33 / 33; smaller batches never reach the cap:
+    // scripts/coop_trial_tpb.py)
+    const int cap = p->tuning.coop_trial_tpb > 0 ? p->tuning.coop_trial_tpb : 64;
+    auto trials_per_block = [&](long groups_of_one, long trials) {
+      int t = 1;
+      while (t < cap && rows_lds(2 * t) <= kLdsLimit && (groups_of_one / t > 2048 || (2L * t <= trials && BR / (2 * t) >= m))) t *= 2;
+      return t;
+    };
+    const int tpb = trials_per_block((long)p->n_sys * p->n_trials, p->n_trials);
+    // (LDS: two operator blocks, the trials' vectors, the row lists of the mean-update block: m + m^2 bytes)
+    const size_t lds_r = rows_lds(tpb);
     const bool rows_off = p->tuning.coop_trial_rows < 0;
     if (!rows_off && m >= 16 && o <= 6 && (nops + BR - 1) / BR <= MAXPF && lds_r <= kLdsLimit) {
       auto kr = coop::k_coop_trial_rows<R, BR>;
       hipError_t er = raise_lds(kr, lds_r);
       if (er != hipSuccess) return er;
-      // time-chunked (few trials, long horizon, log-likelihood only): the scratch follows the operator stream (carve(), scan_plan())
+      // the scratch of this sweep follows the operator stream (carve(), scan_plan()): chunk states, then the row lists
+      const TrialChunkScratch sc = trial_chunk_scratch(p);
+      const size_t ops_bytes = ((size_t)p->n_sys * (size_t)(p->T + 1) * (size_t)nops * sizeof(R) + 255) / 256 * 256;
+      char* base = const_cast<char*>(static_cast<const char*>(ops)) + ops_bytes;
+      // run-time sparsity of the mean update (delay augmentations: 9 % of m^2): listed once per call from the whole stream
+      const long lists_stride = (long)trial_row_lists_bytes(p->dims);
+      unsigned char* lists = nullptr;
+      if (lists_stride > 0 && p->tuning.coop_sparse >= 0 && p->T >= 1) {
+        lists = reinterpret_cast<unsigned char*>(base + sc.lists_off);
+        er = hipMemsetAsync(lists, 0, (size_t)p->n_sys * (size_t)lists_stride, st);
+        if (er != hipSuccess) return er;
+        // (the horizon in slices while the systems alone leave the chip empty: one system of T = 500 in 63 slices of 8 steps)
+        long slices = 2048 / (long)p->n_sys;
+        slices = slices < 1 ? 1 : slices > (p->T + 7) / 8 ? (p->T + 7) / 8 : slices;
+        const int per = (int)((p->T + slices - 1) / slices);
+        hipLaunchKernelGGL((coop::k_coop_trial_flags<R, BR>), dim3((unsigned)p->n_sys, (unsigned)((p->T + per - 1) / per)), dim3(BR), 0, st,
+                           static_cast<const R*>(ops), lists, lists_stride, p->T, m, nops, per);
+        hipLaunchKernelGGL((coop::k_coop_trial_lists<128>), dim3((unsigned)p->n_sys), dim3(128), 0, st, lists, lists_stride, m);
+      }
+      // time-chunked (few trials, long horizon, log-likelihood only)
       const int nc = m > kLaneTrialMaxJoint ? trial_chunks(p) : 1;
       if (nc > 1 && ll && !mu.ptr) {
-        const TrialChunkScratch sc = trial_chunk_scratch(p);
-        const size_t ops_bytes = ((size_t)p->n_sys * (size_t)(p->T + 1) * (size_t)nops * sizeof(R) + 255) / 256 * 256;
-        char* base = const_cast<char*>(static_cast<const char*>(ops)) + ops_bytes;
         coop::TrialChunkRT<R> ch{1, nc, trial_chunk_len(p, nc), reinterpret_cast<R*>(base + sc.state_off),
                                  reinterpret_cast<R*>(base + sc.phi_off), reinterpret_cast<double*>(base + sc.part_off)};
-        int tz = 1;                                          // trials per block of the chunked passes (same rule, their grids)
-        while (tz < 16 && (long)p->n_sys * (nc - 1) * ((p->n_trials + m + tz - 1) / tz) > 2048) tz *= 2;
-        const size_t lds_z = ((size_t)2 * nops + (size_t)tz * 2 * m) * sizeof(R);
+        // trials per block of the chunked passes (same rule, their grids)
+        const int tz = trials_per_block((long)p->n_sys * (nc - 1) * (p->n_trials + m), p->n_trials + m);
+        const size_t lds_z = rows_lds(tz);
         er = raise_lds(kr, lds_z > lds_r ? lds_z : lds_r);
         if (er != hipSuccess) return er;
         const R* o_ = static_cast<const R*>(ops);
         hipLaunchKernelGGL(kr, dim3((unsigned)((p->n_trials + m + tz - 1) / tz), (unsigned)p->n_sys, (unsigned)(nc - 1)), dim3(BR),
-                           lds_z, st, o_, k, tz, ch);
+                           lds_z, st, o_, k, tz, ch, lists, lists_stride);
         if (nc > 2)
           hipLaunchKernelGGL(coop::k_coop_trial_fix<R>, dim3((unsigned)p->n_trials, (unsigned)p->n_sys), dim3(128),
                              (size_t)2 * m * sizeof(R), st, static_cast<const R*>(ch.phi), ch.state, (long)p->n_trials, nc - 1, m);
         ch.mode = 2;
         hipLaunchKernelGGL(kr, dim3((unsigned)((p->n_trials + tz - 1) / tz), (unsigned)p->n_sys, (unsigned)nc), dim3(BR), lds_z, st,
-                           o_, k, tz, ch);
+                           o_, k, tz, ch, lists, lists_stride);
         hipLaunchKernelGGL((lqg::k_trial_sum<R>), dim3((unsigned)((p->n_trials + LQG_BLOCK - 1) / LQG_BLOCK), (unsigned)p->n_sys),
                            dim3(LQG_BLOCK), 0, st, static_cast<const double*>(ch.part), static_cast<R*>(ll), ll_sb, ll_sn,
                            (long)p->n_trials, nc);
         return hipGetLastError();
       }
       const dim3 gr((unsigned)((p->n_trials + tpb - 1) / tpb), (unsigned)p->n_sys);
-      hipLaunchKernelGGL(kr, gr, dim3(BR), lds_r, st, static_cast<const R*>(ops), k, tpb, coop::TrialChunkRT<R>{0, 1, 0, nullptr, nullptr, nullptr});
+      hipLaunchKernelGGL(kr, gr, dim3(BR), lds_r, st, static_cast<const R*>(ops), k, tpb, coop::TrialChunkRT<R>{0, 1, 0, nullptr, nullptr, nullptr},
+                         lists, lists_stride);
       return hipGetLastError();
     }
   }

@@ -19,6 +19,10 @@
 //   moments : the same Kalman construction on the joint (state, belief) system F_j[t], G_j[t] G_j[t]' with the first d
 //             components observed exactly (H = [I_d 0], no observation noise); the prefix products' C are the
 //             conditional covariances, from which Sigma_t = F_j C F_j' + G_j G_j'.
+// Order of the levels: Hillis-Steele (log2 T levels of T combines, ping-pong buffers) while a level fits the chip — the scans of
+// small windows are bound by launches and latency, not by work; the windows of 25 .. 64 (one 1024-lane workgroup per combine, 256
+// in flight) run the WORK-EFFICIENT Brent-Kung order in place once a level would need more than one round (run_scan,
+// lqg_scan_inst.hip): ~2 T combines in 2 log2 T - 2 levels.
 // Everything between the scans is independent per step and runs as one wave per (system, step): gains L_t from S_{t+1},
 // K_t from P_{t-1|t-1}, the joint system, and finally the per-step trial operators (the same stream k_trial reads).
 // Arithmetic is fp64 whatever the problem dtype (there are few systems: the cost is irrelevant, and the fp32 operator
@@ -71,11 +75,15 @@ LQG_DEV void mm_sym(D* c, int n, int K, const D* a, int ars, int acs, const D* b
 // Elements live in global memory as [system][index][A | C | J] (3 n^2 doubles).  Level d of Hillis-Steele:
 //   prefix (left = 0): out[k] = in[k-d] (x) in[k]      suffix stored in reversed order (left = 1): out[k] = in[k] (x) in[k-d]
 // One launch serves up to two independent scans of the same n (the Riccati and the Kalman scan run side by side).
+// k_scan_level_rt also serves the levels of a WORK-EFFICIENT (Brent-Kung) scan run IN PLACE (in == out): a level combines only the
+// elements k = k0 + i ks, i < cnt (cnt < 0: every element, the Hillis-Steele level above).
 struct Seg {
   const D* in;
   D* out;
   int len, d, left;
+  int k0 = 0, ks = 1, cnt = -1;
 };
+__host__ __device__ inline int seg_count(const Seg& s) { return s.cnt < 0 ? s.len : s.cnt; }
 
 template <int NT, typename F>
 LQG_DEV void each_t(int n, F f) {
@@ -406,17 +414,20 @@ __global__ void __launch_bounds__(NW * 64, LQG_SCAN_RT_WGS_PER_CU * NW / 4) k_sc
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nn = n * n, ld = n | 1, panel = n * (n + 1);              // (odd leading dimension: transposed reads conflict-free)
   int k = (int)blockIdx.x;
-  const bool second = k >= s0.len;
-  if (second) k -= s0.len;
+  const int c0 = seg_count(s0);
+  const bool second = k >= c0;
+  if (second) k -= c0;
   const D* in = second ? s1.in : s0.in;
   D* out = second ? s1.out : s0.out;
   const int len = second ? s1.len : s0.len, d = second ? s1.d : s0.d, left = second ? s1.left : s0.left;
+  k = (second ? s1.k0 : s0.k0) + k * (second ? s1.ks : s0.ks);        // (the element this workgroup produces)
   const long sys = blockIdx.y;
   const long es = 3L * nn;
   const D* ek = in + (sys * len + k) * es;
   D* eo = out + (sys * len + k) * es;
   if (k < d) {                                                        // (workgroup-uniform: no barrier is skipped by a part of it)
-    for (int e = tid; e < 3 * nn; e += NT) eo[e] = ek[e];
+    if (eo != ek)
+      for (int e = tid; e < 3 * nn; e += NT) eo[e] = ek[e];
     return;
   }
   const D* ep = in + (sys * len + (k - d)) * es;
@@ -437,6 +448,9 @@ __global__ void __launch_bounds__(NW * 64, LQG_SCAN_RT_WGS_PER_CU * NW / 4) k_sc
       f(TileIdx{ti * 16, (tile - ti * nt) * 16, lane & 15, lane >> 4});
     }
   };
+  // a wave owns at most KEEP tiles of a product — nwv = ceil(n / TI) waves over ceil(n / 16)^2 tiles: 2 at TI = 4, 3 at TI = 8
+  // (n = 49 .. 56)
+  constexpr int KEEP = NW >= 16 ? 2 : 3;
   // D(4 r + g, li) of a tile -> dst(row, col)
   auto scatter = [&](const TileIdx& t, const mfma_acc_t& acc, auto put) {
     LQG_UNROLL for (int r = 0; r < 4; ++r) {
@@ -532,17 +546,23 @@ __global__ void __launch_bounds__(NW * 64, LQG_SCAN_RT_WGS_PER_CU * NW / 4) k_sc
   __syncthreads();
   LQG_SSTAMP(6);
   // ---- A = A2 X1 (out), T1 = A2 X2 -> P2 (rows padded to ld), U = J2 X1 -> P3
+  // (A stays in registers until every read of the operands is behind a barrier: the level may run in place, out == in)
+  mfma_acc_t keepA[KEEP];
   with_q([&](auto qc) {
     constexpr int Q = decltype(qc)::value;
     const MatView mX1{P0, n, 1, n}, mX2{P1, n, 1, n};
-    tiles([&](const TileIdx& t) {
-      mfma_acc_t aA, aT;
-      mfma_tile2<Q>(t, mA2, mX1, mX2, aA, aT);
-      const mfma_acc_t aU = mfma_tile<Q>(t, mJ2, mX1);
-      scatter(t, aA, [&](int i, int j, D v) { eo[i * n + j] = v; });
-      scatter(t, aT, [&](int i, int j, D v) { P2[i * ld + j] = v; });
-      scatter(t, aU, [&](int i, int j, D v) { P3[i * n + j] = v; });
-    });
+    LQG_UNROLL for (int it = 0; it < KEEP; ++it) {
+      const int tile = w + it * nwv;
+      if (tile < nt * nt) {
+        const int ti = tile / nt;
+        const TileIdx t{ti * 16, (tile - ti * nt) * 16, lane & 15, lane >> 4};
+        mfma_acc_t aT;
+        mfma_tile2<Q>(t, mA2, mX1, mX2, keepA[it], aT);
+        const mfma_acc_t aU = mfma_tile<Q>(t, mJ2, mX1);
+        scatter(t, aT, [&](int i, int j, D v) { P2[i * ld + j] = v; });
+        scatter(t, aU, [&](int i, int j, D v) { P3[i * n + j] = v; });
+      }
+    }
   });
   __syncthreads();                                                    // (X1, X2 dead)
   LQG_SSTAMP(7);
@@ -559,17 +579,27 @@ __global__ void __launch_bounds__(NW * 64, LQG_SCAN_RT_WGS_PER_CU * NW / 4) k_sc
   });
   __syncthreads();
   LQG_SSTAMP(8);
-  // ---- the mirror entries of C and J are averaged (C2, J1 are exactly symmetric: they were made so)
+  // ---- the mirror entries of C and J are averaged (C2, J1 are exactly symmetric: they were made so).  In place, C2 or J1 IS the
+  // entry being overwritten: read and written by the same lane.  A: no operand is read after the barrier above.
   LQG_UNROLL for (int r = 0; r < TI; ++r) {
     const int a = w * TI + r;
     if (a < n && lv) {
-      eo[nn + a * n + lane] = 0.5 * (P0[a * ld + lane] + P0[lane * ld + a]) + C2[a * n + lane];
-      eo[2 * nn + a * n + lane] = 0.5 * (P1[a * ld + lane] + P1[lane * ld + a]) + J1[a * n + lane];
+      const D c2 = C2[a * n + lane], j1 = J1[a * n + lane];
+      eo[nn + a * n + lane] = 0.5 * (P0[a * ld + lane] + P0[lane * ld + a]) + c2;
+      eo[2 * nn + a * n + lane] = 0.5 * (P1[a * ld + lane] + P1[lane * ld + a]) + j1;
+    }
+  }
+  LQG_UNROLL for (int it = 0; it < KEEP; ++it) {
+    const int tile = w + it * nwv;
+    if (tile < nt * nt) {
+      const int ti = tile / nt;
+      scatter(TileIdx{ti * 16, (tile - ti * nt) * 16, lane & 15, lane >> 4}, keepA[it], [&](int i, int j, D v) { eo[i * n + j] = v; });
     }
   }
   LQG_SSTAMP(9);
 }
 constexpr int kScanRtMax = 64;            // largest window of k_scan_level_rt (one lane per column)
+constexpr long kScanRtConcurrent = 256;   // combines of k_scan_level_rt in flight on the chip: one workgroup per CU
 inline size_t scan_level_rt_lds(int n) { return (size_t)(4 * n * (n + 1) + 128 + 192 + 192 + 64) * sizeof(D); }
 inline int scan_level_rt_threads(int n, int nw) { const int ti = 64 / nw; return (n + ti - 1) / ti * 64; }
 

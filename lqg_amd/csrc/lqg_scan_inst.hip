@@ -63,7 +63,8 @@ void launch_level_rt_v(const scan::Seg& s0, const scan::Seg& s1, int n, long n_s
   auto kern = scan::k_scan_level_rt<NW>;
   const size_t lds = scan::scan_level_rt_lds(n);
   (void)raise_lds_once(reinterpret_cast<const void*>(kern), lds);
-  hipLaunchKernelGGL(kern, dim3((unsigned)(s0.len + s1.len), (unsigned)n_sys), dim3(scan::scan_level_rt_threads(n, NW)), lds, st, s0, s1, n);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(scan::seg_count(s0) + scan::seg_count(s1)), (unsigned)n_sys),
+                     dim3(scan::scan_level_rt_threads(n, NW)), lds, st, s0, s1, n);
 }
 void launch_level_rt(const scan::Seg& s0, const scan::Seg& s1, int n, long n_sys, const lqg_tuning& tune, hipStream_t st) {
   // 16 waves per window (4 rows each): the elimination is bound by its two barriers and LDS round trips per column, not by
@@ -96,6 +97,33 @@ void run_scan(int n, int nseg, D* const in[2], D* const out[2], const int len[2]
     else go(scan::k_scan_lane<3, 512>);
     res[0] = b[0];
     res[1] = b[1];
+    return;
+  }
+  // Windows of 25 .. 64 with more combines per Hillis-Steele level than the chip runs at once (one 1024-lane workgroup per CU):
+  // the WORK-EFFICIENT order (Brent-Kung, in place) — ~2 len combines in 2 log2(len) - 2 levels instead of len log2(len) in
+  // log2(len).  A level's time is its number of ROUNDS of 256 concurrent combines: one delay-12 system (501 + 500 windows of 39,
+  // then 500 of 63) 54 -> 34 rounds, thirteen systems (central differences over six parameters) 690 -> ~170.
+  // tuning.scan_order: 0 = this rule, 1 = always, -1 = never.
+  const int bk_mode = tune.scan_order;
+  if (n > 24 && bk_mode >= 0 && (bk_mode > 0 || n_sys * (long)(len[0] + l1) > scan::kScanRtConcurrent)) {
+    auto level = [&](int d, bool down) {
+      scan::Seg s[2];
+      int total = 0;
+      for (int i = 0; i < 2; ++i) {
+        const int li = i == 0 ? len[0] : l1;
+        s[i] = scan::Seg{a[i], a[i], li, d, i == 0 ? left[0] : (nseg > 1 ? left[1] : 0)};
+        s[i].ks = 2 * d;
+        s[i].k0 = (down ? 3 : 2) * d - 1;
+        s[i].cnt = down ? (li > d ? (li - d) / (2 * d) : 0) : li / (2 * d);
+        total += s[i].cnt;
+      }
+      if (total > 0) launch_level_rt(s[0], s[1], n, n_sys, tune, st);
+    };
+    int d = 1;
+    for (; 2 * d <= longest; d *= 2) level(d, false);                 // up-sweep: blocks of 2 d ending at k = 2 d - 1 (mod 2 d)
+    for (d /= 2; d >= 1; d /= 2) level(d, true);                      // down-sweep: k = 3 d - 1 (mod 2 d) takes the prefix before its block
+    res[0] = a[0];
+    res[1] = a[1];
     return;
   }
   for (int d = 1; d < longest; d *= 2) {

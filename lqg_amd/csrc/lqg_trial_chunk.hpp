@@ -290,20 +290,29 @@ inline int trial_chunks(const lqg_problem* p) {
 }
 inline int trial_chunk_len(const lqg_problem* p, int n_chunks) { return (p->T + n_chunks - 1) / n_chunks; }
 
+// bytes per system of the row lists of the operator's mean-update block (large joint dimensions, k_coop_trial_rows): count per
+// row | columns per row | one flag byte (lists in use), lqg_coop.hpp k_coop_trial_lists
+inline size_t trial_row_lists_bytes(const lqg_dims& d) {
+  const size_t m = (size_t)(d.x + d.b);
+  return m > (size_t)kLaneTrialMaxJoint ? (m + m * m + 1 + 15) / 16 * 16 : 0;
+}
 struct TrialChunkScratch {
-  size_t state_off, phi_off, part_off, total;
+  size_t state_off, phi_off, part_off, lists_off, total;
 };
 inline TrialChunkScratch trial_chunk_scratch(const lqg_problem* p) {
   TrialChunkScratch s{};
-  const int nc = trial_chunks(p);
-  if (nc <= 1) return s;
-  const size_t esz = p->dtype == LQG_F64 ? 8 : 4;
-  const size_t m = (size_t)(p->dims.x + p->dims.b), B = (size_t)p->n_sys, N = (size_t)p->n_trials;
   auto al = [](size_t v) { return (v + 255) / 256 * 256; };
-  s.state_off = 0;
-  s.phi_off = al(B * (nc - 1) * m * N * esz);
-  s.part_off = s.phi_off + al(B * (nc - 1) * m * m * esz);
-  s.total = s.part_off + al(B * nc * N * sizeof(double));
+  const int nc = trial_chunks(p);
+  if (nc > 1) {
+    const size_t esz = p->dtype == LQG_F64 ? 8 : 4;
+    const size_t m = (size_t)(p->dims.x + p->dims.b), B = (size_t)p->n_sys, N = (size_t)p->n_trials;
+    s.state_off = 0;
+    s.phi_off = al(B * (nc - 1) * m * N * esz);
+    s.part_off = s.phi_off + al(B * (nc - 1) * m * m * esz);
+    s.total = s.part_off + al(B * nc * N * sizeof(double));
+  }
+  s.lists_off = s.total;
+  s.total += al((size_t)p->n_sys * trial_row_lists_bytes(p->dims));
   return s;
 }
 

@@ -17,11 +17,13 @@ SCAN_MIN_STEPS    0         horizon from which it does (0: plan.scan_min_steps(m
 SCAN_MAX_COND     1e7       cond((V V')[:d, :d]) above which the default rule keeps the sequential sweeps
 SCAN_LANE         1         one-launch scans of 1x1 .. 3x3 windows (0: one launch per level)          -> tuning.scan_lane
 SCAN_RT_WAVES     0         waves per window of k_scan_level_rt (0 = 16; 8)                           -> tuning.scan_rt_waves
+SCAN_ORDER        ""        scans over windows of 25 .. 64: "" rule, "1" work-efficient (Brent-Kung) levels always, "0" Hillis-Steele -> tuning.scan_order
 COOP              ""        "" default rule, "1" cooperative kernels wherever supported, "0" never    -> tuning.coop
 COOP_SPARSE       1         run-time sparsity lists of the cooperative sweeps                         -> tuning.coop_sparse
 COOP_TRIAL_ROWS   1         row-parallel per-trial sweep of large joint dimensions                    -> tuning.coop_trial_rows
+COOP_TRIAL_TPB    0         most trials per workgroup of that sweep (0: the rule of coop_trial(); a power of two <= 128)  -> tuning.coop_trial_tpb
 COOP_TRIAL_CHUNKS ""        its cut along time: "" rule, "0" / "1" one pass, k chunks                  -> tuning.coop_trial_chunks
-COOP_ADJOINT      0         1: the cooperative reverse-mode sweep also for shapes with adjoint lane kernels -> tuning.reserved[0]
+COOP_ADJOINT      0         1: the cooperative reverse-mode sweep also for shapes with adjoint lane kernels -> tuning.coop_adjoint
 TRIAL_CHUNKS      ""        lane per-trial sweep cut along time: "" rule, "0" / "1" one pass, k chunks -> tuning.trial_chunks
 TRIAL_CHUNK_WAVES / TRIAL_CHUNK_MAX_WAVES / TRIAL_CHUNK_TPL   0   parameters of that rule             -> tuning.trial_chunk_*
 FUSE_TRIALS_MAX   2048      (system, trial) pairs up to which a small multi-trial evaluation runs as fused pairs (0: never)
@@ -44,8 +46,8 @@ import contextlib
 import os
 
 DEFAULTS = {
-    "SCAN": "", "SCAN_MAX_SYSTEMS": 0, "SCAN_MIN_STEPS": 0, "SCAN_MAX_COND": 1e7, "SCAN_LANE": 1, "SCAN_RT_WAVES": 0,
-    "COOP": "", "COOP_SPARSE": 1, "COOP_TRIAL_ROWS": 1, "COOP_TRIAL_CHUNKS": "", "COOP_ADJOINT": 0, "TRIAL_CHUNKS": "", "TRIAL_CHUNK_WAVES": 0,
+    "SCAN": "", "SCAN_MAX_SYSTEMS": 0, "SCAN_MIN_STEPS": 0, "SCAN_MAX_COND": 1e7, "SCAN_LANE": 1, "SCAN_RT_WAVES": 0, "SCAN_ORDER": "",
+    "COOP": "", "COOP_SPARSE": 1, "COOP_TRIAL_ROWS": 1, "COOP_TRIAL_TPB": 0, "COOP_TRIAL_CHUNKS": "", "COOP_ADJOINT": 0, "TRIAL_CHUNKS": "", "TRIAL_CHUNK_WAVES": 0,
     "TRIAL_CHUNK_MAX_WAVES": 0, "TRIAL_CHUNK_TPL": 0, "FUSE_TRIALS_MAX": 2048, "MIXED": 1, "MIXED_MIN_TRIALS": 3,
     "F32_WIDE": 1, "F32_MAX_COND": 1e7, "NO_SPECIALIZE": 0, "NO_DECOUPLE": 0, "NO_MERGE": 0, "GRAPH": 1, "GRAPH_AFFINE": 1,
     "SETUP_KERNEL": 1, "JIT": 1,
@@ -129,5 +131,7 @@ def fill_tuning(t):
     t.coop_sparse = 0 if flag("COOP_SPARSE") else -1
     t.scan_lane = 0 if flag("SCAN_LANE") else -1
     t.scan_rt_waves = get("SCAN_RT_WAVES")
-    t.reserved[0] = 1 if flag("COOP_ADJOINT") else 0
+    t.coop_adjoint = 1 if flag("COOP_ADJOINT") else 0
+    t.scan_order = _tri("SCAN_ORDER")
+    t.coop_trial_tpb = get("COOP_TRIAL_TPB")
     return t

@@ -129,6 +129,34 @@ def test_time_chunked_row_parallel_sweep_equals_the_one_pass_sweep(dtype, tol, m
                 assert float((got / ref[:, :n] - 1).abs().max()) < tol, (scan, chunks, n)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 2e-6)], ids=["f64", "f32"])
+def test_row_lists_of_the_mean_update_equal_the_dense_rows(dtype, tol, monkeypatch):
+    """k_coop_trial_rows walks the run-time row lists of the operator's mean-update block (k_coop_trial_lists: the union of the
+    non-zero columns over the horizon; 9 % of m^2 for the delay models): equal to the dense rows (LQG_COOP_SPARSE=0 — the terms
+    left out are exact zeros) in one pass, cut along time, with many trials per workgroup, and for the materialised means."""
+    from lqg_amd.plan import LogLikelihoodPlan
+    from lqg_amd.tracking.delay import DelayedSubjectiveActor
+    T = 150
+    sig = torch.tensor([5.0, 8.0, 13.0], dtype=dtype, device="cuda")
+    m = DelayedSubjectiveActor(T=T, sigma_target=sig, device="cuda", dtype=dtype)
+    with torch.no_grad():
+        x = m.simulate(3, n=70)[..., :2].contiguous()
+    monkeypatch.setenv("LQG_SCAN", "0")
+    for chunks, n in (("0", 70), ("0", 3), ("9", 5), ("9", 1)):
+        monkeypatch.setenv("LQG_COOP_TRIAL_CHUNKS", chunks)
+        xs = x[:, :n].contiguous()
+        monkeypatch.setenv("LQG_COOP_SPARSE", "0")
+        dense = LogLikelihoodPlan(m, xs).run().clone()
+        monkeypatch.setenv("LQG_COOP_SPARSE", "1")
+        got = LogLikelihoodPlan(m, xs).run().clone()
+        assert torch.isfinite(got).all() and float((got / dense - 1).abs().max()) < tol, (chunks, n)
+    monkeypatch.setenv("LQG_COOP_SPARSE", "0")
+    mu0, _ = m.conditional_moments(x[:, 0].contiguous())
+    monkeypatch.setenv("LQG_COOP_SPARSE", "1")
+    mu1, _ = m.conditional_moments(x[:, 0].contiguous())
+    assert float((mu1 - mu0).abs().max()) <= tol * float(mu0.abs().max())
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 2e-6)], ids=["f64", "f32"])
 @pytest.mark.parametrize("model", ["pointmass", "hand1d", "subjective2d"])
 def test_cooperative_and_lane_kernels_agree_on_a_batch(model, dtype, tol, monkeypatch):

@@ -38,18 +38,20 @@ def _delay12(dtype, T):
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
-@pytest.mark.parametrize("path", ["coop_one_pass", "coop_chunked", "scan_rt"])
+@pytest.mark.parametrize("path", ["coop_one_pass", "coop_chunked", "scan_rt", "scan_rt_in_place"])
 def test_delay12_m65_replays_are_bitwise_identical(path, dtype, monkeypatch):
     """The reference's largest model (x = 26, b = 39, m = 65): 1024-lane workgroups, hybrid LDS / L2 arena, run-time sparsity
     lists (sequential cooperative sweeps); windows of 39 / 63 in registers of 16 waves, DPP pivot search, fp64 MFMA products
-    (k_scan_level_rt); the row-parallel per-trial sweep in one pass and cut along time."""
+    (k_scan_level_rt), its levels ping-pong (Hillis-Steele) and IN PLACE (Brent-Kung: a workgroup overwrites one of its own
+    operands); the row-parallel per-trial sweep in one pass and cut along time."""
     from lqg_amd.plan import LogLikelihoodPlan
-    monkeypatch.setenv("LQG_SCAN", "1" if path == "scan_rt" else "0")
+    monkeypatch.setenv("LQG_SCAN", "1" if path.startswith("scan_rt") else "0")
+    monkeypatch.setenv("LQG_SCAN_ORDER", "1" if path == "scan_rt_in_place" else "0")
     monkeypatch.setenv("LQG_COOP_TRIAL_CHUNKS", "0" if path == "coop_one_pass" else "7")
     m, x = _delay12(dtype, 120)
     plan = LogLikelihoodPlan(m, x)
-    assert all(wk["scan"] == (path == "scan_rt") for wk in plan.work), plan.description
-    _replay(plan, REPS if path == "scan_rt" else 60)          # (the sequential sweeps of m = 65 cost ~5 ms per replay)
+    assert all(wk["scan"] == path.startswith("scan_rt") for wk in plan.work), plan.description
+    _replay(plan, REPS if path.startswith("scan_rt") else 60)          # (the sequential sweeps of m = 65 cost ~5 ms per replay)
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
