@@ -114,7 +114,8 @@ typedef struct lqg_tuning {
                                     a level holds more combines than the chip runs at once), 1 always, -1 Hillis-Steele    */
   int32_t coop_trial_tpb;        /* row-parallel per-trial sweep: most trials that share a workgroup (and its copy of the
                                     step's operator block): 0 rule, else a power of two <= 128                          */
-  int32_t reserved[3];           /* must be 0                                                                           */
+  int32_t coop_trial_wide;       /* that sweep on 1024-thread workgroups: 0 rule (at 128 trials per workgroup), 1 always, -1 never */
+  int32_t reserved[2];           /* must be 0                                                                           */
 } lqg_tuning;
 
 typedef struct lqg_problem {

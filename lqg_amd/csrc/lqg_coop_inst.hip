@@ -240,7 +240,10 @@ hipError_t coop_trial(const lqg_problem* p, const void* ops, lqg_traj x, lqg_tra
     // most trials per workgroup: 64 (measured, delay-12 model, per-trial sweep in ms at a cap of 16 / 32 / 64 / 128 — 4096 candidates x
     // 120 trials fp32: 135 / 135 / 108 / 172; 512 x 120 fp64: 47.5 / 33 / 33 / 33; smaller batches never reach the cap:
     // scripts/coop_trial_tpb.py)
-    const int cap = p->tuning.coop_trial_tpb > 0 ? p->tuning.coop_trial_tpb : 64;
+    // — and 128 on 1024-thread workgroups only where even 64 per workgroup leave more than ~4096 of them (4096 x 120: 108 -> 83 ms;
+    // on every smaller batch the wide workgroups lose: 512 x 120 17.1 -> 22.7 ms)
+    const long groups = (long)p->n_sys * p->n_trials;
+    const int cap = p->tuning.coop_trial_tpb > 0 ? p->tuning.coop_trial_tpb : (groups / 64 > 4096 ? 128 : 64);
     auto trials_per_block = [&](long groups_of_one, long trials) {
       int t = 1;
       while (t < cap && rows_lds(2 * t) <= kLdsLimit && (groups_of_one / t > 2048 || (2L * t <= trials && BR / (2 * t) >= m))) t *= 2;
@@ -298,6 +301,18 @@ hipError_t coop_trial(const lqg_problem* p, const void* ops, lqg_traj x, lqg_tra
         return hipGetLastError();
       }
       const dim3 gr((unsigned)((p->n_trials + tpb - 1) / tpb), (unsigned)p->n_sys);
+      // 128 trials per workgroup (the largest batches): the same sweep on 1024 threads — 8 instead of 2 threads per trial, four times
+      // the waves per SIMD behind the dependent LDS reads of the list walk
+      const int wide_mode = p->tuning.coop_trial_wide;               // 0 rule, 1 always, -1 never
+      if (wide_mode >= 0 && (wide_mode > 0 || tpb >= 128)) {
+        constexpr int BW = 1024;
+        auto kw = coop::k_coop_trial_rows<R, BW>;
+        er = raise_lds(kw, lds_r);
+        if (er != hipSuccess) return er;
+        hipLaunchKernelGGL(kw, gr, dim3(BW), lds_r, st, static_cast<const R*>(ops), k, tpb, coop::TrialChunkRT<R>{0, 1, 0, nullptr, nullptr, nullptr},
+                           lists, lists_stride);
+        return hipGetLastError();
+      }
       hipLaunchKernelGGL(kr, gr, dim3(BR), lds_r, st, static_cast<const R*>(ops), k, tpb, coop::TrialChunkRT<R>{0, 1, 0, nullptr, nullptr, nullptr},
                          lists, lists_stride);
       return hipGetLastError();

@@ -22,6 +22,7 @@ COOP              ""        "" default rule, "1" cooperative kernels wherever su
 COOP_SPARSE       1         run-time sparsity lists of the cooperative sweeps                         -> tuning.coop_sparse
 COOP_TRIAL_ROWS   1         row-parallel per-trial sweep of large joint dimensions                    -> tuning.coop_trial_rows
 COOP_TRIAL_TPB    0         most trials per workgroup of that sweep (0: the rule of coop_trial(); a power of two <= 128)  -> tuning.coop_trial_tpb
+COOP_TRIAL_WIDE   ""        that sweep on 1024-thread workgroups: "" rule (at 128 trials per workgroup), "1" always, "0" never -> tuning.coop_trial_wide
 COOP_TRIAL_CHUNKS ""        its cut along time: "" rule, "0" / "1" one pass, k chunks                  -> tuning.coop_trial_chunks
 COOP_ADJOINT      0         1: the cooperative reverse-mode sweep also for shapes with adjoint lane kernels -> tuning.coop_adjoint
 TRIAL_CHUNKS      ""        lane per-trial sweep cut along time: "" rule, "0" / "1" one pass, k chunks -> tuning.trial_chunks
@@ -47,7 +48,7 @@ import os
 
 DEFAULTS = {
     "SCAN": "", "SCAN_MAX_SYSTEMS": 0, "SCAN_MIN_STEPS": 0, "SCAN_MAX_COND": 1e7, "SCAN_LANE": 1, "SCAN_RT_WAVES": 0, "SCAN_ORDER": "",
-    "COOP": "", "COOP_SPARSE": 1, "COOP_TRIAL_ROWS": 1, "COOP_TRIAL_TPB": 0, "COOP_TRIAL_CHUNKS": "", "COOP_ADJOINT": 0, "TRIAL_CHUNKS": "", "TRIAL_CHUNK_WAVES": 0,
+    "COOP": "", "COOP_SPARSE": 1, "COOP_TRIAL_ROWS": 1, "COOP_TRIAL_TPB": 0, "COOP_TRIAL_WIDE": "", "COOP_TRIAL_CHUNKS": "", "COOP_ADJOINT": 0, "TRIAL_CHUNKS": "", "TRIAL_CHUNK_WAVES": 0,
     "TRIAL_CHUNK_MAX_WAVES": 0, "TRIAL_CHUNK_TPL": 0, "FUSE_TRIALS_MAX": 2048, "MIXED": 1, "MIXED_MIN_TRIALS": 3,
     "F32_WIDE": 1, "F32_MAX_COND": 1e7, "NO_SPECIALIZE": 0, "NO_DECOUPLE": 0, "NO_MERGE": 0, "GRAPH": 1, "GRAPH_AFFINE": 1,
     "SETUP_KERNEL": 1, "JIT": 1,
@@ -134,4 +135,5 @@ def fill_tuning(t):
     t.coop_adjoint = 1 if flag("COOP_ADJOINT") else 0
     t.scan_order = _tri("SCAN_ORDER")
     t.coop_trial_tpb = get("COOP_TRIAL_TPB")
+    t.coop_trial_wide = _tri("COOP_TRIAL_WIDE")
     return t

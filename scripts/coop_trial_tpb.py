@@ -1,5 +1,5 @@
-"""Row-parallel per-trial sweep of the delay model (k_coop_trial_rows, m = 65): most trials per workgroup (LQG_COOP_TRIAL_TPB) against
-the shape of the batch — every workgroup streams the step's whole operator block, trials that share a workgroup share that traffic."""
+"""Row-parallel per-trial sweep of the delay model (k_coop_trial_rows, m = 65): most trials per workgroup (LQG_COOP_TRIAL_TPB) and 256- against 1024-thread workgroups ("w")
+against the shape of the batch — every workgroup streams the step's whole operator block, trials that share a workgroup share that traffic."""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
@@ -16,8 +16,8 @@ for dtype in (torch.float32, torch.float64):
         x = DelayedSubjectiveActor(T=T, device=dev, dtype=dtype).simulate(3, n=n)[..., :2].contiguous()
         m = DelayedSubjectiveActor(T=T, device=dev, dtype=dtype, sigma_target=torch.linspace(4.0, 9.0, B, device=dev, dtype=dtype))
         row, ref = {}, None
-        for cap in (16, 32, 64, 128):
-            with options.override(SCAN="0", COOP_TRIAL_TPB=cap):
+        for cap, wide in ((16, "0"), (32, "0"), (64, "0"), (128, "0"), (32, "1"), (64, "1"), (128, "1")):
+            with options.override(SCAN="0", COOP_TRIAL_TPB=cap, COOP_TRIAL_WIDE=wide):
                 p = LogLikelihoodPlan(m, x, events=True)
                 out = p.run().clone()
                 reps = 1 if B > 512 else 3
@@ -27,7 +27,7 @@ for dtype in (torch.float32, torch.float64):
                     p.run()
                     torch.cuda.synchronize()
                     ms.append(p.phase_ms()[2])
-                row[cap] = min(ms)
+                row[(cap, wide)] = min(ms)
             ref = out if ref is None else ref
             assert float((out.double() / ref.double() - 1).abs().max()) < 1e-5
-        print(str(dtype)[6:], "systems", B, "trials", n, "per-trial sweep ms by cap:", " ".join("%d: %.3g" % kv for kv in row.items()), flush=True)
+        print(str(dtype)[6:], "systems", B, "trials", n, "per-trial sweep ms by cap:", " ".join("%d%s: %.3g" % (c, "w" if w == "1" else "", v) for (c, w), v in row.items()), flush=True)

@@ -210,3 +210,33 @@ def test_two_ranks_share_the_gpu_config3_trial_split():
     assert two["best_candidate"] == one["best_candidate"]
     assert abs(two["objective_checksum"] / one["objective_checksum"] - 1) < 1e-12
     assert abs(two["objective_max"] / one["objective_max"] - 1) < 1e-12
+
+
+def test_driver_launch_line_on_rccl_with_one_rank():
+    """The launch line the driver uses for N > 1 — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...` — at N = 1 on the one GPU there is: the process group comes up on the `nccl`
+    backend (= RCCL), the objective goes through a real all-reduce, and the line carries the collective fields the first
+    multi-GPU run will be read by (backend, ranks seen, all-reduce latency percentiles)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--log2-batch", "14", "--steps", "3",
+                        "--warmup", "1", "--no-extra", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["all_finite"] and out["value"] > 0
+    assert out["collective"]["backend"].startswith("nccl") and out["collective"]["rccl_ranks_seen"] == 1
+    assert out["parity"]["max_rel_err_vs_fp64_oracle"] < 1e-6
+    one = _run_bench("--log2-batch", "14", "--steps", "3", "--warmup", "1", "--no-extra", "--no-cpu-baseline")
+    assert abs(out["objective_sum"] / one["objective_sum"] - 1) < 1e-12
