@@ -51,8 +51,10 @@ int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %zu ", offsetof(lqg_problem, n_sys), offsetof(lqg_problem, dims),
          offsetof(lqg_problem, actor), offsetof(lqg_problem, dynamics), offsetof(lqg_problem, Sigma0),
          offsetof(lqg_problem, eps), offsetof(lqg_problem, phase_events));
-  printf("%zu %zu %zu %zu\n", sizeof(lqg_tuning), offsetof(lqg_problem, tuning), offsetof(lqg_tuning, coop_trial_chunks),
+  printf("%zu %zu %zu %zu ", sizeof(lqg_tuning), offsetof(lqg_problem, tuning), offsetof(lqg_tuning, coop_trial_chunks),
          offsetof(lqg_tuning, scan_rt_waves));
+  printf("%zu %zu %zu %zu %zu\n", offsetof(lqg_tuning, coop_adjoint), offsetof(lqg_tuning, scan_order), offsetof(lqg_tuning, coop_trial_tpb),
+         offsetof(lqg_tuning, coop_trial_wide), offsetof(lqg_tuning, reserved));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as td:
@@ -65,7 +67,8 @@ int main(void) {
     want = [C.sizeof(_abi.View), C.sizeof(_abi.Traj), C.sizeof(_abi.Spec), C.sizeof(_abi.Dims), C.sizeof(P),
             P.n_sys.offset, P.dims.offset, P.actor.offset, P.dynamics.offset, P.Sigma0.offset, P.eps.offset,
             P.phase_events.offset, C.sizeof(_abi.Tuning), P.tuning.offset, _abi.Tuning.coop_trial_chunks.offset,
-            _abi.Tuning.scan_rt_waves.offset]
+            _abi.Tuning.scan_rt_waves.offset, _abi.Tuning.coop_adjoint.offset, _abi.Tuning.scan_order.offset,
+            _abi.Tuning.coop_trial_tpb.offset, _abi.Tuning.coop_trial_wide.offset, _abi.Tuning.reserved.offset]
     assert got == want
 
 
