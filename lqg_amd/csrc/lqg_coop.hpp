@@ -936,7 +936,7 @@ __global__ void __launch_bounds__(BLOCK) k_coop_trial_rows(const R* __restrict__
                                                            const TrialChunkRT<R> ch, const unsigned char* __restrict__ lists_all,
                                                            const long lists_stride) {
   extern __shared__ double lqg_coop_smem[];
-  constexpr int MAXO = 6, MAXPF = 24;                        // d <= 6 (coop_supported); operator reals per thread per step
+  constexpr int MAXO = 6, MAXPF = 24 * 256 / BLOCK;          // d <= 6 (coop_supported); operator reals per thread per step (nops <= 6144)
   const int m = a.m, o = a.d, rr = m - a.d, tid = threadIdx.x, nops = a.nops;
   const int RT = BLOCK / tpb, g = tid / RT, r = tid - g * RT;
   const long sys = blockIdx.y;
@@ -971,10 +971,21 @@ __global__ void __launch_bounds__(BLOCK) k_coop_trial_rows(const R* __restrict__
     const R* s0 = (ch.mode == 2 && c > 0) ? ch.state + (sys * (ch.n_chunks - 1) + (c - 1)) * m * a.n_trials + n : nullptr;
     for (int i = r; i < m; i += RT) st[i] = s0 ? s0[(long)i * a.n_trials] : (hom && i == unit) ? R(1) : R(0);
   }
-  R pf[MAXPF];
+  // operator blocks in flight.  256 threads: pf holds block t + 1, requested at the top of step t.  1024 threads (DEEP; the largest
+  // batches, 5 instead of 18 reals per thread): pf holds block t + 1 requested one step EARLIER and pf2 block t + 2 requested at the
+  // top of step t — the step's arithmetic on the listed rows is shorter than one L2 / HBM round trip.  (Measured both ways: two blocks
+  // in flight cost the 256-thread sweep its registers — 64 candidates x 120 trials 5.96 -> 7.9 ms — and gain on the wide one:
+  // 4096 x 120 fp32 82.8 -> 75.4 ms, 512 x 120 fp64 39.6 -> 23.2 ms.)
+  constexpr bool DEEP = BLOCK > 256;
+  R pf[MAXPF], pf2[DEEP ? MAXPF : 1];
   const int npf = (nops + BLOCK - 1) / BLOCK;                // <= MAXPF (host-checked)
   LQG_UNROLL for (int k = 0; k < MAXPF; ++k)
     if (k < npf && tid + k * BLOCK < nops) opb[0][tid + k * BLOCK] = op[tid + k * BLOCK];
+  if (DEEP && t0 + 1 < t_hi) {
+    const R* nx = op + (long)nops;
+    LQG_UNROLL for (int k = 0; k < MAXPF; ++k)
+      if (k < npf && tid + k * BLOCK < nops) pf[k] = nx[tid + k * BLOCK];
+  }
   R xprev[MAXO], xnx[MAXO];
   LQG_UNROLL for (int j = 0; j < MAXO; ++j) {
     xprev[j] = (j < o && !hom) ? xr[(long)(t0 > 0 ? t0 - 1 : 0) * a.x.st + j * a.x.sd] : R(0);
@@ -987,7 +998,13 @@ __global__ void __launch_bounds__(BLOCK) k_coop_trial_rows(const R* __restrict__
     const bool more_ops = t + 1 < t_hi;                      // another step of this pass follows
     const bool more = t < a.T && (more_ops || ch.mode == 1); // the state is advanced (the density pass needs no end state)
     // requests of step t + 1: its operator block (into registers, parked in LDS at the end of the step) and its data row
-    if (more_ops) {
+    if constexpr (DEEP) {
+      if (t + 2 < t_hi) {
+        const R* nx = op + (long)(t + 2 - t0) * nops;
+        LQG_UNROLL for (int k = 0; k < MAXPF; ++k)
+          if (k < npf && tid + k * BLOCK < nops) pf2[k] = nx[tid + k * BLOCK];
+      }
+    } else if (more_ops) {
       const R* nx = op + (long)(t + 1 - t0) * nops;
       LQG_UNROLL for (int k = 0; k < MAXPF; ++k)
         if (k < npf && tid + k * BLOCK < nops) pf[k] = nx[tid + k * BLOCK];
@@ -1068,6 +1085,7 @@ __global__ void __launch_bounds__(BLOCK) k_coop_trial_rows(const R* __restrict__
       R* nb = opb[(t + 1 - t0) & 1];
       LQG_UNROLL for (int k = 0; k < MAXPF; ++k)
         if (k < npf && tid + k * BLOCK < nops) nb[tid + k * BLOCK] = pf[k];
+      if constexpr (DEEP) { LQG_UNROLL for (int k = 0; k < MAXPF; ++k) pf[k] = pf2[k]; }
     }
     __syncthreads();                                         // new state + next operator block visible
   }

@@ -301,10 +301,11 @@ hipError_t coop_trial(const lqg_problem* p, const void* ops, lqg_traj x, lqg_tra
         return hipGetLastError();
       }
       const dim3 gr((unsigned)((p->n_trials + tpb - 1) / tpb), (unsigned)p->n_sys);
-      // 128 trials per workgroup (the largest batches): the same sweep on 1024 threads — 8 instead of 2 threads per trial, four times
-      // the waves per SIMD behind the dependent LDS reads of the list walk
+      // 128 trials per workgroup (the largest batches; fp64: from 32): the same sweep on 1024 threads with two operator blocks in
+      // flight — 8 instead of 2 threads per trial, four times the waves per SIMD behind the dependent LDS reads of the list walk
+      // (512 candidates x 120 trials fp64: 33.2 -> 23.2 ms; fp32 17.2 -> 18.4: not taken there)
       const int wide_mode = p->tuning.coop_trial_wide;               // 0 rule, 1 always, -1 never
-      if (wide_mode >= 0 && (wide_mode > 0 || tpb >= 128)) {
+      if (wide_mode >= 0 && (wide_mode > 0 || tpb >= 128 || (sizeof(R) == 8 && tpb >= 32))) {
         constexpr int BW = 1024;
         auto kw = coop::k_coop_trial_rows<R, BW>;
         er = raise_lds(kw, lds_r);

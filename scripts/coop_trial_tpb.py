@@ -16,7 +16,7 @@ for dtype in (torch.float32, torch.float64):
         x = DelayedSubjectiveActor(T=T, device=dev, dtype=dtype).simulate(3, n=n)[..., :2].contiguous()
         m = DelayedSubjectiveActor(T=T, device=dev, dtype=dtype, sigma_target=torch.linspace(4.0, 9.0, B, device=dev, dtype=dtype))
         row, ref = {}, None
-        for cap, wide in ((16, "0"), (32, "0"), (64, "0"), (128, "0"), (32, "1"), (64, "1"), (128, "1")):
+        for cap, wide in ((0, ""), (16, "0"), (32, "0"), (64, "0"), (128, "0"), (32, "1"), (64, "1"), (128, "1")):       # (0, ""): the rule
             with options.override(SCAN="0", COOP_TRIAL_TPB=cap, COOP_TRIAL_WIDE=wide):
                 p = LogLikelihoodPlan(m, x, events=True)
                 out = p.run().clone()
