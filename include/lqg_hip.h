@@ -110,8 +110,8 @@ typedef struct lqg_tuning {
   int32_t scan_lane;             /* one-launch scans of 1x1 .. 3x3 windows (k_scan_lane): 0 on, -1 per-level launches   */
   int32_t scan_rt_waves;         /* waves per window of k_scan_level_rt: 0 = 16, 8                                      */
   int32_t coop_adjoint;          /* 1: the cooperative reverse-mode sweep also for shapes that have adjoint lane kernels  */
-  int32_t scan_order;            /* levels of the scans over windows of 25 .. 64: 0 rule (work-efficient Brent-Kung order once
-                                    a level holds more combines than the chip runs at once), 1 always, -1 Hillis-Steele    */
+  int32_t scan_order;            /* levels of the scans over windows of 25 .. 64: 0 rule (work-efficient order once a level
+                                    holds more combines than the chip runs at once), 1 always, 2 plain Brent-Kung, -1 Hillis-Steele */
   int32_t coop_trial_tpb;        /* row-parallel per-trial sweep: most trials that share a workgroup (and its copy of the
                                     step's operator block): 0 rule, else a power of two <= 128                          */
   int32_t coop_trial_wide;       /* that sweep on 1024-thread workgroups: 0 rule (at 128 trials per workgroup), 1 always, -1 never */

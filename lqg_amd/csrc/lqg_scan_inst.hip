@@ -99,29 +99,54 @@ void run_scan(int n, int nseg, D* const in[2], D* const out[2], const int len[2]
     res[1] = b[1];
     return;
   }
-  // Windows of 25 .. 64 with more combines per Hillis-Steele level than the chip runs at once (one 1024-lane workgroup per CU):
-  // the WORK-EFFICIENT order (Brent-Kung, in place) — ~2 len combines in 2 log2(len) - 2 levels instead of len log2(len) in
-  // log2(len).  A level's time is its number of ROUNDS of 256 concurrent combines: one delay-12 system (501 + 500 windows of 39,
-  // then 500 of 63) 54 -> 34 rounds, thirteen systems (central differences over six parameters) 690 -> ~170.
-  // tuning.scan_order: 0 = this rule, 1 = always, -1 = never.
-  const int bk_mode = tune.scan_order;
-  if (n > 24 && bk_mode >= 0 && (bk_mode > 0 || n_sys * (long)(len[0] + l1) > scan::kScanRtConcurrent)) {
-    auto level = [&](int d, bool down) {
-      scan::Seg s[2];
-      int total = 0;
+  // Windows of 25 .. 64 with more combines per Hillis-Steele level than the chip runs at once (one 1024-lane workgroup per CU, a
+  // level's time is its number of ROUNDS of 256 concurrent combines): a work-efficient order.  Brent-Kung in place — up-sweep
+  // (blocks of 2 d ending at k = 2 d - 1 mod 2 d), down-sweep (k = 3 d - 1 mod 2 d takes the finished prefix before its block):
+  // ~2 len combines in 2 log2(len) - 2 levels instead of len log2(len) in log2(len) — with its nearly empty middle levels
+  // (31, 15, 7, 3, 1, 1, 3, 7, ... combines, each a full 50 .. 95 us round) replaced by a Hillis-Steele scan over the BLOCK TOTALS:
+  // up-sweep to blocks of B, ping-pong scan over the len / B totals at k = B - 1 mod B (log2(len / B) levels of one round each,
+  // B the smallest power of two whose totals fit one round), down-sweep from d = B / 2.  One delay-12 system (501 + 500 windows of
+  // 39, then 500 of 63), rounds: Hillis-Steele 36 + 18, Brent-Kung 18 + 16, this 13 + 10.
+  // tuning.scan_order: 0 = this rule, 1 = always, 2 = plain Brent-Kung, -1 = Hillis-Steele.
+  const int order = tune.scan_order;
+  if (n > 24 && order >= 0 && (order > 0 || n_sys * (long)(len[0] + l1) > scan::kScanRtConcurrent)) {
+    const int lens[2] = {len[0], l1}, lefts[2] = {left[0], nseg > 1 ? left[1] : 0};
+    // one strided level: out[k] = in[k - d] (x) in[k] for k = k0 + i ks, i < cnt (copies where k < d)
+    auto level = [&](D* const from[2], D* const to[2], int d, int k0, int ks, const int cnt[2]) {
+      scan::Seg sg[2];
       for (int i = 0; i < 2; ++i) {
-        const int li = i == 0 ? len[0] : l1;
-        s[i] = scan::Seg{a[i], a[i], li, d, i == 0 ? left[0] : (nseg > 1 ? left[1] : 0)};
-        s[i].ks = 2 * d;
-        s[i].k0 = (down ? 3 : 2) * d - 1;
-        s[i].cnt = down ? (li > d ? (li - d) / (2 * d) : 0) : li / (2 * d);
-        total += s[i].cnt;
+        sg[i] = scan::Seg{from[i], to[i], lens[i], d, lefts[i]};
+        sg[i].k0 = k0;
+        sg[i].ks = ks;
+        sg[i].cnt = cnt[i];
       }
-      if (total > 0) launch_level_rt(s[0], s[1], n, n_sys, tune, st);
+      if (cnt[0] + cnt[1] > 0) launch_level_rt(sg[0], sg[1], n, n_sys, tune, st);
     };
-    int d = 1;
-    for (; 2 * d <= longest; d *= 2) level(d, false);                 // up-sweep: blocks of 2 d ending at k = 2 d - 1 (mod 2 d)
-    for (d /= 2; d >= 1; d /= 2) level(d, true);                      // down-sweep: k = 3 d - 1 (mod 2 d) takes the prefix before its block
+    int B = 2;                                                        // block of the middle scan
+    if (order == 2) B = 2 * longest;                                  // (no middle scan)
+    else while (B < longest && n_sys * (long)(lens[0] / B + lens[1] / B) > scan::kScanRtConcurrent) B *= 2;
+    int nb_max = lens[0] / B > lens[1] / B ? lens[0] / B : lens[1] / B, mid_levels = 0;
+    for (int dj = 1; dj < nb_max; dj *= 2) ++mid_levels;
+    int top = 1;                                                      // largest up-sweep distance: B / 2, or plain Brent-Kung's
+    while (2 * top < B && 4 * top <= longest) top *= 2;
+    for (int d = 1; d <= top; d *= 2) {                               // up-sweep, in place; the level that completes the blocks of B
+      const int cnt[2] = {lens[0] / (2 * d), lens[1] / (2 * d)};      // writes the other buffer when the middle scan has an odd
+      const bool flip = 2 * d == B && (mid_levels & 1);               // number of levels (its last level must land in `a`)
+      level(a, flip ? b : a, d, 2 * d - 1, 2 * d, cnt);
+    }
+    if (mid_levels > 0) {
+      D* cur[2] = {(mid_levels & 1) ? b[0] : a[0], (mid_levels & 1) ? b[1] : a[1]};
+      D* oth[2] = {(mid_levels & 1) ? a[0] : b[0], (mid_levels & 1) ? a[1] : b[1]};
+      const int cnt[2] = {lens[0] / B, lens[1] / B};
+      for (int dj = 1; dj < nb_max; dj *= 2) {
+        level(cur, oth, dj * B, B - 1, B, cnt);
+        for (int i = 0; i < 2; ++i) { D* t = cur[i]; cur[i] = oth[i]; oth[i] = t; }
+      }
+    }
+    for (int d = top; d >= 1; d /= 2) {                               // down-sweep, in place
+      const int cnt[2] = {lens[0] > d ? (lens[0] - d) / (2 * d) : 0, lens[1] > d ? (lens[1] - d) / (2 * d) : 0};
+      level(a, a, d, 3 * d - 1, 2 * d, cnt);
+    }
     res[0] = a[0];
     res[1] = a[1];
     return;

@@ -17,7 +17,7 @@ SCAN_MIN_STEPS    0         horizon from which it does (0: plan.scan_min_steps(m
 SCAN_MAX_COND     1e7       cond((V V')[:d, :d]) above which the default rule keeps the sequential sweeps
 SCAN_LANE         1         one-launch scans of 1x1 .. 3x3 windows (0: one launch per level)          -> tuning.scan_lane
 SCAN_RT_WAVES     0         waves per window of k_scan_level_rt (0 = 16; 8)                           -> tuning.scan_rt_waves
-SCAN_ORDER        ""        scans over windows of 25 .. 64: "" rule, "1" work-efficient (Brent-Kung) levels always, "0" Hillis-Steele -> tuning.scan_order
+SCAN_ORDER        ""        scans over windows of 25 .. 64: "" rule, "1" work-efficient levels always (Brent-Kung around a scan of the block totals), "2" plain Brent-Kung, "0" Hillis-Steele -> tuning.scan_order
 COOP              ""        "" default rule, "1" cooperative kernels wherever supported, "0" never    -> tuning.coop
 COOP_SPARSE       1         run-time sparsity lists of the cooperative sweeps                         -> tuning.coop_sparse
 COOP_TRIAL_ROWS   1         row-parallel per-trial sweep of large joint dimensions                    -> tuning.coop_trial_rows
@@ -133,7 +133,8 @@ def fill_tuning(t):
     t.scan_lane = 0 if flag("SCAN_LANE") else -1
     t.scan_rt_waves = get("SCAN_RT_WAVES")
     t.coop_adjoint = 1 if flag("COOP_ADJOINT") else 0
-    t.scan_order = _tri("SCAN_ORDER")
+    so = get("SCAN_ORDER")
+    t.scan_order = 0 if so == "" else (-1 if int(so) == 0 else int(so))
     t.coop_trial_tpb = get("COOP_TRIAL_TPB")
     t.coop_trial_wide = _tri("COOP_TRIAL_WIDE")
     return t

@@ -1,4 +1,4 @@
-"""System sweeps of the delay model (DelayedSubjectiveActor, m = 65, T = 500) by the time-parallel scans in both level orders and by the
+"""System sweeps of the delay model (DelayedSubjectiveActor, m = 65, T = 500) by the time-parallel scans in their three level orders (hs Hillis-Steele, bk Brent-Kung, we work-efficient default) and by the
 sequential cooperative kernels, against the number of systems (candidates): which route the plan should take where."""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,7 +16,8 @@ for dtype in (torch.float64, torch.float32):
         m = DelayedSubjectiveActor(T=T, device=dev, dtype=dtype, sigma_target=sig)
         row = {}
         ref = None
-        for label, ov in (("seq", dict(SCAN="0")), ("hs", dict(SCAN="1", SCAN_ORDER="0")), ("bk", dict(SCAN="1", SCAN_ORDER="1"))):
+        for label, ov in (("seq", dict(SCAN="0")), ("hs", dict(SCAN="1", SCAN_ORDER="0")), ("bk", dict(SCAN="1", SCAN_ORDER="2")),
+                          ("we", dict(SCAN="1", SCAN_ORDER="1"))):         # we: Brent-Kung around a scan of the block totals (the default)
             with options.override(**ov):
                 p = LogLikelihoodPlan(m, x)
                 out = p.run().clone()

@@ -84,14 +84,15 @@ def test_scan_and_sequential_sweeps_agree_at_full_horizon(model, monkeypatch):
     assert e_scan < max(2e-6, 1.5 * e_seq), (e_scan, e_seq)
 
 
-@pytest.mark.parametrize("order,T", [("", 500), ("1", 500), ("0", 500), ("1", 37), ("1", 64), ("1", 129)],
-                         ids=["rule-T500", "brent_kung-T500", "hillis_steele-T500", "brent_kung-T37", "brent_kung-T64", "brent_kung-T129"])
+@pytest.mark.parametrize("order,T", [("", 500), ("1", 500), ("2", 500), ("0", 500), ("1", 37), ("1", 64), ("1", 129), ("2", 129), ("1", 301)],
+                         ids=["rule-T500", "work_efficient-T500", "brent_kung-T500", "hillis_steele-T500", "work_efficient-T37", "work_efficient-T64",
+                              "work_efficient-T129", "brent_kung-T129", "work_efficient-T301"])
 def test_delay_model_windows_of_64_against_the_sequential_kernels(monkeypatch, order, T):
     """The reference's largest model (DelayedSubjectiveActor, lqg/tracking/delay.py:44-51: x = 26, b = 39) at T = 500:
     windows of 39 (Riccati, Kalman) and 63 (moment recursion) on k_scan_level_rt against the cooperative sequential
-    sweeps, one system and a handful of candidates — in both orders of the levels (Hillis-Steele ping-pong, work-efficient
-    Brent-Kung in place: lqg_scan_inst.hip run_scan) and, for the strided index maps of the latter, at horizons that are not
-    powers of two."""
+    sweeps, one system and a handful of candidates — in every order of the levels (Hillis-Steele ping-pong; Brent-Kung in place;
+    Brent-Kung around a ping-pong scan of the block totals, the default: lqg_scan_inst.hip run_scan) and, for the strided index
+    maps of the latter two, at horizons that are not powers of two."""
     from lqg_amd.plan import LogLikelihoodPlan
     from lqg_amd.tracking.delay import DelayedSubjectiveActor
     dev = torch.device("cuda")
