@@ -235,3 +235,23 @@ def test_system_major_time_varying_specs_get_one_layout_hint_and_pack_systems_fi
     packed = workload.pack_systems(major.A)
     assert packed.stride(0) == 1 and torch.equal(packed, major.A)
     _hip._layout_warned = False
+
+
+def test_scan_level_schedule_restated_on_symbolic_elements():
+    """scripts/scan_schedule_check.py restates the level schedule of run_scan (csrc/lqg_scan_inst.hip: up-sweep to blocks of B,
+    ping-pong scan of the block totals, down-sweep — and plain Brent-Kung) on elements that are step RANGES: every combine joins
+    adjacent ranges, no level reads what nobody wrote, every prefix comes out as [0, k]; the rounds of one delay-12 system are the
+    ones DESIGN.md §3c quotes.  (The GPU tests check the kernels' numbers in each order at several horizons.)"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("scan_schedule_check", os.path.join(root, "scripts", "scan_schedule_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for T in list(range(2, 70)) + [129, 301, 500, 1067]:
+        for n_sys in (1, 3, 13, 400):
+            for order in (0, 2):
+                mod.run(T + 1, T, n_sys, order)
+                mod.run(T, 0, n_sys, order)
+    assert mod.run(501, 500, 1)[1:] == (11, 13) and mod.run(500, 0, 1)[1:] == (10, 10)
+    assert mod.run(501, 500, 1, order=2)[1:] == (16, 18) and mod.run(500, 0, 1, order=2)[1:] == (16, 16)
