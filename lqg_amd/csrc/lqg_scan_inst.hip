@@ -194,7 +194,10 @@ scan::Args<R> make_scan_args(const lqg_problem* p) {
 struct StepLds { long build_rk, gains_rk, build_sigma, ops; };
 StepLds step_lds(const lqg_dims& d) {
   const long x = d.x, b = d.b, u = d.u, y = d.y, o = d.d, m = x + b, mx = b > y ? b : y;
-  return StepLds{12L * mx * mx + 2 * b * u + 2 * u * u + 8, 12L * mx * mx + 3 * b * u + 3 * u * u + 8,
+  (void)mx;
+  // (exact sums of the working sets of build_riccati / build_kalman and of gains_step / kgain_step, lqg_scan.hpp — the round-3
+  // bound of 12 max(b, y)^2 kept the delay models' Riccati / Kalman builders at one workgroup per CU: 146 KB at b = 39, now 63 KB)
+  return StepLds{5L * b * b + 3 * y * b + 3 * y * y + 2 * b * u + 2 * u * u + 8, 5L * b * b + 2 * y * b + 3 * y * y + 3 * b * u + 3 * u * u + 8,
                  3L * m * m + o * o + m * o + scan::joint_scratch((int)x, (int)b, (int)u, (int)y) + 16, 2L * m * m + o * o + 8};
 }
 constexpr long kLdsMaxDoubles = 160 * 1024 / 8;
@@ -208,6 +211,8 @@ bool scan_supported(const lqg_problem* p) {
   if (m <= 24) return true;
   // larger windows (the delay-augmented models): one lane per column of a window, per-step working sets within LDS
   const StepLds l = step_lds(d);
+  const long mx = d.b > d.y ? d.b : d.y;
+  if (12L * mx * mx > kLdsMaxDoubles) return false;              // (the range the round-3 bound admitted and the tests cover: b <= 41)
   return d.b <= scan::kScanRtMax && m - d.d <= scan::kScanRtMax && l.build_rk <= kLdsMaxDoubles && l.gains_rk <= kLdsMaxDoubles &&
          l.build_sigma <= kLdsMaxDoubles && l.ops <= kLdsMaxDoubles;
 }
@@ -235,13 +240,17 @@ hipError_t scan_system_sweeps(const lqg_problem* p, lqg_view Sig, void* workspac
   const dim3 blk(packed ? 16 : m > 24 ? scan::kStepMax : 64, packed ? 4 : 1);      // (m > 24: sixteen waves per element)
   const StepLds sl = step_lds(p->dims);
   hipError_t attr = hipSuccess;
-  auto launch = [&](auto kern, int count, long lds_doubles) {
+  auto launch = [&](auto kern, int count, long lds_doubles, unsigned threads = 0) {
     k.lds_elem = (int)lds_doubles;
     const size_t lds = (size_t)lds_doubles * blk.y * sizeof(D);
     const hipError_t e = raise_lds_once(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) attr = e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((count + blk.y - 1) / blk.y), B), blk, lds, st, k);
+    const dim3 bl(threads ? threads : blk.x, blk.y);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((count + blk.y - 1) / blk.y), B), bl, lds, st, k);
   };
+  // large windows: the Riccati / Kalman builders and finalisers on 512 lanes per element — at ~100 VGPRs and 63 KB of LDS two
+  // workgroups share a CU, and their 2 T + 1 elements per system are four rounds of the chip on 1024 lanes
+  const unsigned rk_threads = m > 24 ? 512 : 0;
   // ---- Riccati (suffix scan over T + 1 elements, reversed storage) and Kalman (prefix scan over T elements) side by side
   {
     D* const in[2] = {rk, rk + 2 * sp.rk_reals};
@@ -250,11 +259,11 @@ hipError_t scan_system_sweeps(const lqg_problem* p, lqg_view Sig, void* workspac
     const D* res[2];
     k.elems = in[0];
     k.elems2 = in[1];
-    launch(scan::k_scan_build_rk<R>, 2 * T + 1, sl.build_rk);
+    launch(scan::k_scan_build_rk<R>, 2 * T + 1, sl.build_rk, rk_threads);
     run_scan(b, 2, in, out, len, left, p->n_sys, res, p->tuning, st);
     k.res = res[0];
     k.res2 = res[1];
-    launch(scan::k_scan_gains_rk<R>, 2 * T, sl.gains_rk);
+    launch(scan::k_scan_gains_rk<R>, 2 * T, sl.gains_rk, rk_threads);
   }
   // ---- moment recursion: joint system per step, prefix scan over T elements of m x m, operators
   {
