@@ -915,11 +915,37 @@ __global__ void __launch_bounds__(kStepMax) k_scan_build_sigma(const Args<R> a) 
     IKH[i2] = ((i == j) ? 1.0 : 0.0) - ((j < o) ? Kk[i * o + j] : 0.0);
   });
   wsync();
-  mm_sym(e + rr2, rr, m, IKH + o * m, m, 1, GG + o, m, 1, zero_init);   // C = ((I - K H) Q)[r, r]   (k = 0: Q = Sigma_0 = GG_0)
+  // Large windows (1024 lanes per element): the unobserved rows of I - K H hold 1 + o entries each — their columns are listed
+  // (coop::RowLists, in the joint system's scratch, dead by now) and the two rr x rr x m products walk the lists: exact, the
+  // terms left out are exact zeros.
+  const bool listed = m > 24;
+  const D* Ar = IKH + o * m;                                           // rows o .. m-1 of I - K H
+  coop::RowLists rl{nullptr, nullptr, 0};
+  if (listed) {
+    unsigned char* lp = reinterpret_cast<unsigned char*>(scratch);
+    rl = coop::take_lists(lp, rr, m);
+    coop::build_lists<kStepMax>((int)threadIdx.x, Ar, m, 1, rr, m, rl);
+    wsync();
+    each(rr2, [&](int i2) {                                            // C = ((I - K H) Q)[r, r], mirror entries averaged
+      const int i = i2 / rr, j = i2 - i * rr;
+      const D v1 = coop::dot_list<D>(rl, i, Ar + i * m, 1, GG + o + j, m, 0.0);
+      const D v2 = coop::dot_list<D>(rl, j, Ar + j * m, 1, GG + o + i, m, 0.0);
+      e[rr2 + i2] = 0.5 * (v1 + v2);
+    });
+  } else {
+    mm_sym(e + rr2, rr, m, Ar, m, 1, GG + o, m, 1, zero_init);         // C = ((I - K H) Q)[r, r]   (k = 0: Q = Sigma_0 = GG_0)
+  }
   if (k == 0) {
     each(rr2, [&](int i) { e[i] = 0.0; e[2 * rr2 + i] = 0.0; });
   } else {
-    mm(e, rr, rr, rr, m, IKH + o * m, m, 1, Fj + o, m, 1, zero_init);   // A = ((I - K H) F)[r, r]
+    if (listed) {
+      each(rr2, [&](int i2) {                                          // A = ((I - K H) F)[r, r]
+        const int i = i2 / rr, j = i2 - i * rr;
+        e[i2] = coop::dot_list<D>(rl, i, Ar + i * m, 1, Fj + o + j, m, 0.0);
+      });
+    } else {
+      mm(e, rr, rr, rr, m, Ar, m, 1, Fj + o, m, 1, zero_init);         // A = ((I - K H) F)[r, r]
+    }
     // J = (F[:o, r])' Q_oo^-1 F[:o, r]
     D* T1 = Kk;                                                      // [o, m] temp (Kk is dead after IKH)
     wsync();
@@ -944,9 +970,31 @@ __global__ void __launch_bounds__(kStepMax) k_scan_ops(const Args<R> a) {
   } else {
     const D* fg = a.FG + (s * a.T + t - 1) * 2L * mm2;
     const D* C = a.res + (s * a.T + t - 1) * 3L * (rr * rr) + rr * rr;      // conditional covariance, unobserved block
+    if (m > 24) {
+      // large windows (1024 lanes per element): F2 = F[:, o:] of the delay augmentations is shift-structured (9 % non-zero at
+      // m = 65) — the columns of its rows are listed once (one wave per row) and both products walk the lists; the terms left
+      // out are exact zeros (coop::RowLists, the lists of the sequential sweeps)
+      unsigned char* lp = reinterpret_cast<unsigned char*>(hls + 1);
+      const coop::RowLists rl = coop::take_lists(lp, m, rr);
+      const D* F2 = fg + o;
+      coop::build_lists<kStepMax>((int)threadIdx.x, F2, m, 1, m, rr, rl);
+      wsync();
+      each(m * rr, [&](int e) {                                      // F2 C        [m, rr]
+        const int i = e / rr, j = e - i * rr;
+        T1[e] = coop::dot_list<D>(rl, i, F2 + i * m, 1, C + j, rr, 0.0);
+      });
+      wsync();
+      each(mm2, [&](int e) {                                         // F2 C F2' + GG, mirror entries averaged
+        const int i = e / m, j = e - i * m;
+        const D v1 = coop::dot_list<D>(rl, j, F2 + j * m, 1, T1 + i * rr, 1, fg[mm2 + i * m + j]);
+        const D v2 = coop::dot_list<D>(rl, i, F2 + i * m, 1, T1 + j * rr, 1, fg[mm2 + j * m + i]);
+        Sg[e] = 0.5 * (v1 + v2);
+      });
+    } else {
     mm(T1, rr, m, rr, rr, fg + o, m, 1, C, rr, 1, zero_init);       // F[:, o:] C        [m, rr]
     wsync();
     mm_sym(Sg, m, rr, T1, rr, 1, fg + o, 1, m, [&](int i, int j) { return fg[mm2 + i * m + j]; });   // F2 C F2' + GG
+    }
     if (a.Sig.p) {
       wsync();
       R* out = const_cast<R*>(a.Sig.p) + s * a.Sig.sb + (long)(t - 1) * a.Sig.st;

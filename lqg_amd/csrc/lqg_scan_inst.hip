@@ -198,7 +198,8 @@ StepLds step_lds(const lqg_dims& d) {
   // (exact sums of the working sets of build_riccati / build_kalman and of gains_step / kgain_step, lqg_scan.hpp — the round-3
   // bound of 12 max(b, y)^2 kept the delay models' Riccati / Kalman builders at one workgroup per CU: 146 KB at b = 39, now 63 KB)
   return StepLds{5L * b * b + 3 * y * b + 3 * y * y + 2 * b * u + 2 * u * u + 8, 5L * b * b + 2 * y * b + 3 * y * y + 3 * b * u + 3 * u * u + 8,
-                 3L * m * m + o * o + m * o + scan::joint_scratch((int)x, (int)b, (int)u, (int)y) + 16, 2L * m * m + o * o + 8};
+                 3L * m * m + o * o + m * o + scan::joint_scratch((int)x, (int)b, (int)u, (int)y) + 16,
+                 2L * m * m + o * o + 8 + (m > 24 ? (coop::row_lists_bytes((int)m, (int)(m - o)) + 7) / 8 : 0)};
 }
 constexpr long kLdsMaxDoubles = 160 * 1024 / 8;
 
