@@ -87,11 +87,11 @@ def scan_max_systems(m, fp64=False):
         return options.get("SCAN_MAX_SYSTEMS")
     if m > 24:
         # windows of 25 .. 64 (k_scan_level_rt: one 1024-lane workgroup per window, 50 .. 95 us per combine, one system's 500
-        # windows already fill the chip twice — the levels run in the work-efficient Brent-Kung order there, round 4):
-        # DelayedSubjectiveActor (m = 65, T = 500, 50 trials) 3.6 ms for one system + 1.4 ms per further one against 25.6 ms
-        # (fp64) / 12.2 ms (fp32) + 0.1 .. 0.2 ms per system for the cooperative sequential sweeps, which give every system
-        # its own CU (scripts/scan_order_time.py: 13 systems 20.8 vs 28.3 ms in fp64, 19.6 vs 14.2 ms in fp32)
-        return 16 if fp64 else 7
+        # windows already fill the chip twice — the levels run in a work-efficient order there, round 4):
+        # DelayedSubjectiveActor (m = 65, T = 500, 50 trials) 2.4 ms for one system + 1.1 ms per further one against 25.4 ms
+        # (fp64) / 12.1 ms (fp32) + 0.1 ms per system for the cooperative sequential sweeps, which give every system
+        # its own CU (profiles/r04_scan_order_time.txt: 13 systems 15.5 vs 26.8 ms in fp64, 15.2 vs 13.5 ms in fp32)
+        return 24 if fp64 else 10
     return int(min(64, max(8, 8 * (m / 4.0) ** 2)))
 
 

@@ -132,7 +132,7 @@ def test_time_parallel_rules():
     assert plan.scan_min_steps(4) == 375 and plan.scan_min_steps(8) == 93 and plan.scan_min_steps(20) == 64
     assert all(plan.scan_max_systems(m) <= plan.scan_max_systems(m + 1) for m in range(2, 24))
     # windows that live in registers (m > 24: the delay-augmented models) are taken for a handful of systems only
-    assert plan.scan_max_systems(65) == 7 and plan.scan_max_systems(65, fp64=True) == 16
+    assert plan.scan_max_systems(65) == 10 and plan.scan_max_systems(65, fp64=True) == 24
     assert all(plan.scan_min_steps(m) >= plan.scan_min_steps(m + 1) for m in range(2, 30))
 
 
