@@ -43,6 +43,7 @@ namespace scan {
 using D = double;
 constexpr int kWave = 64;
 constexpr int kStepMax = 1024;       // lanes per element of the per-step kernels: 64 (16 when packed), 1024 for m > 24
+constexpr int kStepRk = 512;         // ... of the Riccati / Kalman builders and finalisers for m > 24 (two workgroups per CU)
 
 template <typename F>
 LQG_DEV void each(int n, F f) {
@@ -701,7 +702,21 @@ LQG_DEV void gains_step(const Args<R>& a, D* sm, int t, long s) {
   ld(a.aB, s, t, b, u, Bm);
   ld_sym(a.aR, s, t, u, Rm);
   wsync();
-  mm(SA, b, b, b, b, S, b, 1, A, b, 1, zero_init);
+  if (a.x + b > 24) {
+    // large windows (kStepRk lanes per element): the delay augmentations' A is a shift — the non-zero ROWS of each of its columns
+    // are listed (coop::RowLists on the transposed view, behind this function's working set) and S A walks them; exact, the terms
+    // left out are exact zeros
+    unsigned char* lp = reinterpret_cast<unsigned char*>(Hi + u * u);
+    const coop::RowLists cl = coop::take_lists(lp, b, b);
+    coop::build_lists<kStepRk>((int)threadIdx.x, A, 1, b, b, b, cl);
+    wsync();
+    each(nn, [&](int e) {
+      const int i = e / b, j = e - i * b;
+      SA[e] = coop::dot_list<D>(cl, j, A + j, b, S + i * b, 1, 0.0);
+    });
+  } else {
+    mm(SA, b, b, b, b, S, b, 1, A, b, 1, zero_init);
+  }
   mm(SB, u, b, u, b, S, b, 1, Bm, u, 1, zero_init);
   wsync();
   mm_sym(H, u, b, Bm, 1, u, SB, u, 1, [&](int i, int j) { return Rm[i * u + j]; });     // H = R + B'SB
@@ -750,11 +765,33 @@ LQG_DEV void build_kalman(const Args<R>& a, D* sm, int t, long s) {
     IKF[i2] = ((i == j) ? 1.0 : 0.0) - IKF[i2];
   });
   wsync();
-  mm_sym(e + nn, b, b, IKF, b, 1, Pp, b, 1, zero_init);                                    // C = (I - K F) Pp
+  const bool listed = a.x + b > 24;               // large windows: I - K F is the identity plus the few observed columns
+  coop::RowLists rl{nullptr, nullptr, 0};
+  if (listed) {
+    unsigned char* lp = reinterpret_cast<unsigned char*>(IKF + nn);
+    rl = coop::take_lists(lp, b, b);
+    coop::build_lists<kStepRk>((int)threadIdx.x, IKF, b, 1, b, b, rl);
+    wsync();
+    each(nn, [&](int i2) {                                                                 // C = (I - K F) Pp, mirror entries averaged
+      const int i = i2 / b, j = i2 - i * b;
+      const D v1 = coop::dot_list<D>(rl, i, IKF + i * b, 1, Pp + j, b, 0.0);
+      const D v2 = coop::dot_list<D>(rl, j, IKF + j * b, 1, Pp + i, b, 0.0);
+      e[nn + i2] = 0.5 * (v1 + v2);
+    });
+  } else {
+    mm_sym(e + nn, b, b, IKF, b, 1, Pp, b, 1, zero_init);                                  // C = (I - K F) Pp
+  }
   if (t == 0) {
     each(nn, [&](int i) { e[i] = 0.0; e[2 * nn + i] = 0.0; });
   } else {
-    mm(e, b, b, b, b, IKF, b, 1, A, b, 1, zero_init);                                      // A = (I - K F) A_t
+    if (listed) {
+      each(nn, [&](int i2) {                                                               // A = (I - K F) A_t
+        const int i = i2 / b, j = i2 - i * b;
+        e[i2] = coop::dot_list<D>(rl, i, IKF + i * b, 1, A + j, b, 0.0);
+      });
+    } else {
+      mm(e, b, b, b, b, IKF, b, 1, A, b, 1, zero_init);                                    // A = (I - K F) A_t
+    }
     mm(T1, b, y, b, y, Si, y, 1, F, b, 1, zero_init);                                      // S^-1 F            [y, b]
     mm(FP, b, y, b, b, F, b, 1, A, b, 1, zero_init);                                       // F A_t             [y, b] (FP reused)
     wsync();
@@ -782,9 +819,27 @@ LQG_DEV void kgain_step(const Args<R>& a, D* sm, int t, long s) {
     each(nn, [&](int i) { P0[i] = C[i]; });
   }
   wsync();
-  mm(AP, b, b, b, b, A, b, 1, P0, b, 1, zero_init);
-  wsync();
-  mm_sym(Pp, b, b, AP, b, 1, A, 1, b, [&](int i, int j) { return VV[i * b + j]; });
+  if (a.x + b > 24) {                             // (large windows: the rows of the shift-structured A listed, as in gains_step)
+    unsigned char* lp = reinterpret_cast<unsigned char*>(Si + y * y);
+    const coop::RowLists rl = coop::take_lists(lp, b, b);
+    coop::build_lists<kStepRk>((int)threadIdx.x, A, b, 1, b, b, rl);
+    wsync();
+    each(nn, [&](int e) {
+      const int i = e / b, j = e - i * b;
+      AP[e] = coop::dot_list<D>(rl, i, A + i * b, 1, P0 + j, b, 0.0);
+    });
+    wsync();
+    each(nn, [&](int e) {                         // A P A' + V V', mirror entries averaged
+      const int i = e / b, j = e - i * b;
+      const D v1 = coop::dot_list<D>(rl, j, A + j * b, 1, AP + i * b, 1, VV[i * b + j]);
+      const D v2 = coop::dot_list<D>(rl, i, A + i * b, 1, AP + j * b, 1, VV[j * b + i]);
+      Pp[e] = 0.5 * (v1 + v2);
+    });
+  } else {
+    mm(AP, b, b, b, b, A, b, 1, P0, b, 1, zero_init);
+    wsync();
+    mm_sym(Pp, b, b, AP, b, 1, A, 1, b, [&](int i, int j) { return VV[i * b + j]; });
+  }
   wsync();
   mm(FP, b, y, b, b, F, b, 1, Pp, b, 1, zero_init);
   wsync();

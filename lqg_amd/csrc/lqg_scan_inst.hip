@@ -197,7 +197,8 @@ StepLds step_lds(const lqg_dims& d) {
   (void)mx;
   // (exact sums of the working sets of build_riccati / build_kalman and of gains_step / kgain_step, lqg_scan.hpp — the round-3
   // bound of 12 max(b, y)^2 kept the delay models' Riccati / Kalman builders at one workgroup per CU: 146 KB at b = 39, now 63 KB)
-  return StepLds{5L * b * b + 3 * y * b + 3 * y * y + 2 * b * u + 2 * u * u + 8, 5L * b * b + 2 * y * b + 3 * y * y + 3 * b * u + 3 * u * u + 8,
+  const long rkl = m > 24 ? (coop::row_lists_bytes((int)b, (int)b) + 7) / 8 : 0;          // (+ the row / column lists of A, I - K F)
+  return StepLds{5L * b * b + 3 * y * b + 3 * y * y + 2 * b * u + 2 * u * u + 8 + rkl, 5L * b * b + 2 * y * b + 3 * y * y + 3 * b * u + 3 * u * u + 8 + rkl,
                  3L * m * m + o * o + m * o + scan::joint_scratch((int)x, (int)b, (int)u, (int)y) + 16,
                  2L * m * m + o * o + 8 + (m > 24 ? (coop::row_lists_bytes((int)m, (int)(m - o)) + 7) / 8 : 0)};
 }
@@ -251,7 +252,7 @@ hipError_t scan_system_sweeps(const lqg_problem* p, lqg_view Sig, void* workspac
   };
   // large windows: the Riccati / Kalman builders and finalisers on 512 lanes per element — at ~100 VGPRs and 63 KB of LDS two
   // workgroups share a CU, and their 2 T + 1 elements per system are four rounds of the chip on 1024 lanes
-  const unsigned rk_threads = m > 24 ? 512 : 0;
+  const unsigned rk_threads = m > 24 ? scan::kStepRk : 0;
   // ---- Riccati (suffix scan over T + 1 elements, reversed storage) and Kalman (prefix scan over T elements) side by side
   {
     D* const in[2] = {rk, rk + 2 * sp.rk_reals};
