@@ -13,20 +13,30 @@ from lqg_amd import _abi, _hip, _hipev, options, specialize
 # trial instead (N x the per-system work, no [system][step][operator] stream): e.g. 2^18 systems x 2 trials at
 # n=6, T=500 would need 71 GB of stream for 2 trials' worth of work.
 # (16 GiB through round 3, whatever the device held.  288 GB of HBM leave room for more: the limit is the smaller of 64 GiB
-# and 40 % of the device memory that is free when the plan is built — 4096 candidates of the reference's delay-12 model
+# and 40 % of the device's total memory (round 5: a property of the device, not of the process history) — 4096 candidates of the reference's delay-12 model
 # (m = 65: 4.4 k reals per step) x 120 trials need a 36 GB stream; looping over the trials instead re-ran the 4096 system
 # sweeps 120 times: 34 s against 0.3 s.)
 OPS_WORKSPACE_LIMIT = None          # None: ops_workspace_limit(device); an int pins it (tests)
 
 
+_ops_limit_by_device = {}
+
+
 def ops_workspace_limit(device):
+    """min(64 GiB, 40 % of the device's TOTAL memory), evaluated once per device.  (Round 4 used the FREE memory at plan time:
+    a transient figure — the same problem could take the MIXED route or not, or the one-sweep-per-trial route, depending on what
+    the process had allocated before or on which rank it ran; shards of a trial split must agree bitwise, so the limit is now a
+    property of the device.)"""
     if OPS_WORKSPACE_LIMIT is not None:
         return OPS_WORKSPACE_LIMIT
-    try:
-        free, _ = torch.cuda.mem_get_info(device)
-    except Exception:
-        return 16 << 30
-    return int(min(64 << 30, 0.4 * free))
+    key = str(device)
+    if key not in _ops_limit_by_device:
+        try:
+            total = torch.cuda.get_device_properties(device).total_memory
+            _ops_limit_by_device[key] = int(min(64 << 30, 0.4 * total))
+        except Exception:
+            return 16 << 30
+    return _ops_limit_by_device[key]
 # Up to this many (system, trial) pairs a multi-trial evaluation is run as ONE fused sweep per PAIR (the system part is
 # recomputed per trial — the lanes are idle anyway — and the per-trial sweep over the operator stream, a third
 # latency-bound 500-step kernel, disappears): one parameter vector (or the 2P+1 finite-difference candidates) x tens of
@@ -328,6 +338,8 @@ class LogLikelihoodPlan:
             kind += " [system sweeps in fp64, operators rounded to fp32 once, per-trial sweep fp32]"
         if any(k.get("wide") for k in w):
             kind += " [ill-conditioned fp32 problem: every sweep over an fp64 image of specs and data, results rounded to fp32 once]"
+        if any(k.get("loop_trials") for k in w):
+            kind += " [operator stream over the workspace limit: one fused sweep per trial]"
         if len(w) > 1:
             kind += f", {len(w)} decoupled components of dims (x,b,u,y,d)={w[0]['dims']}"
         if self.n_stacked > 1:

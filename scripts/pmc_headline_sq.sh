@@ -1,24 +1,50 @@
 #!/bin/bash
-# SQ wait / issue counters of the headline kernels (python bench.py, fp32)
+# SQ wait / issue counters and the sustained clock (GRBM_GUI_ACTIVE / 8 / kernel time, MI355X_MICROARCH.md "DVFS give-back") of the
+# headline kernels (python bench.py, fp32).  One counter group per pass, --kernel-trace only (no other trace domain).
+# Writes gpurun_out/r05_headline_sq.txt (copy to profiles/).
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_SMEM SQ_INSTS_VMEM_RD" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_INST_CYCLES_VMEM_RD SQ_WAVES"; do
+OUT=${1:-gpurun_out/r05_headline_sq.txt}
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_SMEM SQ_INSTS_VMEM_RD" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_INST_CYCLES_VMEM_RD SQ_WAVES" "GRBM_GUI_ACTIVE"; do
   tag=$(echo $grp | tr ' ' '_')
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d gpurun_out/pmch_$tag -o p -- python3 bench.py --no-extra --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2>&1
+  rm -rf gpurun_out/pmch_$tag
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d gpurun_out/pmch_$tag -o p -- python3 bench.py --no-extra --no-cpu-baseline --steps 10 --warmup 2 > /dev/null 2>&1
 done
-python3 - <<PY
-import csv, glob, collections
+python3 - "$OUT" <<'PY'
+import csv, glob, collections, sys
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+dur = collections.defaultdict(lambda: [0, 0.0])
+want = lambda k: "k_forward_sp" in k or "k_riccati_sp" in k
 for f in glob.glob("gpurun_out/pmch_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "k_forward_sp" in k or "k_riccati_sp" in k:
+        if want(k):
             a = acc[k[:28]][r["Counter_Name"]]
             a[0] += 1; a[1] += float(r["Counter_Value"])
-for k, d in acc.items():
-    print(k)
-    for c, (m, v) in sorted(d.items()):
-        print("   %-24s %.4e per call" % (c, v / m))
-    w = d["SQ_WAVE_CYCLES"][1] / d["SQ_WAVE_CYCLES"][0]
-    print("   wait_any/wave_cycles %.2f   wait_inst/wave_cycles %.2f" % (d["SQ_WAIT_ANY"][1] / d["SQ_WAIT_ANY"][0] / w, d["SQ_WAIT_INST_ANY"][1] / d["SQ_WAIT_INST_ANY"][0] / w))
+# kernel durations of the GRBM pass itself (the clock is cycles / time of the SAME dispatches)
+for f in glob.glob("gpurun_out/pmch_GRBM_GUI_ACTIVE/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if want(k):
+            d = dur[k[:28]]
+            d[0] += 1; d[1] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+with open(sys.argv[1], "w") as out:
+    def P(s):
+        print(s); out.write(s + "\n")
+    P("# scripts/pmc_headline_sq.sh: python3 bench.py --no-extra --no-cpu-baseline --steps 10 --warmup 2, one counter group per pass")
+    for k, d in acc.items():
+        P(k)
+        for c, (m, v) in sorted(d.items()):
+            P("   %-24s %.4e per call (%d calls)" % (c, v / m, m))
+        per = lambda c: d[c][1] / d[c][0] if d[c][0] else float("nan")
+        w = per("SQ_WAVE_CYCLES")
+        P("   wait_any/wave_cycles %.3f   wait_inst_any/wave_cycles %.3f   active_valu/busy(4 SIMD-cycles) %.3f" % (
+            per("SQ_WAIT_ANY") / w, per("SQ_WAIT_INST_ANY") / w, per("SQ_ACTIVE_INST_VALU") / max(per("SQ_BUSY_CYCLES"), 1)))
+        if dur[k][0] and d["GRBM_GUI_ACTIVE"][0]:
+            ns = dur[k][1] / dur[k][0]
+            mhz = per("GRBM_GUI_ACTIVE") / 8.0 / ns * 1e3
+            P("   kernel %.4f ms (in the GRBM pass)   sustained clock %.0f MHz (GRBM_GUI_ACTIVE / 8 / time)" % (ns * 1e-6, mhz))
+            # VALU issue: wave-instructions / (1024 SIMDs x clock x time / 2 cycles per wave64 fp32 instruction on the SIMD-32)
+            P("   valu_issue_frac_at_sustained_clock %.3f   at 2400 MHz %.3f" % (
+                per("SQ_INSTS_VALU") / (1024 * mhz * 1e6 * ns * 1e-9 / 2.0), per("SQ_INSTS_VALU") / (1024 * 2.4e9 * ns * 1e-9 / 2.0)))
 PY
