@@ -276,6 +276,9 @@ def plan(system, d, Sigma0=None, for_grad=False):
         # a class-level probe instead of reading the component's values back from the device (22 synchronisations)
         for i, (sub, _, _) in enumerate(result):
             sub._lqg_zoo_component = (type(system), tuple(sorted(zs.items())), d, i)
+    elif zs is not None and for_grad and Sigma0 is None:
+        for i, (sub, _, _) in enumerate(result):      # (specialize.adjoint_pattern: the constructor's structure serves the gradient too)
+            sub._lqg_zoo_component_grad = (type(system), tuple(sorted(zs.items())), d, i)
     if not for_grad:
         entry["parts"] = result
     return result

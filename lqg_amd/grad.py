@@ -73,8 +73,12 @@ class Sweep:
     the log-likelihood) and `reverse(g)` (the two adjoint sweeps with upstream weights g, returns the bars).  The
     workspace lives as long as this object (an autograd node keeps it between forward and backward)."""
 
-    def __init__(self, actor, dynamics, x, Sigma0=None, eps=1e-8):
+    def __init__(self, actor, dynamics, x, Sigma0=None, eps=1e-8, system=None):
+        """system: the System that owns the two specs — with it (time-invariant specs, no affine cost terms) the sweep runs on
+        the structure-specialised adjoint library of the specs' sparsity pattern (round 5: csrc/lqg_adjoint_sp.hpp — matrix
+        adjoints once per SYSTEM, trials reduced to per-step sums, bars returned summed over the trials)."""
         d = x.shape[-1]
+        self.sp = None
         # fp32 with EVERY state observed (the point-mass model seen in full: cond(Sigma_oo) ~ 5e8): the reverse sweep
         # conditions through the explicit S_oo^-1, which fp32 cannot carry -- same policy as the mixed forward problem
         # LQG_F32_SYS64 (include/lqg_hip.h): the sweeps run over an fp64 image, value and bars are rounded to fp32 once
@@ -100,6 +104,19 @@ class Sweep:
         self.ln = ln
         self.x, self.xb = _hip._prep_x(ln, x)
         self.N = self.x.shape[-3]
+        self.sp = _specialised_adjoint(ln, system, d)
+        if self.sp is not None:
+            self.per_sys, self.lanes = 1, ln.B
+            self.ld = (self.lanes + 63) // 64 * 64
+            self.lay, self.total = _layout(ln.dims)
+            self.slabs = 1
+            self.nbytes = int(self.sp.lqg_grad_workspace_bytes_sp(C.byref(ln.p)))
+            if self.nbytes == 0:
+                self.sp = None
+            else:
+                self.ws = torch.empty(max(self.nbytes, 256), dtype=torch.uint8, device=ln.device)
+                self.fresh = False
+                return
         # lanes of the gradient array per system: the trials (lane kernels: the caller sums over them) or 1 (cooperative
         # sweep: bars already summed over the trials) — include/lqg_hip.h: lqg_grad_lanes_per_system
         self.per_sys = int(self.lib.lqg_grad_lanes_per_system(C.byref(ln.p)))
@@ -115,8 +132,9 @@ class Sweep:
     def _call(self, phases, g, ll, out):
         ln, N = self.ln, self.N
         ptr = lambda t: C.c_void_p(t.data_ptr() if t is not None else None)
+        entry = self.sp.lqg_log_likelihood_grad_sp if self.sp is not None else self.lib.lqg_log_likelihood_grad
         with torch.cuda.device(ln.device):
-            _abi.check(self.lib.lqg_log_likelihood_grad(
+            _abi.check(entry(
                 C.byref(ln.p), ln.traj(self.x, self.xb), ptr(g), N if ln.batched else 0, 1, ptr(ll),
                 N if ln.batched else 0, 1, ptr(out), self.ld, ptr(self.ws), self.nbytes, phases, ln.stream()),
                 "lqg_log_likelihood_grad")
@@ -147,10 +165,31 @@ class Sweep:
         return bars
 
 
-def raw_grad(actor, dynamics, x, g=None, Sigma0=None, eps=1e-8, want_value=True):
+def _specialised_adjoint(ln, system, d):
+    """The adjoint library of the system's sparsity pattern (lqg_amd/specialize.py: padj_<key>.so), or None: specs that vary
+    in time, affine cost terms, joint dimensions beyond the lane kernels, LQG_ADJOINT_SP=0, LQG_COOP_ADJOINT=1, no compiler."""
+    from lqg_amd import options, specialize
+    if system is None or not options.flag("ADJOINT_SP") or options.get("COOP_ADJOINT") or ln.m > ADJOINT_SP_MAX_JOINT:
+        return None
+    p = ln.p
+    if ln.T > 1:
+        for spec, fields in ((p.actor, ("Q", "R", "A", "B", "V", "F", "W")), (p.dynamics, ("A", "B", "V", "F", "W"))):
+            if any(getattr(spec, f).st != 0 for f in fields):
+                return None
+    if any(getattr(p.actor, f).ptr for f in ("q", "qf", "P", "r")):
+        return None
+    dims, masks, key = specialize.adjoint_pattern(system, d)
+    return specialize.load_adjoint_pattern(key, dims, masks)
+
+
+ADJOINT_SP_MAX_JOINT = 12       # largest x + b the specialised adjoint libraries are generated for (registers: the chunk's states)
+
+
+def raw_grad(actor, dynamics, x, g=None, Sigma0=None, eps=1e-8, want_value=True, system=None):
     """Both phases at once.  x[n,T+1,d] or [B,n,T+1,d]; g like the log-likelihood ([n] / [B,n]) or None.
-    Returns (ll, {name: [B, N, r, c] per-(system, trial) bars}, launch)."""
-    sw = Sweep(actor, dynamics, x, Sigma0=Sigma0, eps=eps)
+    Returns (ll, {name: [B, N, r, c] per-(system, trial) bars — [B, 1, r, c], summed over the trials, from the specialised
+    adjoint libraries and the cooperative sweep}, launch)."""
+    sw = Sweep(actor, dynamics, x, Sigma0=Sigma0, eps=eps, system=system)
     ll = sw.forward()
     return ll, sw.reverse(g), sw.ln
 
@@ -165,7 +204,7 @@ class _LogLikelihood(torch.autograd.Function):
         ctx.save_for_backward(*(mats + ((Sigma0,) if Sigma0 is not None else ())))
         ctx.has_s0 = Sigma0 is not None
         with torch.no_grad():
-            ctx.sweep = Sweep(system.actor, system.dynamics, x, Sigma0=Sigma0)
+            ctx.sweep = Sweep(system.actor, system.dynamics, x, Sigma0=Sigma0, system=system)
             return ctx.sweep.forward()
 
     @staticmethod

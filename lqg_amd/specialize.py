@@ -244,6 +244,97 @@ def load_pattern(key, dims, masks, verbose=False):
     return lib
 
 
+# ---------------------------------------------------------------- adjoint libraries (round 5: csrc/lqg_adjoint_sp.hpp)
+_adj_libs = {}
+ADJ_EXTRA_FLAGS = []           # (no value-changing flags: the bars are compared with the restatement entry by entry)
+
+
+def generate_adjoint_source(key, dims, masks):
+    def lit(m):
+        return "{{" + ", ".join("true" if v else "false" for v in m.reshape(-1)) + "}}"
+    d = dims
+    tpl = f"Pat, {d['x']}, {d['b']}, {d['u']}, {d['y']}, {d['d']}"
+    lines = ["// GENERATED by lqg_amd/specialize.py — structure-specialised reverse-mode sweep, pattern " + key,
+             '#include "lqg_adjoint_sp_entry.hpp"', "", "namespace {", "struct Pat {"]
+    for k in _FIELDS:
+        r, c = masks[k].shape
+        lines.append(f"  static constexpr lqg::Mask<{r}, {c}> {k}{lit(masks[k])};")
+    lines += ["};", "}  // namespace", "",
+              'extern "C" int lqg_log_likelihood_grad_sp(const lqg_problem* p, lqg_traj x, const void* g, int64_t g_sb, int64_t g_sn,',
+              "                                          void* ll, int64_t ll_sb, int64_t ll_sn, void* grad, int64_t ld, void* workspace,",
+              "                                          size_t workspace_bytes, int32_t phases, void* stream) {",
+              f"  return lqg::host::log_likelihood_grad_sp<{tpl}>(p, x, g, g_sb, g_sn, ll, ll_sb, ll_sn, grad, ld, workspace,",
+              "                                                   workspace_bytes, phases, stream);", "}",
+              'extern "C" size_t lqg_grad_workspace_bytes_sp(const lqg_problem* p) {',
+              f"  return lqg::host::grad_workspace_bytes_sp<{tpl}>(p);", "}",
+              f'extern "C" const char* lqg_sp_pattern_key(void) {{ return "{key}"; }}', ""]
+    return "\n".join(lines)
+
+
+def _adj_headers_hash():
+    h = hashlib.sha1(" ".join(ADJ_EXTRA_FLAGS).encode())
+    for f in ("lqg_small.hpp", "lqg_sparse.hpp", "lqg_kernels.hpp", "lqg_kernels_sp.hpp", "lqg_launch.hpp", "lqg_trial_chunk.hpp",
+              "lqg_adjoint.hpp", "lqg_adjoint_sp.hpp", "lqg_adjoint_trial_sp.hpp", "lqg_adjoint_sp_entry.hpp", "../../include/lqg_hip.h"):
+        h.update(open(os.path.join(_build.CSRC, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def compile_adjoint_pattern(key, dims, masks, verbose=False):
+    """Generate + compile <pattern dir>/padj_<key>.so — the reverse-mode twin of pat_<key>.so (same masks, same locking
+    discipline as compile_pattern)."""
+    pdir = _build.cache_dir(PAT_DIR, "pat")
+    so = os.path.join(pdir, f"padj_{key}.so")
+    hh = _adj_headers_hash()
+    if _build.stamped(so, hh):
+        return so
+    hipcc = _build.HIPCC if os.path.exists(_build.HIPCC) else shutil.which("hipcc")
+    if not hipcc:
+        return None
+    with _build.locked(so):
+        if _build.stamped(so, hh):
+            return so
+        src = os.path.join(pdir, f"padj_{key}.hip")
+        _build.atomic_write(src, generate_adjoint_source(key, dims, masks))
+        flags = [fl for fl in _build.FLAGS if not fl.startswith("-std=")] + ["-std=c++20"] + ADJ_EXTRA_FLAGS
+        flags += ["-I", _build.CSRC] + os.environ.get("LQG_ADJ_FLAGS", "").split()
+        tmp = f"{so}.tmp.{os.getpid()}"
+        cmd = [hipcc] + flags + ["-shared", src, "-o", tmp]
+        if verbose:
+            print(f"[lqg_amd.specialize] compiling adjoint pattern {key} dims={dims} density={density(masks):.2f}", flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-6000:]}")
+        os.replace(tmp, so)
+        _build.atomic_write(so + ".stamp", hh)
+    return so
+
+
+def load_adjoint_pattern(key, dims, masks, verbose=False):
+    """ctypes handle of the adjoint library of this pattern (compiled on first use), or None (the caller then runs the
+    round-1 lane kernels of the main library)."""
+    if key in _adj_libs:
+        return _adj_libs[key]
+    lib = None
+    try:
+        so = compile_adjoint_pattern(key, dims, masks, verbose=verbose)
+        if so is not None:
+            lib = C.CDLL(so)
+            lib.lqg_log_likelihood_grad_sp.argtypes = [C.POINTER(_abi.Problem), _abi.Traj, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                                       C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t,
+                                                       C.c_int32, C.c_void_p]
+            lib.lqg_log_likelihood_grad_sp.restype = C.c_int
+            lib.lqg_grad_workspace_bytes_sp.argtypes = [C.POINTER(_abi.Problem)]
+            lib.lqg_grad_workspace_bytes_sp.restype = C.c_size_t
+    except (OSError, RuntimeError) as e:
+        import warnings
+        warnings.warn(f"lqg_amd: no adjoint library for pattern {key} ({e!s:.300}); using the generic adjoint kernels")
+        lib = None
+    _adj_libs[key] = lib
+    return lib
+
+
 # ---------------------------------------------------------------- model-zoo patterns (probe instances)
 def class_pattern(cls, d, **structure_kw):
     """Pattern of a model-zoo class from a CPU probe instance with random positive parameters."""
@@ -322,6 +413,42 @@ def system_pattern(system, d, grad_full=False):
             dims, masks = pattern_of(system, d_in, grad_full=grad_full)
             cache[d] = (dims, masks, pattern_key(dims, masks))
     return cache[d]
+
+
+def adjoint_pattern(system, d):
+    """(dims, masks, key) for the reverse-mode sweep of a System: the constructor's structure for the model zoo and its
+    decoupled components (a structural zero of a zoo constructor is a constant: its adjoint is never needed), else the pattern
+    with every field that requires grad counted as FULL (pattern_of(grad_full=True))."""
+    hint = getattr(system, "_lqg_zoo_component", None) or getattr(system, "_lqg_zoo_component_grad", None)
+    if hint is not None:
+        pat = zoo_component_pattern(hint)
+        if pat is not None and pat[0]["d"] == d:
+            return pat
+    return system_pattern(system, d, grad_full=True)
+
+
+def prebuild_zoo_adjoint(verbose=True, workers=None):
+    """AOT: the adjoint libraries of the model zoo (1-D classes and the decoupled components of the dim = 2 ones), so that
+    torch.autograd through a zoo constructor never compiles on the GPU box."""
+    import concurrent.futures as cf
+    import lqg_amd
+    pats = {}
+    for cls, d, kw in [(lqg_amd.BoundedActor, 2, dict(dim=1)), (lqg_amd.OptimalActor, 2, dict(dim=1)),
+                       (lqg_amd.RelativeObservationBoundedActor, 2, dict(dim=1)), (lqg_amd.SubjectiveActor, 2, dict(dim=1)),
+                       (lqg_amd.PointMassBoundedActor, 2, {}), (lqg_amd.PointMassBoundedActor, 4, {})]:
+        dims, masks, key = class_pattern(cls, d, **kw)
+        pats[key] = (dims, masks)
+    for cls, d, kw in [(lqg_amd.BoundedActor, 4, dict(dim=2)), (lqg_amd.SubjectiveActor, 4, dict(dim=2))]:
+        i = 0
+        while True:
+            pat = zoo_component_pattern((cls, tuple(sorted(kw.items())), d, i))
+            if pat is None:
+                break
+            pats[pat[2]] = (pat[0], pat[1])
+            i += 1
+    with cf.ThreadPoolExecutor(workers or min(8, os.cpu_count() or 1)) as ex:
+        list(ex.map(lambda kv: compile_adjoint_pattern(kv[0], kv[1][0], kv[1][1], verbose=verbose), pats.items()))
+    return sorted(pats)
 
 
 def prebuild_zoo(verbose=True, workers=None):

@@ -1,10 +1,9 @@
 """Value + gradient through torch.autograd on the two shapes the review names (GPU box):
-import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
   headline   SubjectiveActor(dim=2), T=500, B candidates x 1 trial each (own trajectory)
   config3    BoundedActor, T=1067, C candidates x N shared trials
 Prints one JSON line per (shape, dtype): ms per value+grad, solves+grad/s, forward-only ms beside it."""
-import argparse, json, time
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import lqg_amd
 from lqg_amd import workload
