@@ -25,6 +25,10 @@
 #include "lqg_adjoint.hpp"
 #include "lqg_kernels_sp.hpp"
 
+#ifndef LQG_ASP_SYS_WAVES_F32
+#define LQG_ASP_SYS_WAVES_F32 2   // waves per SIMD the fp32 system sweeps are allocated for (fp64: 1)
+#endif
+
 namespace lqg {
 namespace asp {
 
@@ -94,12 +98,13 @@ LQG_DEV void load_tri_arr(const R* __restrict__ p, long ld, R (&A)[N * N]) {
 }
 
 // ---------------------------------------------------------------- the trial sums of one (system, step)
-// g = sum_n g_n | W2 (lower triangle, by rows) = sum_n g_n a_n(t+1) a_n(t+1)' | CA[RR, O] = sum_n ch_n a_n(t)' |
+// W2 (lower triangle, by rows) = sum_n g_n a_n(t+1) a_n(t+1)' | CA[RR, O] = sum_n ch_n a_n(t)' |
 // MC on the mask FM of the joint dynamics (row-major order of its set entries) = sum_n post_n c_n'
+// (sum_n g_n, the same at every step, travels once per system: AspArgs::gsum)
 template <int M, int ND, Mask<M, M> FM>
 struct Sums {
   static constexpr int O = ND, RR = M - ND;
-  static constexpr int G_OFF = 0, W_OFF = 1, NW = O * (O + 1) / 2;
+  static constexpr int W_OFF = 0, NW = O * (O + 1) / 2;
   static constexpr int C_OFF = W_OFF + NW;
   static constexpr int M_OFF = C_OFF + RR * O;
   static constexpr int NMC = FM.count();
@@ -122,6 +127,7 @@ struct AspArgs {
   long ll_sn;
   R* ck;                     // system checkpoints [nck + 1][CKW][ldb]   (CKW: see sys kernels)
   R* sums;                   // trial sums [parts][n_sys][T][Sums::N]    (stream path)
+  const R* gsum;             // [parts][n_sys] sums of the upstream weights     (stream path)
   int parts;
   R* Lbar;                   // [T][NU * NB][ldb]
   R* out;                    // gradient [Layout::TOTAL][ld]
@@ -279,7 +285,7 @@ struct Masks {
 // NTR >= 1: the NTR trials of each system are swept in-lane (value written here); NTR == 0: the per-step trial operators go
 // to the operator stream (lqg_kernels.hpp TrialOps) for k_asp_trial_fwd / k_asp_trial_rev.
 template <typename R, int NX, int NB, int NU, int NY, int ND, typename PAT, int NTR, bool DENSE_P, int CK>
-__global__ void __launch_bounds__(LQG_BLOCK, 1) k_asp_sys_fwd(const AspArgs<R> A) {
+__global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES_F32 : 1)) k_asp_sys_fwd(const AspArgs<R> A) {
   constexpr int M = NX + NB, O = ND, RR = M - ND;
   constexpr int NT = NTR > 0 ? NTR : 1;
   using Ops = TrialOps<M, ND>;
@@ -407,7 +413,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, 1) k_asp_sys_fwd(const AspArgs<R> A
 // chunk's checkpoint into registers, then the steps are differentiated backward.  NTR == 0: the trial sums come from
 // k_asp_trial_rev (A.sums, A.parts partial records per step); NTR >= 1: formed in-lane.
 template <typename R, int NX, int NB, int NU, int NY, int ND, typename PAT, int NTR, bool DENSE_P, int CK>
-__global__ void __launch_bounds__(LQG_BLOCK, 1) k_asp_sys_rev(const AspArgs<R> A) {
+__global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES_F32 : 1)) k_asp_sys_rev(const AspArgs<R> A) {
   constexpr int M = NX + NB, O = ND, RR = M - ND;
   constexpr int NT = NTR > 0 ? NTR : 1;
   using Rec = CkRec<NB, M, NTR>;
@@ -457,6 +463,10 @@ __global__ void __launch_bounds__(LQG_BLOCK, 1) k_asp_sys_rev(const AspArgs<R> A
     }
   }
 
+  R gs_stream = R(0);
+  if constexpr (NTR == 0) {
+    for (int part = 0; part < A.parts; ++part) gs_stream += A.gsum[(long)part * a.n_sys + s];
+  }
   R Lbuf[CK][NU * NB];
   R Pst[CK][NSB], Sst[CK][NSM];                         // register stack of the chunk's states (static indices only)
   TrialState<R, M, ND> Tst[CK][NT];
@@ -615,9 +625,9 @@ __global__ void __launch_bounds__(LQG_BLOCK, 1) k_asp_sys_rev(const AspArgs<R> A
             LQG_UNROLL for (int i = 0; i < O * O; ++i) W2[i] = R(0);
             LQG_UNROLL for (int i = 0; i < RR * O; ++i) CA[i] = R(0);
             set_zero(MC);
+            gs = gs_stream;
             for (int part = 0; part < A.parts; ++part) {
               const R* sm = A.sums + (((long)part * a.n_sys + s) * a.T + t) * SM::N;
-              gs += sm[SM::G_OFF];
               int e = 0;
               LQG_UNROLL for (int i = 0; i < O; ++i)
                 LQG_UNROLL for (int k = 0; k <= i; ++k) {
@@ -780,7 +790,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, 1) k_asp_sys_rev(const AspArgs<R> A
 // ================================================================= phase 2: adjoint of the Riccati recursion (forward in time)
 // consumes Lbar_t; the chunk's S_{t+1} are recomputed backward from the checkpoint into registers.   lqr.py:16-42
 template <typename R, int NB, int NU, int NX, int NY, typename PAT, int CK>
-__global__ void __launch_bounds__(LQG_BLOCK, 1) k_asp_ric_rev(const AspArgs<R> A) {
+__global__ void __launch_bounds__(LQG_BLOCK, 2) k_asp_ric_rev(const AspArgs<R> A) {
   using Lay = adj::Layout<NX, NB, NU, NY>;
   constexpr int NS = NB * (NB + 1) / 2;
   const RiccatiArgs<R>& rc = A.rc;

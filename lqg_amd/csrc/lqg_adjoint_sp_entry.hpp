@@ -20,7 +20,7 @@ namespace host {
 #endif
 
 struct AspWorkspace {
-  size_t sck_off, ck_off, ops_off, tck_off, sums_off, lbar_off, total;
+  size_t sck_off, ck_off, ops_off, tck_off, sums_off, gsum_off, lbar_off, total;
   long ldb, npad;
   int nck, nckt, parts;
 };
@@ -50,6 +50,8 @@ inline AspWorkspace asp_carve(const lqg_problem* p) {
   off += fused ? 0 : al((size_t)p->n_sys * (size_t)(w.nckt + 1) * M * w.npad * esz);
   w.sums_off = off;
   off += fused ? 0 : al((size_t)w.parts * p->n_sys * (size_t)p->T * NSUM * esz);
+  w.gsum_off = off;
+  off += fused ? 0 : al((size_t)w.parts * p->n_sys * esz);
   w.lbar_off = off;
   off += al((size_t)p->T * NU * NB * w.ldb * esz);
   w.total = off;
@@ -109,11 +111,11 @@ int run_asp(const lqg_problem* p, lqg_traj x, const void* g, long g_sb, long g_s
   A.ck = reinterpret_cast<R*>(base + w.ck_off);
   A.sums = fused ? nullptr : reinterpret_cast<R*>(base + w.sums_off);
   A.parts = w.parts;
+  A.gsum = fused ? nullptr : reinterpret_cast<R*>(base + w.gsum_off);
   A.Lbar = reinterpret_cast<R*>(base + w.lbar_off);
   A.out = static_cast<R*>(grad);
   A.ld = ld;
   lqg::asp::TrialRevArgs<R> tr{};
-  tr.ops = ops;
   tr.x = dt<R>(x);
   tr.g = static_cast<const R*>(g);
   tr.g_sb = g_sb;
@@ -125,6 +127,7 @@ int run_asp(const lqg_problem* p, lqg_traj x, const void* g, long g_sb, long g_s
   tr.npad = w.npad;
   tr.nckt = w.nckt;
   tr.sums = A.sums;
+  tr.gsum = fused ? nullptr : reinterpret_cast<R*>(base + w.gsum_off);
   tr.n_sys = (long)p->n_sys;
   tr.n_trials = (long)p->n_trials;
   tr.T = p->T;
@@ -142,14 +145,22 @@ int run_asp(const lqg_problem* p, lqg_traj x, const void* g, long g_sb, long g_s
     else if (p->n_trials == 2) LQG_ASP_SYS(k_asp_sys_fwd, 2);
     else LQG_ASP_SYS(k_asp_sys_fwd, 0);
     mark(2);
-    if (!fused)
-      hipLaunchKernelGGL((lqg::asp::k_asp_trial_fwd<R, M, ND, LQG_ASP_TPL, LQG_ASP_CKT, MK::FJ>), tgrid, tblock, 0, st, tr);
+    if (!fused) {   // the per-trial sweep of the forward path (k_trial_sp), keeping the mean state every CKT steps
+      lqg::TrialArgs<R> tk{dt<R>(x), dt<R>(no_traj), static_cast<R*>(ll), ll_sb, ll_sn, (long)p->n_trials, p->T, tr.tck, w.npad, w.nckt};
+      constexpr auto FMT = lqg::trial_operator_mask<PAT, NX, NB, NU, NY, ND, DENSE_P>();
+      const long lanes4 = (long)p->n_sys * ((p->n_trials + 4 * LQG_BLOCK - 1) / (4 * LQG_BLOCK)) * LQG_BLOCK;
+      const bool wide = lanes4 >= 2L * 1024 * 64;
+      const long per_block = (long)LQG_BLOCK * (wide ? LQG_TRIALS_PER_LANE : 1);
+      const dim3 fgrid((unsigned)((p->n_trials + per_block - 1) / per_block), (unsigned)p->n_sys);
+      if (wide) hipLaunchKernelGGL((lqg::k_trial_sp<R, M, ND, LQG_TRIALS_PER_LANE, FMT, LQG_ASP_CKT>), fgrid, block, 0, st, ops, tk);
+      else hipLaunchKernelGGL((lqg::k_trial_sp<R, M, ND, 1, FMT, LQG_ASP_CKT>), fgrid, block, 0, st, ops, tk);
+    }
     mark(3);
   }
   if (phases & 2) {
     if (!grad) return LQG_ERR_NULL;
     if (!fused)
-      hipLaunchKernelGGL((lqg::asp::k_asp_trial_rev<R, M, ND, LQG_ASP_TPL, LQG_ASP_CKT, MK::FJ>), tgrid, tblock, 0, st, tr);
+      hipLaunchKernelGGL((lqg::asp::k_asp_trial_rev<R, M, ND, LQG_ASP_TPL, LQG_ASP_CKT, MK::FJ>), tgrid, tblock, 0, st, ops, tr);
     if (p->n_trials == 1) LQG_ASP_SYS(k_asp_sys_rev, 1);
     else if (p->n_trials == 2) LQG_ASP_SYS(k_asp_sys_rev, 2);
     else LQG_ASP_SYS(k_asp_sys_rev, 0);

@@ -1,7 +1,7 @@
 // lqg_adjoint_trial_sp.hpp — the per-TRIAL half of the round-5 reverse-mode sweep (lqg_adjoint_sp.hpp), gfx950.
 //
-//   k_asp_trial_fwd   mean recursion + log-density over the operator stream (lqg/system.py:219-221, 244-248; the arithmetic of
-//                     k_trial_sp), keeping the mean state every CKT steps
+//   (forward)         k_trial_sp<..., CKT> of lqg_kernels_sp.hpp: mean recursion + log-density over the operator stream
+//                     (lqg/system.py:219-221, 244-248), keeping the mean state every CKT steps
 //   k_asp_trial_rev   the mu-bar recursion backward over the same stream: per chunk the steps' (w, c) are recomputed from the
 //                     chunk's checkpoint into registers, then walked backward; per step the workgroup's trials are reduced to
 //                     the TRIAL SUMS of asp::Sums (wave butterfly: log2 stages in which every lane hands half of its values to
@@ -23,7 +23,6 @@ namespace asp {
 
 template <typename R>
 struct TrialRevArgs {
-  const R* ops;              // operator stream [n_sys][T + 1][TrialOps::N]
   DTraj<R> x;
   const R* g;                // upstream weights, null = 1
   long g_sb, g_sn;
@@ -33,154 +32,145 @@ struct TrialRevArgs {
   long npad;
   int nckt;
   R* sums;                   // [parts = gridDim.x][n_sys][T][Sums::N]
+  R* gsum;                   // [parts][n_sys]: sum of the upstream weights of the part's trials
   long n_sys, n_trials;
   int T;
 };
 
-// ---------------------------------------------------------------- forward
-template <typename R, int M, int ND, int TPL, int CKT, Mask<M, M> FM>
-__global__ void __launch_bounds__(LQG_ASP_TRIAL_BLOCK) k_asp_trial_fwd(const TrialRevArgs<R> a) {
-  constexpr int O = ND, RR = M - ND, BLK = LQG_ASP_TRIAL_BLOCK;
-  using Ops = TrialOps<M, ND>;
-  // the FM of the sums is the mask of Fj; the operator stream holds Fj - I: its diagonal is always present
-  constexpr auto FMD = mask_or(FM, mask_eye<M>());
-  const long sys = blockIdx.y;
-  const long n0 = (long)blockIdx.x * (BLK * TPL) + threadIdx.x;
-  const R* __restrict__ op = a.ops + sys * (long)(a.T + 1) * Ops::N;
-  const R* xr[TPL];
-  bool live[TPL];
-  R xprev[TPL][O], dO[TPL][O], muR[TPL][RR], part[TPL];
-  double acc[TPL];
-  long nn[TPL];
-  LQG_UNROLL for (int k = 0; k < TPL; ++k) {
-    long n = n0 + (long)k * BLK;
-    live[k] = n < a.n_trials;
-    n = live[k] ? n : (a.n_trials - 1);
-    nn[k] = n;
-    xr[k] = a.x.p + sys * a.x.sb + n * a.x.sn;
-    LQG_UNROLL for (int i = 0; i < O; ++i) { xprev[k][i] = xr[k][i * a.x.sd]; dO[k][i] = R(0); }
-    LQG_UNROLL for (int i = 0; i < RR; ++i) muR[k][i] = R(0);
-    acc[k] = 0.0;
-    part[k] = R(0);
-  }
-  const R none[1] = {R(0)};
-  for (int t = 0; t <= a.T; ++t) {
-    const R* __restrict__ opt = op + (long)t * Ops::N;
-    if (t % CKT == 0 || t == a.T) {
-      const int rec = t == a.T ? a.nckt : t / CKT;
-      R* dst = a.tck + ((sys * (a.nckt + 1) + rec) * M) * a.npad;
-      LQG_UNROLL for (int k = 0; k < TPL; ++k)
-        if (live[k]) {
-          LQG_UNROLL for (int i = 0; i < O; ++i) dst[i * a.npad + nn[k]] = dO[k][i];
-          LQG_UNROLL for (int i = 0; i < RR; ++i) dst[(O + i) * a.npad + nn[k]] = muR[k][i];
-        }
+// ---------------------------------------------------------------- wave butterfly
+// V <= 32 values per lane -> lane l (< 32) holds the wave's total of value bitrev5(l).  Stage s pairs lane l with l ^ 2^s: each
+// hands the partner the half of its values the partner keeps, so the stages cost 16 + 8 + 4 + 2 + 1 pair operations instead
+// of 32 full six-stage reductions.  Partner exchange: DPP quad permutes (xor 1, 2), ds_swizzle (xor 4, 8, 16: the LDS
+// crossbar, no memory), one ds_bpermute for the two half-waves.
+template <int S>
+LQG_DEV float lane_xor(float v) {
+  if constexpr (S == 0) return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
+  else if constexpr (S == 1) return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));
+  else if constexpr (S <= 4) return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), ((1 << S) << 10) | 0x1F));
+  else return __shfl_xor(v, 32);
+}
+template <int S>
+LQG_DEV double lane_xor(double v) {
+  const long long b = __double_as_longlong(v);
+  int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+  if constexpr (S == 0) { lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, false); }
+  else if constexpr (S == 1) { lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, false); }
+  else if constexpr (S <= 4) { lo = __builtin_amdgcn_ds_swizzle(lo, ((1 << S) << 10) | 0x1F); hi = __builtin_amdgcn_ds_swizzle(hi, ((1 << S) << 10) | 0x1F); }
+  else return __shfl_xor(v, 32);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// stage S (partner = lane ^ 2^S) over the slots [0, 2 H): slot k + H is handed over / received.  Slots whose indices all lie
+// beyond the V live values (BASE + k + H >= V) hold nothing: there both lanes just add the partner's slot k (one instruction;
+// what the `up` lanes then hold stands for an index >= V and is never read).
+template <int S, int H, int BASE, int V, int VP, typename R>
+LQG_DEV void butterfly_stage(R (&cur)[VP], const bool up) {
+  LQG_UNROLL for (int k = 0; k < H; ++k) {
+    if (BASE + k + H >= V) {
+      cur[k] = cur[k] + lane_xor<S>(cur[k]);
+    } else {
+      const R lo = cur[k], hi = cur[k + H];
+      const R keepv = up ? hi : lo;
+      const R send = up ? lo : hi;
+      cur[k] = keepv + lane_xor<S>(send);
     }
-    R Li[O * (O + 1) / 2];
-    LQG_UNROLL for (int i = 0; i < O * (O + 1) / 2; ++i) Li[i] = opt[Ops::L_OFF + i];
-    const R hlc = opt[Ops::H_OFF];
-    LQG_UNROLL for (int k = 0; k < TPL; ++k) {
-      R cv[M], w[O];
-      LQG_UNROLL for (int i = 0; i < O; ++i) cv[i] = xr[k][(long)t * a.x.st + i * a.x.sd];
-      R zz = R(0);
-      {
-        int e = 0;
-        LQG_UNROLL for (int i = 0; i < O; ++i) {
-          R v = R(0);
-          LQG_UNROLL for (int j = 0; j <= i; ++j) v += Li[e++] * ((cv[j] - xprev[k][j]) - dO[k][j]);
-          w[i] = v;
-          zz += v * v;
-        }
-      }
-      if (t > 0) part[k] += R(0.5) * zz + hlc;
-      if ((t & 7) == 0 || t == a.T) { acc[k] -= (double)part[k]; part[k] = R(0); }
-      if (t < a.T) {
-        LQG_UNROLL for (int p = 0; p < RR; ++p) {
-          R v = muR[k][p];
-          LQG_UNROLL for (int j = 0; j < O; ++j) v += opt[Ops::U_OFF + p * O + j] * w[j];
-          cv[O + p] = v;
-        }
-        R mn[M];
-        trial_mean_rows<R, M, ND, FMD, false, 1, 0>(none, opt, cv, mn);
-        LQG_UNROLL for (int i = 0; i < O; ++i) { dO[k][i] = mn[i]; xprev[k][i] = cv[i]; }
-        LQG_UNROLL for (int p = 0; p < RR; ++p) muR[k][p] = cv[O + p] + mn[O + p];     // (the stream holds Fj - I)
-      }
-    }
-  }
-  if (a.ll) {
-    LQG_UNROLL for (int k = 0; k < TPL; ++k)
-      if (live[k]) a.ll[sys * a.ll_sb + nn[k] * a.ll_sn] = (R)acc[k];
   }
 }
 
-// ---------------------------------------------------------------- wave butterfly: V <= 32 values per lane -> lane l (< 32)
-// holds the wave's total of value bitrev5(l)
-LQG_DEV int bitrev5(int l) { return ((l & 1) << 4) | ((l & 2) << 2) | (l & 4) | ((l & 8) >> 2) | ((l & 16) >> 4); }
+constexpr int pow2_at_least(int v) { return v <= 8 ? 8 : (v <= 16 ? 16 : 32); }
+// index whose total lane l holds after the VP-slot butterfly: the low log2(VP) lane bits, reversed
+template <int VP>
+LQG_DEV int butterfly_index(int l) {
+  if constexpr (VP == 8) return ((l & 1) << 2) | (l & 2) | ((l & 4) >> 2);
+  else if constexpr (VP == 16) return ((l & 1) << 3) | ((l & 2) << 1) | ((l & 4) >> 1) | ((l & 8) >> 3);
+  else return ((l & 1) << 4) | ((l & 2) << 2) | (l & 4) | ((l & 8) >> 2) | ((l & 16) >> 4);
+}
 
-template <typename R, int V>
-LQG_DEV R wave_transpose_reduce(const R (&v)[V], int base) {
-  static_assert(V > 0, "values");
+// values v[BASE .. BASE + VP) of every lane -> lane l holds the wave's total of value BASE + butterfly_index<VP>(l)
+template <typename R, int V, int BASE, int VP>
+LQG_DEV R wave_transpose_reduce(const R (&v)[V]) {
   const int lane = threadIdx.x & 63;
-  R cur[32];
-  LQG_UNROLL for (int i = 0; i < 32; ++i) cur[i] = R(0);
-  LQG_UNROLL for (int i = 0; i < 32; ++i)
-    if (base + i < V) cur[i] = v[base + i < V ? base + i : 0];
-  // which of the 32 slots can be non-zero is known at compile time; stages on all-zero pairs fold away only partly — the
-  // explicit bound below skips them
-  constexpr int h0 = 16;
-  int hbit = 0;
-  (void)hbit;
-  LQG_UNROLL for (int s = 0; s < 5; ++s) {
-    const int h = h0 >> s;
-    const bool up = (lane >> s) & 1;
-    LQG_UNROLL for (int k = 0; k < 16; ++k)
-      if (k < h) {
-        const R lo = cur[k], hi = cur[k + h];
-        const R keepv = up ? hi : lo;
-        const R send = up ? lo : hi;
-        cur[k] = keepv + __shfl_xor(send, 1 << s);
-      }
+  R cur[VP];
+  LQG_UNROLL for (int i = 0; i < VP; ++i) cur[i] = (BASE + i < V) ? v[BASE + i < V ? BASE + i : 0] : R(0);
+  if constexpr (VP == 32) {
+    butterfly_stage<0, 16, BASE, V>(cur, (lane & 1) != 0);
+    butterfly_stage<1, 8, BASE, V>(cur, (lane & 2) != 0);
+    butterfly_stage<2, 4, BASE, V>(cur, (lane & 4) != 0);
+    butterfly_stage<3, 2, BASE, V>(cur, (lane & 8) != 0);
+    butterfly_stage<4, 1, BASE, V>(cur, (lane & 16) != 0);
+    return cur[0] + lane_xor<5>(cur[0]);
+  } else if constexpr (VP == 16) {
+    butterfly_stage<0, 8, BASE, V>(cur, (lane & 1) != 0);
+    butterfly_stage<1, 4, BASE, V>(cur, (lane & 2) != 0);
+    butterfly_stage<2, 2, BASE, V>(cur, (lane & 4) != 0);
+    butterfly_stage<3, 1, BASE, V>(cur, (lane & 8) != 0);
+    R t = cur[0] + lane_xor<4>(cur[0]);
+    return t + lane_xor<5>(t);
+  } else {
+    butterfly_stage<0, 4, BASE, V>(cur, (lane & 1) != 0);
+    butterfly_stage<1, 2, BASE, V>(cur, (lane & 2) != 0);
+    butterfly_stage<2, 1, BASE, V>(cur, (lane & 4) != 0);
+    R t = cur[0] + lane_xor<3>(cur[0]);
+    t = t + lane_xor<4>(t);
+    return t + lane_xor<5>(t);
   }
-  return cur[0] + __shfl_xor(cur[0], 32);
 }
 
-// reduce V per-lane values over the workgroup and store them contiguously at out[0 .. V); `lds` holds 2 x NW x VP reals,
-// `parity` alternates per call so that ONE barrier per call suffices
+// reduce V per-lane values over the workgroup and store them contiguously at out[0 .. V); `lds` holds 2 x NW x VPT reals,
+// `parity` alternates per call so that ONE barrier per call suffices.  Groups of 32 values, the last one of 8 / 16 / 32.
+template <int V>
+struct ReduceShape {
+  static constexpr int NG = (V + 31) / 32;
+  static constexpr int LAST = pow2_at_least(V - (NG - 1) * 32);
+  static constexpr int VPT = (NG - 1) * 32 + LAST;
+};
+template <int GQ, typename R, int V>
+LQG_DEV void block_reduce_groups(const R (&v)[V], R* buf, int lane, int wave) {
+  using RS = ReduceShape<V>;
+  if constexpr (GQ < RS::NG) {
+    constexpr int VP = (GQ == RS::NG - 1) ? RS::LAST : 32;
+    const R tot = wave_transpose_reduce<R, V, GQ * 32, VP>(v);
+    if (lane < VP) buf[wave * RS::VPT + GQ * 32 + butterfly_index<VP>(lane)] = tot;
+    block_reduce_groups<GQ + 1>(v, buf, lane, wave);
+  }
+}
 template <typename R, int V>
 LQG_DEV void block_reduce_store(const R (&v)[V], R* lds, int parity, R* __restrict__ out) {
   constexpr int NW = LQG_ASP_TRIAL_BLOCK / 64;
-  constexpr int NG = (V + 31) / 32, VP = NG * 32;
+  using RS = ReduceShape<V>;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  R* buf = lds + (long)parity * NW * VP;
-  LQG_UNROLL for (int gq = 0; gq < NG; ++gq) {
-    const R tot = wave_transpose_reduce<R, V>(v, gq * 32);
-    if (lane < 32) buf[wave * VP + gq * 32 + bitrev5(lane)] = tot;
-  }
+  R* buf = lds + (long)parity * NW * RS::VPT;
+  block_reduce_groups<0>(v, buf, lane, wave);
   __syncthreads();
   if ((int)threadIdx.x < V) {
     R tsum = buf[threadIdx.x];
-    LQG_UNROLL for (int w = 1; w < NW; ++w) tsum += buf[w * VP + threadIdx.x];
+    LQG_UNROLL for (int w = 1; w < NW; ++w) tsum += buf[w * RS::VPT + threadIdx.x];
     out[threadIdx.x] = tsum;
   }
 }
 
 // ---------------------------------------------------------------- reverse
+// FMD: mask of the stream's F block (Fj - I: the joint-dynamics mask FM plus the diagonal).  The chunk's operator blocks are
+// staged in LDS once per workgroup (double-buffered: the next chunk's block is requested while this one is walked), so every
+// candidate's stream crosses HBM once per pass whatever the number of its trials.
 template <typename R, int M, int ND, int TPL, int CKT, Mask<M, M> FM>
-__global__ void __launch_bounds__(LQG_ASP_TRIAL_BLOCK) k_asp_trial_rev(const TrialRevArgs<R> a) {
+__global__ void __launch_bounds__(LQG_ASP_TRIAL_BLOCK, (sizeof(R) == 4 ? 2 : 1)) k_asp_trial_rev(const R* __restrict__ ops_all, const TrialRevArgs<R> a) {
   constexpr int O = ND, RR = M - ND, BLK = LQG_ASP_TRIAL_BLOCK;
   using Ops = TrialOps<M, ND>;
   using SM = Sums<M, ND, FM>;
   constexpr auto FMD = mask_or(FM, mask_eye<M>());
-  constexpr int NG = (SM::RAW + 31) / 32;
-  __shared__ R lds[2 * (BLK / 64) * NG * 32];
+  constexpr int CKN = CKT * Ops::N;                     // reals of one chunk's operator blocks
+  __shared__ R lds[2 * (BLK / 64) * ReduceShape<SM::RAW>::VPT];
+  __shared__ R lops[2][CKN];
   const long sys = blockIdx.y;
   const long n0 = (long)blockIdx.x * (BLK * TPL) + threadIdx.x;
-  const R* __restrict__ op = a.ops + sys * (long)(a.T + 1) * Ops::N;
+  const R* __restrict__ op = ops_all + sys * (long)(a.T + 1) * Ops::N;
+  const long op_len = (long)(a.T + 1) * Ops::N;
   R* sums = a.sums + (((long)blockIdx.x * a.n_sys + sys) * a.T) * SM::N;
   const R* xr[TPL];
   bool live[TPL];
   long nn[TPL];
   R gw[TPL], pre[TPL][M], a1[TPL][O];
-  const R none[1] = {R(0)};
   LQG_UNROLL for (int k = 0; k < TPL; ++k) {
     long n = n0 + (long)k * BLK;
     live[k] = n < a.n_trials;
@@ -206,10 +196,45 @@ __global__ void __launch_bounds__(LQG_ASP_TRIAL_BLOCK) k_asp_trial_rev(const Tri
       a1[k][i] = v;
     }
   }
+  {   // sum of the workgroup's upstream weights (the same at every step): once
+    R gl = R(0);
+    LQG_UNROLL for (int k = 0; k < TPL; ++k) gl += gw[k];
+    LQG_UNROLL for (int off = 32; off >= 1; off >>= 1) gl += __shfl_xor(gl, off);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = gl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      R tsum = R(0);
+      LQG_UNROLL for (int w = 0; w < BLK / 64; ++w) tsum += lds[w];
+      a.gsum[(long)blockIdx.x * a.n_sys + sys] = tsum;
+    }
+    __syncthreads();
+  }
+  // operator blocks of a chunk: thread `tid` fetches reals tid, tid + BLK, ... of the chunk
+  constexpr int NLD = (CKN + BLK - 1) / BLK;
+  R nx[NLD];
+  LQG_UNROLL for (int q = 0; q < NLD; ++q) nx[q] = R(0);
+  auto request = [&](int c) LQG_LAMBDA_INLINE {
+    const long base = (long)c * CKN;
+    LQG_UNROLL for (int q = 0; q < NLD; ++q) {
+      const int i = q * BLK + (int)threadIdx.x;
+      if (i < CKN && base + i < op_len) nx[q] = op[base + i];
+    }
+  };
+  auto publish = [&](int buf) LQG_LAMBDA_INLINE {
+    LQG_UNROLL for (int q = 0; q < NLD; ++q) {
+      const int i = q * BLK + (int)threadIdx.x;
+      if (i < CKN) lops[buf][i] = nx[q];
+    }
+  };
   R wst[CKT][TPL][O], cst[CKT][TPL][RR];
-  int parity = 0;
+  int parity = 0, obuf = 0;
+  request(a.nckt - 1);
   for (int c = a.nckt - 1; c >= 0; --c) {
     const int t0 = c * CKT;
+    publish(obuf);
+    __syncthreads();
+    if (c > 0) request(c - 1);
+    const R* __restrict__ lo = lops[obuf];
     // ---- recompute the chunk's (w, c)
     {
       R xprev[TPL][O], dO[TPL][O], muR[TPL][RR];
@@ -224,27 +249,37 @@ __global__ void __launch_bounds__(LQG_ASP_TRIAL_BLOCK) k_asp_trial_rev(const Tri
       LQG_UNROLL for (int j = 0; j < CKT; ++j) {
         const int t = t0 + j;
         if (t < a.T) {
-          const R* __restrict__ opt = op + (long)t * Ops::N;
+          const R* __restrict__ opt = lo + j * Ops::N;
+          R Li[O * (O + 1) / 2], U2[RR * O];
+          LQG_UNROLL for (int i = 0; i < O * (O + 1) / 2; ++i) Li[i] = opt[Ops::L_OFF + i];
+          LQG_UNROLL for (int i = 0; i < RR * O; ++i) U2[i] = opt[Ops::U_OFF + i];
+          R Fv[M * M];
+          LQG_UNROLL for (int i = 0; i < M * M; ++i) if (FMD.b[i]) Fv[i] = opt[Ops::F_OFF + i];
           LQG_UNROLL for (int k = 0; k < TPL; ++k) {
             R cv[M], w[O];
             LQG_UNROLL for (int i = 0; i < O; ++i) cv[i] = xr[k][(long)t * a.x.st + i * a.x.sd];
             int e = 0;
             LQG_UNROLL for (int i = 0; i < O; ++i) {
               R v = R(0);
-              LQG_UNROLL for (int q = 0; q <= i; ++q) v += opt[Ops::L_OFF + (e++)] * ((cv[q] - xprev[k][q]) - dO[k][q]);
+              LQG_UNROLL for (int q = 0; q <= i; ++q) v += Li[e++] * ((cv[q] - xprev[k][q]) - dO[k][q]);
               w[i] = v;
               wst[j][k][i] = v;
             }
             LQG_UNROLL for (int p = 0; p < RR; ++p) {
               R v = muR[k][p];
-              LQG_UNROLL for (int q = 0; q < O; ++q) v += opt[Ops::U_OFF + p * O + q] * w[q];
+              LQG_UNROLL for (int q = 0; q < O; ++q) v += U2[p * O + q] * w[q];
               cv[O + p] = v;
               cst[j][k][p] = v;
             }
-            R mn[M];
-            trial_mean_rows<R, M, ND, FMD, false, 1, 0>(none, opt, cv, mn);
-            LQG_UNROLL for (int i = 0; i < O; ++i) { dO[k][i] = mn[i]; xprev[k][i] = cv[i]; }
-            LQG_UNROLL for (int p = 0; p < RR; ++p) muR[k][p] = cv[O + p] + mn[O + p];
+            if (j + 1 < CKT) {                                  // (the state after the chunk's last step is not needed)
+              LQG_UNROLL for (int i = 0; i < M; ++i) {
+                R v = R(0);
+                LQG_UNROLL for (int q = 0; q < M; ++q) if (FMD.b[i * M + q]) v += Fv[i * M + q] * cv[q];
+                if (i < O) { dO[k][i < O ? i : 0] = v; }
+                else muR[k][i >= O ? i - O : 0] = cv[i] + v;      // (the stream holds Fj - I)
+              }
+              LQG_UNROLL for (int i = 0; i < O; ++i) xprev[k][i] = cv[i];
+            }
           }
         }
       }
@@ -253,34 +288,42 @@ __global__ void __launch_bounds__(LQG_ASP_TRIAL_BLOCK) k_asp_trial_rev(const Tri
     LQG_UNROLL for (int j = CKT - 1; j >= 0; --j) {
       const int t = t0 + j;
       if (t < a.T) {
-        const R* __restrict__ opt = op + (long)t * Ops::N;
+        const R* __restrict__ opt = lo + j * Ops::N;
+        R Li[O * (O + 1) / 2], U2[RR * O];
+        LQG_UNROLL for (int i = 0; i < O * (O + 1) / 2; ++i) Li[i] = opt[Ops::L_OFF + i];
+        LQG_UNROLL for (int i = 0; i < RR * O; ++i) U2[i] = opt[Ops::U_OFF + i];
+        R F2v[M * RR];                                              // Fj[:, o:] - I's columns
+        LQG_UNROLL for (int i = 0; i < M; ++i)
+          LQG_UNROLL for (int p = 0; p < RR; ++p) if (FMD.b[i * M + O + p]) F2v[i * RR + p] = opt[Ops::F_OFF + i * M + O + p];
         R acc[SM::RAW];
         LQG_UNROLL for (int i = 0; i < SM::RAW; ++i) acc[i] = R(0);
         LQG_UNROLL for (int k = 0; k < TPL; ++k) {
           R a0[O], cv[M], post[M], ch[RR];
           LQG_UNROLL for (int i = 0; i < O; ++i) {
             R v = R(0);
-            LQG_UNROLL for (int q = i; q < O; ++q) v += opt[Ops::L_OFF + q * (q + 1) / 2 + i] * wst[j][k][q];
+            LQG_UNROLL for (int q = i; q < O; ++q) v += Li[q * (q + 1) / 2 + i] * wst[j][k][q];
             a0[i] = v;
           }
           LQG_UNROLL for (int i = 0; i < O; ++i) cv[i] = xr[k][(long)t * a.x.st + i * a.x.sd];
           LQG_UNROLL for (int p = 0; p < RR; ++p) cv[O + p] = cst[j][k][p];
           const R g = gw[k];
           LQG_UNROLL for (int i = 0; i < M; ++i) post[i] = pre[k][i] + (i < O ? g * a1[k][i < O ? i : 0] : R(0));
-          acc[SM::G_OFF] += g;
           {
             int e = 0;
             LQG_UNROLL for (int i = 0; i < O; ++i)
               LQG_UNROLL for (int q = 0; q <= i; ++q) acc[SM::W_OFF + (e++)] += g * a1[k][i] * a1[k][q];
           }
-          LQG_UNROLL for (int i = 0; i < M; ++i)
-            LQG_UNROLL for (int q = 0; q < M; ++q)
-              if (FM.b[i * M + q]) acc[SM::mc(i, q)] += post[i] * cv[q];
+          {
+            int e = 0;
+            LQG_UNROLL for (int i = 0; i < M; ++i)
+              LQG_UNROLL for (int q = 0; q < M; ++q)
+                if (FM.b[i * M + q]) acc[SM::M_OFF + (e++)] += post[i] * cv[q];
+          }
           // ch = Fj[:, o:]' post   (the stream holds Fj - I)
           LQG_UNROLL for (int p = 0; p < RR; ++p) {
             R v = post[O + p];
             LQG_UNROLL for (int i = 0; i < M; ++i)
-              if (FMD.b[i * M + O + p]) v += opt[Ops::F_OFF + i * M + O + p] * post[i];
+              if (FMD.b[i * M + O + p]) v += F2v[i * RR + p] * post[i];
             ch[p] = v;
           }
           LQG_UNROLL for (int p = 0; p < RR; ++p)
@@ -289,12 +332,12 @@ __global__ void __launch_bounds__(LQG_ASP_TRIAL_BLOCK) k_asp_trial_rev(const Tri
           R uc[O];
           LQG_UNROLL for (int q = 0; q < O; ++q) {
             R v = R(0);
-            LQG_UNROLL for (int p = 0; p < RR; ++p) v += opt[Ops::U_OFF + p * O + q] * ch[p];
+            LQG_UNROLL for (int p = 0; p < RR; ++p) v += U2[p * O + q] * ch[p];
             uc[q] = v;
           }
           LQG_UNROLL for (int i = 0; i < O; ++i) {
             R v = R(0);
-            LQG_UNROLL for (int q = i; q < O; ++q) v += opt[Ops::L_OFF + q * (q + 1) / 2 + i] * uc[q];
+            LQG_UNROLL for (int q = i; q < O; ++q) v += Li[q * (q + 1) / 2 + i] * uc[q];
             pre[k][i] = -v;
           }
           LQG_UNROLL for (int p = 0; p < RR; ++p) pre[k][O + p] = ch[p];
@@ -304,6 +347,7 @@ __global__ void __launch_bounds__(LQG_ASP_TRIAL_BLOCK) k_asp_trial_rev(const Tri
         parity ^= 1;
       }
     }
+    obuf ^= 1;
   }
 }
 

@@ -537,6 +537,11 @@ struct TrialArgs {
   long ll_sb, ll_sn;
   long n_trials;
   int T;
+  // k_trial_sp<..., CKT > 0> (the reverse-mode sweep's forward pass, lqg_adjoint_trial_sp.hpp): the mean state (dO, muR) BEFORE
+  // every CKT-th row, and before the last row T, kept at tck[((sys * (nckt + 1) + rec) * M + e) * npad + trial]
+  R* tck;
+  long npad;
+  int nckt;
 };
 
 // grid.x covers trials (LQG_BLOCK * TPL per block), grid.y = system.  The operator stream of the block's system is

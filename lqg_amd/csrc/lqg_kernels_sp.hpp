@@ -735,7 +735,8 @@ LQG_DEV void trial_mean_rows(const R (&opc)[NPF], const R* __restrict__ op, cons
   }
 }
 
-template <typename R, int M, int ND, int TPL, Mask<M, M> FM>
+// CKT > 0: the mean state is also KEPT every CKT steps (TrialArgs::tck) — the forward pass of the reverse-mode sweep.
+template <typename R, int M, int ND, int TPL, Mask<M, M> FM, int CKT = 0>
 __global__ void __launch_bounds__(LQG_BLOCK) k_trial_sp(const R* __restrict__ ops_all, const TrialArgs<R> a) {
   constexpr int O = ND, RR = M - ND;
   constexpr int kAccChunk = 8;
@@ -769,10 +770,25 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial_sp(const R* __restrict__ op
   // 117 VGPRs: config 3 3.54 -> 4.59 ms (measured).  Larger ones (M >= 8: the 2-D hand model of config 4,
   // m = 10) are arithmetic-heavy and already register-bound: first / last step peeled, blocks of 8 unguarded steps, one
   // flush of the fp32 partial sums per block: config 4 (262 144 trials) per-trial sweep 1.92 -> 1.35 ms.
+  [[maybe_unused]] auto keep = [&](int t) LQG_LAMBDA_INLINE {
+    if constexpr (CKT > 0) {
+      if ((t % CKT) == 0 || t == a.T) {
+        const int rec = t == a.T ? a.nckt : t / CKT;
+        R* dst = a.tck + ((sys * (a.nckt + 1) + rec) * M) * a.npad;
+        LQG_UNROLL for (int k = 0; k < TPL; ++k)
+          if (live[k]) {
+            const long n = n0 + (long)k * LQG_BLOCK;
+            LQG_UNROLL for (int i = 0; i < O; ++i) dst[i * a.npad + n] = dO[k][i];
+            LQG_UNROLL for (int i = 0; i < RR; ++i) dst[(O + i) * a.npad + n] = muR[k][i];
+          }
+      }
+    }
+  };
   constexpr bool BLOCK8 = M >= 8;
   if constexpr (BLOCK8) {
     auto body8 = [&]<bool FIRST, bool LAST>(int t, const R (&cur)[NPF], const R* __restrict__ opt) LQG_LAMBDA_INLINE {
 #define LQG_OP(i_) (PF ? cur[PF ? (i_) : 0] : opt[i_])
+      keep(t);
       R Li[O * (O + 1) / 2];
       LQG_UNROLL for (int i = 0; i < O * (O + 1) / 2; ++i) Li[i] = LQG_OP(Ops::L_OFF + i);
       const R hlc = LQG_OP(Ops::H_OFF);
@@ -855,6 +871,7 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial_sp(const R* __restrict__ op
     // read through `opt`
     auto body = [&](int t, const R (&cur)[NPF], const R* __restrict__ opt) {
   #define LQG_OP(i_) (PF ? cur[PF ? (i_) : 0] : opt[i_])
+      keep(t);
       R Li[O * (O + 1) / 2];
       LQG_UNROLL for (int i = 0; i < O * (O + 1) / 2; ++i) Li[i] = LQG_OP(Ops::L_OFF + i);
       const R hlc = LQG_OP(Ops::H_OFF);

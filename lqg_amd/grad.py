@@ -79,14 +79,42 @@ class Sweep:
         adjoints once per SYSTEM, trials reduced to per-step sums, bars returned summed over the trials)."""
         d = x.shape[-1]
         self.sp = None
-        # fp32 with EVERY state observed (the point-mass model seen in full: cond(Sigma_oo) ~ 5e8): the reverse sweep
-        # conditions through the explicit S_oo^-1, which fp32 cannot carry -- same policy as the mixed forward problem
-        # LQG_F32_SYS64 (include/lqg_hip.h): the sweeps run over an fp64 image, value and bars are rounded to fp32 once
         self.out_dtype = None
+
+        def promoted():
+            return (_promote64(actor), _promote64(dynamics), x.double(), Sigma0.double() if Sigma0 is not None else None)
+
+        # ---- the structure-specialised adjoint library first (no on-demand compile of lane kernels it would not use).  fp32
+        # stays fp32 there unless the observed noise block is ill-conditioned (plan.f32_needs_wide: the rule of the forward path;
+        # the point mass seen in full, cond ~ 5e8): then the sweeps run over an fp64 image, value and bars rounded once
+        if system is not None and actor.A.is_cuda:
+            ln = _hip.Launch(actor, dynamics, d=d, n_trials=x.shape[-3], Sigma0=Sigma0, eps=eps)
+            self.sp = _specialised_adjoint(ln, system, d)
+            if self.sp is not None:
+                from lqg_amd import plan as _plan
+                if actor.A.dtype == torch.float32 and _plan.f32_needs_wide(system, d):
+                    self.out_dtype = torch.float32
+                    actor, dynamics, x, Sigma0 = promoted()
+                    ln = _hip.Launch(actor, dynamics, d=d, n_trials=x.shape[-3], Sigma0=Sigma0, eps=eps)
+                self.ln = ln
+                self.x, self.xb = _hip._prep_x(ln, x)
+                self.N = self.x.shape[-3]
+                self.per_sys, self.lanes = 1, ln.B
+                self.ld = (self.lanes + 63) // 64 * 64
+                self.lay, self.total = _layout(ln.dims)
+                self.slabs = 1
+                self.nbytes = int(self.sp.lqg_grad_workspace_bytes_sp(C.byref(ln.p)))
+                if self.nbytes > 0:
+                    self.ws = torch.empty(max(self.nbytes, 256), dtype=torch.uint8, device=ln.device)
+                    self.fresh = False
+                    return
+                self.sp = None
+        # ---- round-1 lane kernels / cooperative sweep.  fp32 with EVERY state observed (the point-mass model seen in full:
+        # cond(Sigma_oo) ~ 5e8): that reverse sweep conditions through the explicit S_oo^-1, which fp32 cannot carry -- same policy
+        # as the mixed forward problem LQG_F32_SYS64 (include/lqg_hip.h): fp64 image, value and bars rounded to fp32 once
         if actor.A.dtype == torch.float32 and d == dynamics.A.shape[-1]:
             self.out_dtype = torch.float32
-            actor, dynamics, x = _promote64(actor), _promote64(dynamics), x.double()
-            Sigma0 = Sigma0.double() if Sigma0 is not None else None
+            actor, dynamics, x, Sigma0 = promoted()
         ln = _hip.Launch(actor, dynamics, d=d, n_trials=x.shape[-3], Sigma0=Sigma0, eps=eps)
         self.lib = ln.require_gpu(_abi.FAM_ADJOINT)     # lane kernels (an unlisted small shape is compiled on first use) or,
         # for every other shape (x + b > 12: the delay models), the cooperative sweep of the main library — fp64 only: an fp32
@@ -94,8 +122,7 @@ class Sweep:
         if not self.lib.lqg_grad_supported(ln.p.dtype, C.byref(ln.p.dims)) and actor.A.dtype == torch.float32 \
                 and self.lib.lqg_grad_supported(_abi.F64, C.byref(ln.p.dims)):
             self.out_dtype = torch.float32
-            actor, dynamics, x = _promote64(actor), _promote64(dynamics), x.double()
-            Sigma0 = Sigma0.double() if Sigma0 is not None else None
+            actor, dynamics, x, Sigma0 = promoted()
             ln = _hip.Launch(actor, dynamics, d=d, n_trials=x.shape[-3], Sigma0=Sigma0, eps=eps)
         if not self.lib.lqg_grad_supported(ln.p.dtype, C.byref(ln.p.dims)):
             raise _abi.LqgHipError(f"no adjoint kernels for model shape {tuple(ln.dims[k] for k in 'xbuyd')} "
@@ -104,19 +131,6 @@ class Sweep:
         self.ln = ln
         self.x, self.xb = _hip._prep_x(ln, x)
         self.N = self.x.shape[-3]
-        self.sp = _specialised_adjoint(ln, system, d)
-        if self.sp is not None:
-            self.per_sys, self.lanes = 1, ln.B
-            self.ld = (self.lanes + 63) // 64 * 64
-            self.lay, self.total = _layout(ln.dims)
-            self.slabs = 1
-            self.nbytes = int(self.sp.lqg_grad_workspace_bytes_sp(C.byref(ln.p)))
-            if self.nbytes == 0:
-                self.sp = None
-            else:
-                self.ws = torch.empty(max(self.nbytes, 256), dtype=torch.uint8, device=ln.device)
-                self.fresh = False
-                return
         # lanes of the gradient array per system: the trials (lane kernels: the caller sums over them) or 1 (cooperative
         # sweep: bars already summed over the trials) — include/lqg_hip.h: lqg_grad_lanes_per_system
         self.per_sys = int(self.lib.lqg_grad_lanes_per_system(C.byref(ln.p)))

@@ -80,6 +80,18 @@ def pattern_of(system, d, grad_full=False):
                  Ad=Ad, AdmI=Ad - torch.eye(Ad.shape[-1], dtype=Ad.dtype, device=Ad.device), Bd=Bd, Fd=Fd, N1=N1, WWd=Wd @ T_(Wd), FAa=Fa @ Aa, FAd=Fd @ Ad, DB=Fd @ Bd - Fa @ Ba,
                  N2=Fd @ N1, N3=Fd @ N1 @ T_(Fd) + Wd @ T_(Wd))
     out = {k: _any_nz(v) for k, v in masks.items()}
+    if grad_full:
+        # The masks of the hoisted PRODUCTS must not be read off values here: Fd Bd - Fa Ba cancels numerically for a shared
+        # spec (and for matrices of ones), A - I has a zero diagonal for A = ones — yet d ll / d Bd, d ll / d A_ii are not
+        # zero.  Boolean algebra of the factors' masks instead (conservative, as pattern_of_time_varying).
+        bm = lambda p, q: (p.astype(np.int64) @ q.astype(np.int64)) > 0
+        o = out
+        o["FAa"], o["FAd"] = bm(o["Fa"], o["Aa"]), bm(o["Fd"], o["Ad"])
+        o["DB"] = bm(o["Fd"], o["Bd"]) | bm(o["Fa"], o["Ba"])
+        o["N2"] = bm(o["Fd"], o["N1"])
+        o["N3"] = bm(bm(o["Fd"], o["N1"]), o["Fd"].T) | o["WWd"]
+        if dy.A.requires_grad:
+            o["AdmI"] = o["Ad"] | np.eye(o["Ad"].shape[0], dtype=bool)
     for k in ("VVa", "WWa", "Q", "Rr", "N1", "WWd", "N3"):      # symmetric quantities: keep the mask symmetric
         out[k] = out[k] | out[k].T
     for k, v in (("Va", Va), ("Wa", Wa), ("Vd", Vd), ("Wd", Wd)):

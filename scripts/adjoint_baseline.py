@@ -76,8 +76,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--dtypes", default="f32,f64")
     ap.add_argument("--shapes", default="headline,config3")
+    ap.add_argument("--sp", default="1", help="LQG_ADJOINT_SP: 1 = split sweep on the pattern libraries (round 5), 0 = round-1 lane kernels")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
+    from lqg_amd import options
+    options.set("ADJOINT_SP", int(a.sp))
     for dn in a.dtypes.split(","):
         dt = torch.float32 if dn == "f32" else torch.float64
         if "headline" in a.shapes:
@@ -85,14 +88,14 @@ def main():
             try:
                 vg, fw = headline(B, 500, dt, dev, a.steps, a.warmup)
                 print(json.dumps({"shape": "headline", "dtype": dn, "B": B, "T": 500, "value_and_grad_ms": vg, "forward_ms": fw,
-                                  "solves_with_grad_per_s": B / vg * 1e3}), flush=True)
+                                  "solves_with_grad_per_s": B / vg * 1e3, "adjoint_sp": int(a.sp)}), flush=True)
             except Exception as e:
                 print(json.dumps({"shape": "headline", "dtype": dn, "error": repr(e)[:300]}), flush=True)
         if "config3" in a.shapes:
             try:
                 vg, fw = config3(a.cands, a.trials, 1067, dt, dev, a.steps, a.warmup)
                 print(json.dumps({"shape": "config3", "dtype": dn, "C": a.cands, "N": a.trials, "T": 1067, "value_and_grad_ms": vg,
-                                  "forward_ms": fw}), flush=True)
+                                  "forward_ms": fw, "adjoint_sp": int(a.sp)}), flush=True)
             except Exception as e:
                 print(json.dumps({"shape": "config3", "dtype": dn, "error": repr(e)[:300]}), flush=True)
 

@@ -14,6 +14,11 @@ CASES = ["bounded_T100", "subjective1d_T50", "relobs_T40", "pointmass_d2_T50"]
 
 
 def build(name, dtype, device, n):
+    import test_adjoint
+    return test_adjoint._dense_grad_system(name, dtype, n, device=device)
+
+
+def build_old(name, dtype, device, n):
     from gpu_common import system_from_golden
     g, actor, dyn = load_golden(name)
     x = g["x"]
@@ -58,8 +63,10 @@ def main():
                 w = np.linspace(0.5, 1.5, n)
                 ll_ref, ga, gd, _ = ADJ.loglik_grad(actor, dyn, x, w)
                 with torch.no_grad():
-                    ll, bars, _ = G.raw_grad(s.actor, s.dynamics, torch.as_tensor(x, dtype=dtype, device="cuda"),
-                                             g=torch.as_tensor(w, dtype=dtype, device="cuda"), system=s)
+                    sw = G.Sweep(s.actor, s.dynamics, torch.as_tensor(x, dtype=dtype, device="cuda"), system=s)
+                    assert sw.sp is not None
+                    ll = sw.forward()
+                    bars = sw.reverse(torch.as_tensor(w, dtype=dtype, device="cuda"))
                 e_ll = np.abs(ll.double().cpu().numpy() - ll_ref).max() / np.abs(ll_ref).max()
                 tot = {k: v.sum(1)[0].double().cpu().numpy() for k, v in bars.items()}
                 sym2 = lambda M: M + M.T
@@ -73,7 +80,7 @@ def main():
                 errs = {k: float(np.abs(got[k] - r).max() / max(np.abs(r).max(), 1e-3 * scale)) for k, r in ref.items()}
                 bad = {k: v for k, v in errs.items() if not v < tol}
                 worst = max(worst, max(errs.values()) / tol)
-                print(f"{name:20s} {str(dtype)[6:]:8s} n={n}  ll {e_ll:.1e}  max bar err {max(errs.values()):.2e} (tol {tol:g})", "BAD " + str(bad) if bad else "ok", flush=True)
+                print(f"{name:20s} {str(dtype)[6:]:8s} n={n}  ll {e_ll:.1e}  max bar err {max(errs.values()):.2e} (tol {tol:g})", "BAD " + str({k: float("%.2g" % v) for k, v in errs.items()}) if bad else "ok", flush=True)
     if not compile_only:
         print("WORST/TOL", worst)
 

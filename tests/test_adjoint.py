@@ -65,6 +65,28 @@ def test_numpy_adjoint_matches_finite_differences_of_the_c_oracle(oracle_lib):
             assert abs(fd - an) < 2e-6 * max(1.0, abs(an)), (who, k, fd, an)
 
 
+@pytest.mark.parametrize("name,T,n", [("subjective1d_T50", 50, 3), ("pointmass_d2_T50", 25, 2), ("tutorial_lqg_T100", 60, 4),
+                                      ("bounded_T100", 100, 3), ("pointmass_d4_T50", 20, 2), ("relobs_T40", 40, 2),
+                                      ("subjective2d_T60", 30, 3)])
+def test_split_restatement_equals_the_per_lane_restatement(name, T, n):
+    """oracle/lqg_adjoint_split_np.py — the sweep cut as the round-5 kernels cut it (matrix adjoints once per system, the trials
+    entering through per-step sums, conditioning in Cholesky form) — against the per-(system, trial) restatement that is pinned
+    to autograd of the literal restatement above: value, every bar, the Sigma0 bar."""
+    import lqg_adjoint_split_np as SPL
+    g, actor, dyn = load_golden(name)
+    actor, dyn, x = _cut(actor, T), _cut(dyn, T), g["x"][:n, :T + 1]
+    w = np.linspace(0.6, 1.4, x.shape[0])
+    for S0 in (None, g.get("Sigma0")) if g.get("Sigma0") is not None else (None,):
+        ll, ga, gd, s0 = ADJ.loglik_grad(actor, dyn, x, w, S0)
+        ll2, ga2, gd2, s02, sums = SPL.loglik_grad(actor, dyn, x, w, S0)
+        assert np.abs(ll - ll2).max() < 1e-11 * np.abs(ll).max()
+        for a_, b_ in ((ga, ga2), (gd, gd2)):
+            for k in a_:
+                assert np.abs(a_[k] - b_[k]).max() < 1e-8 * max(np.abs(a_[k]).max(), 1e-3), k
+        assert np.abs(s0 - s02).max() < 1e-8 * max(np.abs(s0).max(), 1e-3)
+        assert abs(sums["g"] - w.sum()) < 1e-12
+
+
 # ------------------------------------------------------------------------------------------------------------ GPU
 gpu = pytest.mark.gpu
 TI_CASES = ["bounded_T100", "optimal_T30", "relobs_T40", "subjective1d_T50", "pointmass_d2_T50", "pointmass_d4_T50",
@@ -111,6 +133,134 @@ def test_hip_adjoint_matches_the_restatement(name, dtype, tol):
     scale = max(np.abs(v).max() for v in ref.values())
     for k, r in ref.items():
         assert np.abs(got[k] - r).max() < tol * max(np.abs(r).max(), 1e-3 * scale), k
+
+
+def _dense_grad_system(name, dtype, n, device="cuda", T=None):
+    """A golden case as a System whose differentiable fields all REQUIRE GRAD (time-invariant views of one leaf each): its
+    adjoint pattern is the dense one, so every entry of every bar is formed and can be compared with the restatement."""
+    import lqg_amd
+    from gpu_common import system_from_golden
+    g, actor, dyn = load_golden(name)
+    x = g["x"]
+    if T is not None:
+        actor, dyn, x = _cut(actor, T), _cut(dyn, T), x[:, :T + 1]
+    rng = np.random.default_rng(5)
+    while x.shape[0] < n:                                  # more trials: smooth perturbations of the first one
+        x = np.concatenate([x, x[:1] + 0.05 * rng.standard_normal(x[:1].shape).cumsum(1)], 0)
+    x = x[:n]
+    s = system_from_golden(actor, dyn, dtype, device)
+
+    def leafed(spec):
+        out = {}
+        for f in spec._fields:
+            t = getattr(spec, f)
+            if f in ("A", "B", "F", "V", "W", "Q", "R", "q", "P", "r"):
+                base = t[:1].clone()
+                if f in ("A", "B", "F", "V", "W", "Q", "R"):
+                    base.requires_grad_(True)
+                t2 = base.expand_as(t)
+                if getattr(t, "_lqg_zero", False):
+                    from lqg_amd.utils import mark_zero
+                    t2 = mark_zero(t2)
+                t = t2
+            out[f] = t
+        return spec._replace(**out)
+
+    a = leafed(s.actor)
+    d = a if s.actor is s.dynamics else leafed(s.dynamics)
+    return lqg_amd.System(actor=a, dynamics=d), actor, dyn, x, g
+
+
+def split_sweep_test_patterns():
+    """(dims, masks, key) of the dense adjoint patterns the GPU tests below use (compiled by __graft_entry__.build())."""
+    from lqg_amd import specialize
+    out = []
+    for name in ("bounded_T100", "subjective1d_T50", "relobs_T40", "pointmass_d2_T50"):
+        s, _, _, x, _ = _dense_grad_system(name, torch.float64, 1, device="cpu")
+        out.append(specialize.adjoint_pattern(s, x.shape[-1]))
+    return out
+
+
+def _compare_bars(bars, actor, dyn, ga, gd, tol):
+    tot = {k: v.sum(1)[0].double().cpu().numpy() for k, v in bars.items()}
+    sym2 = lambda M: M + M.T
+    got = {"dA": tot["dA"], "dB": tot["dB"], "dF": tot["dF"], "dV": sym2(tot["dVV"]) @ dyn["V"][0],
+           "dW": sym2(tot["dWW"]) @ dyn["W"][0], "aA": tot["aA"] + tot["aA2"], "aB": tot["aB"] + tot["aB2"],
+           "aF": tot["aF"], "aV": sym2(tot["aVV"]) @ actor["V"][0], "aW": sym2(tot["aWW"]) @ actor["W"][0],
+           "aQ": tot["aQ"], "aR": tot["aR"], "aQf": tot["aQf"]}
+    ref = {"d" + k: v.sum(0) for k, v in gd.items()}
+    ref.update({"a" + k: (v.sum(0) if v.ndim == 3 else v) for k, v in ga.items()})
+    scale = max(np.abs(v).max() for v in ref.values())
+    for k, r in ref.items():
+        assert np.abs(got[k] - r).max() < tol * max(np.abs(r).max(), 1e-3 * scale), k
+
+
+@gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 1e-4)], ids=["f64", "f32"])
+@pytest.mark.parametrize("n", [1, 2, 5])
+@pytest.mark.parametrize("name", ["bounded_T100", "subjective1d_T50", "relobs_T40", "pointmass_d2_T50"])
+def test_split_sweep_matches_the_restatement(name, n, dtype, tol):
+    """The round-5 sweep (csrc/lqg_adjoint_sp.hpp: matrix adjoints once per system; 1 / 2 trials swept in the system's lane, more
+    through the operator stream + the per-trial mu-bar sweep and its per-step trial sums) against oracle/lqg_adjoint_np.py:
+    value and every entry of every bar, upstream weights included.  fp32 stays fp32 here (the round-1 kernels ran these
+    fully observed models over an fp64 image)."""
+    from lqg_amd import grad as G
+    s, actor, dyn, x, g = _dense_grad_system(name, dtype, n)
+    w = np.linspace(0.5, 1.5, n)
+    ll_ref, ga, gd, _ = ADJ.loglik_grad(actor, dyn, x, w)
+    with torch.no_grad():
+        sw = G.Sweep(s.actor, s.dynamics, torch.as_tensor(x, dtype=dtype, device="cuda"), system=s)
+        assert sw.sp is not None and sw.per_sys == 1 and sw.out_dtype is None
+        ll = sw.forward()
+        bars = sw.reverse(torch.as_tensor(w, dtype=dtype, device="cuda"))
+    assert np.abs(ll.double().cpu().numpy() - ll_ref).max() < max(tol * 1e-2, 1e-10) * np.abs(ll_ref).max()
+    _compare_bars(bars, actor, dyn, ga, gd, tol)
+
+
+@gpu
+def test_split_sweep_many_trials_several_workgroups_per_system():
+    """More trials than one workgroup holds (1024): the per-step trial sums arrive as several partial records per system; a
+    candidate axis on top (two systems sharing the trials)."""
+    import lqg_adjoint_split_np as SPL
+    from lqg_amd import grad as G
+    import lqg_amd
+    name, n, T = "bounded_T100", 2500, 24
+    sT, actor, dyn, x, g = _dense_grad_system(name, torch.float64, n, T=T)
+    w = np.cos(np.arange(n))
+    ll_ref, ga, gd, _, _ = SPL.loglik_grad(actor, dyn, x, w)
+    with torch.no_grad():
+        sw = G.Sweep(sT.actor, sT.dynamics, torch.as_tensor(x, dtype=torch.float64, device="cuda"), system=sT)
+        assert sw.sp is not None
+        ll = sw.forward()
+        bars = sw.reverse(torch.as_tensor(w, dtype=torch.float64, device="cuda"))
+    assert np.abs(ll.cpu().numpy() - ll_ref).max() < 1e-10 * np.abs(ll_ref).max()
+    _compare_bars(bars, actor, dyn, ga, gd, 1e-9)
+
+
+@gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 2e-4)], ids=["f64", "f32"])
+@pytest.mark.parametrize("ctor,kw,n", [("BoundedActor", dict(T=150), 7), ("SubjectiveActor", dict(T=90, dim=2), 1),
+                                       ("SubjectiveActor", dict(T=90, dim=2), 4), ("PointMassBoundedActor", dict(T=70), 3)])
+def test_split_sweep_equals_the_round1_lane_kernels_through_the_constructors(ctor, kw, n, dtype, tol):
+    """Parameter gradients through the zoo constructors (class patterns: structural zeros compiled out, identical components
+    merged as trials) from the split sweep against the round-1 kernels (LQG_ADJOINT_SP=0), a candidate axis of 3."""
+    import lqg_amd
+    from lqg_amd import options
+    cls = getattr(lqg_amd, ctor)
+    d = 4 if kw.get("dim") == 2 else 2
+    base = dict(sigma_target=[4.0, 6.0, 9.0], action_cost=[0.05, 0.1, 0.3])
+    with torch.no_grad():
+        x = cls(device="cuda", dtype=torch.float64, **kw).simulate(3, n=n)[..., :d].to(dtype).contiguous()
+    out = {}
+    for sp in (1, 0):
+        with options.override(ADJOINT_SP=sp):
+            th = {k: torch.tensor(v, dtype=dtype, device="cuda", requires_grad=True) for k, v in base.items()}
+            ll = cls(device="cuda", dtype=dtype, **kw, **th).log_likelihood(x)
+            (ll * torch.linspace(0.5, 1.5, n, dtype=dtype, device="cuda")).sum().backward()
+            out[sp] = (ll.detach().double().cpu().numpy(), {k: v.grad.double().cpu().numpy() for k, v in th.items()})
+    assert np.abs(out[1][0] - out[0][0]).max() < max(tol * 1e-2, 1e-10) * np.abs(out[0][0]).max()
+    for k in base:
+        assert np.abs(out[1][1][k] - out[0][1][k]).max() < tol * max(np.abs(out[0][1][k]).max(), 1e-3), k
 
 
 def _fd(make, x, names, h=1e-6):
