@@ -25,8 +25,11 @@
 #include "lqg_adjoint.hpp"
 #include "lqg_kernels_sp.hpp"
 
+#ifndef LQG_ASP_STACK0
+#define LQG_ASP_STACK0 1          // 1: the state before a chunk's first step stays in registers too (0: re-read from its checkpoint)
+#endif
 #ifndef LQG_ASP_SYS_WAVES_F32
-#define LQG_ASP_SYS_WAVES_F32 2   // waves per SIMD the fp32 system sweeps are allocated for (fp64: 1)
+#define LQG_ASP_SYS_WAVES_F32 1   // waves per SIMD the fp32 system sweeps are allocated for (2: the reverse sweep spills 180 registers, 4.1 -> 10.6 ms measured)
 #endif
 
 namespace lqg {
@@ -224,7 +227,7 @@ LQG_DEV void sys_step(const SysConst<R, NX, NB, NU, NY, PAT>& c, const Mat<R, NB
 }
 
 // control gains of the steps t0 .. t0 + CK - 1 recomputed backward from the checkpoint S_{t0 + CK} (k_riccati_sp<CK>)
-template <typename R, int NB, int NU, int CK, typename MA, typename MB, typename MQ, typename MR>
+template <typename R, int NB, int NU, int CK, bool WHOLE = false, typename MA, typename MB, typename MQ, typename MR>
 LQG_DEV void refill_gains(const RiccatiArgs<R>& rc, long s, int t0, const MA& Aa, const MB& Ba, const MQ& rQ, const MR& rR,
                           R (&Lbuf)[CK][NU * NB]) {
   constexpr int NS = NB * (NB + 1) / 2;
@@ -234,7 +237,7 @@ LQG_DEV void refill_gains(const RiccatiArgs<R>& rc, long s, int t0, const MA& Aa
   LQG_UNROLL for (int i = 0; i < NB; ++i)
     LQG_UNROLL for (int j = i; j < NB; ++j) { const R v = src[(e++) * rc.ldb]; Sr[i * NB + j] = v; Sr[j * NB + i] = v; }
   LQG_UNROLL for (int j = CK - 1; j >= 0; --j)
-    if (t0 + j < rc.T) riccati_step_sp<R, NB, NU>(Sr, Aa, Ba, rQ, rR, rc.eps, Lbuf[j]);
+    if (WHOLE || t0 + j < rc.T) riccati_step_sp<R, NB, NU>(Sr, Aa, Ba, rQ, rR, rc.eps, Lbuf[j]);
 }
 
 // the mean state of one trial in deviation form (lqg_kernels.hpp): observed mean = x_{t-1} + dO
@@ -331,15 +334,17 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES
     }
   };
   R Lbuf[CK][NU * NB];
-  for (int t0 = 0; t0 < a.T; t0 += CK) {
-    refill_gains<R, NB, NU, CK>(A.rc, s, t0, c.Aa, c.Ba, rQ, rR, Lbuf);
+  // Whole chunks run WITHOUT per-step `t < T` tests (as k_forward_sp): one basic block per chunk, so
+  // that the chunk's loads are scheduled ahead of the arithmetic that hides them; only the last, partial chunk is guarded.
+  auto chunk = [&]<bool WHOLE>(const int t0) LQG_LAMBDA_INLINE {      // WHOLE: CK full steps, none of them step 0
+    refill_gains<R, NB, NU, CK, WHOLE>(A.rc, s, t0, c.Aa, c.Ba, rQ, rR, Lbuf);
     keep(t0 / CK);
     LQG_UNROLL for (int j = 0; j < CK; ++j) {
       const int t = t0 + j;
-      if (t < a.T) {
+      if (WHOLE || t < a.T) {
         Mat<R, NU, NB> L;
         LQG_UNROLL for (int e = 0; e < NU * NB; ++e) L.v[e] = Lbuf[j][e];
-        sys_step<ND>(c, Pm, Sg, L, t == 0, [&](const auto& AP, const auto& Pp, const auto& FP, const auto& Gi, const auto& K,
+        sys_step<ND>(c, Pm, Sg, L, !WHOLE && t == 0, [&](const auto& AP, const auto& Pp, const auto& FP, const auto& Gi, const auto& K,
                                                 const auto& Pn, const auto& BK, const auto& Fj, const auto& KN2, const auto& KN3,
                                                 const auto& GG, const R (&Li)[O * O], const R (&dinv)[O], const R (&U2)[RR * O],
                                                 const auto& C, const auto& F2, const auto& F2C) LQG_LAMBDA_INLINE {
@@ -354,7 +359,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES
               trial_forward<R, M, ND>(Fj, Li, U2, xt, xprev[n], st[n], w, cv, true);
               R zz = R(0);
               LQG_UNROLL for (int i = 0; i < O; ++i) zz += w[i] * w[i];
-              if (t > 0) acc[n] += (double)(lpd - R(0.5) * zz - kLogNorm);
+              if (WHOLE || t > 0) acc[n] += (double)(lpd - R(0.5) * zz - kLogNorm);
               LQG_UNROLL for (int i = 0; i < O; ++i) xprev[n][i] = xt[i];
             }
           } else {
@@ -374,6 +379,12 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES
         });
       }
     }
+  };
+  {
+    chunk.template operator()<false>(0);                                // (step 0 initialises Sigma and is not scored)
+    int t0 = CK;
+    for (; t0 + CK <= a.T; t0 += CK) chunk.template operator()<true>(t0);
+    if (t0 < a.T) chunk.template operator()<false>(t0);
   }
   keep((a.T + CK - 1) / CK);                                            // the final state
   // the score of the last row x_T
@@ -468,10 +479,14 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES
     for (int part = 0; part < A.parts; ++part) gs_stream += A.gsum[(long)part * a.n_sys + s];
   }
   R Lbuf[CK][NU * NB];
-  R Pst[CK][NSB], Sst[CK][NSM];                         // register stack of the chunk's states (static indices only)
-  TrialState<R, M, ND> Tst[CK][NT];
-  for (int t0 = (nck - 1) * CK; t0 >= 0; t0 -= CK) {
-    refill_gains<R, NB, NU, CK>(A.rc, s, t0, c.Aa, c.Ba, rQ, rR, Lbuf);
+  // register stack of the chunk's states (static indices only).  LQG_ASP_STACK0 = 0: the state before the chunk's FIRST step, its
+  // checkpoint, is not stacked but read again when the walk back reaches it
+  constexpr int S0 = LQG_ASP_STACK0 ? 0 : 1;             // first stacked slot
+  constexpr int CKS = CK - S0 > 0 ? CK - S0 : 1;
+  R Pst[CKS][NSB], Sst[CKS][NSM];
+  TrialState<R, M, ND> Tst[CKS][NT];
+  auto chunk = [&]<bool WHOLE>(const int t0) LQG_LAMBDA_INLINE {      // WHOLE: CK full steps, none of them step 0
+    refill_gains<R, NB, NU, CK, WHOLE>(A.rc, s, t0, c.Aa, c.Ba, rQ, rR, Lbuf);
     // ---- recompute: states before the steps t0 .. t0 + CK - 1
     {
       Mat<R, NB, NB, MK::PM> Pm;
@@ -495,22 +510,22 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES
       }
       LQG_UNROLL for (int j = 0; j < CK; ++j) {
         const int t = t0 + j;
-        if (t < a.T) {
-          {
+        if (WHOLE || t < a.T) {
+          if (j >= S0) {
             R Pd[NB * NB];
             to_dense(Pm, Pd);
             int e = 0;
             LQG_UNROLL for (int i = 0; i < NB; ++i)
-              LQG_UNROLL for (int k = 0; k <= i; ++k) Pst[j][e++] = Pd[i * NB + k];
+              LQG_UNROLL for (int k = 0; k <= i; ++k) Pst[j >= S0 ? j - S0 : 0][e++] = Pd[i * NB + k];
             e = 0;
             LQG_UNROLL for (int i = 0; i < M; ++i)
-              LQG_UNROLL for (int k = 0; k <= i; ++k) Sst[j][e++] = Sg[i * M + k];
-            LQG_UNROLL for (int n = 0; n < NT; ++n) Tst[j][n] = st[n];
+              LQG_UNROLL for (int k = 0; k <= i; ++k) Sst[j >= S0 ? j - S0 : 0][e++] = Sg[i * M + k];
+            LQG_UNROLL for (int n = 0; n < NT; ++n) Tst[j >= S0 ? j - S0 : 0][n] = st[n];
           }
-          if (j + 1 < CK && t + 1 < a.T) {              // (the state after the chunk's last step is carried from the later chunk)
+          if (j + 1 < CK && (WHOLE || t + 1 < a.T)) {   // (the state after the chunk's last step is carried from the later chunk)
             Mat<R, NU, NB> L;
             LQG_UNROLL for (int e = 0; e < NU * NB; ++e) L.v[e] = Lbuf[j][e];
-            sys_step<ND>(c, Pm, Sg, L, t == 0, [&](const auto&, const auto&, const auto&, const auto&, const auto&, const auto& Pn,
+            sys_step<ND>(c, Pm, Sg, L, !WHOLE && t == 0, [&](const auto&, const auto&, const auto&, const auto&, const auto&, const auto& Pn,
                                                     const auto&, const auto& Fj, const auto&, const auto&, const auto& GG,
                                                     const R (&Li)[O * O], const R (&)[O], const R (&U2)[RR * O], const auto&,
                                                     const auto& F2, const auto& F2C) LQG_LAMBDA_INLINE {
@@ -533,24 +548,36 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES
     // ---- reverse over the chunk
     LQG_UNROLL for (int j = CK - 1; j >= 0; --j) {
       const int t = t0 + j;
-      if (t < a.T) {
+      if (WHOLE || t < a.T) {
         Mat<R, NB, NB, MK::PM> Pm;
         R Sg[M * M];
-        {
+        TrialState<R, M, ND> st0[NT];
+        if (j >= S0) {
           int e = 0;
           LQG_UNROLL for (int i = 0; i < NB; ++i)
             LQG_UNROLL for (int k = 0; k <= i; ++k) {
-              const R v = Pst[j][e++];
+              const R v = Pst[j >= S0 ? j - S0 : 0][e++];
               if (MK::PM.b[i * NB + k]) Pm.v[i * NB + k] = v;
               if (MK::PM.b[k * NB + i]) Pm.v[k * NB + i] = v;
             }
           e = 0;
           LQG_UNROLL for (int i = 0; i < M; ++i)
-            LQG_UNROLL for (int k = 0; k <= i; ++k) { const R v = Sst[j][e++]; Sg[i * M + k] = v; Sg[k * M + i] = v; }
+            LQG_UNROLL for (int k = 0; k <= i; ++k) { const R v = Sst[j >= S0 ? j - S0 : 0][e++]; Sg[i * M + k] = v; Sg[k * M + i] = v; }
+          LQG_UNROLL for (int n = 0; n < NT; ++n) st0[n] = Tst[j >= S0 ? j - S0 : 0][n];
+        } else {                                                       // the chunk's checkpoint
+          const R* src = A.ck + (long)(t0 / CK) * Rec::W * a.ldb + s;
+          R Pd[NB * NB];
+          load_tri_arr<R, NB>(src + Rec::P_OFF * a.ldb, a.ldb, Pd);
+          LQG_UNROLL for (int i = 0; i < NB * NB; ++i) if (MK::PM.b[i]) Pm.v[i] = Pd[i];
+          load_tri_arr<R, M>(src + Rec::S_OFF * a.ldb, a.ldb, Sg);
+          LQG_UNROLL for (int n = 0; n < NT; ++n) {
+            LQG_UNROLL for (int i = 0; i < O; ++i) st0[n].dO[i] = NTR > 0 ? src[(Rec::T_OFF + n * M + i) * a.ldb] : R(0);
+            LQG_UNROLL for (int i = 0; i < RR; ++i) st0[n].muR[i] = NTR > 0 ? src[(Rec::T_OFF + n * M + O + i) * a.ldb] : R(0);
+          }
         }
         Mat<R, NU, NB> L;
         LQG_UNROLL for (int e = 0; e < NU * NB; ++e) L.v[e] = Lbuf[j][e];
-        sys_step<ND>(c, Pm, Sg, L, t == 0, [&](const auto& AP, const auto& Pp, const auto& FP, const auto& Gi, const auto& K,
+        sys_step<ND>(c, Pm, Sg, L, !WHOLE && t == 0, [&](const auto& AP, const auto& Pp, const auto& FP, const auto& Gi, const auto& K,
                                                 const auto& Pn, const auto& BK, const auto& Fj, const auto& KN2, const auto& KN3,
                                                 const auto& GG, const R (&Li)[O * O], const R (&dinv)[O], const R (&U2)[RR * O],
                                                 const auto& C, const auto& F2, const auto& F2C) LQG_LAMBDA_INLINE {
@@ -584,7 +611,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES
                 x1[i] = xr[(long)(t + 1) * a.x.st + i * a.x.sd];
                 xm1[i] = xr[(long)(t > 0 ? t - 1 : 0) * a.x.st + i * a.x.sd];
               }
-              TrialState<R, M, ND> s0 = Tst[j][n];
+              TrialState<R, M, ND> s0 = st0[n];
               trial_forward<R, M, ND>(Fj, Li, U2, xt, xm1, s0, w0, cv, false);
               LQG_UNROLL for (int i = 0; i < O; ++i) {
                 R v = R(0);
@@ -619,7 +646,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES
                 pre[n][k] = -v;
               }
               LQG_UNROLL for (int p = 0; p < RR; ++p) pre[n][O + p] = ch[p];
-              stN[n] = Tst[j][n];
+              stN[n] = st0[n];
             }
           } else {
             LQG_UNROLL for (int i = 0; i < O * O; ++i) W2[i] = R(0);
@@ -690,7 +717,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES
             LQG_UNROLL for (int p = 0; p < RR; ++p)
               LQG_UNROLL for (int q = 0; q < RR; ++q) Sigb[(O + p) * M + O + q] = Chd[p * RR + q];
           }
-          if (t == 0) {                                                                    // Sigma_0 = G_0 G_0'
+          if (!WHOLE && t == 0) {                                                          // Sigma_0 = G_0 G_0'
             const auto S0 = from_dense<R, M, M>(Sigb);
             accum(G11, blk<0, 0, NX, NX>(S0));
             accum(G21, blk<NX, 0, NB, NX>(S0));
@@ -747,6 +774,12 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES
         });
       }
     }
+  };
+  {
+    int t0 = (nck - 1) * CK;
+    if (t0 + CK > a.T && t0 > 0) { chunk.template operator()<false>(t0); t0 -= CK; }     // the last, partial chunk
+    for (; t0 > 0; t0 -= CK) chunk.template operator()<true>(t0);
+    chunk.template operator()<false>(0);                                // (step 0: Sigma_0 = G_0 G_0')
   }
   // ---- chain the hoisted products' bars to the stored matrices, write the gradient
   // FAa = Fa Aa, FAd = Fd Ad, DB = Fd Bd - Fa Ba, N2 = Fd N1, N3 = Fd N1 Fd' + WWd
@@ -768,21 +801,30 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES
     accum(bN1, mul_tn(c.Fd, bN2));
     accum(bN1, mul_tn(c.Fd, mul(bN3, c.Fd)));
     if (!(DENSE_P && a.Sigma0.p)) accum(bVVa, Pb);                                         // default Sigma0 = V_0 V_0'  system.py:160
-    store_col(o + Lay::DA * ld, ld, bAd);
-    store_col(o + Lay::DB * ld, ld, bBd);
-    store_col(o + Lay::DF * ld, ld, bFd);
-    store_col(o + Lay::DVV * ld, ld, bN1);
+    // bars of fields that no parameter moves (PAT::live_*: lqg_amd/specialize.py) are written as zeros — everything that only
+    // feeds them (their accumulators, the hoisted products' bars, the F11 block of MC, ...) is dead code and compiled out
+    auto put = [&]<bool LIVE>(int off, const auto& m) LQG_LAMBDA_INLINE {
+      if constexpr (LIVE) store_col(o + off * ld, ld, m);
+      else {
+        using MT = std::remove_cvref_t<decltype(m)>;
+        LQG_UNROLL for (int i = 0; i < MT::rows * MT::cols; ++i) o[(off + i) * ld] = R(0);
+      }
+    };
+    put.template operator()<PAT::live_Ad>(Lay::DA, bAd);
+    put.template operator()<PAT::live_Bd>(Lay::DB, bBd);
+    put.template operator()<PAT::live_Fd>(Lay::DF, bFd);
+    put.template operator()<PAT::live_Vd>(Lay::DVV, bN1);
     {
       Mat<R, NY, NY, PAT::WWd> bWWd;
       set_zero(bWWd);
       accum(bWWd, bN3);
-      store_col(o + Lay::DWW * ld, ld, bWWd);
+      put.template operator()<PAT::live_Wd>(Lay::DWW, bWWd);
     }
-    store_col(o + Lay::AA * ld, ld, bAa);
-    store_col(o + Lay::AB * ld, ld, bBa);
-    store_col(o + Lay::AF * ld, ld, bFa);
-    store_col(o + Lay::AVV * ld, ld, bVVa);
-    store_col(o + Lay::AWW * ld, ld, bWWa);
+    put.template operator()<PAT::live_Aa>(Lay::AA, bAa);
+    put.template operator()<PAT::live_Ba>(Lay::AB, bBa);
+    put.template operator()<PAT::live_Fa>(Lay::AF, bFa);
+    put.template operator()<PAT::live_Va>(Lay::AVV, bVVa);
+    put.template operator()<PAT::live_Wa>(Lay::AWW, bWWa);
     store_col(o + Lay::AS0 * ld, ld, Pb);
   }
 }
@@ -872,6 +914,10 @@ __global__ void __launch_bounds__(LQG_BLOCK, 2) k_asp_ric_rev(const AspArgs<R> A
   }
   R* o = A.out + s;
   const long ld = A.ld;
+  if constexpr (!PAT::live_Aa) adj::zero<R, NB * NB>(bA);
+  if constexpr (!PAT::live_Ba) adj::zero<R, NB * NU>(bB);
+  if constexpr (!PAT::live_Q) adj::zero<R, NB * NB>(bQ);
+  if constexpr (!PAT::live_R) adj::zero<R, NU * NU>(bR);
   adj::store_flat<R, NB * NB>(o + Lay::AA2 * ld, ld, bA);
   adj::store_flat<R, NB * NU>(o + Lay::AB2 * ld, ld, bB);
   adj::store_flat<R, NB * NB>(o + Lay::AQ * ld, ld, bQ);

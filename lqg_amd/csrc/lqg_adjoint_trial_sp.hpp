@@ -134,19 +134,12 @@ LQG_DEV void block_reduce_groups(const R (&v)[V], R* buf, int lane, int wave) {
     block_reduce_groups<GQ + 1>(v, buf, lane, wave);
   }
 }
+// the wave's totals of V per-lane values, deposited at buf[wave][0 .. V) (natural order)
 template <typename R, int V>
-LQG_DEV void block_reduce_store(const R (&v)[V], R* lds, int parity, R* __restrict__ out) {
-  constexpr int NW = LQG_ASP_TRIAL_BLOCK / 64;
+LQG_DEV void wave_reduce_deposit(const R (&v)[V], R* buf) {
   using RS = ReduceShape<V>;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  R* buf = lds + (long)parity * NW * RS::VPT;
   block_reduce_groups<0>(v, buf, lane, wave);
-  __syncthreads();
-  if ((int)threadIdx.x < V) {
-    R tsum = buf[threadIdx.x];
-    LQG_UNROLL for (int w = 1; w < NW; ++w) tsum += buf[w * RS::VPT + threadIdx.x];
-    out[threadIdx.x] = tsum;
-  }
 }
 
 // ---------------------------------------------------------------- reverse
@@ -160,23 +153,31 @@ __global__ void __launch_bounds__(LQG_ASP_TRIAL_BLOCK, (sizeof(R) == 4 ? 2 : 1))
   using SM = Sums<M, ND, FM>;
   constexpr auto FMD = mask_or(FM, mask_eye<M>());
   constexpr int CKN = CKT * Ops::N;                     // reals of one chunk's operator blocks
-  __shared__ R lds[2 * (BLK / 64) * ReduceShape<SM::RAW>::VPT];
+  constexpr int NW = BLK / 64, VPT = ReduceShape<SM::RAW>::VPT;
+  __shared__ R lds[2 * CKT * NW * VPT];       // per-wave totals of the chunk's steps, double-buffered by chunk
   __shared__ R lops[2][CKN];
   const long sys = blockIdx.y;
   const long n0 = (long)blockIdx.x * (BLK * TPL) + threadIdx.x;
   const R* __restrict__ op = ops_all + sys * (long)(a.T + 1) * Ops::N;
   const long op_len = (long)(a.T + 1) * Ops::N;
   R* sums = a.sums + (((long)blockIdx.x * a.n_sys + sys) * a.T) * SM::N;
-  const R* xr[TPL];
+  // data rows: a wave-uniform row pointer (SGPRs) + a 32-bit per-lane BYTE offset of the trial — the form the hardware
+  // addresses in one instruction (global_load v, v_offset, s[base]); a 64-bit per-lane pointer costs an address add per load
+  const char* xbase = reinterpret_cast<const char*>(a.x.p + sys * a.x.sb);
+  unsigned xo[TPL];
+  auto xat = [&](int k, long t, int i) LQG_LAMBDA_INLINE -> R {
+    const char* row = xbase + ((long)t * a.x.st + (long)i * a.x.sd) * (long)sizeof(R);
+    return *reinterpret_cast<const R*>(row + xo[k]);
+  };
   bool live[TPL];
-  long nn[TPL];
+  unsigned nn[TPL];
   R gw[TPL], pre[TPL][M], a1[TPL][O];
   LQG_UNROLL for (int k = 0; k < TPL; ++k) {
     long n = n0 + (long)k * BLK;
     live[k] = n < a.n_trials;
     n = live[k] ? n : (a.n_trials - 1);
-    nn[k] = n;
-    xr[k] = a.x.p + sys * a.x.sb + n * a.x.sn;
+    nn[k] = (unsigned)n;
+    xo[k] = (unsigned)(n * a.x.sn * (long)sizeof(R));
     gw[k] = live[k] ? (a.g ? a.g[sys * a.g_sb + n * a.g_sn] : R(1)) : R(0);
     LQG_UNROLL for (int i = 0; i < M; ++i) pre[k][i] = R(0);
     // a_n(T) = Li_T' w_n(T) from the final mean state
@@ -187,7 +188,7 @@ __global__ void __launch_bounds__(LQG_ASP_TRIAL_BLOCK, (sizeof(R) == 4 ? 2 : 1))
     LQG_UNROLL for (int i = 0; i < O; ++i) {
       R v = R(0);
       LQG_UNROLL for (int j = 0; j <= i; ++j)
-        v += opT[Ops::L_OFF + (e++)] * ((xr[k][(long)a.T * a.x.st + j * a.x.sd] - xr[k][(long)(a.T - 1) * a.x.st + j * a.x.sd]) - src[j * a.npad]);
+        v += opT[Ops::L_OFF + (e++)] * ((xat(k, a.T, j) - xat(k, a.T - 1, j)) - src[j * a.npad]);
       w[i] = v;
     }
     LQG_UNROLL for (int i = 0; i < O; ++i) {
@@ -226,13 +227,28 @@ __global__ void __launch_bounds__(LQG_ASP_TRIAL_BLOCK, (sizeof(R) == 4 ? 2 : 1))
       if (i < CKN) lops[buf][i] = nx[q];
     }
   };
+  // the waves' totals of a chunk are summed and stored by the whole workgroup after the NEXT chunk's barrier: one barrier
+  // per chunk instead of one per step
+  auto flush = [&](int c, int rb) LQG_LAMBDA_INLINE {
+    const R* buf = lds + (long)rb * CKT * NW * VPT;
+    for (int i = threadIdx.x; i < CKT * SM::RAW; i += BLK) {
+      const int j = i / SM::RAW, e = i - j * SM::RAW;
+      const int t = c * CKT + j;
+      if (t < a.T) {
+        R tsum = buf[(j * NW) * VPT + e];
+        LQG_UNROLL for (int w = 1; w < NW; ++w) tsum += buf[(j * NW + w) * VPT + e];
+        sums[(long)t * SM::N + e] = tsum;
+      }
+    }
+  };
   R wst[CKT][TPL][O], cst[CKT][TPL][RR];
-  int parity = 0, obuf = 0;
+  int rb = 0, obuf = 0;
   request(a.nckt - 1);
-  for (int c = a.nckt - 1; c >= 0; --c) {
+  auto chunk = [&]<bool WHOLE>(const int c) LQG_LAMBDA_INLINE {        // WHOLE: CKT full steps (no per-step `t < T` tests)
     const int t0 = c * CKT;
     publish(obuf);
     __syncthreads();
+    if (c < a.nckt - 1) flush(c + 1, rb ^ 1);
     if (c > 0) request(c - 1);
     const R* __restrict__ lo = lops[obuf];
     // ---- recompute the chunk's (w, c)
@@ -242,13 +258,13 @@ __global__ void __launch_bounds__(LQG_ASP_TRIAL_BLOCK, (sizeof(R) == 4 ? 2 : 1))
       LQG_UNROLL for (int k = 0; k < TPL; ++k) {
         LQG_UNROLL for (int i = 0; i < O; ++i) {
           dO[k][i] = src[i * a.npad + nn[k]];
-          xprev[k][i] = xr[k][(long)(t0 > 0 ? t0 - 1 : 0) * a.x.st + i * a.x.sd];
+          xprev[k][i] = xat(k, t0 > 0 ? t0 - 1 : 0, i);
         }
         LQG_UNROLL for (int i = 0; i < RR; ++i) muR[k][i] = src[(O + i) * a.npad + nn[k]];
       }
       LQG_UNROLL for (int j = 0; j < CKT; ++j) {
         const int t = t0 + j;
-        if (t < a.T) {
+        if (WHOLE || t < a.T) {
           const R* __restrict__ opt = lo + j * Ops::N;
           R Li[O * (O + 1) / 2], U2[RR * O];
           LQG_UNROLL for (int i = 0; i < O * (O + 1) / 2; ++i) Li[i] = opt[Ops::L_OFF + i];
@@ -257,7 +273,7 @@ __global__ void __launch_bounds__(LQG_ASP_TRIAL_BLOCK, (sizeof(R) == 4 ? 2 : 1))
           LQG_UNROLL for (int i = 0; i < M * M; ++i) if (FMD.b[i]) Fv[i] = opt[Ops::F_OFF + i];
           LQG_UNROLL for (int k = 0; k < TPL; ++k) {
             R cv[M], w[O];
-            LQG_UNROLL for (int i = 0; i < O; ++i) cv[i] = xr[k][(long)t * a.x.st + i * a.x.sd];
+            LQG_UNROLL for (int i = 0; i < O; ++i) cv[i] = xat(k, t, i);
             int e = 0;
             LQG_UNROLL for (int i = 0; i < O; ++i) {
               R v = R(0);
@@ -287,7 +303,7 @@ __global__ void __launch_bounds__(LQG_ASP_TRIAL_BLOCK, (sizeof(R) == 4 ? 2 : 1))
     // ---- backward
     LQG_UNROLL for (int j = CKT - 1; j >= 0; --j) {
       const int t = t0 + j;
-      if (t < a.T) {
+      if (WHOLE || t < a.T) {
         const R* __restrict__ opt = lo + j * Ops::N;
         R Li[O * (O + 1) / 2], U2[RR * O];
         LQG_UNROLL for (int i = 0; i < O * (O + 1) / 2; ++i) Li[i] = opt[Ops::L_OFF + i];
@@ -304,7 +320,7 @@ __global__ void __launch_bounds__(LQG_ASP_TRIAL_BLOCK, (sizeof(R) == 4 ? 2 : 1))
             LQG_UNROLL for (int q = i; q < O; ++q) v += Li[q * (q + 1) / 2 + i] * wst[j][k][q];
             a0[i] = v;
           }
-          LQG_UNROLL for (int i = 0; i < O; ++i) cv[i] = xr[k][(long)t * a.x.st + i * a.x.sd];
+          LQG_UNROLL for (int i = 0; i < O; ++i) cv[i] = xat(k, t, i);
           LQG_UNROLL for (int p = 0; p < RR; ++p) cv[O + p] = cst[j][k][p];
           const R g = gw[k];
           LQG_UNROLL for (int i = 0; i < M; ++i) post[i] = pre[k][i] + (i < O ? g * a1[k][i < O ? i : 0] : R(0));
@@ -343,12 +359,19 @@ __global__ void __launch_bounds__(LQG_ASP_TRIAL_BLOCK, (sizeof(R) == 4 ? 2 : 1))
           LQG_UNROLL for (int p = 0; p < RR; ++p) pre[k][O + p] = ch[p];
           LQG_UNROLL for (int i = 0; i < O; ++i) a1[k][i] = a0[i];
         }
-        block_reduce_store<R, SM::RAW>(acc, lds, parity, sums + (long)t * SM::N);
-        parity ^= 1;
+        wave_reduce_deposit<R, SM::RAW>(acc, lds + ((long)rb * CKT + j) * NW * VPT);
       }
     }
     obuf ^= 1;
+    rb ^= 1;
+  };
+  for (int c = a.nckt - 1; c >= 0; --c) {
+    // (whole chunks without per-step guards were measured at compile time and not kept: one basic block per chunk lets the
+    // compiler hoist the chunk's 64 data loads, 408 registers spilled at two waves per SIMD)
+    chunk.template operator()<false>(c);
   }
+  __syncthreads();
+  flush(0, rb ^ 1);
 }
 
 }  // namespace asp

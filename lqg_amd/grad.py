@@ -192,8 +192,8 @@ def _specialised_adjoint(ln, system, d):
                 return None
     if any(getattr(p.actor, f).ptr for f in ("q", "qf", "P", "r")):
         return None
-    dims, masks, key = specialize.adjoint_pattern(system, d)
-    return specialize.load_adjoint_pattern(key, dims, masks)
+    dims, masks, key, live = specialize.adjoint_pattern(system, d)
+    return specialize.load_adjoint_pattern(key, dims, masks, live=live)
 
 
 ADJOINT_SP_MAX_JOINT = 12       # largest x + b the specialised adjoint libraries are generated for (registers: the chunk's states)

@@ -261,7 +261,19 @@ _adj_libs = {}
 ADJ_EXTRA_FLAGS = []           # (no value-changing flags: the bars are compared with the restatement entry by entry)
 
 
-def generate_adjoint_source(key, dims, masks):
+LIVE_FIELDS = ("Aa", "Ba", "Fa", "Va", "Wa", "Q", "R", "Ad", "Bd", "Fd", "Vd", "Wd")
+ALL_LIVE = {k: True for k in LIVE_FIELDS}
+
+
+def adjoint_key(key, live):
+    """Key of an adjoint library: the pattern's key + which spec fields any parameter moves (bars of the others are not formed)."""
+    bits = "".join("1" if live[k] else "0" for k in LIVE_FIELDS)
+    return key if all(live[k] for k in LIVE_FIELDS) else f"{key}_{int(bits, 2):03x}"
+
+
+def generate_adjoint_source(key, dims, masks, live=None):
+    live = live or ALL_LIVE
+
     def lit(m):
         return "{{" + ", ".join("true" if v else "false" for v in m.reshape(-1)) + "}}"
     d = dims
@@ -271,6 +283,8 @@ def generate_adjoint_source(key, dims, masks):
     for k in _FIELDS:
         r, c = masks[k].shape
         lines.append(f"  static constexpr lqg::Mask<{r}, {c}> {k}{lit(masks[k])};")
+    for k in LIVE_FIELDS:
+        lines.append(f"  static constexpr bool live_{k} = {'true' if live[k] else 'false'};")
     lines += ["};", "}  // namespace", "",
               'extern "C" int lqg_log_likelihood_grad_sp(const lqg_problem* p, lqg_traj x, const void* g, int64_t g_sb, int64_t g_sn,',
               "                                          void* ll, int64_t ll_sb, int64_t ll_sn, void* grad, int64_t ld, void* workspace,",
@@ -291,9 +305,11 @@ def _adj_headers_hash():
     return h.hexdigest()[:12]
 
 
-def compile_adjoint_pattern(key, dims, masks, verbose=False):
+def compile_adjoint_pattern(key, dims, masks, verbose=False, live=None):
     """Generate + compile <pattern dir>/padj_<key>.so — the reverse-mode twin of pat_<key>.so (same masks, same locking
-    discipline as compile_pattern)."""
+    discipline as compile_pattern).  live: which spec fields a parameter moves (LIVE_FIELDS; None = all)."""
+    live = live or ALL_LIVE
+    key = adjoint_key(key, live)
     pdir = _build.cache_dir(PAT_DIR, "pat")
     so = os.path.join(pdir, f"padj_{key}.so")
     hh = _adj_headers_hash()
@@ -306,7 +322,7 @@ def compile_adjoint_pattern(key, dims, masks, verbose=False):
         if _build.stamped(so, hh):
             return so
         src = os.path.join(pdir, f"padj_{key}.hip")
-        _build.atomic_write(src, generate_adjoint_source(key, dims, masks))
+        _build.atomic_write(src, generate_adjoint_source(key, dims, masks, live))
         flags = [fl for fl in _build.FLAGS if not fl.startswith("-std=")] + ["-std=c++20"] + ADJ_EXTRA_FLAGS
         flags += ["-I", _build.CSRC] + os.environ.get("LQG_ADJ_FLAGS", "").split()
         tmp = f"{so}.tmp.{os.getpid()}"
@@ -323,14 +339,16 @@ def compile_adjoint_pattern(key, dims, masks, verbose=False):
     return so
 
 
-def load_adjoint_pattern(key, dims, masks, verbose=False):
+def load_adjoint_pattern(key, dims, masks, verbose=False, live=None):
     """ctypes handle of the adjoint library of this pattern (compiled on first use), or None (the caller then runs the
     round-1 lane kernels of the main library)."""
+    live = live or ALL_LIVE
+    base_key, key = key, adjoint_key(key, live)
     if key in _adj_libs:
         return _adj_libs[key]
     lib = None
     try:
-        so = compile_adjoint_pattern(key, dims, masks, verbose=verbose)
+        so = compile_adjoint_pattern(base_key, dims, masks, verbose=verbose, live=live)
         if so is not None:
             lib = C.CDLL(so)
             lib.lqg_log_likelihood_grad_sp.argtypes = [C.POINTER(_abi.Problem), _abi.Traj, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
@@ -427,16 +445,64 @@ def system_pattern(system, d, grad_full=False):
     return cache[d]
 
 
+_zoo_live = {}
+
+
+def _live_between(sa, sb):
+    """Which spec fields differ between two systems built by the same constructor from different parameters."""
+    pairs = dict(Aa=("actor", "A"), Ba=("actor", "B"), Fa=("actor", "F"), Va=("actor", "V"), Wa=("actor", "W"), R=("actor", "R"),
+                 Ad=("dynamics", "A"), Bd=("dynamics", "B"), Fd=("dynamics", "F"), Vd=("dynamics", "V"), Wd=("dynamics", "W"))
+    diff = lambda which, f: not torch.equal(getattr(getattr(sa, which), f), getattr(getattr(sb, which), f))
+    live = {k: diff(*v) for k, v in pairs.items()}
+    live["Q"] = diff("actor", "Q") or diff("actor", "Qf")
+    return live
+
+
+def zoo_live(cls, zs, d, component=None):
+    """LIVE_FIELDS of a model-zoo class (or of component `component` of a decoupling one): the spec fields that ANY constructor
+    parameter moves, from two CPU probe instances with different random positive parameters."""
+    ck = (cls, zs, d)
+    if ck not in _zoo_live:
+        from lqg_amd import decouple
+        from lqg_amd.infer.models import get_model_params
+        probes = []
+        for seed in (12345, 54321):
+            g = torch.Generator()
+            g.manual_seed(seed)
+            params = {k: float(0.3 + torch.rand((), generator=g)) for k in get_model_params(cls)}
+            probes.append(cls(T=2, device="cpu", dtype=torch.float64, **params, **dict(zs)))
+        whole = _live_between(*probes)
+        parts = [decouple.plan(p, d) or [] for p in probes]
+        comps = [_live_between(pa[0], pb[0]) for pa, pb in zip(*parts)] if len(parts[0]) == len(parts[1]) else []
+        _zoo_live[ck] = (whole, comps)
+    whole, comps = _zoo_live[ck]
+    if component is None:
+        return whole
+    return comps[component] if component < len(comps) else dict(ALL_LIVE)
+
+
 def adjoint_pattern(system, d):
-    """(dims, masks, key) for the reverse-mode sweep of a System: the constructor's structure for the model zoo and its
-    decoupled components (a structural zero of a zoo constructor is a constant: its adjoint is never needed), else the pattern
-    with every field that requires grad counted as FULL (pattern_of(grad_full=True))."""
+    """(dims, masks, key, live) for the reverse-mode sweep of a System: the constructor's structure for the model zoo and its
+    decoupled components (a structural zero of a zoo constructor is a constant: its adjoint is never needed; `live` = the fields
+    its parameters move), else the pattern with every field that requires grad counted as FULL (pattern_of(grad_full=True)) and
+    live = the fields that require grad."""
+    a, dy = system.actor, system.dynamics
+    rg = lambda t: bool(getattr(t, "requires_grad", False))
+    live = dict(Aa=rg(a.A), Ba=rg(a.B), Fa=rg(a.F), Va=rg(a.V), Wa=rg(a.W), Q=rg(a.Q) or rg(a.Qf), R=rg(a.R),
+                Ad=rg(dy.A), Bd=rg(dy.B), Fd=rg(dy.F), Vd=rg(dy.V), Wd=rg(dy.W))
+    # zoo classes: the class-level set (ONE library per class, prebuilt) united with what this instance differentiates — a
+    # constructor argument outside get_model_params (dt, process_noise) that requires grad makes its fields live as well
+    union = lambda cl: {k: bool(cl[k] or live[k]) for k in LIVE_FIELDS}
     hint = getattr(system, "_lqg_zoo_component", None) or getattr(system, "_lqg_zoo_component_grad", None)
     if hint is not None:
         pat = zoo_component_pattern(hint)
         if pat is not None and pat[0]["d"] == d:
-            return pat
-    return system_pattern(system, d, grad_full=True)
+            return pat + (union(zoo_live(hint[0], hint[1], hint[2], component=hint[3])),)
+    zs = zoo_structure(system)
+    pat = system_pattern(system, d, grad_full=True)
+    if zs is not None:
+        return pat + (union(zoo_live(type(system), tuple(sorted(zs.items())), d)),)
+    return pat + (live,)
 
 
 def prebuild_zoo_adjoint(verbose=True, workers=None):
@@ -449,17 +515,20 @@ def prebuild_zoo_adjoint(verbose=True, workers=None):
                        (lqg_amd.RelativeObservationBoundedActor, 2, dict(dim=1)), (lqg_amd.SubjectiveActor, 2, dict(dim=1)),
                        (lqg_amd.PointMassBoundedActor, 2, {}), (lqg_amd.PointMassBoundedActor, 4, {})]:
         dims, masks, key = class_pattern(cls, d, **kw)
-        pats[key] = (dims, masks)
+        live = zoo_live(cls, tuple(sorted(kw.items())), d)
+        pats[adjoint_key(key, live)] = (key, dims, masks, live)
     for cls, d, kw in [(lqg_amd.BoundedActor, 4, dict(dim=2)), (lqg_amd.SubjectiveActor, 4, dict(dim=2))]:
         i = 0
         while True:
-            pat = zoo_component_pattern((cls, tuple(sorted(kw.items())), d, i))
+            zs = tuple(sorted(kw.items()))
+            pat = zoo_component_pattern((cls, zs, d, i))
             if pat is None:
                 break
-            pats[pat[2]] = (pat[0], pat[1])
+            live = zoo_live(cls, zs, d, component=i)
+            pats[adjoint_key(pat[2], live)] = (pat[2], pat[0], pat[1], live)
             i += 1
     with cf.ThreadPoolExecutor(workers or min(8, os.cpu_count() or 1)) as ex:
-        list(ex.map(lambda kv: compile_adjoint_pattern(kv[0], kv[1][0], kv[1][1], verbose=verbose), pats.items()))
+        list(ex.map(lambda v: compile_adjoint_pattern(v[0], v[1], v[2], verbose=verbose, live=v[3]), pats.values()))
     return sorted(pats)
 
 

@@ -53,10 +53,10 @@ def main():
         for dtype, tol in ((torch.float64, 1e-8), (torch.float32, 3e-4)):
             for n in (1, 2, 5):
                 s, actor, dyn, x, g = build(name, dtype, device, n)
-                dims, masks, key = specialize.adjoint_pattern(s, x.shape[-1])
+                dims, masks, key, live = specialize.adjoint_pattern(s, x.shape[-1])
                 if compile_only:
                     if dtype == torch.float64 and n == 1:
-                        print(name, dims, key, specialize.compile_adjoint_pattern(key, dims, masks, verbose=True), flush=True)
+                        print(name, dims, key, specialize.compile_adjoint_pattern(key, dims, masks, verbose=True, live=live), flush=True)
                     continue
                 import lqg_adjoint_np as ADJ
                 from lqg_amd import grad as G

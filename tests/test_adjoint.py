@@ -172,7 +172,7 @@ def _dense_grad_system(name, dtype, n, device="cuda", T=None):
 
 
 def split_sweep_test_patterns():
-    """(dims, masks, key) of the dense adjoint patterns the GPU tests below use (compiled by __graft_entry__.build())."""
+    """(dims, masks, key, live) of the dense adjoint patterns the GPU tests below use (compiled by __graft_entry__.build())."""
     from lqg_amd import specialize
     out = []
     for name in ("bounded_T100", "subjective1d_T50", "relobs_T40", "pointmass_d2_T50"):
