@@ -33,7 +33,7 @@ PEAK_FP64_TFLOPS = 78.6    # datasheet FP64 vector == FP64 matrix peak
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 COPY_HBM_GBS = 6290.0      # MI355X_MICROARCH.md: measured device copy rate
 VALU_WAVE_INSTS_PER_S = 1024 * 2.4e9 / 2    # 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")      # scripts/pmc_legs.sh + scripts/pmc_records.py
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc.json")      # scripts/pmc_legs.sh + scripts/pmc_records.py
 
 
 def algorithmic_flops_per_step(x, b, u, y, d):
@@ -844,7 +844,146 @@ def leg_delay12_batch(torch, args, dev):
     return out
 
 
+def _grad_leg(torch, dev, system, x, B, n_trials, T, dims, leg_name, steps=5, warmup=2, fd_check=None):
+    """Value + reverse-mode gradient of the summed log-likelihood — what every inference driver of the reference runs
+    (`jit(grad(fun))` lqg/optim.py:142, NUTS lqg/infer/utils.py:14-18, SVI-Adam lqg/infer/mle.py:14-25) — through a persistent
+    lqg_amd.grad.GradPlan: the sweep's kernels only (specs resident in HBM, as the headline's forward sweeps are timed)."""
+    import numpy as np
+    from lqg_amd import grad as G
+    gp = G.GradPlan(system, x, events=True)
+    for _ in range(warmup):
+        gp.run()
+    torch.cuda.synchronize()
+    tm = Timer(torch, steps)
+    ph = []
+    t0 = time.perf_counter()
+    for it in range(steps):
+        tm.ev[it][0].record()
+        ll, bars = gp.run()
+        tm.ev[it][1].record()
+        ph.append(gp.phase_ms())
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps * 1e3
+    ms = float(np.median(tm.ms()))
+    phm = {k: float(np.median([p[k] for p in ph])) for k in ph[0]}
+    kernel_ms = sum(phm.values())
+    x_, b_, u_, y_, d_ = dims
+    w = 4
+    n_out = sum(int(np.prod(v.shape[-2:])) for v in bars[0].values())
+    # algorithmic bytes: the forward's (SURVEY 8d mode M1: specs + trajectories in, one scalar out) + the bars out
+    alg = B * (algorithmic_bytes_per_solve(x_, b_, u_, y_, d_, T, w) + (n_trials - 1) * ((T + 1) * d_ + 1) * w * (1 if x.dim() == 4 else 0)
+               + n_out * w * len(bars))
+    if x.dim() == 3:                       # trials shared by all candidates: read once
+        alg += n_trials * (T + 1) * d_ * w
+    fin = bool(torch.isfinite(ll).all()) and all(bool(torch.isfinite(v).all()) for bd in bars for v in bd.values())
+    out = {"value": B / (ms * 1e-3), "unit": "solves+gradient/s", "ms_per_value_and_grad": ms, "wall_ms_incl_host": wall,
+           "candidates": B, "trials_per_candidate": n_trials, "T": T, "dtype": "f32", "path": gp.description,
+           "kernel_ms": phm, "kernel_ms_total": kernel_ms, "all_finite": fin,
+           "roofline": {"bound": "hbm", "achieved": alg / (kernel_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": alg / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                        "algorithmic_bytes_per_launch_set": alg,
+                        "note": "instruction-issue-bound sweeps: the matrix adjoints are O(m^3) register arithmetic per system-step, "
+                                "the per-trial mu-bar recursion O(m^2) per trial-step (limits.valu_issue_frac below, from the PMC pass)"}}
+    recs = {k: pmc_record(leg_name, k) for k in ("sys_fwd", "sys_rev", "ric_rev", "trial_fwd", "trial_rev", "riccati")}
+    recs = {k: v for k, v in recs.items() if v}
+    if recs:
+        out["roofline"]["traffic"] = sum(v.get("hbm_bytes_per_launch") or 0.0 for v in recs.values())
+        out["roofline"]["traffic_kernels"] = {k: v.get("hbm_bytes_per_launch") for k, v in recs.items()}
+        insts = sum(v.get("valu_wave_insts_per_launch") or 0.0 for v in recs.values())
+        out["roofline"]["limits"] = {"valu_wave_insts_per_launch_set": insts,
+                                     "valu_issue_frac": insts / (kernel_ms * 1e-3) / VALU_WAVE_INSTS_PER_S,
+                                     "valu_insts_per_kernel": {k: v.get("valu_wave_insts_per_launch") for k, v in recs.items()}}
+        out["roofline"]["profile"] = next(iter(recs.values())).get("profile")
+    if fd_check is not None:
+        try:
+            out["parity"] = fd_check(ll)
+        except Exception as e:
+            out["parity"] = {"error": repr(e)[:300]}
+    return out
+
+
+def leg_value_and_grad_headline(torch, args, dev):
+    """Headline shape: SubjectiveActor(dim=2), T = 500, 2^18 candidates x ONE trajectory each, fp32.  Parity: the parameter
+    gradient of 3 sampled candidates through torch.autograd (the same sweep) against central differences of the fp64 C oracle."""
+    import numpy as np
+    import lqg_amd
+    from lqg_amd import workload
+    B, T = 1 << 18, 500
+    system, params = workload.headline_system(B, T, seed=1234, device=dev, dtype=torch.float32)
+    x_ref = workload.simulate_one_trial_each(system, seed=3)
+    x = workload.pack_trials(x_ref)
+
+    def check(ll):
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as OC
+        OC.build()
+        idx = [0, B // 2, B - 1]
+        names = list(params)
+        th = {k: params[k][idx].double().clone().requires_grad_(True) for k in names}
+        m = lqg_amd.SubjectiveActor(dim=2, T=T, process_noise=1.0, dt=1.0 / 60, device=dev, dtype=torch.float64, **th)
+        xs = x_ref[torch.as_tensor(idx, device=dev)].double()
+        l3 = m.log_likelihood(xs)
+        l3.sum().backward()
+        worst = 0.0
+        val_err = float((ll[torch.as_tensor(idx, device=dev), 0].double() / l3[:, 0].detach() - 1).abs().max())
+        h = 1e-5
+        for k in ("sigma_target", "action_cost", "subj_noise"):
+            for j in range(len(idx)):
+                vals = []
+                for sgn in (+1, -1):
+                    kw = {q: (th[q][j].item() * ((1 + sgn * h) if q == k else 1.0)) for q in names}
+                    mm = lqg_amd.SubjectiveActor(dim=2, T=T, process_noise=1.0, dt=1.0 / 60, device="cpu", dtype=torch.float64, **kw)
+                    host = lambda spec: {f: getattr(spec, f).numpy()[None] if getattr(spec, f).dim() == workload._batched_ndim(f) - 1
+                                         else getattr(spec, f).numpy() for f in lqg_amd.LQGSpec._fields}
+                    vals.append(float(OC.log_likelihood(host(mm.actor), host(mm.dynamics), xs[j:j + 1].cpu().numpy())[0, 0]))
+                fd = (vals[0] - vals[1]) / (2 * h * th[k][j].item())
+                an = float(th[k].grad[j])
+                worst = max(worst, abs(an - fd) / max(1.0, abs(fd)))
+        return {"samples": len(idx), "value_max_rel_err_f32_vs_f64_sweep": val_err,
+                "grad_max_rel_err_vs_central_differences_of_the_fp64_oracle": worst}
+
+    return _grad_leg(torch, dev, system, x, B, 1, T, (4, 6, 2, 4, 4), "value_and_grad_headline", fd_check=check)
+
+
+def leg_value_and_grad_config3(torch, args, dev):
+    """BASELINE config 3's shape: BoundedActor, T = 1067, 4096 candidates x 1024 shared trials, fp32: the per-trial mu-bar
+    sweep (4.4e9 trial-steps) carries the time; the matrix adjoints run once per candidate."""
+    import lqg_amd
+    from lqg_amd import workload
+    Bc, Nt, T = 4096, 1024, 1067
+    system, _ = workload.bounded_system(Bc, T, seed=5, device=dev, dtype=torch.float32)
+    truth = lqg_amd.BoundedActor(T=T, sigma_target=20.0, sigma_cursor=3.0, action_cost=0.3, action_variability=0.5, device=dev,
+                                 dtype=torch.float32)
+    x = workload.pack_trials(truth.simulate(13, n=Nt).contiguous())
+
+    def check(ll):
+        # the same sweep on 2 candidates x 24 trials, T = 120 against the round-1 lane kernels in fp64 (tests/test_adjoint.py
+        # holds the full comparisons with the restatement)
+        from lqg_amd import grad as G, options
+        sub, _ = workload.bounded_system(2, 120, seed=5, device=dev, dtype=torch.float64)
+        xs = truth.to(torch.float64).simulate(13, n=24)[:, :121].contiguous() if hasattr(truth, "to") else None
+        out = {}
+        for sp in (1, 0):
+            with options.override(ADJOINT_SP=sp):
+                sw = G.Sweep(sub.actor, sub.dynamics, xs, system=sub)
+                l_ = sw.forward()
+                b_ = sw.reverse(None)
+                out[sp] = (l_.double(), {k: v.sum(1).double() for k, v in b_.items()})
+        # (the split sweep forms the bars on the pattern's masks only: compared where it has entries)
+        err = 0.0
+        for k in ("aVV", "aWW", "dVV", "dWW", "aR"):
+            nz = out[1][1][k] != 0
+            err = max(err, float(((out[1][1][k] - out[0][1][k]).abs()[nz].max() / out[0][1][k].abs()[nz].max().clamp_min(1e-9))))
+        return {"candidates": 2, "trials": 24, "T": 120, "bars_max_rel_diff_split_vs_round1_kernels_f64": err,
+                "value_max_rel_diff": float((out[1][0] / out[0][0] - 1).abs().max())}
+
+    out = _grad_leg(torch, dev, system, x, Bc, Nt, T, (2, 2, 1, 2, 2), "value_and_grad_config3", fd_check=check)
+    out["trial_steps_per_s"] = float(Bc) * Nt * T / (out["ms_per_value_and_grad"] * 1e-3)
+    return out
+
+
 LEGS = {
+    "value_and_grad_headline": leg_value_and_grad_headline, "value_and_grad_config3": leg_value_and_grad_config3,
     "headline_other": leg_headline_other, "reference_layout": leg_reference_layout,
     "dense_generic_f32": leg_dense_generic("f32"), "dense_generic_f64": leg_dense_generic("f64"),
     "config2_one_system": leg_one_system(2), "config4_one_system": leg_one_system(4),

@@ -26,7 +26,7 @@
 #include "lqg_kernels_sp.hpp"
 
 #ifndef LQG_ASP_STACK0
-#define LQG_ASP_STACK0 1          // 1: the state before a chunk's first step stays in registers too (0: re-read from its checkpoint)
+#define LQG_ASP_STACK0 0          // 1: the state before a chunk's first step stays in registers too; 0: re-read from its checkpoint (measured: 4.14 vs 4.32 ms)
 #endif
 #ifndef LQG_ASP_SYS_WAVES_F32
 #define LQG_ASP_SYS_WAVES_F32 1   // waves per SIMD the fp32 system sweeps are allocated for (2: the reverse sweep spills 180 registers, 4.1 -> 10.6 ms measured)
@@ -351,6 +351,8 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES
           R pd = dinv[0];
           LQG_UNROLL for (int i = 1; i < O; ++i) pd *= dinv[i];
           if constexpr (NTR > 0) {
+            // (k_forward_sp's scoring — one v_log_f32 per step, partial sums flushed per chunk — was measured here and not kept:
+            // 1.43 -> 2.10 ms per 2^18 systems)
             const R lpd = log_<R>(pd);
             LQG_UNROLL for (int n = 0; n < NT; ++n) {
               R xt[O], w[O], cv[M];
@@ -851,7 +853,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, 2) k_asp_ric_rev(const AspArgs<R> A
   adj::zero<R, NB * NB>(bA); adj::zero<R, NB * NU>(bB); adj::zero<R, NB * NB>(bQ); adj::zero<R, NU * NU>(bR); adj::zero<R, NB * NB>(Sb);
   adj::RicStep<R, NB, NU> st;
   R Sst[CK][NS];
-  for (int t0 = 0; t0 < rc.T; t0 += CK) {
+  auto chunk = [&]<bool WHOLE>(const int t0) LQG_LAMBDA_INLINE {
     {   // S_{t+1} of the chunk's steps, backward from the checkpoint S_{t0 + CK}
       R Sr[NB * NB], Lt[NU * NB];
       const R* src = rc.Ls + (long)(t0 / CK) * NS * rc.ldb + s;
@@ -859,7 +861,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, 2) k_asp_ric_rev(const AspArgs<R> A
       LQG_UNROLL for (int i = 0; i < NB; ++i)
         LQG_UNROLL for (int j = i; j < NB; ++j) { const R v = src[(e++) * rc.ldb]; Sr[i * NB + j] = v; Sr[j * NB + i] = v; }
       LQG_UNROLL for (int j = CK - 1; j >= 0; --j)
-        if (t0 + j < rc.T) {
+        if (WHOLE || t0 + j < rc.T) {
           int k = 0;
           LQG_UNROLL for (int i = 0; i < NB; ++i)
             LQG_UNROLL for (int q = 0; q <= i; ++q) Sst[j][k++] = Sr[i * NB + q];
@@ -868,7 +870,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, 2) k_asp_ric_rev(const AspArgs<R> A
     }
     LQG_UNROLL for (int j = 0; j < CK; ++j) {
       const int t = t0 + j;
-      if (t < rc.T) {
+      if (WHOLE || t < rc.T) {
         R S[NB * NB], Lb[NU * NB];
         {
           int k = 0;
@@ -911,6 +913,11 @@ __global__ void __launch_bounds__(LQG_BLOCK, 2) k_asp_ric_rev(const AspArgs<R> A
         adj::symmetrise<R, NB>(Sb);
       }
     }
+  };
+  {
+    int t0 = 0;
+    for (; t0 + CK <= rc.T; t0 += CK) chunk.template operator()<true>(t0);
+    if (t0 < rc.T) chunk.template operator()<false>(t0);
   }
   R* o = A.out + s;
   const long ld = A.ld;

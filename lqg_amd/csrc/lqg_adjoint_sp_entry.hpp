@@ -159,12 +159,19 @@ int run_asp(const lqg_problem* p, lqg_traj x, const void* g, long g_sb, long g_s
   }
   if (phases & 2) {
     if (!grad) return LQG_ERR_NULL;
+    // (a reverse-only call records the same four caller events: [0] before the per-trial reverse sweep, [1] after it,
+    // [2] after the system reverse sweep, [3] after the Riccati adjoint)
+    const bool rev_only = !(phases & 1);
+    if (rev_only) mark(0);
     if (!fused)
       hipLaunchKernelGGL((lqg::asp::k_asp_trial_rev<R, M, ND, LQG_ASP_TPL, LQG_ASP_CKT, MK::FJ>), tgrid, tblock, 0, st, ops, tr);
+    if (rev_only) mark(1);
     if (p->n_trials == 1) LQG_ASP_SYS(k_asp_sys_rev, 1);
     else if (p->n_trials == 2) LQG_ASP_SYS(k_asp_sys_rev, 2);
     else LQG_ASP_SYS(k_asp_sys_rev, 0);
+    if (rev_only) mark(2);
     hipLaunchKernelGGL((lqg::asp::k_asp_ric_rev<R, NB, NU, NX, NY, PAT, CK>), grid, block, 0, st, A);
+    if (rev_only) mark(3);
   }
 #undef LQG_ASP_SYS
   (void)sizeof(SM);

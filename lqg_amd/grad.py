@@ -199,6 +199,82 @@ def _specialised_adjoint(ln, system, d):
 ADJOINT_SP_MAX_JOINT = 12       # largest x + b the specialised adjoint libraries are generated for (registers: the chunk's states)
 
 
+class GradPlan:
+    """Value + gradient of one (system, data) pair, decided ONCE (decoupling into components, identical components merged as
+    trials, adjoint libraries, workspaces, argument structs) so that repeated evaluations are pure launches — the analogue of
+    plan.LogLikelihoodPlan for the reverse mode; bench.py keeps one per timed leg.  `run(g)` -> (ll[(B,) n], [bars per
+    component]): the bars are those of the components' spec matrices ({name: [B, 1, r, c]}, summed over the trials)."""
+
+    def __init__(self, system, x, events=False):
+        from lqg_amd import _hipev, decouple
+        from lqg_amd.plan import _trial_stack
+        import lqg_amd
+        d = x.shape[-1]
+        with torch.no_grad():
+            parts = system.decoupled(d, None, for_grad=True)
+            whole = parts is None
+            parts = parts or [(system, list(range(d)), None)]
+            zoo = (lqg_amd.BoundedActor, lqg_amd.OptimalActor, lqg_amd.RelativeObservationBoundedActor, lqg_amd.SubjectiveActor)
+            by_class = len(parts) > 1 and type(system) in zoo and getattr(system, "_zoo_structure", None) is not None
+            groups = decouple.identical_groups(system, d, parts, None) if by_class else [[i] for i in range(len(parts))]
+            self.items = []
+            for gr in groups:
+                sub, cols, _ = parts[gr[0]]
+                # (a system that does not decouple keeps the caller's trajectory layout — e.g. workload.pack_trials' trial-fastest
+                # storage; an index copy would re-lay it trial-major: 3.5x slower per-trial sweeps, measured)
+                xs = x if whole else (_trial_stack(x, [parts[i][1] for i in gr]) if len(gr) > 1 else x[..., cols].contiguous())
+                sw = Sweep(sub.actor, sub.dynamics, xs, system=sub)
+                ev = None
+                if events:
+                    ev = ([_hipev.Event() for _ in range(4)], [_hipev.Event() for _ in range(4)])
+                self.items.append(dict(sweep=sw, group=len(gr), ev=ev))
+        self.n = x.shape[-3]
+
+    @property
+    def description(self):
+        sw = self.items[0]["sweep"]
+        dims = tuple(sw.ln.dims[k] for k in "xbuyd")
+        kind = ("split reverse-mode sweep on the pattern library (k_riccati_sp + k_asp_sys_fwd"
+                + (")" if sw.N <= 2 else " + k_trial_sp keeping checkpoints)") + " / (" + ("" if sw.N <= 2 else "k_asp_trial_rev + ")
+                + "k_asp_sys_rev + k_asp_ric_rev)") if sw.sp is not None else "round-1 lane kernels (one (system, trial) pair per lane)"
+        if len(self.items) > 1 or self.items[0]["group"] > 1:
+            kind += (f"; {sum(it['group'] for it in self.items)} decoupled components of dims (x,b,u,y,d)={dims}"
+                     + (f", {self.items[0]['group']} identical ones as trials of one system" if self.items[0]["group"] > 1 else ""))
+        return kind
+
+    def _set_events(self, it, which):
+        if it["ev"] is not None:
+            for i in range(4):
+                it["sweep"].ln.p.phase_events[i] = it["ev"][which][i].h
+
+    def run(self, g=None):
+        ll_tot, bars = None, []
+        with torch.no_grad():
+            for it in self.items:
+                sw, G = it["sweep"], it["group"]
+                self._set_events(it, 0)
+                ll = sw.forward()
+                gg = None
+                if g is not None:
+                    gg = g.repeat_interleave(1, -1) if G == 1 else torch.cat([g] * G, dim=-1)
+                self._set_events(it, 1)
+                bars.append(sw.reverse(gg))
+                ll = ll.view(*ll.shape[:-1], G, -1).sum(-2) if G > 1 else ll
+                ll_tot = ll if ll_tot is None else ll_tot + ll
+        return ll_tot, bars
+
+    def phase_ms(self):
+        """Kernel milliseconds of the last run, summed over components (events=True): forward (riccati, system, trial) and
+        reverse (trial, system, riccati)."""
+        out = {"fwd_riccati": 0.0, "fwd_system": 0.0, "fwd_trial": 0.0, "rev_trial": 0.0, "rev_system": 0.0, "rev_riccati": 0.0}
+        for it in self.items:
+            f, r = it["ev"]
+            r[3].synchronize()
+            for k, (ev, i) in zip(out, [(f, 0), (f, 1), (f, 2), (r, 0), (r, 1), (r, 2)]):
+                out[k] += ev[i].elapsed_ms(ev[i + 1])
+        return out
+
+
 def raw_grad(actor, dynamics, x, g=None, Sigma0=None, eps=1e-8, want_value=True, system=None):
     """Both phases at once.  x[n,T+1,d] or [B,n,T+1,d]; g like the log-likelihood ([n] / [B,n]) or None.
     Returns (ll, {name: [B, N, r, c] per-(system, trial) bars — [B, 1, r, c], summed over the trials, from the specialised

@@ -271,30 +271,47 @@ def adjoint_key(key, live):
     return key if all(live[k] for k in LIVE_FIELDS) else f"{key}_{int(bits, 2):03x}"
 
 
-def generate_adjoint_source(key, dims, masks, live=None):
+def generate_adjoint_sources(key, dims, masks, live=None):
+    """{file name: text} of one adjoint library: the pattern as a NAMED struct in a header, four translation units that each
+    instantiate the sweep for one (dtype, explicit-Sigma0) combination — compiled in parallel: the m = 8 point-mass kernels
+    took 10+ minutes as one unit — and the entry points."""
     live = live or ALL_LIVE
 
     def lit(m):
         return "{{" + ", ".join("true" if v else "false" for v in m.reshape(-1)) + "}}"
     d = dims
-    tpl = f"Pat, {d['x']}, {d['b']}, {d['u']}, {d['y']}, {d['d']}"
-    lines = ["// GENERATED by lqg_amd/specialize.py — structure-specialised reverse-mode sweep, pattern " + key,
-             '#include "lqg_adjoint_sp_entry.hpp"', "", "namespace {", "struct Pat {"]
+    pat = "Pat_" + key
+    tpl = f"lqg::{pat}, {d['x']}, {d['b']}, {d['u']}, {d['y']}, {d['d']}"
+    hdr = ["// GENERATED by lqg_amd/specialize.py — sparsity pattern " + key, "#pragma once", '#include "lqg_sparse.hpp"',
+           "namespace lqg {", f"struct {pat} {{"]
     for k in _FIELDS:
         r, c = masks[k].shape
-        lines.append(f"  static constexpr lqg::Mask<{r}, {c}> {k}{lit(masks[k])};")
+        hdr.append(f"  static constexpr Mask<{r}, {c}> {k}{lit(masks[k])};")
     for k in LIVE_FIELDS:
-        lines.append(f"  static constexpr bool live_{k} = {'true' if live[k] else 'false'};")
-    lines += ["};", "}  // namespace", "",
-              'extern "C" int lqg_log_likelihood_grad_sp(const lqg_problem* p, lqg_traj x, const void* g, int64_t g_sb, int64_t g_sn,',
-              "                                          void* ll, int64_t ll_sb, int64_t ll_sn, void* grad, int64_t ld, void* workspace,",
-              "                                          size_t workspace_bytes, int32_t phases, void* stream) {",
-              f"  return lqg::host::log_likelihood_grad_sp<{tpl}>(p, x, g, g_sb, g_sn, ll, ll_sb, ll_sn, grad, ld, workspace,",
-              "                                                   workspace_bytes, phases, stream);", "}",
-              'extern "C" size_t lqg_grad_workspace_bytes_sp(const lqg_problem* p) {',
-              f"  return lqg::host::grad_workspace_bytes_sp<{tpl}>(p);", "}",
-              f'extern "C" const char* lqg_sp_pattern_key(void) {{ return "{key}"; }}', ""]
-    return "\n".join(lines)
+        hdr.append(f"  static constexpr bool live_{k} = {'true' if live[k] else 'false'};")
+    hdr += ["};", "}  // namespace lqg", ""]
+    args = ("const lqg_problem*, lqg_traj, const void*, long, long, void*, long, long, void*, long, void*, size_t, int, hipStream_t")
+    files = {f"padj_{key}_pat.hpp": "\n".join(hdr)}
+    combos = [(r, dp) for r in ("float", "double") for dp in ("false", "true")]
+    for r, dp in combos:
+        files[f"padj_{key}_{r[0]}{'1' if dp == 'true' else '0'}.hip"] = "\n".join([
+            "// GENERATED by lqg_amd/specialize.py — structure-specialised reverse-mode sweep, pattern " + key + f" ({r}, Sigma0 given: {dp})",
+            f'#include "padj_{key}_pat.hpp"', '#include "lqg_adjoint_sp_entry.hpp"',
+            f"template int lqg::host::run_asp<{r}, {tpl}, {dp}>({args});", ""])
+    main = ["// GENERATED by lqg_amd/specialize.py — structure-specialised reverse-mode sweep, pattern " + key + " (entry points)",
+            f'#include "padj_{key}_pat.hpp"', '#include "lqg_adjoint_sp_entry.hpp"']
+    for r, dp in combos:
+        main.append(f"extern template int lqg::host::run_asp<{r}, {tpl}, {dp}>({args});")
+    main += ['extern "C" int lqg_log_likelihood_grad_sp(const lqg_problem* p, lqg_traj x, const void* g, int64_t g_sb, int64_t g_sn,',
+             "                                          void* ll, int64_t ll_sb, int64_t ll_sn, void* grad, int64_t ld, void* workspace,",
+             "                                          size_t workspace_bytes, int32_t phases, void* stream) {",
+             f"  return lqg::host::log_likelihood_grad_sp<{tpl}>(p, x, g, g_sb, g_sn, ll, ll_sb, ll_sn, grad, ld, workspace,",
+             "                                                   workspace_bytes, phases, stream);", "}",
+             'extern "C" size_t lqg_grad_workspace_bytes_sp(const lqg_problem* p) {',
+             f"  return lqg::host::grad_workspace_bytes_sp<{tpl}>(p);", "}",
+             f'extern "C" const char* lqg_sp_pattern_key(void) {{ return "{key}"; }}', ""]
+    files[f"padj_{key}.hip"] = "\n".join(main)
+    return files
 
 
 def _adj_headers_hash():
@@ -321,19 +338,32 @@ def compile_adjoint_pattern(key, dims, masks, verbose=False, live=None):
     with _build.locked(so):
         if _build.stamped(so, hh):
             return so
-        src = os.path.join(pdir, f"padj_{key}.hip")
-        _build.atomic_write(src, generate_adjoint_source(key, dims, masks, live))
+        import concurrent.futures as cf
+        files = generate_adjoint_sources(key, dims, masks, live)
+        for name, text in files.items():
+            _build.atomic_write(os.path.join(pdir, name), text)
         flags = [fl for fl in _build.FLAGS if not fl.startswith("-std=")] + ["-std=c++20"] + ADJ_EXTRA_FLAGS
-        flags += ["-I", _build.CSRC] + os.environ.get("LQG_ADJ_FLAGS", "").split()
-        tmp = f"{so}.tmp.{os.getpid()}"
-        cmd = [hipcc] + flags + ["-shared", src, "-o", tmp]
+        flags += ["-I", _build.CSRC, "-I", pdir] + os.environ.get("LQG_ADJ_FLAGS", "").split()
         if verbose:
             print(f"[lqg_amd.specialize] compiling adjoint pattern {key} dims={dims} density={density(masks):.2f}", flush=True)
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            if os.path.exists(tmp):
-                os.remove(tmp)
-            raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-6000:]}")
+        units = [n for n in files if n.endswith(".hip")]
+        objs = [os.path.join(pdir, n[:-4] + f".{os.getpid()}.o") for n in units]
+
+        def cc(pair):
+            return subprocess.run([hipcc] + flags + ["-c", os.path.join(pdir, pair[0]), "-o", pair[1]], capture_output=True, text=True)
+        try:
+            with cf.ThreadPoolExecutor(len(units)) as ex:
+                for r, n in zip(ex.map(cc, zip(units, objs)), units):
+                    if r.returncode != 0:
+                        raise RuntimeError(f"hipcc failed on {os.path.join(pdir, n)}:\n{r.stderr[-6000:]}")
+            tmp = f"{so}.tmp.{os.getpid()}"
+            r = subprocess.run([hipcc, "--offload-arch=" + _build.ARCH, "-shared", "-fPIC", "-o", tmp] + objs, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"link of {so} failed:\n{r.stderr[-4000:]}")
+        finally:
+            for o in objs:
+                if os.path.exists(o):
+                    os.remove(o)
         os.replace(tmp, so)
         _build.atomic_write(so + ".stamp", hh)
     return so
