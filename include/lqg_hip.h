@@ -115,7 +115,10 @@ typedef struct lqg_tuning {
   int32_t coop_trial_tpb;        /* row-parallel per-trial sweep: most trials that share a workgroup (and its copy of the
                                     step's operator block): 0 rule, else a power of two <= 128                          */
   int32_t coop_trial_wide;       /* that sweep on 1024-thread workgroups: 0 rule (at 128 trials per workgroup), 1 always, -1 never */
-  int32_t reserved[2];           /* must be 0                                                                           */
+  int32_t trial_lds;             /* lane per-trial sweep with the operator stream staged in LDS, one 256-lane workgroup per 1024
+                                    trials of a candidate (k_trial_lds, round 5): 0 rule (>= 768 trials per system and >= 256
+                                    systems), 1 wherever a pattern library serves the sweep, -1 never (k_trial_sp)        */
+  int32_t reserved[1];           /* must be 0                                                                           */
 } lqg_tuning;
 
 typedef struct lqg_problem {

@@ -200,6 +200,17 @@ int check_problem(const lqg_problem* p, const char* who, bool mixed = false) {
   if (p->n_sys < 0 || p->n_trials < 0) return fail(LQG_ERR_ARG, "%s: negative batch", who);
   const lqg_dims& d = p->dims;
   if (d.x < 1 || d.b < 1 || d.u < 1 || d.y < 1) return fail(LQG_ERR_DIMS, "%s: non-positive dims", who);
+  // lqg_tuning (include/lqg_hip.h): enumerated values only — an out-of-range value must not reach a kernel's launch geometry
+  // (coop_trial_tpb > 128 made k_coop_trial_rows divide by RT = BLOCK / tpb = 0)
+  const lqg_tuning& tn = p->tuning;
+  auto tri = [](int v) { return v >= -1 && v <= 1; };
+  const int tpb = tn.coop_trial_tpb;
+  if (!tri(tn.coop) || !tri(tn.coop_trial_rows) || !tri(tn.coop_sparse) || !tri(tn.scan_lane) || !tri(tn.coop_trial_wide) ||
+      !tri(tn.trial_lds) || tn.coop_adjoint < 0 || tn.coop_adjoint > 1 || tn.scan_order < -1 || tn.scan_order > 2 ||
+      (tn.scan_rt_waves != 0 && tn.scan_rt_waves != 8 && tn.scan_rt_waves != 16) || tn.trial_chunks < -1 ||
+      tn.coop_trial_chunks < -1 || tn.trial_chunk_waves < 0 || tn.trial_chunk_max_waves < 0 || tn.trial_chunk_tpl < 0 ||
+      tn.trial_chunk_tpl > 2 || tpb < 0 || tpb > 128 || (tpb & (tpb - 1)) != 0 || tn.reserved[0] != 0)
+    return fail(LQG_ERR_ARG, "%s: lqg_tuning holds a value outside its documented range (include/lqg_hip.h)", who);
   return 0;
 }
 int need(const lqg_view& v, const char* who, const char* name) {

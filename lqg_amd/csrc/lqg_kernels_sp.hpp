@@ -937,6 +937,138 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial_sp(const R* __restrict__ op
   }
 }
 
+// ---------------------------------------------------------------- per-trial sweep, operator stream staged in LDS (round 5)
+// k_trial_sp gives each 64-lane workgroup 64 x TPL trials and reads the step's operator block through the scalar cache: with
+// 1024 trials per candidate (BASELINE config 3) eight workgroups re-stream every candidate's whole operator stream — 6.8 GB of
+// HBM traffic per launch against 25 MB of data rows (round-4 PMC), neither VALU- nor HBM-bound: stalled on those loads.  Here ONE
+// 256-lane workgroup owns up to 256 x TPL trials of one candidate; the operator blocks of CKL steps are fetched ONCE per
+// workgroup by coalesced vector loads into LDS (double-buffered: the next chunk is requested while this one is walked) and
+// read back as LDS broadcasts.  Same arithmetic, same order as k_trial_sp: results agree bitwise (tests/test_gpu_parity.py).
+// CKT > 0 keeps the mean state every CKT steps (TrialArgs::tck), as k_trial_sp<..., CKT>.
+#ifndef LQG_TRIAL_LDS_BLOCK
+#define LQG_TRIAL_LDS_BLOCK 256
+#endif
+#ifndef LQG_TRIAL_LDS_TPL
+#define LQG_TRIAL_LDS_TPL 4
+#endif
+#ifndef LQG_TRIAL_LDS_CHUNK
+#define LQG_TRIAL_LDS_CHUNK 8
+#endif
+template <typename R, int M, int ND, int TPL, Mask<M, M> FM, int CKT = 0>
+__global__ void __launch_bounds__(LQG_TRIAL_LDS_BLOCK) k_trial_lds(const R* __restrict__ ops_all, const TrialArgs<R> a) {
+  constexpr int O = ND, RR = M - ND, BLK = LQG_TRIAL_LDS_BLOCK, CKL = LQG_TRIAL_LDS_CHUNK;
+  constexpr int kAccChunk = 8;
+  using Ops = TrialOps<M, ND>;
+  constexpr int CKN = CKL * Ops::N, NLD = (CKN + BLK - 1) / BLK;
+  __shared__ R lops[2][CKN];
+  const long sys = blockIdx.y;
+  const long n0 = (long)blockIdx.x * (BLK * TPL) + threadIdx.x;
+  const R* __restrict__ op = ops_all + sys * (long)(a.T + 1) * Ops::N;
+  const long op_len = (long)(a.T + 1) * Ops::N;
+  const R* xr[TPL];
+  bool live[TPL];
+  R xprev[TPL][O], dO[TPL][O], muR[TPL][RR], part[TPL];
+  double acc[TPL];
+  LQG_UNROLL for (int k = 0; k < TPL; ++k) {
+    long n = n0 + (long)k * BLK;
+    live[k] = n < a.n_trials;
+    n = live[k] ? n : (a.n_trials - 1);
+    xr[k] = a.x.p + sys * a.x.sb + n * a.x.sn;
+    LQG_UNROLL for (int i = 0; i < O; ++i) { xprev[k][i] = xr[k][i * a.x.sd]; dO[k][i] = R(0); }
+    LQG_UNROLL for (int i = 0; i < RR; ++i) muR[k][i] = R(0);
+    acc[k] = 0.0;
+    part[k] = R(0);
+  }
+  R xq[TPL][O];                                           // data rows one step ahead
+  LQG_UNROLL for (int k = 0; k < TPL; ++k)
+    LQG_UNROLL for (int i = 0; i < O; ++i) xq[k][i] = xprev[k][i];
+  R nx[NLD];
+  LQG_UNROLL for (int q = 0; q < NLD; ++q) nx[q] = R(0);
+  auto request = [&](int c) LQG_LAMBDA_INLINE {
+    const long base = (long)c * CKN;
+    LQG_UNROLL for (int q = 0; q < NLD; ++q) {
+      const int i = q * BLK + (int)threadIdx.x;
+      if (i < CKN && base + i < op_len) nx[q] = op[base + i];
+    }
+  };
+  auto publish = [&](int buf) LQG_LAMBDA_INLINE {
+    LQG_UNROLL for (int q = 0; q < NLD; ++q) {
+      const int i = q * BLK + (int)threadIdx.x;
+      if (i < CKN) lops[buf][i] = nx[q];
+    }
+  };
+  [[maybe_unused]] auto keep = [&](int t) LQG_LAMBDA_INLINE {
+    if constexpr (CKT > 0) {
+      if ((t % CKT) == 0 || t == a.T) {
+        const int rec = t == a.T ? a.nckt : t / CKT;
+        R* dst = a.tck + ((sys * (a.nckt + 1) + rec) * M) * a.npad;
+        LQG_UNROLL for (int k = 0; k < TPL; ++k)
+          if (live[k]) {
+            const long n = n0 + (long)k * BLK;
+            LQG_UNROLL for (int i = 0; i < O; ++i) dst[i * a.npad + n] = dO[k][i];
+            LQG_UNROLL for (int i = 0; i < RR; ++i) dst[(O + i) * a.npad + n] = muR[k][i];
+          }
+      }
+    }
+  };
+  const R none[1] = {R(0)};
+  const int nchunk = (a.T + 1 + CKL - 1) / CKL;           // rows 0 .. T
+  int obuf = 0;
+  request(0);
+  for (int c = 0; c < nchunk; ++c) {
+    publish(obuf);
+    __syncthreads();
+    if (c + 1 < nchunk) request(c + 1);
+    LQG_UNROLL for (int j = 0; j < CKL; ++j) {
+      const int t = c * CKL + j;
+      if (t <= a.T) {
+        const R* __restrict__ opt = lops[obuf] + j * Ops::N;
+        keep(t);
+        R Li[O * (O + 1) / 2];
+        LQG_UNROLL for (int i = 0; i < O * (O + 1) / 2; ++i) Li[i] = opt[Ops::L_OFF + i];
+        const R hlc = opt[Ops::H_OFF];
+        const bool flush = ((t & (kAccChunk - 1)) == 0) || t == a.T;
+        LQG_UNROLL for (int k = 0; k < TPL; ++k) {
+          R cv[M], w[O];                                      // cv = [x_t ; c]
+          LQG_UNROLL for (int i = 0; i < O; ++i) cv[i] = xq[k][i];
+          {
+            const long row = (t + 1 < a.T) ? (long)(t + 1) : (long)a.T;
+            LQG_UNROLL for (int i = 0; i < O; ++i) xq[k][i] = xr[k][row * a.x.st + i * a.x.sd];
+          }
+          R zz = R(0);
+          {
+            int e = 0;
+            LQG_UNROLL for (int i = 0; i < O; ++i) {
+              R v = R(0);
+              LQG_UNROLL for (int q = 0; q <= i; ++q) v += Li[e++] * ((cv[q] - xprev[k][q]) - dO[k][q]);
+              w[i] = v;
+              zz += v * v;
+            }
+          }
+          if (t > 0) part[k] += R(0.5) * zz + hlc;
+          if (flush) { acc[k] -= (double)part[k]; part[k] = R(0); }
+          if (t < a.T) {
+            LQG_UNROLL for (int p = 0; p < RR; ++p) {
+              R v = muR[k][p];
+              LQG_UNROLL for (int q = 0; q < O; ++q) v += opt[Ops::U_OFF + p * O + q] * w[q];
+              cv[O + p] = v;
+            }
+            R mn[M];
+            trial_mean_rows<R, M, ND, FM, false, 1, 0>(none, opt, cv, mn);
+            LQG_UNROLL for (int i = 0; i < O; ++i) { dO[k][i] = mn[i]; xprev[k][i] = cv[i]; }
+            LQG_UNROLL for (int p = 0; p < RR; ++p) muR[k][p] = cv[O + p] + mn[O + p];   // (the stream holds Fj - I)
+          }
+        }
+      }
+    }
+    obuf ^= 1;
+  }
+  if (a.ll) {
+    LQG_UNROLL for (int k = 0; k < TPL; ++k)
+      if (live[k]) a.ll[sys * a.ll_sb + (n0 + (long)k * BLK) * a.ll_sn] = (R)acc[k];
+  }
+}
+
 // dense pattern (every constant may be non-zero everywhere): the specialised kernels reduce to the generic ones
 template <int NX, int NB, int NU, int NY>
 struct DensePattern {

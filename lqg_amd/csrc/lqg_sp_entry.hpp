@@ -40,6 +40,16 @@ hipError_t trial_sweep_sp(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb
     return launch_trial_chunked<R, NX + NB, ND, lqg::MaskPolicy<NX + NB, FM_noise>>(p, ops, x, ll, ll_sb, ll_sn, scratch, st);
   }
   lqg::TrialArgs<R> tk{dt<R>(x), dt<R>(no_traj), static_cast<R*>(ll), ll_sb, ll_sn, (long)p->n_trials, p->T};
+  // many trials per candidate and many candidates: one 256-lane workgroup per 1024 trials of a candidate, the operator stream
+  // staged in LDS (read once per candidate instead of once per 128 trials; lqg_kernels_sp.hpp k_trial_lds)
+  if (p->tuning.trial_lds > 0 || (p->tuning.trial_lds == 0 && p->n_trials >= 768 && p->n_sys >= 256)) {
+    const long per = (long)LQG_TRIAL_LDS_BLOCK * LQG_TRIAL_LDS_TPL;
+    const dim3 lgrid((unsigned)((p->n_trials + per - 1) / per), (unsigned)p->n_sys), lblock(LQG_TRIAL_LDS_BLOCK);
+    const R* o = static_cast<const R*>(ops);
+    if (dense_p) hipLaunchKernelGGL((lqg::k_trial_lds<R, NX + NB, ND, LQG_TRIAL_LDS_TPL, FM_dense>), lgrid, lblock, 0, st, o, tk);
+    else hipLaunchKernelGGL((lqg::k_trial_lds<R, NX + NB, ND, LQG_TRIAL_LDS_TPL, FM_noise>), lgrid, lblock, 0, st, o, tk);
+    return hipGetLastError();
+  }
   const long lanes4 = (long)p->n_sys * ((p->n_trials + 4 * LQG_BLOCK - 1) / (4 * LQG_BLOCK)) * LQG_BLOCK;
   const bool wide = lanes4 >= 2L * 1024 * 64;
   const long per_block = (long)LQG_BLOCK * (wide ? LQG_TRIALS_PER_LANE : 1);

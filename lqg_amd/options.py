@@ -28,6 +28,7 @@ COOP_ADJOINT      0         1: the cooperative reverse-mode sweep also for shape
 ADJOINT_SP        1         reverse-mode sweep on the structure-specialised adjoint libraries (matrix adjoints once per system, trial sums; csrc/lqg_adjoint_sp.hpp); 0: the round-1 lane kernels (one (system, trial) pair per lane)
 TRIAL_CHUNKS      ""        lane per-trial sweep cut along time: "" rule, "0" / "1" one pass, k chunks -> tuning.trial_chunks
 TRIAL_CHUNK_WAVES / TRIAL_CHUNK_MAX_WAVES / TRIAL_CHUNK_TPL   0   parameters of that rule             -> tuning.trial_chunk_*
+TRIAL_LDS         ""        lane per-trial sweep with the operator stream staged in LDS (k_trial_lds): "" rule (>= 768 trials per system, >= 256 systems), "1" always, "0" never -> tuning.trial_lds
 FUSE_TRIALS_MAX   2048      (system, trial) pairs up to which a small multi-trial evaluation runs as fused pairs (0: never)
 MIXED             1         fp32 problems on the operator stream run their system sweeps in fp64 (LQG_F32_SYS64)
 MIXED_MIN_TRIALS  3         trials per system from which they do
@@ -49,7 +50,7 @@ import os
 
 DEFAULTS = {
     "SCAN": "", "SCAN_MAX_SYSTEMS": 0, "SCAN_MIN_STEPS": 0, "SCAN_MAX_COND": 1e7, "SCAN_LANE": 1, "SCAN_RT_WAVES": 0, "SCAN_ORDER": "",
-    "COOP": "", "COOP_SPARSE": 1, "COOP_TRIAL_ROWS": 1, "COOP_TRIAL_TPB": 0, "COOP_TRIAL_WIDE": "", "COOP_TRIAL_CHUNKS": "", "COOP_ADJOINT": 0, "ADJOINT_SP": 1, "TRIAL_CHUNKS": "", "TRIAL_CHUNK_WAVES": 0,
+    "COOP": "", "COOP_SPARSE": 1, "COOP_TRIAL_ROWS": 1, "COOP_TRIAL_TPB": 0, "COOP_TRIAL_WIDE": "", "COOP_TRIAL_CHUNKS": "", "COOP_ADJOINT": 0, "ADJOINT_SP": 1, "TRIAL_CHUNKS": "", "TRIAL_LDS": "", "TRIAL_CHUNK_WAVES": 0,
     "TRIAL_CHUNK_MAX_WAVES": 0, "TRIAL_CHUNK_TPL": 0, "FUSE_TRIALS_MAX": 2048, "MIXED": 1, "MIXED_MIN_TRIALS": 3,
     "F32_WIDE": 1, "F32_MAX_COND": 1e7, "NO_SPECIALIZE": 0, "NO_DECOUPLE": 0, "NO_MERGE": 0, "GRAPH": 1, "GRAPH_AFFINE": 1,
     "SETUP_KERNEL": 1, "JIT": 1,
@@ -138,4 +139,5 @@ def fill_tuning(t):
     t.scan_order = 0 if so == "" else (-1 if int(so) == 0 else int(so))
     t.coop_trial_tpb = get("COOP_TRIAL_TPB")
     t.coop_trial_wide = _tri("COOP_TRIAL_WIDE")
+    t.trial_lds = _tri("TRIAL_LDS")
     return t

@@ -53,8 +53,8 @@ int main(void) {
          offsetof(lqg_problem, eps), offsetof(lqg_problem, phase_events));
   printf("%zu %zu %zu %zu ", sizeof(lqg_tuning), offsetof(lqg_problem, tuning), offsetof(lqg_tuning, coop_trial_chunks),
          offsetof(lqg_tuning, scan_rt_waves));
-  printf("%zu %zu %zu %zu %zu\n", offsetof(lqg_tuning, coop_adjoint), offsetof(lqg_tuning, scan_order), offsetof(lqg_tuning, coop_trial_tpb),
-         offsetof(lqg_tuning, coop_trial_wide), offsetof(lqg_tuning, reserved));
+  printf("%zu %zu %zu %zu %zu %zu\n", offsetof(lqg_tuning, coop_adjoint), offsetof(lqg_tuning, scan_order), offsetof(lqg_tuning, coop_trial_tpb),
+         offsetof(lqg_tuning, coop_trial_wide), offsetof(lqg_tuning, trial_lds), offsetof(lqg_tuning, reserved));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as td:
@@ -68,7 +68,8 @@ int main(void) {
             P.n_sys.offset, P.dims.offset, P.actor.offset, P.dynamics.offset, P.Sigma0.offset, P.eps.offset,
             P.phase_events.offset, C.sizeof(_abi.Tuning), P.tuning.offset, _abi.Tuning.coop_trial_chunks.offset,
             _abi.Tuning.scan_rt_waves.offset, _abi.Tuning.coop_adjoint.offset, _abi.Tuning.scan_order.offset,
-            _abi.Tuning.coop_trial_tpb.offset, _abi.Tuning.coop_trial_wide.offset, _abi.Tuning.reserved.offset]
+            _abi.Tuning.coop_trial_tpb.offset, _abi.Tuning.coop_trial_wide.offset, _abi.Tuning.trial_lds.offset,
+            _abi.Tuning.reserved.offset]
     assert got == want
 
 
@@ -109,6 +110,21 @@ def test_argument_errors_do_not_launch(lib):
     p.dims = _abi.Dims(2, 2, 1, 2, 2, 2, 2, 2, 2)
     assert lib.lqg_kalman_forward(C.byref(p), nv, None) == -1          # missing spec pointers
     assert b"actor.A" in lib.lqg_last_error()
+    # lqg_tuning: values outside the documented ranges are refused before any launch (round-4 advisor: coop_trial_tpb > 128
+    # reached a kernel as a division by zero)
+    for field, bad in (("coop_trial_tpb", 512), ("coop_trial_tpb", 3), ("scan_rt_waves", 5), ("scan_order", 7), ("coop", 2),
+                       ("trial_lds", -2)):
+        q = _abi.Problem()
+        q.dtype, q.T, q.n_sys, q.n_trials = _abi.F32, 10, 1, 1
+        q.dims = _abi.Dims(2, 2, 1, 2, 2, 2, 2, 2, 2)
+        setattr(q.tuning, field, bad)
+        assert lib.lqg_kalman_forward(C.byref(q), nv, None) == -3, field
+        assert b"lqg_tuning" in lib.lqg_last_error()
+    q = _abi.Problem()
+    q.dtype, q.T, q.n_sys, q.n_trials = _abi.F32, 10, 1, 1
+    q.dims = _abi.Dims(2, 2, 1, 2, 2, 2, 2, 2, 2)
+    q.tuning.reserved[0] = 1
+    assert lib.lqg_kalman_forward(C.byref(q), nv, None) == -3
 
 
 def test_setup_entry_checks_its_arguments_before_launching(lib):
