@@ -206,7 +206,7 @@ int check_problem(const lqg_problem* p, const char* who, bool mixed = false) {
   auto tri = [](int v) { return v >= -1 && v <= 1; };
   const int tpb = tn.coop_trial_tpb;
   if (!tri(tn.coop) || !tri(tn.coop_trial_rows) || !tri(tn.coop_sparse) || !tri(tn.scan_lane) || !tri(tn.coop_trial_wide) ||
-      !tri(tn.trial_lds) || tn.coop_adjoint < 0 || tn.coop_adjoint > 1 || tn.scan_order < -1 || tn.scan_order > 2 ||
+      tn.trial_lds < -1 || tn.trial_lds > 5 || tn.coop_adjoint < 0 || tn.coop_adjoint > 1 || tn.scan_order < -1 || tn.scan_order > 2 ||
       (tn.scan_rt_waves != 0 && tn.scan_rt_waves != 8 && tn.scan_rt_waves != 16) || tn.trial_chunks < -1 ||
       tn.coop_trial_chunks < -1 || tn.trial_chunk_waves < 0 || tn.trial_chunk_max_waves < 0 || tn.trial_chunk_tpl < 0 ||
       tn.trial_chunk_tpl > 2 || tpb < 0 || tpb > 128 || (tpb & (tpb - 1)) != 0 || tn.reserved[0] != 0)

@@ -17,6 +17,9 @@ namespace host {
 // for batches (2^20 systems: +5 %; 4096 systems of a small model, config 3: forward sweep 0.55 -> 0.32 ms — the per-step
 // gain load's latency disappears), a loss when ONE wave walks a large model alone (every extra instruction is latency:
 // config 2, m = 8, forward sweep 0.95 -> 1.26 ms).  Below this many systems the gains stream through HBM as in round 1.
+#ifndef LQG_TRIAL_WIDE_RULE
+#define LQG_TRIAL_WIDE_RULE 5      // geometry the default rule takes for many trials x many candidates (see trial_sweep_sp)
+#endif
 #ifndef LQG_SP_CHUNK_MIN_SYS
 #define LQG_SP_CHUNK_MIN_SYS 1024
 #endif
@@ -42,7 +45,33 @@ hipError_t trial_sweep_sp(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb
   lqg::TrialArgs<R> tk{dt<R>(x), dt<R>(no_traj), static_cast<R*>(ll), ll_sb, ll_sn, (long)p->n_trials, p->T};
   // many trials per candidate and many candidates: one 256-lane workgroup per 1024 trials of a candidate, the operator stream
   // staged in LDS (read once per candidate instead of once per 128 trials; lqg_kernels_sp.hpp k_trial_lds)
-  if (p->tuning.trial_lds > 0 || (p->tuning.trial_lds == 0 && p->n_trials >= 768 && p->n_sys >= 256)) {
+  // Many trials per candidate and many candidates: k_trial_sp on WIDER workgroups, so that 1024 trials of a candidate walk its
+  // operator stream together through one CU's scalar cache instead of as eight independent 64-lane workgroups.  Measured on
+  // BASELINE config 3 (4096 x 1024, per-trial sweep, ms; bitwise identical results): 64 x 2: 3.63 | 512 x 2: 3.37 | 1024 x 2: 6.27 |
+  // LDS-staged operators (k_trial_lds, 256 x 4): 4.33.  tuning.trial_lds: 0 rule (256 x 2 from 768 trials per system and 256
+  // systems), -1 64-lane workgroups, 1 k_trial_lds, 2..5 the A/B geometries below (second box: 64 x 2: 3.53, 512 x 2: 3.42,
+  // 256 x 4: 3.40, 256 x 2: 3.35 -> the rule takes 256 x 2).
+  {
+    int geo = p->tuning.trial_lds;
+    if (geo == 0 && p->n_trials >= 768 && p->n_sys >= 256) geo = LQG_TRIAL_WIDE_RULE;
+    if (geo >= 2) {
+      const R* o = static_cast<const R*>(ops);
+#define LQG_TRIAL_GEO(BLK_, TPL_)                                                                                          \
+  do {                                                                                                                    \
+    const long per_ = (long)(BLK_) * (TPL_);                                                                              \
+    const dim3 gg((unsigned)((p->n_trials + per_ - 1) / per_), (unsigned)p->n_sys);                                       \
+    if (dense_p) hipLaunchKernelGGL((lqg::k_trial_sp<R, NX + NB, ND, TPL_, FM_dense, 0, BLK_>), gg, dim3(BLK_), 0, st, o, tk); \
+    else hipLaunchKernelGGL((lqg::k_trial_sp<R, NX + NB, ND, TPL_, FM_noise, 0, BLK_>), gg, dim3(BLK_), 0, st, o, tk);    \
+  } while (0)
+      if (geo == 2) LQG_TRIAL_GEO(512, 2);
+      else if (geo == 3) LQG_TRIAL_GEO(1024, 2);
+      else if (geo == 4) LQG_TRIAL_GEO(256, 4);
+      else LQG_TRIAL_GEO(256, 2);
+#undef LQG_TRIAL_GEO
+      return hipGetLastError();
+    }
+  }
+  if (p->tuning.trial_lds == 1) {
     const long per = (long)LQG_TRIAL_LDS_BLOCK * LQG_TRIAL_LDS_TPL;
     const dim3 lgrid((unsigned)((p->n_trials + per - 1) / per), (unsigned)p->n_sys), lblock(LQG_TRIAL_LDS_BLOCK);
     const R* o = static_cast<const R*>(ops);

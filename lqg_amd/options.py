@@ -139,5 +139,6 @@ def fill_tuning(t):
     t.scan_order = 0 if so == "" else (-1 if int(so) == 0 else int(so))
     t.coop_trial_tpb = get("COOP_TRIAL_TPB")
     t.coop_trial_wide = _tri("COOP_TRIAL_WIDE")
-    t.trial_lds = _tri("TRIAL_LDS")
+    v = get("TRIAL_LDS")
+    t.trial_lds = 0 if v == "" else (-1 if int(v) == 0 else int(v))
     return t
