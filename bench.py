@@ -131,7 +131,7 @@ def launch_ranks(args):
 
 def pmc_record(leg, kernel):
     """The PMC-derived HBM bytes / VALU instructions per launch of `kernel` (a family name: "forward", "riccati", "trial")
-    inside bench leg `leg`, but only if the committed profile (profiles/r04_pmc.json, collected by scripts/pmc_legs.sh as
+    inside bench leg `leg`, but only if the committed profile (profiles/r05_pmc.json, collected by scripts/pmc_legs.sh as
     separate --pmc passes of `bench.py --only <leg>`) was taken on exactly this build: same library source hash, same
     pattern-library header hash.  None otherwise — a leg then reports `traffic: null` rather than a stale figure."""
     try:
@@ -139,7 +139,8 @@ def pmc_record(leg, kernel):
         pj = json.load(open(PMC_FILE))
         for rec in pj.get("records", []):
             if (rec.get("leg") == leg and rec.get("kernel") == kernel and rec.get("source_hash") == build.source_hash()
-                    and rec.get("sp_headers_hash") == specialize._headers_hash()):
+                    and rec.get("sp_headers_hash") == specialize._headers_hash()
+                    and rec.get("adj_headers_hash", specialize._adj_headers_hash()) == specialize._adj_headers_hash()):
                 return rec
     except Exception:
         pass
@@ -418,6 +419,14 @@ def headline_leg(torch, dist, args, dev, rank, world, dtype_name, log2_batch, st
         if rec.get("valu_wave_insts_per_launch"):
             limits["valu_issue_frac"] = rec["valu_wave_insts_per_launch"] / (fwd_avg_ms * 1e-3) / VALU_WAVE_INSTS_PER_S
             limits["valu_insts_per_step_per_wave"] = rec.get("valu_insts_per_step_per_wave")
+            if rec.get("sustained_mhz"):
+                # the chip does not hold 2.4 GHz under this load (GRBM_GUI_ACTIVE / 8 XCDs / kernel time of the PMC pass): at
+                # the clock it sustains the same instruction stream is this fraction of what the SIMDs can issue — the kernel is
+                # within ~1.4x of its VALU floor for this formulation, not waiting on HBM
+                limits["sustained_mhz"] = rec["sustained_mhz"]
+                limits["valu_issue_frac_at_sustained_clock"] = (rec["valu_wave_insts_per_launch"] / (fwd_avg_ms * 1e-3)
+                                                                / (1024 * rec["sustained_mhz"] * 1e6 / 2))
+                limits["bound"] = "VALU issue (hbm is the contract's word for the algorithmic-bytes view, not the kernel's limiter)"
         limits["profile"] = rec.get("profile")
     solves = float(B) * world * steps
     out = {
@@ -440,6 +449,8 @@ def headline_leg(torch, dist, args, dev, rank, world, dtype_name, log2_batch, st
         # committed profile was taken on exactly this build).
         "roofline": {"bound": "hbm", "achieved": alg_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": alg_gbs / PEAK_HBM_GBS, "traffic": traffic,
+                     # the same algorithmic bytes over the WHOLE step (Riccati sweep + forward sweep + objective reduction)
+                     "whole_step_frac": bytes_solve * B / (elapsed / steps) / 1e9 / PEAK_HBM_GBS,
                      "kernel": "forward sweep (Kalman + joint system + Sigma recursion + mean + log-density) of: "
                                + plan.description,
                      "kernel_ms": fwd_avg_ms, "riccati_kernel_ms": ric_avg_ms,
@@ -602,7 +613,8 @@ def config4(torch, dist, args, dev, rank, world, n_total=262144, steps=None, war
         "roofline": {"bound": "hbm", "kernel": f"per-trial sweep over {n_loc} trajectories per rank (x streamed once)",
                      "kernel_ms": ph[2], "system_sweeps_ms": ph[0] + ph[1], "achieved": b4 / (ph[2] * 1e-3) / 1e9,
                      "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": b4 / (ph[2] * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                     "traffic": None, "algorithmic_bytes_per_launch": b4},
+                     "traffic": ((pmc_record("config4_sharded", "trial") or {}).get("hbm_bytes_per_launch") if world == 1 else None),
+                     "algorithmic_bytes_per_launch": b4},
     }
 
 
@@ -649,13 +661,33 @@ def leg_dense_generic(dn):
         # dense joint n=6 (m=10) kernel: VALU-bound; the algorithmic flop rate is SURVEY 8(d)'s reference formulation
         fl_rate = r["algorithmic_flops_per_solve"] * leg["value"] / 1e12
         peak = PEAK_FP32_TFLOPS if dn == "f32" else PEAK_FP64_TFLOPS
+        # achieved = wave64 VALU instructions actually ISSUED per second (PMC SQ_INSTS_VALU of this build's forward kernel) against
+        # what the SIMDs can issue; the reference formulation's nominal flop rate (no symmetry, no hoisting) is kept beside it as
+        # context only — it is not an achieved-FLOP figure
+        rec = pmc_record("dense_generic_" + dn, "forward")
+        rate = 2.0 if dn == "f32" else 4.0            # cycles per wave64 VALU instruction (fp64: half rate)
+        ach = rec["valu_wave_insts_per_launch"] / (r["kernel_ms"] * 1e-3) if rec and rec.get("valu_wave_insts_per_launch") else None
         return {"value": leg["value"], "unit": leg["unit"], "ms_per_step": leg["ms_per_step"], "dtype": dn,
                 "solves_per_gpu": 1 << 17, "path": leg["config"]["path"], "parity": leg.get("parity"),
                 "env": "LQG_NO_SPECIALIZE=1 LQG_NO_DECOUPLE=1",
-                "roofline": {"bound": "valu", "achieved": fl_rate, "unit": "TFLOP/s (algorithmic, SURVEY 8d)", "peak": peak,
-                             "frac": fl_rate / peak, "kernel_ms": r["kernel_ms"], "riccati_kernel_ms": r["riccati_kernel_ms"],
-                             "traffic": None}}
+                "roofline": {"bound": "valu", "achieved": ach, "unit": "wave64 VALU instructions/s (issued, PMC)",
+                             "peak": 1024 * 2.4e9 / rate, "frac": (ach / (1024 * 2.4e9 / rate)) if ach else None,
+                             "kernel_ms": r["kernel_ms"], "riccati_kernel_ms": r["riccati_kernel_ms"],
+                             "traffic": rec.get("hbm_bytes_per_launch") if rec else None,
+                             "profile": rec.get("profile") if rec else None,
+                             "nominal_reference_formulation_tflops": fl_rate, "nominal_frac_of_vector_peak": fl_rate / peak}}
     return run
+
+
+def leg_specialised_joint(torch, args, dev):
+    """What a user with a genuinely COUPLED n = 6 model gets: the headline workload with block decoupling switched off
+    (LQG_NO_DECOUPLE=1) — the joint (x=4, b=6, u=2, y=4) problem on its pattern library (structural zeros compiled out, nothing
+    split, nothing merged).  Between the decoupled headline and the dense generic floor."""
+    leg = headline_leg(torch, None, args, dev, 0, 1, "f32", 18, min(args.steps, 10), 2, env={"LQG_NO_DECOUPLE": "1"},
+                       leg="specialised_joint_n6")
+    out = {k: leg[k] for k in ("value", "unit", "ms_per_step", "dtype", "parity", "roofline")}
+    out.update(solves_per_gpu=1 << 18, path=leg["config"]["path"], env="LQG_NO_DECOUPLE=1")
+    return out
 
 
 def leg_one_system(cfg):
@@ -985,6 +1017,7 @@ def leg_value_and_grad_config3(torch, args, dev):
 LEGS = {
     "value_and_grad_headline": leg_value_and_grad_headline, "value_and_grad_config3": leg_value_and_grad_config3,
     "headline_other": leg_headline_other, "reference_layout": leg_reference_layout,
+    "specialised_joint_n6": leg_specialised_joint,
     "dense_generic_f32": leg_dense_generic("f32"), "dense_generic_f64": leg_dense_generic("f64"),
     "config2_one_system": leg_one_system(2), "config4_one_system": leg_one_system(4),
     "one_vector_value_and_grad": leg_one_vector, "m2_f32": leg_m2, "config3": leg_config3, "config4_sharded": leg_config4,

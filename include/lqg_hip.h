@@ -115,9 +115,10 @@ typedef struct lqg_tuning {
   int32_t coop_trial_tpb;        /* row-parallel per-trial sweep: most trials that share a workgroup (and its copy of the
                                     step's operator block): 0 rule, else a power of two <= 128                          */
   int32_t coop_trial_wide;       /* that sweep on 1024-thread workgroups: 0 rule (at 128 trials per workgroup), 1 always, -1 never */
-  int32_t trial_lds;             /* lane per-trial sweep with the operator stream staged in LDS, one 256-lane workgroup per 1024
-                                    trials of a candidate (k_trial_lds, round 5): 0 rule (>= 768 trials per system and >= 256
-                                    systems), 1 wherever a pattern library serves the sweep, -1 never (k_trial_sp)        */
+  int32_t trial_lds;             /* geometry of the lane per-trial sweep of the pattern libraries: 0 rule (256-lane workgroups,
+                                    two trials per lane, from 768 trials per system and 256 systems: a candidate's trials walk
+                                    its operator stream together through one CU's scalar cache), -1 64-lane workgroups,
+                                    1 k_trial_lds (operators staged in LDS), 2 .. 5 A/B geometries (csrc/lqg_sp_entry.hpp)  */
   int32_t reserved[1];           /* must be 0                                                                           */
 } lqg_tuning;
 
@@ -344,6 +345,19 @@ size_t lqg_grad_workspace_bytes(const lqg_problem* p, int64_t ld);
  * sweep of csrc/lqg_coop_adjoint.hip — one workgroup per system — returns the bars ALREADY summed over the trials with the
  * weights g; then ld >= n_sys and lane = system).  lqg_grad_workspace_bytes accounts for either. */
 int32_t lqg_grad_lanes_per_system(const lqg_problem* p);
+/* Structure-specialised twin (NOT in liblqg_hip.so; round 5): the adjoint libraries generated per sparsity pattern by
+ * lqg_amd/specialize.py (lqg_amd/csrc/pat/padj_<key>.so; kernels in csrc/lqg_adjoint_sp.hpp, lqg_adjoint_trial_sp.hpp) export
+ *     int    lqg_log_likelihood_grad_sp(<exactly the argument list of lqg_log_likelihood_grad>);
+ *     size_t lqg_grad_workspace_bytes_sp(const lqg_problem* p);
+ * for time-invariant specs without affine cost terms and the dims / pattern they were compiled for (anything else returns
+ * LQG_ERR_ARG / LQG_ERR_DIMS without launching).  The sweep is cut like the forward path: Riccati, Kalman, joint system, moment
+ * recursion AND their adjoints run once per SYSTEM (one lane each); the trials enter through per-step trial sums formed by a
+ * per-trial mu-bar sweep over the operator stream (1 or 2 trials: in the system's lane); nothing per step is parked in HBM but
+ * checkpoints every few steps.  The bars come back ALREADY SUMMED over the trials with the weights g: grad is
+ * [lqg_grad_elements(dims)][ld] with ld >= n_sys, lane = system (as lqg_grad_lanes_per_system == 1); same element order; bars of
+ * fields that no model parameter moves (the pattern's live flags) are written as zeros, bars of structurally zero entries are
+ * not formed.  phases as above: a phases = 2 call records phase_events [0] before the per-trial reverse sweep, [1] after it,
+ * [2] after the system reverse sweep, [3] after the Riccati adjoint. */
 int lqg_log_likelihood_grad(const lqg_problem* p, lqg_traj x, const void* g, int64_t g_sb, int64_t g_sn, void* ll,
                             int64_t ll_sb, int64_t ll_sn, void* grad, int64_t ld, void* workspace,
                             size_t workspace_bytes, int32_t phases, void* stream);

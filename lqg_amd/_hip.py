@@ -188,6 +188,18 @@ def conditional_moments(actor, dynamics, x, Sigma0=None, eps=1e-8, want_mu=True,
     """x[n,T+1,d] | [B,n,T+1,d] -> mu[(B,)n,T,m], Sigma[(B,)T,m,m].  system: the System that owns the two specs — the
     scan-eligibility checks (eigenvalue floor, conditioning: one host synchronisation each) are cached on it."""
     d, n = x.shape[-1], x.shape[-3]
+    if actor.A.dtype == torch.float32 and actor.A.is_cuda:
+        # an fp32 problem whose observed noise block is ill-conditioned (plan.F32_MAX_COND: the point mass seen in full,
+        # cond 5.6e8) is evaluated over an fp64 image of specs and data and rounded once — the policy of the log-likelihood
+        # (plan.f32_needs_wide), whatever kernel family a caller forces: all-fp32 sweeps return 1e-3-wrong moments or NaN there
+        from lqg_amd import plan as _plan
+        from lqg_amd.system import System
+        owner = system if system is not None else System(actor=actor, dynamics=dynamics)
+        if _plan.f32_needs_wide(owner, d):
+            o64 = owner.to(torch.float64)
+            mu, Sig = conditional_moments(o64.actor, o64.dynamics, x.double(), None if Sigma0 is None else Sigma0.double(), eps,
+                                          want_mu, want_sigma, system=o64)
+            return (None if mu is None else mu.float()), (None if Sig is None else Sig.float())
     ln = Launch(actor, dynamics, d=d, n_trials=n, Sigma0=Sigma0, eps=eps)
     lib = ln.require_gpu()
     x, xb = _prep_x(ln, x)

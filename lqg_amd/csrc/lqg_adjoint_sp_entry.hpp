@@ -150,10 +150,15 @@ int run_asp(const lqg_problem* p, lqg_traj x, const void* g, long g_sb, long g_s
       constexpr auto FMT = lqg::trial_operator_mask<PAT, NX, NB, NU, NY, ND, DENSE_P>();
       const long lanes4 = (long)p->n_sys * ((p->n_trials + 4 * LQG_BLOCK - 1) / (4 * LQG_BLOCK)) * LQG_BLOCK;
       const bool wide = lanes4 >= 2L * 1024 * 64;
-      const long per_block = (long)LQG_BLOCK * (wide ? LQG_TRIALS_PER_LANE : 1);
-      const dim3 fgrid((unsigned)((p->n_trials + per_block - 1) / per_block), (unsigned)p->n_sys);
-      if (wide) hipLaunchKernelGGL((lqg::k_trial_sp<R, M, ND, LQG_TRIALS_PER_LANE, FMT, LQG_ASP_CKT>), fgrid, block, 0, st, ops, tk);
-      else hipLaunchKernelGGL((lqg::k_trial_sp<R, M, ND, 1, FMT, LQG_ASP_CKT>), fgrid, block, 0, st, ops, tk);
+      if (p->n_trials >= 768 && p->n_sys >= 256) {      // many trials x many candidates: 256-lane workgroups (lqg_sp_entry.hpp)
+        const dim3 wgrid((unsigned)((p->n_trials + 511) / 512), (unsigned)p->n_sys);
+        hipLaunchKernelGGL((lqg::k_trial_sp<R, M, ND, 2, FMT, LQG_ASP_CKT, 256>), wgrid, dim3(256), 0, st, ops, tk);
+      } else {
+        const long per_block = (long)LQG_BLOCK * (wide ? LQG_TRIALS_PER_LANE : 1);
+        const dim3 fgrid((unsigned)((p->n_trials + per_block - 1) / per_block), (unsigned)p->n_sys);
+        if (wide) hipLaunchKernelGGL((lqg::k_trial_sp<R, M, ND, LQG_TRIALS_PER_LANE, FMT, LQG_ASP_CKT>), fgrid, block, 0, st, ops, tk);
+        else hipLaunchKernelGGL((lqg::k_trial_sp<R, M, ND, 1, FMT, LQG_ASP_CKT>), fgrid, block, 0, st, ops, tk);
+      }
     }
     mark(3);
   }

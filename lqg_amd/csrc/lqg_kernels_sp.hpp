@@ -285,7 +285,14 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sp_fwd_waves<R, NX + NB>()))
   auto flush = [&]() LQG_LAMBDA_INLINE {
     double ld;
     if constexpr (sizeof(R) == 4) { ld = 0.6931471805599453 * (double)ldet; ldet = R(0); }
-    else { ld = (double)log_<R>(ldet); ldet = R(1); }
+    else {
+      // (the PRODUCT of the block's pivot products can leave (0, inf) although every factor is inside — |log10| beyond ~38 per
+      // step: it is keyed like the factors, so that such a block poisons the result instead of returning +-inf silently)
+      const unsigned key = pos_finite_key(ldet);
+      pois = key > pois ? key : pois;
+      ld = (double)log_<R>(ldet);
+      ldet = R(1);
+    }
     LQG_UNROLL for (int k = 0; k < NT; ++k) { acc[k] += ld - (double)part[k]; part[k] = R(0); }
   };
   auto condition = [&]() LQG_LAMBDA_INLINE {

@@ -327,7 +327,41 @@ class _LogLikelihood(torch.autograd.Function):
         return (None, None, gS0) + tuple(outs)
 
 
+def _candidate_chunks(system, x, Sigma0):
+    """Candidate ranges [(lo, hi)] such that the reverse sweep's workspace of each fits plan.ops_workspace_limit — for the shapes
+    the cooperative sweep serves (x + b > ADJOINT_SP_MAX_JOINT: it keeps S, L, P, Sigma and every trial's mean per step, ~42 MB per
+    system for DelayedSubjectiveActor at T = 500 x 50 trials: 4096 candidates would ask for 172 GB in one piece) — or None."""
+    B = system.n_systems
+    if not B or B <= 1 or system.xdim + system.bdim <= ADJOINT_SP_MAX_JOINT or not system.actor.A.is_cuda:
+        return None
+    from lqg_amd import plan as _plan, workload
+    with torch.no_grad():
+        one = workload.slice_system(system, 0, 1)
+        one64 = one.to(torch.float64)
+        ln = _hip.Launch(one64.actor, one64.dynamics, d=x.shape[-1], n_trials=x.shape[-3],
+                         Sigma0=None if Sigma0 is None else (Sigma0[:1] if Sigma0.dim() == 3 else Sigma0).double())
+        lib = ln.require_gpu(_abi.FAM_ADJOINT)
+        per = int(lib.lqg_grad_workspace_bytes(C.byref(ln.p), 64))
+    limit = _plan.ops_workspace_limit(system.actor.A.device)
+    if per <= 0 or per * B <= limit:
+        return None
+    size = max(1, int(limit // per))
+    return [(lo, min(B, lo + size)) for lo in range(0, B, size)]
+
+
 def _one(system, x, Sigma0):
+    chunks = _candidate_chunks(system, x, Sigma0)
+    if chunks is not None and len(chunks) > 1:
+        from lqg_amd import workload
+        outs = []
+        for lo, hi in chunks:                      # (slices are views: the bars flow back to the caller's leaves through autograd)
+            S0 = Sigma0 if (Sigma0 is None or Sigma0.dim() == 2) else Sigma0[lo:hi]
+            outs.append(_one_piece(workload.slice_system(system, lo, hi), x if x.dim() == 3 else x[lo:hi], S0))
+        return torch.cat(outs, dim=0)
+    return _one_piece(system, x, Sigma0)
+
+
+def _one_piece(system, x, Sigma0):
     a, dy = system.actor, system.dynamics
     if not (getattr(a.P, "_lqg_zero", False) or not a.P.requires_grad):
         raise NotImplementedError("gradient w.r.t. the cross-cost P is not provided")

@@ -115,8 +115,9 @@ def _observed_noise_cond(sub, d):
     key = (int(d), specialize.spec_versions(sub))
     if key in cache:
         return cache[key]
-    V = specialize._first(sub.dynamics.V.detach())[..., :d, :]       # (one time slice when the spec is time-invariant)
-    VV = (V @ V.transpose(-1, -2)).double()
+    V = specialize._first(sub.dynamics.V.detach())[..., :d, :].double()   # (one time slice when the spec is time-invariant;
+    VV = V @ V.transpose(-1, -2)                                          # widened BEFORE the product: an fp32 Gram matrix near
+    #                                                                       the threshold has a rounding-noise smallest eigenvalue)
     if VV.numel() <= d * d * 4096:
         ev = np.linalg.eigvalsh(VV.cpu().numpy())
         lo, hi = np.maximum(ev[..., 0], 0.0), ev[..., -1]

@@ -599,3 +599,26 @@ def test_leaf_matrices_get_their_off_block_gradients():
         Sm[0, 1] -= h; Sm[1, 0] -= h
         fd = float(f(A0, Sp) - f(A0, Sm)) / (2 * h)
     assert abs(float(S0.grad[0, 1] + S0.grad[1, 0]) - fd) < 1e-5 * max(1.0, abs(fd))
+
+
+@gpu
+def test_grad_plan_is_the_persistent_form_of_the_autograd_path():
+    """lqg_amd.grad.GradPlan (what bench.py times): decisions taken once, repeated runs are pure launches — same value as
+    log_likelihood, same bars as a fresh Sweep of the merged component, run after run."""
+    import lqg_amd
+    from lqg_amd import grad as G, workload
+    dev = torch.device("cuda")
+    system, _ = workload.headline_system(96, 80, seed=3, device=dev, dtype=torch.float64)
+    x = workload.pack_trials(workload.simulate_one_trial_each(system, seed=4))
+    gp = G.GradPlan(system, x, events=True)
+    assert len(gp.items) == 1 and gp.items[0]["group"] == 2 and gp.items[0]["sweep"].sp is not None, gp.description
+    ll1, bars1 = gp.run()
+    ll2, bars2 = gp.run()
+    with torch.no_grad():
+        ref = system.log_likelihood(x)
+    assert torch.allclose(ll1, ref, rtol=1e-12) and torch.equal(ll1, ll2)
+    for k in bars1[0]:
+        assert torch.equal(bars1[0][k], bars2[0][k]), k
+    ph = gp.phase_ms()
+    assert all(v >= 0 for v in ph.values()) and ph["rev_system"] > 0
+    assert gp.items[0]["sweep"].per_sys == 1

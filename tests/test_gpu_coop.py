@@ -48,9 +48,10 @@ def test_cooperative_kernels_match_golden(name, dtype, monkeypatch):
     g, actor, dyn = load_golden(name)
     tol = dict(TOL[dtype])
     if name in ILL:
-        if dtype == torch.float32:
-            pytest.skip("fp32 cannot represent the ill-conditioned observed block (see test_gpu_parity)")
-        tol = dict(ll=1e-7, mat=1e-6)
+        # (fp32: a caller who forces the cooperative kernels still gets the fp64 image of an ill-conditioned problem — moments and
+        # log-likelihood route WIDE, plan.f32_needs_wide — never 1e-3-wrong numbers or NaN; compared with the golden vector at the
+        # tolerance the ROUNDING OF THE INPUTS to fp32 leaves: 4.4e-6 on this model's log-likelihood, test_gpu_parity)
+        tol = dict(ll=1e-7, mat=1e-6) if dtype == torch.float64 else dict(ll=2e-5, mat=2e-4)
     S0 = torch.as_tensor(g["Sigma0"], dtype=dtype, device="cuda") if "Sigma0" in g else None
     x = torch.as_tensor(g["x"], dtype=dtype, device="cuda")
     n = x.shape[0]

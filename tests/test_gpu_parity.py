@@ -466,7 +466,8 @@ def test_time_varying_structured_specs_materialise_through_the_pattern_library(o
         assert abs(float(o_sp["ll"][j, 0]) / float(llr[0]) - 1) < max(tol * 0.1, 1e-10)
 
 
-def test_fp32_candidate_ranges_point_mass():
+@pytest.mark.parametrize("T,tol_default", [(500, 1e-6), (1067, 5e-6)])
+def test_fp32_candidate_ranges_point_mass(T, tol_default):
     """PointMassBoundedActor over the bench's candidate ranges, fp32 default routes against the fp64 path on the fp64 image of the SAME
     fp32 inputs.  A log-likelihood is a sum of T d per-step terms of either sign; for candidates with a small action variability they nearly
     cancel on these data (|ll| down to 0.1 against ~1e3 for the rest), and an error relative to |ll| then measures the zero crossing, not
@@ -475,7 +476,10 @@ def test_fp32_candidate_ranges_point_mass():
     import lqg_amd
     from lqg_amd import options, workload
     dev = torch.device("cuda")
-    B, T, n, d = 256, 500, 8, 2
+    # T = 1067 (config 3's horizon): the OPEN item of DESIGN.md §8 — the default fp32 routes sit at 1.5e-6 .. 3.3e-6 of scale there
+    # (rounded operators x magnitude-50 belief states x a whitening gain of 10-30); pinned at 5e-6 so that it cannot get worse
+    # unnoticed; fp64 is the remedy until the operator stream changes coordinates
+    B, n, d = 256, 8, 2
     gen = torch.Generator(device=dev); gen.manual_seed(5)
     names = ("action_variability", "sigma_target", "sigma_cursor", "action_cost")
     kw = {k: workload.log_uniform(B, *workload.RANGES[k], gen, dev, torch.float32) for k in names}
@@ -484,7 +488,7 @@ def test_fp32_candidate_ranges_point_mass():
     ref = m32.to(torch.float64).log_likelihood(x.double())
     scale = ref.abs().clamp_min(float(T * d))
     # (MIXED=0, every sweep in fp32, is a developer route — the default runs the per-system sweeps in fp64: it gives 1.02e-6 here)
-    for ov, tol in (({}, 1e-6), (dict(F32_WIDE=0), 1e-6), (dict(F32_WIDE=0, MIXED=0), 3e-6)):
+    for ov, tol in (({}, tol_default), (dict(F32_WIDE=0), tol_default), (dict(F32_WIDE=0, MIXED=0), 3 * tol_default)):
         with options.override(**ov):
             ll = m32.log_likelihood(x).double()
         err = (ll - ref).abs()
@@ -494,3 +498,25 @@ def test_fp32_candidate_ranges_point_mass():
         small = ref.abs() < 0.1 * T * d
         if bool(small.any()):
             assert float(err[small].max()) <= 2.0 * float(err[~small].max()), ov
+
+
+def test_per_trial_sweep_geometries_are_bitwise_identical():
+    """lqg_tuning.trial_lds (round 5): the lane per-trial sweep on 64-lane workgroups, on the wider workgroups the default rule
+    takes for many trials x many candidates, with the operator stream staged in LDS (k_trial_lds) and the A/B geometries — the
+    same arithmetic per trial in the same order: every log-likelihood bitwise equal (a trial split over ranks may change the
+    geometry a shard runs on; the shards must still agree bitwise)."""
+    import lqg_amd
+    from lqg_amd import options, workload
+    dev = torch.device("cuda")
+    for dtype in (torch.float32, torch.float64):
+        sig = torch.linspace(3.0, 40.0, 300, device=dev, dtype=dtype)
+        m = lqg_amd.BoundedActor(T=60, sigma_target=sig, action_cost=0.2, device=dev, dtype=dtype)
+        x = workload.pack_trials(lqg_amd.BoundedActor(T=60, device=dev, dtype=dtype).simulate(5, n=800).contiguous())
+        ref = None
+        for v in ("0", "", "1", "2", "4", "5"):
+            with options.override(TRIAL_LDS=v):
+                ll = m.log_likelihood(x).clone()
+            assert bool(torch.isfinite(ll).all())
+            if ref is None:
+                ref = ll
+            assert torch.equal(ll, ref), v

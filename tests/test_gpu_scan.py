@@ -28,9 +28,8 @@ def test_scan_sweeps_match_golden(name, dtype, monkeypatch):
     g, actor, dyn = load_golden(name)
     tol = dict(TOL[dtype])
     if name in ILL:
-        if dtype == torch.float32:
-            pytest.skip("fp32 per-trial sweep cannot carry cond(Sigma_oo) ~ 1e12 (see test_gpu_parity)")
-        tol = dict(ll=5e-6, mat=1e-6)      # cond 5.6e8 of the observed noise block costs the scans ~4 digits more than the sequential
+        # (fp32: the plan evaluates an ill-conditioned fp32 problem over its fp64 image on the forced scan route too, plan.f32_needs_wide)
+        tol = dict(ll=5e-6, mat=1e-6) if dtype == torch.float64 else dict(ll=2e-5, mat=2e-4)      # cond 5.6e8 of the observed noise block costs the scans ~4 digits more than the sequential
                                             # recursion; the default rule keeps such systems off the scan (plan.SCAN_MAX_COND)
     sys_ = system_from_golden(actor, dyn, dtype)
     S0 = torch.as_tensor(g["Sigma0"], dtype=dtype, device="cuda") if "Sigma0" in g else None
