@@ -15,6 +15,9 @@ namespace host {
 #ifndef LQG_ASP_CK
 #define LQG_ASP_CK 4            // steps per checkpoint of the system sweeps (the chunk's states live in registers)
 #endif
+#ifndef LQG_ASP_FWD_WIDE
+#define LQG_ASP_FWD_WIDE 1      // the checkpoint-keeping forward per-trial sweep on 256-lane workgroups for many trials x many candidates
+#endif
 #ifndef LQG_ASP_CKT
 #define LQG_ASP_CKT 8           // steps per checkpoint of the per-trial sweeps
 #endif
@@ -150,7 +153,7 @@ int run_asp(const lqg_problem* p, lqg_traj x, const void* g, long g_sb, long g_s
       constexpr auto FMT = lqg::trial_operator_mask<PAT, NX, NB, NU, NY, ND, DENSE_P>();
       const long lanes4 = (long)p->n_sys * ((p->n_trials + 4 * LQG_BLOCK - 1) / (4 * LQG_BLOCK)) * LQG_BLOCK;
       const bool wide = lanes4 >= 2L * 1024 * 64;
-      if (p->n_trials >= 768 && p->n_sys >= 256) {      // many trials x many candidates: 256-lane workgroups (lqg_sp_entry.hpp)
+      if (LQG_ASP_FWD_WIDE && p->n_trials >= 768 && p->n_sys >= 256) {      // many trials x many candidates: 256-lane workgroups (lqg_sp_entry.hpp)
         const dim3 wgrid((unsigned)((p->n_trials + 511) / 512), (unsigned)p->n_sys);
         hipLaunchKernelGGL((lqg::k_trial_sp<R, M, ND, 2, FMT, LQG_ASP_CKT, 256>), wgrid, dim3(256), 0, st, ops, tk);
       } else {

@@ -17,6 +17,12 @@
 #ifndef LQG_ASP_TPL
 #define LQG_ASP_TPL 4
 #endif
+#ifndef LQG_ASP_XPREFETCH
+#define LQG_ASP_XPREFETCH 1       // data rows requested one step ahead in the reverse sweep's two passes
+#endif
+#ifndef LQG_ASP_OPS_SCALAR
+#define LQG_ASP_OPS_SCALAR 0      // 1: the reverse sweep reads the operator blocks through the scalar cache (as k_trial_sp) instead of LDS
+#endif
 
 namespace lqg {
 namespace asp {
@@ -40,33 +46,67 @@ struct TrialRevArgs {
 // ---------------------------------------------------------------- wave butterfly
 // V <= 32 values per lane -> lane l (< 32) holds the wave's total of value bitrev5(l).  Stage s pairs lane l with l ^ 2^s: each
 // hands the partner the half of its values the partner keeps, so the stages cost 16 + 8 + 4 + 2 + 1 pair operations instead
-// of 32 full six-stage reductions.  Partner exchange: DPP quad permutes (xor 1, 2), ds_swizzle (xor 4, 8, 16: the LDS
-// crossbar, no memory), one ds_bpermute for the two half-waves.
+// of 32 full six-stage reductions.
+// Partner exchange without the LDS pipeline (round 5, after the PMC pass showed the sweep waiting, not issuing): xor 1 / 2 DPP quad
+// permutes, xor 4 two banked DPP row shifts, xor 8 a DPP row rotate, xor 16 / 32 the gfx950 permlane swaps — every stage is
+// VALU-only (ds_swizzle / ds_bpermute share lgkmcnt with the LDS reads of the operator blocks).
 template <int S>
-LQG_DEV float lane_xor(float v) {
-  if constexpr (S == 0) return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
-  else if constexpr (S == 1) return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));
-  else if constexpr (S <= 4) return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), ((1 << S) << 10) | 0x1F));
-  else return __shfl_xor(v, 32);
+LQG_DEV int lane_xor_bits(int v) {
+  static_assert(S >= 0 && S <= 3, "xor 1, 2, 4, 8 within a row of 16 lanes");
+  if constexpr (S == 0) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);          // quad_perm [1,0,3,2]
+  else if constexpr (S == 1) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);     // quad_perm [2,3,0,1]
+  else if constexpr (S == 2) {
+    int t = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xf, 0x5, false);                             // row_shl:4 into banks 0, 2
+    return __builtin_amdgcn_update_dpp(t, v, 0x114, 0xf, 0xa, false);                              // row_shr:4 into banks 1, 3
+  } else return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);                         // row_ror:8
 }
+template <int S>
+LQG_DEV float lane_xor(float v) { return __int_as_float(lane_xor_bits<S>(__float_as_int(v))); }
 template <int S>
 LQG_DEV double lane_xor(double v) {
   const long long b = __double_as_longlong(v);
-  int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
-  if constexpr (S == 0) { lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, false); }
-  else if constexpr (S == 1) { lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, false); }
-  else if constexpr (S <= 4) { lo = __builtin_amdgcn_ds_swizzle(lo, ((1 << S) << 10) | 0x1F); hi = __builtin_amdgcn_ds_swizzle(hi, ((1 << S) << 10) | 0x1F); }
-  else return __shfl_xor(v, 32);
+  const int lo = lane_xor_bits<S>((int)(b & 0xffffffffll)), hi = lane_xor_bits<S>((int)(b >> 32));
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// lo + (partner's lo) in the lanes whose bit 4 (WIDE = 0) / bit 5 (WIDE = 1) is clear, hi + (partner's hi) in the others: one
+// v_permlane16_swap / v_permlane32_swap (odd rows / the upper half of the first operand trade places with even rows / the lower
+// half of the second) and one add — no selects
+template <int WIDE>
+LQG_DEV float swap_add(float lo, float hi) {
+  if constexpr (WIDE == 0) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  } else {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+}
+template <int WIDE>
+LQG_DEV double swap_add(double lo, double hi) {
+  const unsigned long long bl = (unsigned long long)__double_as_longlong(lo), bh = (unsigned long long)__double_as_longlong(hi);
+  unsigned a0, a1, b0, b1;
+  if constexpr (WIDE == 0) {
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)bl, (unsigned)bh, false, false);
+    const auto q = __builtin_amdgcn_permlane16_swap((unsigned)(bl >> 32), (unsigned)(bh >> 32), false, false);
+    a0 = r[0]; b0 = r[1]; a1 = q[0]; b1 = q[1];
+  } else {
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)bl, (unsigned)bh, false, false);
+    const auto q = __builtin_amdgcn_permlane32_swap((unsigned)(bl >> 32), (unsigned)(bh >> 32), false, false);
+    a0 = r[0]; b0 = r[1]; a1 = q[0]; b1 = q[1];
+  }
+  return __longlong_as_double((long long)(((unsigned long long)a1 << 32) | a0)) +
+         __longlong_as_double((long long)(((unsigned long long)b1 << 32) | b0));
 }
 
 // stage S (partner = lane ^ 2^S) over the slots [0, 2 H): slot k + H is handed over / received.  Slots whose indices all lie
-// beyond the V live values (BASE + k + H >= V) hold nothing: there both lanes just add the partner's slot k (one instruction;
-// what the `up` lanes then hold stands for an index >= V and is never read).
+// beyond the V live values (BASE + k + H >= V) hold nothing: there both lanes just add the partner's slot k (what the `up` lanes
+// then hold stands for an index >= V and is never read).
 template <int S, int H, int BASE, int V, int VP, typename R>
 LQG_DEV void butterfly_stage(R (&cur)[VP], const bool up) {
   LQG_UNROLL for (int k = 0; k < H; ++k) {
-    if (BASE + k + H >= V) {
+    if constexpr (S == 4) {
+      cur[k] = (BASE + k + H >= V) ? swap_add<0>(cur[k], cur[k]) : swap_add<0>(cur[k], cur[k + H]);
+    } else if (BASE + k + H >= V) {
       cur[k] = cur[k] + lane_xor<S>(cur[k]);
     } else {
       const R lo = cur[k], hi = cur[k + H];
@@ -75,6 +115,13 @@ LQG_DEV void butterfly_stage(R (&cur)[VP], const bool up) {
       cur[k] = keepv + lane_xor<S>(send);
     }
   }
+}
+// total over the partner pair in BOTH lanes (the stages past the last halving one)
+template <int S, typename R>
+LQG_DEV R lane_sum(R v) {
+  if constexpr (S == 4) return swap_add<0>(v, v);
+  else if constexpr (S == 5) return swap_add<1>(v, v);
+  else return v + lane_xor<S>(v);
 }
 
 constexpr int pow2_at_least(int v) { return v <= 8 ? 8 : (v <= 16 ? 16 : 32); }
@@ -98,21 +145,18 @@ LQG_DEV R wave_transpose_reduce(const R (&v)[V]) {
     butterfly_stage<2, 4, BASE, V>(cur, (lane & 4) != 0);
     butterfly_stage<3, 2, BASE, V>(cur, (lane & 8) != 0);
     butterfly_stage<4, 1, BASE, V>(cur, (lane & 16) != 0);
-    return cur[0] + lane_xor<5>(cur[0]);
+    return lane_sum<5>(cur[0]);
   } else if constexpr (VP == 16) {
     butterfly_stage<0, 8, BASE, V>(cur, (lane & 1) != 0);
     butterfly_stage<1, 4, BASE, V>(cur, (lane & 2) != 0);
     butterfly_stage<2, 2, BASE, V>(cur, (lane & 4) != 0);
     butterfly_stage<3, 1, BASE, V>(cur, (lane & 8) != 0);
-    R t = cur[0] + lane_xor<4>(cur[0]);
-    return t + lane_xor<5>(t);
+    return lane_sum<5>(lane_sum<4>(cur[0]));
   } else {
     butterfly_stage<0, 4, BASE, V>(cur, (lane & 1) != 0);
     butterfly_stage<1, 2, BASE, V>(cur, (lane & 2) != 0);
     butterfly_stage<2, 1, BASE, V>(cur, (lane & 4) != 0);
-    R t = cur[0] + lane_xor<3>(cur[0]);
-    t = t + lane_xor<4>(t);
-    return t + lane_xor<5>(t);
+    return lane_sum<5>(lane_sum<4>(lane_sum<3>(cur[0])));
   }
 }
 
@@ -242,15 +286,24 @@ __global__ void __launch_bounds__(LQG_ASP_TRIAL_BLOCK, (sizeof(R) == 4 ? 2 : 1))
     }
   };
   R wst[CKT][TPL][O], cst[CKT][TPL][RR];
+  R xq[TPL][O];                                            // data rows requested one step ahead
   int rb = 0, obuf = 0;
+#if !LQG_ASP_OPS_SCALAR
   request(a.nckt - 1);
+#endif
   auto chunk = [&]<bool WHOLE>(const int c) LQG_LAMBDA_INLINE {        // WHOLE: CKT full steps (no per-step `t < T` tests)
     const int t0 = c * CKT;
+#if LQG_ASP_OPS_SCALAR
+    __syncthreads();
+    if (c < a.nckt - 1) flush(c + 1, rb ^ 1);
+    const R* __restrict__ lo = op + (long)t0 * Ops::N;
+#else
     publish(obuf);
     __syncthreads();
     if (c < a.nckt - 1) flush(c + 1, rb ^ 1);
     if (c > 0) request(c - 1);
     const R* __restrict__ lo = lops[obuf];
+#endif
     // ---- recompute the chunk's (w, c)
     {
       R xprev[TPL][O], dO[TPL][O], muR[TPL][RR];
@@ -259,6 +312,7 @@ __global__ void __launch_bounds__(LQG_ASP_TRIAL_BLOCK, (sizeof(R) == 4 ? 2 : 1))
         LQG_UNROLL for (int i = 0; i < O; ++i) {
           dO[k][i] = src[i * a.npad + nn[k]];
           xprev[k][i] = xat(k, t0 > 0 ? t0 - 1 : 0, i);
+          xq[k][i] = xat(k, t0, i);
         }
         LQG_UNROLL for (int i = 0; i < RR; ++i) muR[k][i] = src[(O + i) * a.npad + nn[k]];
       }
@@ -273,7 +327,18 @@ __global__ void __launch_bounds__(LQG_ASP_TRIAL_BLOCK, (sizeof(R) == 4 ? 2 : 1))
           LQG_UNROLL for (int i = 0; i < M * M; ++i) if (FMD.b[i]) Fv[i] = opt[Ops::F_OFF + i];
           LQG_UNROLL for (int k = 0; k < TPL; ++k) {
             R cv[M], w[O];
+            // (data rows one step ahead in both passes: at two waves per SIMD a row requested where it is used exposes the whole
+            // memory latency — the PMC pass showed this sweep issuing 0.45 of the VALU rate at its sustained clock)
+#if LQG_ASP_XPREFETCH
+            LQG_UNROLL for (int i = 0; i < O; ++i) cv[i] = xq[k][i];
+            {   // next: step t + 1 of this pass, or — after the chunk's last executed step — this row again: the backward pass
+                // starts where the recompute pass ends
+              const int tn = (j + 1 < CKT && t + 1 < a.T) ? t + 1 : t;
+              LQG_UNROLL for (int i = 0; i < O; ++i) xq[k][i] = xat(k, tn, i);
+            }
+#else
             LQG_UNROLL for (int i = 0; i < O; ++i) cv[i] = xat(k, t, i);
+#endif
             int e = 0;
             LQG_UNROLL for (int i = 0; i < O; ++i) {
               R v = R(0);
@@ -320,7 +385,15 @@ __global__ void __launch_bounds__(LQG_ASP_TRIAL_BLOCK, (sizeof(R) == 4 ? 2 : 1))
             LQG_UNROLL for (int q = i; q < O; ++q) v += Li[q * (q + 1) / 2 + i] * wst[j][k][q];
             a0[i] = v;
           }
+#if LQG_ASP_XPREFETCH
+          LQG_UNROLL for (int i = 0; i < O; ++i) cv[i] = xq[k][i];
+          {
+            const int tp = t > 0 ? t - 1 : 0;
+            LQG_UNROLL for (int i = 0; i < O; ++i) xq[k][i] = xat(k, tp, i);
+          }
+#else
           LQG_UNROLL for (int i = 0; i < O; ++i) cv[i] = xat(k, t, i);
+#endif
           LQG_UNROLL for (int p = 0; p < RR; ++p) cv[O + p] = cst[j][k][p];
           const R g = gw[k];
           LQG_UNROLL for (int i = 0; i < M; ++i) post[i] = pre[k][i] + (i < O ? g * a1[k][i < O ? i : 0] : R(0));

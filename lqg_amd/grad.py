@@ -90,6 +90,8 @@ class Sweep:
         if system is not None and actor.A.is_cuda:
             ln = _hip.Launch(actor, dynamics, d=d, n_trials=x.shape[-3], Sigma0=Sigma0, eps=eps)
             self.sp = _specialised_adjoint(ln, system, d)
+            if self.sp is not None and not _trial_offsets_fit(x, x.shape[-3]):
+                self.sp = None
             if self.sp is not None:
                 from lqg_amd import plan as _plan
                 if actor.A.dtype == torch.float32 and _plan.f32_needs_wide(system, d):
@@ -194,6 +196,12 @@ def _specialised_adjoint(ln, system, d):
         return None
     dims, masks, key, live = specialize.adjoint_pattern(system, d)
     return specialize.load_adjoint_pattern(key, dims, masks, live=live)
+
+
+def _trial_offsets_fit(x, n_trials):
+    """The per-trial reverse sweep addresses a trial's rows by a 32-bit byte offset from a wave-uniform row pointer
+    (csrc/lqg_adjoint_trial_sp.hpp): the trials of one system must lie within 2 GiB of each other (packed trajectories always do)."""
+    return n_trials <= 2 or abs(x.stride(-3)) * (n_trials - 1) * x.element_size() < (1 << 31)
 
 
 ADJOINT_SP_MAX_JOINT = 12       # largest x + b the specialised adjoint libraries are generated for (registers: the chunk's states)
