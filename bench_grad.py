@@ -7,8 +7,8 @@ Two workloads, one JSON line each:
   eval   the reference's inference inner loop: BoundedActor, T=500, 50 trials, 4 parameters, ONE parameter vector —
          `jax.value_and_grad(ll)` per NUTS leapfrog / Adam step (lqg/infer/utils.py:18, lqg/optim.py:142-147).
          Reported for the adjoint sweep and for the batched finite-difference sweep (2P+1 candidates).
-  sweep  B independent (system, trial) pairs, one lane each (x=b=2, T=500): solves+adjoint per second, with the
-         per-kernel times from HIP events.
+  sweep  B independent (system, trial) pairs (x=b=2, T=500): solves+adjoint per second on the split sweep of round 5 (per-kernel
+         times from HIP events) and on the round-1 lane kernels.
 """
 import argparse
 import json
@@ -78,23 +78,26 @@ def eval_workload(args, dev):
 
 
 def sweep_workload(args, dev, dt):
-    # ---- sweep: B lanes, one (system, trial) each
+    """B candidates, one (system, trial) pair each (BoundedActor, x=b=2, T=500): solves + reverse-mode gradient per second on a
+    persistent lqg_amd.grad.GradPlan — the split sweep of round 5 (csrc/lqg_adjoint_sp.hpp) — and, beside it, the round-1 lane
+    kernels (LQG_ADJOINT_SP=0).  The headline and config-3 shapes are legs of bench.py (`extra.value_and_grad_*`)."""
+    from lqg_amd import options, workload
     B = 1 << args.log2_lanes
     sig = torch.linspace(5.0, 50.0, B, device=dev, dtype=dt)
     model = lqg_amd.BoundedActor(T=500, sigma_target=sig, device=dev, dtype=dt)
     with torch.no_grad():
         xs = lqg_amd.BoundedActor(T=500, sigma_target=25.0, device=dev, dtype=dt).simulate(1, n=1)          # [1, 501, 2]
-    xs = xs.expand(B, 1, 501, 2).contiguous()
-    fn = lambda: G.raw_grad(model.actor, model.dynamics, xs, g=None, want_value=True)
-    sec = timed(fn, args.steps, args.warmup)
-    # per-lane step traffic of the kept state: S 3 + L 2 + P 3 + Sigma 10 + mu 4 reals written once, read once (+L rewritten)
-    reals = 3 + 2 + 3 + 10 + 4
-    esz = 8 if dt == torch.float64 else 4
-    bytes_ = B * 500 * (2 * reals + 2 * 2) * esz
-    print(json.dumps({"metric": "solves_with_gradient_per_s", "value": B / sec, "unit": "solves+adjoint/s",
-                      "ms_per_step": sec * 1e3, "dtype": args.dtype, "n_gpus": 1,
-                      "config": {"workload": f"{B} (system, trial) lanes, BoundedActor x=b=2, T=500, four adjoint sweeps"},
-                      "scratch_GB_per_step": bytes_ / 1e9, "scratch_GBps": bytes_ / sec / 1e9}))
+    xs = workload.pack_trials(xs.expand(B, 1, 501, 2).contiguous())
+    for sp in (1, 0):
+        with options.override(ADJOINT_SP=sp):
+            gp = G.GradPlan(model, xs, events=bool(sp))
+            sec = timed(lambda: gp.run(), args.steps, args.warmup)
+            rec = {"metric": "solves_with_gradient_per_s", "value": B / sec, "unit": "solves+adjoint/s", "ms_per_step": sec * 1e3,
+                   "dtype": args.dtype, "n_gpus": 1, "adjoint_sp": sp, "path": gp.description,
+                   "config": {"workload": f"{B} candidates x 1 trial, BoundedActor x=b=2, T=500"}}
+            if sp:
+                rec["kernel_ms"] = gp.phase_ms()
+            print(json.dumps(rec))
 
 
 if __name__ == "__main__":

@@ -255,3 +255,36 @@ def test_scan_level_schedule_restated_on_symbolic_elements():
                 mod.run(T, 0, n_sys, order)
     assert mod.run(501, 500, 1)[1:] == (11, 13) and mod.run(500, 0, 1)[1:] == (10, 10)
     assert mod.run(501, 500, 1, order=2)[1:] == (16, 18) and mod.run(500, 0, 1, order=2)[1:] == (16, 16)
+
+
+def test_adjoint_patterns_take_structure_from_constructors_and_booleans_not_values():
+    """lqg_amd.specialize.adjoint_pattern (round 5): (i) for a System whose fields require grad the masks of the hoisted products
+    follow from boolean algebra — Fd Bd - Fa Ba cancels numerically for a shared spec (and for matrices of ones) although
+    d ll / d Bd != 0, and A - I has a zero diagonal for A = ones; (ii) zoo classes keep the constructor's structure and report which
+    fields ANY parameter moves (for the tracking models only V, W, R); a field that requires grad is always live."""
+    import numpy as np
+    import torch
+    import lqg_amd
+    from lqg_amd import specialize
+    m = lqg_amd.BoundedActor(T=3, device="cpu", dtype=torch.float64)
+    leaf = lambda t: t[:1].clone().requires_grad_(True).expand_as(t)
+    a = m.actor._replace(**{f: leaf(getattr(m.actor, f)) for f in ("A", "B", "F", "V", "W", "Q", "R")})
+    s = lqg_amd.System(actor=a, dynamics=a)
+    dims, masks, key, live = specialize.adjoint_pattern(s, 2)
+    assert all(live.values())
+    assert masks["DB"].all() and masks["AdmI"].all() and masks["FAa"].all() and masks["N3"].all()
+    # the same spec WITHOUT grad: values decide (the products cancel, the diagonal of A - I vanishes)
+    _, masks0 = specialize.pattern_of(lqg_amd.System(actor=m.actor, dynamics=m.actor), 2)
+    assert not masks0["DB"].any() and not masks0["AdmI"].diagonal().any()
+    # zoo class: class-level structure + live fields
+    dz, mz, kz, lz = specialize.adjoint_pattern(m, 2)
+    assert (dz, kz) == specialize.class_pattern(lqg_amd.BoundedActor, 2, dim=1)[::2]
+    assert {k for k, v in lz.items() if v} == {"Va", "Wa", "R", "Vd", "Wd"}
+    pm = specialize.zoo_live(lqg_amd.PointMassBoundedActor, (), 2)
+    assert pm["Aa"] and pm["Bd"] and not pm["Fa"]
+    assert specialize.adjoint_key("abc", specialize.ALL_LIVE) == "abc" and specialize.adjoint_key("abc", lz) != "abc"
+    # a constructor argument that requires grad makes its fields live on top of the class-level set
+    sig = torch.tensor(6.0, dtype=torch.float64, requires_grad=True)
+    mg = lqg_amd.BoundedActor(T=3, sigma_target=sig, device="cpu", dtype=torch.float64)
+    _, _, _, lg = specialize.adjoint_pattern(mg, 2)
+    assert lg["Wa"] and lg["Wd"] and not lg["Aa"]
