@@ -217,7 +217,9 @@ constexpr Mask<NX + NB, NX + NB> trial_operator_mask() {
 // to the operator stream for k_trial (many trials per system), exactly as k_forward does.  ll_sn: trial stride of ll.
 // CK > 0: checkpointed gains (see k_riccati_sp): `rc` carries the actor's cost matrices and the checkpoint stream.
 // OT: element type of the operator stream (NTR == 0), see k_forward.
-template <typename R, int NX, int NB, int NU, int NY, int ND, typename PAT, int NTR, bool DENSE_P, int CK, typename OT = R>
+// X4 (round 5, fp32, NTR x d = 4): the lane's data row is ONE 16-byte vector — trajectories laid [T+1][system][trial][component]
+// (plan._trial_stack(rows=True)): one global_load_dwordx4 per step instead of four dword loads from four rows.
+template <typename R, int NX, int NB, int NU, int NY, int ND, typename PAT, int NTR, bool DENSE_P, int CK, typename OT = R, bool X4 = false>
 __global__ void __launch_bounds__(LQG_BLOCK, (sp_fwd_waves<R, NX + NB>()))
     k_forward_sp(const ForwardArgs<R> a, const long ll_sn, const RiccatiArgs<R> rc) {
   constexpr bool FUSED = NTR > 0;
@@ -263,10 +265,17 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sp_fwd_waves<R, NX + NB>()))
   double acc[NT];
   const R* xp = nullptr;
   LQG_UNROLL for (int k = 0; k < NT; ++k) acc[k] = 0.0;
+  static_assert(!X4 || (FUSED && sizeof(R) == 4 && NT * O == 4), "X4: four floats per lane and row");
   if (FUSED) {
     xp = a.x.p + s * a.x.sb;
+    if constexpr (X4) {
+      const float4 v = *reinterpret_cast<const float4*>(xp);
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+      LQG_UNROLL for (int k = 0; k < NT; ++k)
+        LQG_UNROLL for (int i = 0; i < O; ++i) xprev[k][i] = vv[k * O + i];
+    }
     LQG_UNROLL for (int k = 0; k < NT; ++k) {
-      LQG_UNROLL for (int i = 0; i < O; ++i) { xprev[k][i] = xp[k * a.x.sn + i * a.x.sd]; dO[k][i] = R(0); }
+      LQG_UNROLL for (int i = 0; i < O; ++i) { if constexpr (!X4) xprev[k][i] = xp[k * a.x.sn + i * a.x.sd]; dO[k][i] = R(0); }
       LQG_UNROLL for (int i = 0; i < RR; ++i) muR[k][i] = R(0);
     }
   }
@@ -462,9 +471,16 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sp_fwd_waves<R, NX + NB>()))
         LQG_UNROLL for (int e = 0; e < NU * NB; ++e) Lnx[e] = src[e * a.ldb];
       }
       if (FUSED) {
-        LQG_UNROLL for (int k = 0; k < NT; ++k) {
-          const R* xr = xp + k * a.x.sn + (long)(t + 1) * a.x.st;
-          LQG_UNROLL for (int i = 0; i < O; ++i) xnx[k][i] = xr[i * a.x.sd];
+        if constexpr (X4) {
+          const float4 v = *reinterpret_cast<const float4*>(xp + (long)(t + 1) * a.x.st);
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+          LQG_UNROLL for (int k = 0; k < NT; ++k)
+            LQG_UNROLL for (int i = 0; i < O; ++i) xnx[k][i] = vv[k * O + i];
+        } else {
+          LQG_UNROLL for (int k = 0; k < NT; ++k) {
+            const R* xr = xp + k * a.x.sn + (long)(t + 1) * a.x.st;
+            LQG_UNROLL for (int i = 0; i < O; ++i) xnx[k][i] = xr[i * a.x.sd];
+          }
         }
       }
     }

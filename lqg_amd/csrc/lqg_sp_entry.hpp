@@ -5,6 +5,7 @@
 // Anything else is refused with LQG_ERR_ARG / LQG_ERR_DIMS before launching; the caller then uses the generic
 // library.  The pattern's validity for the data (structural zeros really are zero) is the generator's contract.
 #pragma once
+#include <cstdint>
 #include <cstdio>
 
 #include "lqg_kernels_sp.hpp"
@@ -149,7 +150,22 @@ int run_sp_ck(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll_sn
   hipLaunchKernelGGL((lqg::k_forward_sp<R, NX, NB, NU, NY, ND, PAT, NTR_, DP_, CK>), grid, block, 0, st,           \
                      k, ll_sn, rc)
     const bool dense_p = p->Sigma0.ptr != nullptr;
-    if (p->n_trials == 1) { if (dense_p) LQG_SP_FWD(1, true); else LQG_SP_FWD(1, false); }
+    // the lane's data row as one 16-byte vector (fp32, trials x d = 4, rows laid [T+1][system][trial][component])
+    bool x4 = false;
+    if constexpr (sizeof(R) == 4 && CK > 0) {
+      if constexpr (ND == 2 || ND == 4) {
+        x4 = !dense_p && p->n_trials * ND == 4 && x.sd == 1 && x.sn == ND && x.sb == 4 && x.st % 4 == 0 &&
+             (reinterpret_cast<uintptr_t>(x.ptr) & 15u) == 0;
+        if (x4) {
+          if constexpr (ND == 2)
+            hipLaunchKernelGGL((lqg::k_forward_sp<R, NX, NB, NU, NY, ND, PAT, 2, false, CK, R, true>), grid, block, 0, st, k, ll_sn, rc);
+          else
+            hipLaunchKernelGGL((lqg::k_forward_sp<R, NX, NB, NU, NY, ND, PAT, 1, false, CK, R, true>), grid, block, 0, st, k, ll_sn, rc);
+        }
+      }
+    }
+    if (x4) {}
+    else if (p->n_trials == 1) { if (dense_p) LQG_SP_FWD(1, true); else LQG_SP_FWD(1, false); }
     else if (p->n_trials == 2) { if (dense_p) LQG_SP_FWD(2, true); else LQG_SP_FWD(2, false); }
     else { if (dense_p) LQG_SP_FWD(0, true); else LQG_SP_FWD(0, false); }
 #undef LQG_SP_FWD

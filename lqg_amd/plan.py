@@ -467,12 +467,17 @@ def _pairs_as_systems(sub, xs, S0, B, n):
     return System(actor=a, dynamics=d), xe, S0
 
 
-def _trial_stack(x, cols_list):
+def _trial_stack(x, cols_list, rows=None):
     """Data columns of G identical components as G*n trials of one system: x[(B,) n, T+1, d] -> [(B,) G*n, T+1, d_c],
-    re-laid so that the system index (or, without one, the trial index) is the fastest-varying one in HBM."""
+    re-laid so that the system index (or, without one, the trial index) is the fastest-varying one in HBM.
+    rows (default: option X4_LAYOUT): fp32 batches whose lane reads exactly four floats per row (G*n*d_c == 4) are laid
+    [T+1][B][G*n][d_c] instead — one 16-byte vector per lane and step (k_forward_sp<X4>)."""
     comps = [x[..., c] for c in cols_list]
     st = torch.stack(comps, dim=-4)                                   # [(B,) G, n, T+1, d_c]
     st = st.reshape(*st.shape[:-4], st.shape[-4] * st.shape[-3], *st.shape[-2:])
+    rows = options.flag("X4_LAYOUT") if rows is None else rows
+    if rows and st.dim() == 4 and st.dtype == torch.float32 and st.shape[1] * st.shape[3] == 4:
+        return st.permute(2, 0, 1, 3).contiguous().permute(1, 2, 0, 3)    # storage [T+1][B][G*n][d_c]
     if st.dim() == 4:
         return st.permute(1, 2, 3, 0).contiguous().permute(3, 0, 1, 2)    # storage [G*n][T+1][d_c][B]
     return st.permute(1, 2, 0).contiguous().permute(2, 0, 1)              # storage [T+1][d_c][G*n]
