@@ -274,6 +274,11 @@ struct ForwardArgs {
   DView<R> Kout;                 // optional Kalman gain output [B,T,b,y]
   long n_sys;
   int T, nva, nwa, nvd, nwd;
+  // MIXED mode of the structure-specialised libraries (k_forward_sp<double, ..., OT = float>), both may be null: the rounding
+  // residual of the operator's Fj - I block, fl32(F - fl32(F)), as [n_sys][T+1][hilo_reals], and per system whether
+  // max_t |Fj - I| reached LQG_HILO_MIN — the per-trial sweep then applies hi + lo (k_trial_sp<..., HL>)
+  float* ops_lo;
+  int* hl;
 };
 
 // MAT = materialise (Sigma / mu / K outputs requested): kept out of the pure log-likelihood instantiation so that the
@@ -529,6 +534,10 @@ __global__ void __launch_bounds__(LQG_BLOCK, LQG_FWD_WAVES) k_forward(const Forw
 }
 
 // ===================================================================== per-trial sweep ===============
+// reals per step of the MIXED mode's residual stream (ForwardArgs::ops_lo): the dense m x m image of the Fj - I block's residual
+template <int M>
+constexpr int hilo_len() { return (M * M + 3) / 4 * 4; }
+
 template <typename R>
 struct TrialArgs {
   DTraj<R> x;         // observed data
@@ -542,6 +551,9 @@ struct TrialArgs {
   R* tck;
   long npad;
   int nckt;
+  // MIXED mode (see ForwardArgs): when hl is set, a launch of k_trial_sp<..., HL> walks only the systems whose flag equals HL
+  const float* ops_lo;
+  const int* hl;
 };
 
 // grid.x covers trials (LQG_BLOCK * TPL per block), grid.y = system.  The operator stream of the block's system is

@@ -13,6 +13,7 @@
 #ifndef LQG_SP_PREFETCH
 #define LQG_SP_PREFETCH 1
 #endif
+#include <type_traits>
 #include <utility>
 
 #include "lqg_kernels.hpp"
@@ -212,6 +213,28 @@ constexpr Mask<NX + NB, NX + NB> trial_operator_mask() {
   return joint_mask_impl<PAT, NX, NB, NU, NY, DENSE_P, true>();
 }
 
+// MIXED mode (k_forward_sp<double, ..., OT = float>): an operator rounded once to fp32 carries eps32 |F - I| |state| of
+// SYSTEMATIC error per step into every trial — the same rounding every step of a stationary filter.  Measured (NumPy emulation
+// of the fp32 per-trial sweep, PointMassBoundedActor over the bench's candidate ranges, T = 1067, error / max(|ll|, T d)):
+// rounded operators 1.19e-6 worst, hi + lo operators 1.2e-7, exact operators 1.07e-7; the 1-D tracking models (|F - I| <= 0.6
+// against 5 .. 74 for the point mass) sit at 1e-7 either way.  So systems whose block reaches LQG_HILO_MIN anywhere on the
+// horizon get their residual stream applied by the per-trial sweep; the others never read it.
+#ifndef LQG_HILO_MIN
+#define LQG_HILO_MIN 2.0
+#endif
+template <int I, typename OT, typename R, int M, int N, Mask<M, N> MK>
+LQG_DEV void store_residual(const Mat<R, M, N, MK>& a, OT* __restrict__ p, R& mx) {
+  if constexpr (I < M * N) {
+    if constexpr (MK.b[I]) {
+      const R v = a.v[I];
+      p[I] = (OT)(v - (R)(OT)v);
+      const R av = v < R(0) ? -v : v;
+      mx = av > mx ? av : mx;
+    }
+    store_residual<I + 1, OT>(a, p, mx);
+  }
+}
+
 // NTR >= 1 (fused): the NTR trials of each system are swept in-lane (1: the headline; 2: two identical decoupled
 // components solved as ONE system with two trials, lqg_amd/plan.py); NTR == 0: the per-step trial operators are written
 // to the operator stream for k_trial (many trials per system), exactly as k_forward does.  ll_sn: trial stride of ll.
@@ -283,6 +306,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sp_fwd_waves<R, NX + NB>()))
 
   R Li[O * O], U2[RR * O], hl = R(0), pd = R(1);
   unsigned pois = 0u;                             // largest pos_finite_key of the pivot products (lqg_small.hpp)
+  [[maybe_unused]] R fmx = R(0);                  // MIXED: max_t |Fj - I| of this system (ForwardArgs::hl)
   // FUSED scoring (round 4): log N(x_t; mu, S) = -1/2 |w|^2 + log(prod of the Cholesky pivots' reciprocal roots) - (d/2) log 2 pi.
   // Per step only  part[n] += 1/2 |w|^2  (one fma per trial) and the log-determinant term run: fp32 takes ONE v_log_f32
   // (log2, 1 ulp; the ln 2 factor is applied in fp64 at the flush), fp64 multiplies the pivot products of the block together
@@ -444,6 +468,12 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sp_fwd_waves<R, NX + NB>()))
       static_assert(mask_eq(decltype(FjD)::mask, trial_operator_mask<PAT, NX, NB, NU, NY, ND, DENSE_P>()),
                     "trial_operator_mask() must mirror the mask algebra of the operator built here");
       store_dense<0>(FjD, op + Ops::F_OFF);
+      if constexpr (!std::is_same_v<OT, R>) {
+        // MIXED: what the rounding to OT dropped from the block, and the block's largest entry (round 5)
+        if (a.ops_lo) {
+          store_residual<0, OT>(FjD, a.ops_lo + ((long)s * (a.T + 1) + t) * (long)hilo_len<M>(), fmx);
+        }
+      }
       LQG_UNROLL for (int i = 0; i < RR * O; ++i) op[Ops::U_OFF + i] = (OT)U2[i];
       {
         int e = 0;
@@ -536,6 +566,9 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sp_fwd_waves<R, NX + NB>()))
     LQG_UNROLL for (int i = 0; i < O; ++i)
       LQG_UNROLL for (int j = 0; j <= i; ++j) op[Ops::L_OFF + (e++)] = (OT)Li[i * O + j];
     store_or_nan(&op[Ops::H_OFF], (OT)(hl + kLogNorm), pois >= kPosFiniteLimit<R>);
+    if constexpr (!std::is_same_v<OT, R>) {
+      if (a.hl) a.hl[s] = fmx >= R(LQG_HILO_MIN) ? 1 : 0;
+    }
   }
 }
 
@@ -758,15 +791,41 @@ LQG_DEV void trial_mean_rows(const R (&opc)[NPF], const R* __restrict__ op, cons
   }
 }
 
+// hi + lo operators (HL): mn += lo (Fj - I block's rounding residual, ForwardArgs::ops_lo) x cv, summed apart from the main
+// terms and added last
+template <typename R, int M, Mask<M, M> FM, int I, int J>
+LQG_DEV void trial_lo_term(const float* __restrict__ lo, const R (&cv)[M], R& v) {
+  if constexpr (J < M) {
+    if constexpr (FM.b[I * M + J]) v += (R)lo[I * M + J] * cv[J];
+    trial_lo_term<R, M, FM, I, J + 1>(lo, cv, v);
+  }
+}
+template <typename R, int M, Mask<M, M> FM, int I>
+LQG_DEV void trial_lo_rows(const float* __restrict__ lo, const R (&cv)[M], R (&mn)[M]) {
+  if constexpr (I < M) {
+    R v = R(0);
+    trial_lo_term<R, M, FM, I, 0>(lo, cv, v);
+    mn[I] += v;
+    trial_lo_rows<R, M, FM, I + 1>(lo, cv, mn);
+  }
+}
+
 // CKT > 0: the mean state is also KEPT every CKT steps (TrialArgs::tck) — the forward pass of the reverse-mode sweep.
 // BLK: lanes per workgroup.  64 by default; 512 / 1024 put 1024+ trials of ONE candidate into one workgroup, whose waves walk
 // the candidate's operator stream together through the CU's scalar cache (one fetch per CU instead of one per 128 trials).
-template <typename R, int M, int ND, int TPL, Mask<M, M> FM, int CKT = 0, int BLK = LQG_BLOCK>
+// HL (MIXED mode, TrialArgs::hl set): the launch with HL walks the systems flagged by the builder (|Fj - I| large somewhere on
+// the horizon) and applies hi + lo operators; the launch without walks the others — the unflagged systems' loop is untouched.
+template <typename R, int M, int ND, int TPL, Mask<M, M> FM, int CKT = 0, int BLK = LQG_BLOCK, bool HL = false>
 __global__ void __launch_bounds__(BLK) k_trial_sp(const R* __restrict__ ops_all, const TrialArgs<R> a) {
   constexpr int O = ND, RR = M - ND;
   constexpr int kAccChunk = 8;
   using Ops = TrialOps<M, ND>;
+  static_assert(!HL || (sizeof(R) == 4 && CKT == 0), "hi + lo operators: the fp32 per-trial sweep of the MIXED mode");
   const long sys = blockIdx.y;
+  if (a.hl) {
+    if ((a.hl[sys] != 0) != HL) return;
+  }
+  [[maybe_unused]] const float* __restrict__ lo_sys = HL ? a.ops_lo + sys * (long)(a.T + 1) * hilo_len<M>() : nullptr;
   const long n0 = (long)blockIdx.x * (BLK * TPL) + threadIdx.x;
   const R* __restrict__ op = ops_all + sys * (long)(a.T + 1) * Ops::N;
   const R* xr[TPL];
@@ -842,6 +901,7 @@ __global__ void __launch_bounds__(BLK) k_trial_sp(const R* __restrict__ ops_all,
           }
           R mn[M];
           trial_mean_rows<R, M, ND, FM, PF, NPF, 0>(cur, opt, cv, mn);
+          if constexpr (HL) trial_lo_rows<R, M, FM, 0>(lo_sys + (long)t * hilo_len<M>(), cv, mn);
           LQG_UNROLL for (int i = 0; i < O; ++i) { dO[k][i] = mn[i]; xprev[k][i] = cv[i]; }
           LQG_UNROLL for (int p = 0; p < RR; ++p) muR[k][p] = cv[O + p] + mn[O + p];   // (the stream holds Fj - I)
         }
@@ -928,6 +988,7 @@ __global__ void __launch_bounds__(BLK) k_trial_sp(const R* __restrict__ ops_all,
           }
           R mn[M];
           trial_mean_rows<R, M, ND, FM, PF, NPF, 0>(cur, opt, cv, mn);
+          if constexpr (HL) trial_lo_rows<R, M, FM, 0>(lo_sys + (long)t * hilo_len<M>(), cv, mn);
           LQG_UNROLL for (int i = 0; i < O; ++i) { dO[k][i] = mn[i]; xprev[k][i] = cv[i]; }
           LQG_UNROLL for (int p = 0; p < RR; ++p) muR[k][p] = cv[O + p] + mn[O + p];   // (the stream holds Fj - I)
         }
@@ -987,6 +1048,9 @@ __global__ void __launch_bounds__(LQG_TRIAL_LDS_BLOCK) k_trial_lds(const R* __re
   constexpr int CKN = CKL * Ops::N, NLD = (CKN + BLK - 1) / BLK;
   __shared__ R lops[2][CKN];
   const long sys = blockIdx.y;
+  if (a.hl) {
+    if (a.hl[sys] != 0) return;                              // (flagged systems: k_trial_sp<..., HL>)
+  }
   const long n0 = (long)blockIdx.x * (BLK * TPL) + threadIdx.x;
   const R* __restrict__ op = ops_all + sys * (long)(a.T + 1) * Ops::N;
   const long op_len = (long)(a.T + 1) * Ops::N;

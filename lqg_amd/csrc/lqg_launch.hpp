@@ -52,7 +52,13 @@ inline bool affine(const lqg_problem* p) {
 struct Workspace {
   size_t ls_off, ls_bytes, ops_off, ops_bytes, total;
   long ldb;
+  size_t lo_off, hl_off;      // LQG_F32_SYS64 only (0 otherwise): residual stream of the operator's F block, per-system flags
 };
+// reals per step of the residual stream (the dense m x m image of the Fj - I block's rounding residual)
+inline size_t hilo_reals(const lqg_dims& d) {
+  const size_t m = d.x + d.b;
+  return (m * m + 3) / 4 * 4;
+}
 inline size_t ops_reals(const lqg_dims& d) {
   const size_t m = d.x + d.b, o = d.d, rr = m - o;
   const size_t raw = m * m + rr * o + o * (o + 1) / 2 + 1;
@@ -75,6 +81,13 @@ inline Workspace carve(const lqg_problem* p, bool need_ops) {
   w.ops_bytes = need_ops ? (size_t)p->n_sys * (size_t)(p->T + 1) * ops_reals(p->dims) * esz : 0;
   // (+ the scratch of the time-chunked per-trial sweep, lqg_trial_chunk.hpp: by convention it FOLLOWS the operator stream)
   w.total = w.ops_off + (w.ops_bytes + 255) / 256 * 256 + (need_ops ? trial_chunk_scratch(p).total : 0);
+  if (need_ops && p->dtype == LQG_F32_SYS64) {
+    // operators rounded ONCE to fp32 carry a systematic error of eps32 |F - I| |state| per step into every trial; where the
+    // block is large (point-mass models: whitening gains of 10 .. 70) the per-trial sweep adds the residual back (hi + lo)
+    w.lo_off = (w.total + 255) / 256 * 256;
+    w.hl_off = w.lo_off + ((size_t)p->n_sys * (size_t)(p->T + 1) * hilo_reals(p->dims) * 4 + 255) / 256 * 256;
+    w.total = w.hl_off + ((size_t)p->n_sys * sizeof(int) + 255) / 256 * 256;
+  }
   return w;
 }
 

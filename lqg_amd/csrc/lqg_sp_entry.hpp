@@ -29,7 +29,8 @@ namespace host {
 // long horizon — the time-chunked sweep (lqg_trial_chunk.hpp; its scratch follows the operator stream).  Trials-per-lane
 // rule of launch_trial (lqg_launch.hpp).
 template <typename R, typename PAT, int NX, int NB, int NU, int NY, int ND>
-hipError_t trial_sweep_sp(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll_sn, const void* ops, hipStream_t st) {
+hipError_t trial_sweep_sp_main(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll_sn, const void* ops, hipStream_t st,
+                               const float* ops_lo, const int* hl) {
   const lqg_traj no_traj{nullptr, 0, 0, 0, 0};
   const dim3 block(LQG_BLOCK);
   constexpr auto FM_dense = lqg::trial_operator_mask<PAT, NX, NB, NU, NY, ND, true>();
@@ -39,11 +40,22 @@ hipError_t trial_sweep_sp(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb
     const size_t esz = traj_esz(p);
     const size_t ops_bytes = (size_t)p->n_sys * (size_t)(p->T + 1) * ops_reals(p->dims) * esz;
     void* scratch = static_cast<char*>(const_cast<void*>(ops)) + (ops_bytes + 255) / 256 * 256;
+    if constexpr (sizeof(R) == 4) {
+      if (hl) {            // MIXED: the chunk kernels apply hi + lo operators to the flagged systems (lqg_trial_chunk.hpp: HLC)
+        if (dense_p)
+          return launch_trial_chunked<R, NX + NB, ND, lqg::MaskPolicy<NX + NB, FM_dense>, true>(p, ops, x, ll, ll_sb, ll_sn, scratch,
+                                                                                                st, ops_lo, hl);
+        return launch_trial_chunked<R, NX + NB, ND, lqg::MaskPolicy<NX + NB, FM_noise>, true>(p, ops, x, ll, ll_sb, ll_sn, scratch, st,
+                                                                                              ops_lo, hl);
+      }
+    }
     if (dense_p)
       return launch_trial_chunked<R, NX + NB, ND, lqg::MaskPolicy<NX + NB, FM_dense>>(p, ops, x, ll, ll_sb, ll_sn, scratch, st);
     return launch_trial_chunked<R, NX + NB, ND, lqg::MaskPolicy<NX + NB, FM_noise>>(p, ops, x, ll, ll_sb, ll_sn, scratch, st);
   }
   lqg::TrialArgs<R> tk{dt<R>(x), dt<R>(no_traj), static_cast<R*>(ll), ll_sb, ll_sn, (long)p->n_trials, p->T};
+  tk.ops_lo = ops_lo;                 // (MIXED mode: this pass leaves the systems flagged in hl to the hi + lo pass below)
+  tk.hl = hl;
   // many trials per candidate and many candidates: one 256-lane workgroup per 1024 trials of a candidate, the operator stream
   // staged in LDS (read once per candidate instead of once per 128 trials; lqg_kernels_sp.hpp k_trial_lds)
   // Many trials per candidate and many candidates: k_trial_sp on WIDER workgroups, so that 1024 trials of a candidate walk its
@@ -91,6 +103,38 @@ hipError_t trial_sweep_sp(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb
   } else {
     if (wide) hipLaunchKernelGGL((lqg::k_trial_sp<R, NX + NB, ND, LQG_TRIALS_PER_LANE, FM_noise>), tgrid, block, 0, st, o, tk);
     else hipLaunchKernelGGL((lqg::k_trial_sp<R, NX + NB, ND, 1, FM_noise>), tgrid, block, 0, st, o, tk);
+  }
+  return hipGetLastError();
+}
+
+// ops_lo / hl (MIXED mode, run_sp_mixed): a second launch walks the systems the builder flagged, with hi + lo operators
+// (lqg_kernels_sp.hpp: LQG_HILO_MIN); its geometry follows the default rule.
+template <typename R, typename PAT, int NX, int NB, int NU, int NY, int ND>
+hipError_t trial_sweep_sp(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll_sn, const void* ops, hipStream_t st,
+                          const float* ops_lo = nullptr, const int* hl = nullptr) {
+  const hipError_t e = trial_sweep_sp_main<R, PAT, NX, NB, NU, NY, ND>(p, x, ll, ll_sb, ll_sn, ops, st, ops_lo, hl);
+  if (e != hipSuccess || !hl || trial_chunks(p) > 1) return e;       // (the time-chunked sweep handled its flagged systems itself)
+  if constexpr (sizeof(R) == 4) {
+    constexpr auto FM_dense = lqg::trial_operator_mask<PAT, NX, NB, NU, NY, ND, true>();
+    constexpr auto FM_noise = lqg::trial_operator_mask<PAT, NX, NB, NU, NY, ND, false>();
+    const lqg_traj no_traj{nullptr, 0, 0, 0, 0};
+    const bool dense_p = p->Sigma0.ptr != nullptr;
+    lqg::TrialArgs<R> tk{dt<R>(x), dt<R>(no_traj), static_cast<R*>(ll), ll_sb, ll_sn, (long)p->n_trials, p->T};
+    tk.ops_lo = ops_lo;
+    tk.hl = hl;
+    const R* o = static_cast<const R*>(ops);
+#define LQG_TRIAL_HL(BLK_, TPL_)                                                                                           \
+  do {                                                                                                                    \
+    const long per_ = (long)(BLK_) * (TPL_);                                                                              \
+    const dim3 gg((unsigned)((p->n_trials + per_ - 1) / per_), (unsigned)p->n_sys);                                       \
+    if (dense_p) hipLaunchKernelGGL((lqg::k_trial_sp<R, NX + NB, ND, TPL_, FM_dense, 0, BLK_, true>), gg, dim3(BLK_), 0, st, o, tk); \
+    else hipLaunchKernelGGL((lqg::k_trial_sp<R, NX + NB, ND, TPL_, FM_noise, 0, BLK_, true>), gg, dim3(BLK_), 0, st, o, tk);    \
+  } while (0)
+    const long lanes4 = (long)p->n_sys * ((p->n_trials + 4 * LQG_BLOCK - 1) / (4 * LQG_BLOCK)) * LQG_BLOCK;
+    if (p->tuning.trial_lds >= 0 && p->n_trials >= 768 && p->n_sys >= 256) LQG_TRIAL_HL(256, 2);
+    else if (lanes4 >= 2L * 1024 * 64) LQG_TRIAL_HL(LQG_BLOCK, LQG_TRIALS_PER_LANE);
+    else LQG_TRIAL_HL(LQG_BLOCK, 1);
+#undef LQG_TRIAL_HL
   }
   return hipGetLastError();
 }
@@ -193,6 +237,9 @@ int run_sp_mixed(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll
   char* base = static_cast<char*>(workspace);
   R* Ls = reinterpret_cast<R*>(base + w.ls_off);
   R* ops = reinterpret_cast<R*>(base + w.ops_off);  // (written as float by the kernel: OT)
+  // hi + lo operators for the systems whose Fj - I block is large (lqg_kernels_sp.hpp: LQG_HILO_MIN)
+  float* ops_lo = reinterpret_cast<float*>(base + w.lo_off);
+  int* hl = reinterpret_cast<int*>(base + w.hl_off);
   auto mark = [&](int i) {
     if (p->phase_events[i]) (void)hipEventRecord(static_cast<hipEvent_t>(p->phase_events[i]), st);
   };
@@ -212,14 +259,14 @@ int run_sp_mixed(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll
                           dv<R>(d.A), dv<R>(d.B), dv<R>(d.F), dv<R>(d.V), dv<R>(d.W),
                           dv<R>(p->Sigma0), Ls, w.ldb, dt<R>(no_traj), nullptr, 0, ops, dv<R>(none),
                           dt<R>(no_traj), dv<R>(none), (long)p->n_sys, p->T,
-                          p->dims.nva, p->dims.nwa, p->dims.nvd, p->dims.nwd};
+                          p->dims.nva, p->dims.nwa, p->dims.nvd, p->dims.nwd, ops_lo, hl};
     if (p->Sigma0.ptr)
       hipLaunchKernelGGL((lqg::k_forward_sp<R, NX, NB, NU, NY, ND, PAT, 0, true, CK, float>), grid, block, 0, st, k, ll_sn, rc);
     else
       hipLaunchKernelGGL((lqg::k_forward_sp<R, NX, NB, NU, NY, ND, PAT, 0, false, CK, float>), grid, block, 0, st, k, ll_sn, rc);
   }
   mark(2);
-  const hipError_t te = trial_sweep_sp<float, PAT, NX, NB, NU, NY, ND>(p, x, ll, ll_sb, ll_sn, ops, st);
+  const hipError_t te = trial_sweep_sp<float, PAT, NX, NB, NU, NY, ND>(p, x, ll, ll_sb, ll_sn, ops, st, ops_lo, hl);
   if (te != hipSuccess) return (int)te;
   mark(3);
   const hipError_t e = hipGetLastError();

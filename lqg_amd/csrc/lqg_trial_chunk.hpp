@@ -38,7 +38,28 @@ struct TrialChunkArgs {
   R* state;          // [sys][n_chunks-1][M][n_trials]: zero-state ends, then (k_trial_fix) start states of chunk c+1
   R* phi;            // [sys][n_chunks-1][M][M]
   double* part;      // [sys][n_chunks][n_trials]
+  // MIXED mode (ForwardArgs::ops_lo / hl in lqg_kernels.hpp), kernels compiled with HLC: the systems flagged in hl add the
+  // rounding residual of the operator's Fj - I block to every mean update (hi + lo), unit-vector pushes included
+  const float* ops_lo;
+  const int* hl;
 };
+
+template <typename R, int M, class FMP, int I, int J>
+LQG_DEV void tc_lo_term(const float* __restrict__ lo, const R (&cv)[M], R& v) {
+  if constexpr (J < M) {
+    if constexpr (FMP::at(I, J)) v += (R)lo[I * M + J] * cv[J];
+    tc_lo_term<R, M, FMP, I, J + 1>(lo, cv, v);
+  }
+}
+template <typename R, int M, class FMP, int I>
+LQG_DEV void tc_lo_rows(const float* __restrict__ lo, const R (&cv)[M], R (&mn)[M]) {
+  if constexpr (I < M) {
+    R v = R(0);
+    tc_lo_term<R, M, FMP, I, 0>(lo, cv, v);
+    mn[I] += v;
+    tc_lo_rows<R, M, FMP, I + 1>(lo, cv, mn);
+  }
+}
 
 template <typename R, int M, int ND, class FMP, int I, int J>
 LQG_DEV void tc_mean_term(const R* __restrict__ op, const R (&cv)[M], R& v) {
@@ -58,8 +79,10 @@ LQG_DEV void tc_mean_rows(const R* __restrict__ op, const R (&cv)[M], R (&mn)[M]
 }
 
 // one step of the recursion: whitened innovation w (and its square zz), then — when `update` — the new state
-template <typename R, int M, int ND, class FMP>
-LQG_DEV R tc_step(const R* __restrict__ op, const R (&xt)[ND], R (&xprev)[ND], R (&dO)[ND], R (&muR)[M - ND], bool update) {
+// (lo: the step's residual block, or null — tested only in kernels compiled with HLC)
+template <typename R, int M, int ND, class FMP, bool HLC = false>
+LQG_DEV R tc_step(const R* __restrict__ op, const R (&xt)[ND], R (&xprev)[ND], R (&dO)[ND], R (&muR)[M - ND], bool update,
+                  const float* __restrict__ lo = nullptr) {
   constexpr int O = ND, RR = M - ND;
   using Ops = TrialOps<M, ND>;
   R cv[M], w[O];
@@ -82,6 +105,9 @@ LQG_DEV R tc_step(const R* __restrict__ op, const R (&xt)[ND], R (&xprev)[ND], R
     }
     R mn[M];
     tc_mean_rows<R, M, ND, FMP, 0>(op, cv, mn);
+    if constexpr (HLC) {
+      if (lo) tc_lo_rows<R, M, FMP, 0>(lo, cv, mn);
+    }
     LQG_UNROLL for (int i = 0; i < O; ++i) { dO[i] = mn[i]; xprev[i] = cv[i]; }
     LQG_UNROLL for (int p = 0; p < RR; ++p) muR[p] = cv[O + p] + mn[O + p];      // (the stream holds Fj - I)
   }
@@ -91,7 +117,7 @@ LQG_DEV R tc_step(const R* __restrict__ op, const R (&xt)[ND], R (&xprev)[ND], R
 // grid: (trial blocks + 1, n_sys, n_chunks - 1); the last block in x carries the unit vectors.  TPL trials per lane share
 // the step's operator loads (the passes wait on their scalar loads more than half of the time: SQ_WAIT_ANY / SQ_WAVE_CYCLES =
 // 0.57 at one trial per lane, scripts/pmc_trial.sh).
-template <typename R, int M, int ND, class FMP, int TPL>
+template <typename R, int M, int ND, class FMP, int TPL, bool HLC = false>
 __global__ void __launch_bounds__(LQG_BLOCK) k_trial_zs(const R* __restrict__ ops_all, const TrialChunkArgs<R> a) {
   constexpr int O = ND, RR = M - ND;
   using Ops = TrialOps<M, ND>;
@@ -101,6 +127,10 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial_zs(const R* __restrict__ op
   const long n0 = hom ? (long)threadIdx.x : (long)blockIdx.x * (LQG_BLOCK * TPL) + threadIdx.x;
   const int t0 = c * a.chunk_len, t1 = t0 + a.chunk_len;               // (c <= n_chunks - 2: the chunk is complete)
   const R* __restrict__ op = ops_all + (sys * (long)(a.T + 1) + t0) * Ops::N;
+  [[maybe_unused]] const float* lo = nullptr;
+  if constexpr (HLC) {
+    if (a.hl && a.hl[sys] != 0) lo = a.ops_lo + (sys * (long)(a.T + 1) + t0) * hilo_len<M>();
+  }
   const R* xr[TPL];
   bool live[TPL];
   R xprev[TPL][O], dO[TPL][O], muR[TPL][RR], xq[TPL][O];
@@ -121,9 +151,12 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial_zs(const R* __restrict__ op
       R xt[O];
       LQG_UNROLL for (int i = 0; i < O; ++i) xt[i] = xq[k][i];
       LQG_UNROLL for (int i = 0; i < O; ++i) xq[k][i] = hom ? R(0) : xr[k][row * a.x.st + i * a.x.sd];
-      (void)tc_step<R, M, ND, FMP>(op, xt, xprev[k], dO[k], muR[k], true);
+      (void)tc_step<R, M, ND, FMP, HLC>(op, xt, xprev[k], dO[k], muR[k], true, lo);
     }
     op += Ops::N;
+    if constexpr (HLC) {
+      if (lo) lo += hilo_len<M>();
+    }
   }
   const long slot = sys * (a.n_chunks - 1) + c;
   LQG_UNROLL for (int k = 0; k < TPL; ++k) {
@@ -167,7 +200,7 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial_fix(const R* __restrict__ p
 }
 
 // grid: (trial blocks, n_sys, n_chunks)
-template <typename R, int M, int ND, class FMP, int TPL>
+template <typename R, int M, int ND, class FMP, int TPL, bool HLC = false>
 __global__ void __launch_bounds__(LQG_BLOCK) k_trial_ll(const R* __restrict__ ops_all, const TrialChunkArgs<R> a) {
   constexpr int O = ND, RR = M - ND;
   constexpr int kAccChunk = 8;
@@ -179,6 +212,10 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial_ll(const R* __restrict__ op
   const bool last = c == a.n_chunks - 1;
   const int t1 = last ? a.T : t0 + a.chunk_len;
   const R* __restrict__ op = ops_all + (sys * (long)(a.T + 1) + t0) * Ops::N;
+  [[maybe_unused]] const float* lo = nullptr;
+  if constexpr (HLC) {
+    if (a.hl && a.hl[sys] != 0) lo = a.ops_lo + (sys * (long)(a.T + 1) + t0) * hilo_len<M>();
+  }
   const R* xr[TPL];
   bool live[TPL];
   R xprev[TPL][O], dO[TPL][O], muR[TPL][RR], xq[TPL][O];
@@ -213,11 +250,14 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial_ll(const R* __restrict__ op
       R xt[O];
       LQG_UNROLL for (int i = 0; i < O; ++i) xt[i] = xq[k][i];
       LQG_UNROLL for (int i = 0; i < O; ++i) xq[k][i] = xr[k][row * a.x.st + i * a.x.sd];
-      const R zz = tc_step<R, M, ND, FMP>(op, xt, xprev[k], dO[k], muR[k], t < a.T);
+      const R zz = tc_step<R, M, ND, FMP, HLC>(op, xt, xprev[k], dO[k], muR[k], t < a.T, lo);
       if (t > 0) part[k] += R(0.5) * zz + hlc;
       if (flush) { acc[k] -= (double)part[k]; part[k] = R(0); }
     }
     op += Ops::N;
+    if constexpr (HLC) {
+      if (lo) lo += hilo_len<M>();
+    }
   }
   LQG_UNROLL for (int k = 0; k < TPL; ++k)
     if (live[k]) a.part[(sys * a.n_chunks + c) * a.n_trials + n0 + (long)k * LQG_BLOCK] = acc[k];
@@ -317,16 +357,16 @@ inline TrialChunkScratch trial_chunk_scratch(const lqg_problem* p) {
 }
 
 // scratch: trial_chunk_scratch(p).total bytes (by convention it follows the operator stream in the workspace)
-template <typename R, int M, int ND, class FMP>
+template <typename R, int M, int ND, class FMP, bool HLC = false>
 hipError_t launch_trial_chunked(const lqg_problem* p, const void* ops, lqg_traj x, void* ll, long ll_sb, long ll_sn,
-                                void* scratch, hipStream_t st) {
+                                void* scratch, hipStream_t st, const float* ops_lo = nullptr, const int* hl = nullptr) {
   const int nc = trial_chunks(p);
   const TrialChunkScratch sc = trial_chunk_scratch(p);
   char* base = static_cast<char*>(scratch);
   lqg::TrialChunkArgs<R> k{lqg::DTraj<R>{static_cast<const R*>(x.ptr), (long)x.sb, (long)x.sn, (long)x.st, (long)x.sd},
                            (long)p->n_trials, p->T, nc, trial_chunk_len(p, nc),
                            reinterpret_cast<R*>(base + sc.state_off), reinterpret_cast<R*>(base + sc.phi_off),
-                           reinterpret_cast<double*>(base + sc.part_off)};
+                           reinterpret_cast<double*>(base + sc.part_off), ops_lo, hl};
   const unsigned tb = (unsigned)((p->n_trials + LQG_BLOCK - 1) / LQG_BLOCK), B = (unsigned)p->n_sys;
   const dim3 block(LQG_BLOCK);
   const R* o = static_cast<const R*>(ops);
@@ -334,13 +374,13 @@ hipError_t launch_trial_chunked(const lqg_problem* p, const void* ops, lqg_traj 
   const int tpl_mode = p->tuning.trial_chunk_tpl;
   const bool two = tpl_mode == 2 || (tpl_mode == 0 && (long)tb * B * nc > 8192L);
   const unsigned tb2 = (unsigned)((p->n_trials + 2 * LQG_BLOCK - 1) / (2 * LQG_BLOCK));
-  if (two) hipLaunchKernelGGL((lqg::k_trial_zs<R, M, ND, FMP, 2>), dim3(tb2 + 1, B, nc - 1), block, 0, st, o, k);
-  else hipLaunchKernelGGL((lqg::k_trial_zs<R, M, ND, FMP, 1>), dim3(tb + 1, B, nc - 1), block, 0, st, o, k);
+  if (two) hipLaunchKernelGGL((lqg::k_trial_zs<R, M, ND, FMP, 2, HLC>), dim3(tb2 + 1, B, nc - 1), block, 0, st, o, k);
+  else hipLaunchKernelGGL((lqg::k_trial_zs<R, M, ND, FMP, 1, HLC>), dim3(tb + 1, B, nc - 1), block, 0, st, o, k);
   if (nc > 2)
     hipLaunchKernelGGL((lqg::k_trial_fix<R, M>), dim3(tb, B), block, 0, st, static_cast<const R*>(k.phi), k.state,
                        (long)p->n_trials, nc - 1);
-  if (two) hipLaunchKernelGGL((lqg::k_trial_ll<R, M, ND, FMP, 2>), dim3(tb2, B, nc), block, 0, st, o, k);
-  else hipLaunchKernelGGL((lqg::k_trial_ll<R, M, ND, FMP, 1>), dim3(tb, B, nc), block, 0, st, o, k);
+  if (two) hipLaunchKernelGGL((lqg::k_trial_ll<R, M, ND, FMP, 2, HLC>), dim3(tb2, B, nc), block, 0, st, o, k);
+  else hipLaunchKernelGGL((lqg::k_trial_ll<R, M, ND, FMP, 1, HLC>), dim3(tb, B, nc), block, 0, st, o, k);
   hipLaunchKernelGGL((lqg::k_trial_sum<R>), dim3(tb, B), block, 0, st, static_cast<const double*>(k.part),
                      static_cast<R*>(ll), ll_sb, ll_sn, (long)p->n_trials, nc);
   return hipGetLastError();

@@ -205,7 +205,7 @@ def test_product_does_not_import_the_oracle():
 def test_mixed_dtype_is_served_by_the_log_likelihood_entry_only(lib, monkeypatch):
     """ABI 2: LQG_F32_SYS64 (fp32 problem, fp64 spec arrays and system sweeps) — accepted by lqg_log_likelihood /
     lqg_workspace_bytes, refused (before any launch) everywhere a single dtype is assumed; its workspace holds an fp64
-    gain scratch and an fp32 operator stream."""
+    gain scratch, an fp32 operator stream and the fp32 residual stream of its F block."""
     from lqg_amd import _hip
     import lqg_amd
     monkeypatch.setenv("LQG_TRIAL_CHUNKS", "0")
@@ -217,7 +217,10 @@ def test_mixed_dtype_is_served_by_the_log_likelihood_entry_only(lib, monkeypatch
     w32 = lib.lqg_workspace_bytes(C.byref(ln32.p), _abi.OP_LOG_LIKELIHOOD)
     wmx = lib.lqg_workspace_bytes(C.byref(mix.p), _abi.OP_LOG_LIKELIHOOD)
     gains32 = 500 * 2 * 6 * 128 * 4
-    assert wmx - w32 == gains32                     # the gain scratch doubles (fp64), the operator stream stays fp32
+    al = lambda v: (v + 255) // 256 * 256           # noqa: E731
+    # round 5: + the residual stream of the operator's Fj - I block ([n_sys][T+1][m m] floats, m = 10) and one flag per system
+    resid = al(100 * 501 * 100 * 4) + al(100 * 4)
+    assert wmx - w32 == gains32 + resid             # the gain scratch doubles (fp64), the operator stream stays fp32
     nv, nt = _abi.NULL_VIEW, _abi.NULL_TRAJ
     assert lib.lqg_kalman_forward(C.byref(mix.p), nv, None) == -3 and b"LQG_F32_SYS64" in lib.lqg_last_error()
     assert lib.lqg_riccati_backward(C.byref(mix.p), nv, nv, nv, None) == -3
@@ -227,7 +230,7 @@ def test_mixed_dtype_is_served_by_the_log_likelihood_entry_only(lib, monkeypatch
     assert lib.lqg_log_likelihood(C.byref(mix.p), nt, None, 0, 1, None, 0, None) == -1        # x.ptr NULL
     mix.p.n_trials = 1                              # mixed always goes through the operator stream, one trial included
     assert lib.lqg_workspace_bytes(C.byref(mix.p), _abi.OP_LOG_LIKELIHOOD) == \
-        2 * gains32 + (100 * 501 * 136 * 4 + 255) // 256 * 256
+        2 * gains32 + al(100 * 501 * 136 * 4) + resid
     x = torch.zeros(1, 501, 4)
     rc = lib.lqg_log_likelihood(C.byref(mix.p), mix.traj(x, False), C.c_void_p(x.data_ptr()), 0, 1,
                                 C.c_void_p(x.data_ptr()), 16, None)

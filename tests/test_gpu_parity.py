@@ -466,8 +466,8 @@ def test_time_varying_structured_specs_materialise_through_the_pattern_library(o
         assert abs(float(o_sp["ll"][j, 0]) / float(llr[0]) - 1) < max(tol * 0.1, 1e-10)
 
 
-@pytest.mark.parametrize("T,tol_default", [(500, 1e-6), (1067, 5e-6)])
-def test_fp32_candidate_ranges_point_mass(T, tol_default):
+@pytest.mark.parametrize("T,tol_default,tol_fp32", [(500, 1e-6, 3e-6), (1067, 1e-6, 1.5e-5), (2000, 1e-6, 1.5e-5)])
+def test_fp32_candidate_ranges_point_mass(T, tol_default, tol_fp32):
     """PointMassBoundedActor over the bench's candidate ranges, fp32 default routes against the fp64 path on the fp64 image of the SAME
     fp32 inputs.  A log-likelihood is a sum of T d per-step terms of either sign; for candidates with a small action variability they nearly
     cancel on these data (|ll| down to 0.1 against ~1e3 for the rest), and an error relative to |ll| then measures the zero crossing, not
@@ -476,9 +476,10 @@ def test_fp32_candidate_ranges_point_mass(T, tol_default):
     import lqg_amd
     from lqg_amd import options, workload
     dev = torch.device("cuda")
-    # T = 1067 (config 3's horizon): the OPEN item of DESIGN.md §8 — the default fp32 routes sit at 1.5e-6 .. 3.3e-6 of scale there
-    # (rounded operators x magnitude-50 belief states x a whitening gain of 10-30); pinned at 5e-6 so that it cannot get worse
-    # unnoticed; fp64 is the remedy until the operator stream changes coordinates
+    # T >= 1000 (config 3's horizon and beyond): operators rounded ONCE to fp32 left 1.5e-6 .. 3.3e-6 of scale here (rounds 3-5:
+    # eps32 x |Fj - I| of 10 .. 70 x magnitude-50 belief states, the same rounding every step); since round 5 the MIXED mode keeps
+    # the rounding residual of that block and the per-trial sweeps apply hi + lo operators to such systems (DESIGN.md §8,
+    # scripts/pointmass_hilo_emulation.py, scripts/pointmass_hilo_diag.py): plain 1e-6
     B, n, d = 256, 8, 2
     gen = torch.Generator(device=dev); gen.manual_seed(5)
     names = ("action_variability", "sigma_target", "sigma_cursor", "action_cost")
@@ -487,8 +488,9 @@ def test_fp32_candidate_ranges_point_mass(T, tol_default):
     x = lqg_amd.PointMassBoundedActor(T=T, device=dev, dtype=torch.float32).simulate(3, n=n)[..., :d].contiguous()
     ref = m32.to(torch.float64).log_likelihood(x.double())
     scale = ref.abs().clamp_min(float(T * d))
-    # (MIXED=0, every sweep in fp32, is a developer route — the default runs the per-system sweeps in fp64: it gives 1.02e-6 here)
-    for ov, tol in (({}, tol_default), (dict(F32_WIDE=0), tol_default), (dict(F32_WIDE=0, MIXED=0), 3 * tol_default)):
+    # (MIXED=0, every sweep in fp32, is a developer route — the default runs the per-system sweeps in fp64: 1.0e-6 at T = 500,
+    # 2.4e-6 at 1067, 4.6e-6 at 2000 on these inputs)
+    for ov, tol in (({}, tol_default), (dict(F32_WIDE=0), tol_default), (dict(F32_WIDE=0, MIXED=0), tol_fp32)):
         with options.override(**ov):
             ll = m32.log_likelihood(x).double()
         err = (ll - ref).abs()
@@ -498,6 +500,28 @@ def test_fp32_candidate_ranges_point_mass(T, tol_default):
         small = ref.abs() < 0.1 * T * d
         if bool(small.any()):
             assert float(err[small].max()) <= 2.0 * float(err[~small].max()), ov
+
+
+@pytest.mark.parametrize("B,n", [(300, 500), (256, 800)])
+def test_fp32_point_mass_many_trials_hi_lo_operators(B, n):
+    """The one-pass per-trial sweeps of the MIXED mode (64-lane workgroups: 300 x 500; the 256 x 2 geometry: 256 x 800) on the
+    point mass at T = 1067: the systems whose Fj - I block is large are walked by k_trial_sp<..., HL> with hi + lo operators
+    (the test above runs 8 trials per candidate: the time-chunked sweep).  Same statement: 1e-6 of max(|ll|, T d)."""
+    import lqg_amd
+    from lqg_amd import options, workload
+    dev = torch.device("cuda")
+    T, d = 1067, 2
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    names = ("action_variability", "sigma_target", "sigma_cursor", "action_cost")
+    kw = {k: workload.log_uniform(B, *workload.RANGES[k], gen, dev, torch.float32) for k in names}
+    m32 = lqg_amd.PointMassBoundedActor(T=T, device=dev, dtype=torch.float32, **kw)
+    x = lqg_amd.PointMassBoundedActor(T=T, device=dev, dtype=torch.float32).simulate(4, n=n)[..., :d].contiguous()
+    ref = m32.to(torch.float64).log_likelihood(x.double())
+    scale = ref.abs().clamp_min(float(T * d))
+    for ov in ({}, dict(F32_WIDE=0)):
+        with options.override(**ov):
+            ll = m32.log_likelihood(x).double()
+        assert float(((ll - ref).abs() / scale).max()) < 1e-6, ov
 
 
 def test_per_trial_sweep_geometries_are_bitwise_identical():
