@@ -48,8 +48,8 @@ extern "C" {
  * log-likelihood at horizons >= 1000.  Spec strides are then in elements of double.
  * The structure-specialised libraries (lqg_log_likelihood_sp) additionally keep what that one rounding dropped from the
  * operator's Fj - I block (a second float stream in the workspace, sized by lqg_workspace_bytes) and apply hi + lo in the
- * per-trial sweep of every system whose block reaches 2.0 in magnitude anywhere on the horizon (point-mass models: whitening
- * gains of 10 .. 70): rounded operators leave eps32 |Fj - I| |state| of systematic error per step there. */
+ * per-trial sweep of every system whose block reaches 2.0 in magnitude, from the first such step on (point-mass models:
+ * whitening gains of 10 .. 70): rounded operators leave eps32 |Fj - I| |state| of systematic error per step there. */
 typedef enum lqg_dtype { LQG_F32 = 0, LQG_F64 = 1, LQG_F32_SYS64 = 2 } lqg_dtype;
 
 /* error codes (negative return values) */

@@ -50,7 +50,7 @@ inline AspWorkspace asp_carve(const lqg_problem* p) {
   w.ops_off = off;
   off += fused ? 0 : al((size_t)p->n_sys * (size_t)(p->T + 1) * ops_reals(p->dims) * esz);
   w.tck_off = off;
-  off += fused ? 0 : al((size_t)p->n_sys * (size_t)(w.nckt + 1) * M * w.npad * esz);
+  off += fused ? 0 : al((size_t)p->n_sys * (size_t)(w.nckt + 1) * (M - ND) * w.npad * esz);   // (c_{t-1}: M - ND reals per record)
   w.sums_off = off;
   off += fused ? 0 : al((size_t)w.parts * p->n_sys * (size_t)p->T * NSUM * esz);
   w.gsum_off = off;
@@ -148,7 +148,7 @@ int run_asp(const lqg_problem* p, lqg_traj x, const void* g, long g_sb, long g_s
     else if (p->n_trials == 2) LQG_ASP_SYS(k_asp_sys_fwd, 2);
     else LQG_ASP_SYS(k_asp_sys_fwd, 0);
     mark(2);
-    if (!fused) {   // the per-trial sweep of the forward path (k_trial_sp), keeping the mean state every CKT steps
+    if (!fused) {   // the per-trial sweep of the forward path (k_trial_sp), keeping c_{t-1} for every CKT-th row
       lqg::TrialArgs<R> tk{dt<R>(x), dt<R>(no_traj), static_cast<R*>(ll), ll_sb, ll_sn, (long)p->n_trials, p->T, tr.tck, w.npad, w.nckt};
       constexpr auto FMT = lqg::trial_operator_mask<PAT, NX, NB, NU, NY, ND, DENSE_P>();
       const long lanes4 = (long)p->n_sys * ((p->n_trials + 4 * LQG_BLOCK - 1) / (4 * LQG_BLOCK)) * LQG_BLOCK;

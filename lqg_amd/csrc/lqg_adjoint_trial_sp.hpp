@@ -1,7 +1,7 @@
 // lqg_adjoint_trial_sp.hpp — the per-TRIAL half of the round-5 reverse-mode sweep (lqg_adjoint_sp.hpp), gfx950.
 //
 //   (forward)         k_trial_sp<..., CKT> of lqg_kernels_sp.hpp: mean recursion + log-density over the operator stream
-//                     (lqg/system.py:219-221, 244-248), keeping the mean state every CKT steps
+//                     (lqg/system.py:219-221, 244-248), keeping c_{t-1} (TrialArgs::tck) for every CKT-th row
 //   k_asp_trial_rev   the mu-bar recursion backward over the same stream: per chunk the steps' (w, c) are recomputed from the
 //                     chunk's checkpoint into registers, then walked backward; per step the workgroup's trials are reduced to
 //                     the TRIAL SUMS of asp::Sums (wave butterfly: log2 stages in which every lane hands half of its values to
@@ -34,7 +34,7 @@ struct TrialRevArgs {
   long g_sb, g_sn;
   R* ll;                     // value out (k_asp_trial_fwd), may be null
   long ll_sb, ll_sn;
-  R* tck;                    // mean-state checkpoints [n_sys][nckt + 1][M][npad]
+  R* tck;                    // restart data c_{t-1} of the chunk rows [n_sys][nckt + 1][M - ND][npad] (TrialArgs::tck)
   long npad;
   int nckt;
   R* sums;                   // [parts = gridDim.x][n_sys][T][Sums::N]
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(LQG_ASP_TRIAL_BLOCK, (sizeof(R) == 4 ? 2 : 1))
   using Ops = TrialOps<M, ND>;
   using SM = Sums<M, ND, FM>;
   constexpr auto FMD = mask_or(FM, mask_eye<M>());
-  constexpr int CKN = CKT * Ops::N;                     // reals of one chunk's operator blocks
+  constexpr int CKN = (CKT + 1) * Ops::N;               // reals of one chunk's operator blocks + the block of the step before it
   constexpr int NW = BLK / 64, VPT = ReduceShape<SM::RAW>::VPT;
   __shared__ R lds[2 * CKT * NW * VPT];       // per-wave totals of the chunk's steps, double-buffered by chunk
   __shared__ R lops[2][CKN];
@@ -224,15 +224,24 @@ __global__ void __launch_bounds__(LQG_ASP_TRIAL_BLOCK, (sizeof(R) == 4 ? 2 : 1))
     xo[k] = (unsigned)(n * a.x.sn * (long)sizeof(R));
     gw[k] = live[k] ? (a.g ? a.g[sys * a.g_sb + n * a.g_sn] : R(1)) : R(0);
     LQG_UNROLL for (int i = 0; i < M; ++i) pre[k][i] = R(0);
-    // a_n(T) = Li_T' w_n(T) from the final mean state
-    const R* src = a.tck + ((sys * (a.nckt + 1) + a.nckt) * M) * a.npad + n;
+    // a_n(T) = Li_T' w_n(T): the mean entering row T from the kept c_{T-1} and the operator of step T - 1
+    const R* src = a.tck + ((sys * (a.nckt + 1) + a.nckt) * RR) * a.npad + n;       // c_{T-1}
     const R* __restrict__ opT = op + (long)a.T * Ops::N;
+    const R* __restrict__ opP = op + (long)(a.T - 1) * Ops::N;
+    R cvp[M], dOT[O];
+    LQG_UNROLL for (int i = 0; i < O; ++i) cvp[i] = xat(k, a.T - 1, i);
+    LQG_UNROLL for (int i = 0; i < RR; ++i) cvp[O + i] = src[i * a.npad];
+    LQG_UNROLL for (int i = 0; i < O; ++i) {
+      R v = R(0);
+      LQG_UNROLL for (int q = 0; q < M; ++q) if (FMD.b[i * M + q]) v += opP[Ops::F_OFF + i * M + q] * cvp[q];
+      dOT[i] = v;
+    }
     R w[O];
     int e = 0;
     LQG_UNROLL for (int i = 0; i < O; ++i) {
       R v = R(0);
       LQG_UNROLL for (int j = 0; j <= i; ++j)
-        v += opT[Ops::L_OFF + (e++)] * ((xat(k, a.T, j) - xat(k, a.T - 1, j)) - src[j * a.npad]);
+        v += opT[Ops::L_OFF + (e++)] * ((xat(k, a.T, j) - cvp[j]) - dOT[j]);
       w[i] = v;
     }
     LQG_UNROLL for (int i = 0; i < O; ++i) {
@@ -259,10 +268,10 @@ __global__ void __launch_bounds__(LQG_ASP_TRIAL_BLOCK, (sizeof(R) == 4 ? 2 : 1))
   R nx[NLD];
   LQG_UNROLL for (int q = 0; q < NLD; ++q) nx[q] = R(0);
   auto request = [&](int c) LQG_LAMBDA_INLINE {
-    const long base = (long)c * CKN;
+    const long base = ((long)c * CKT - 1) * Ops::N;      // rows t0 - 1 .. t0 + CKT - 1 (the first restarts the chunk's mean state)
     LQG_UNROLL for (int q = 0; q < NLD; ++q) {
       const int i = q * BLK + (int)threadIdx.x;
-      if (i < CKN && base + i < op_len) nx[q] = op[base + i];
+      if (i < CKN && base + i >= 0 && base + i < op_len) nx[q] = op[base + i];
     }
   };
   auto publish = [&](int buf) LQG_LAMBDA_INLINE {
@@ -302,19 +311,39 @@ __global__ void __launch_bounds__(LQG_ASP_TRIAL_BLOCK, (sizeof(R) == 4 ? 2 : 1))
     __syncthreads();
     if (c < a.nckt - 1) flush(c + 1, rb ^ 1);
     if (c > 0) request(c - 1);
-    const R* __restrict__ lo = lops[obuf];
+    const R* __restrict__ lo = lops[obuf] + Ops::N;
 #endif
     // ---- recompute the chunk's (w, c)
     {
       R xprev[TPL][O], dO[TPL][O], muR[TPL][RR];
-      const R* src = a.tck + ((sys * (a.nckt + 1) + c) * M) * a.npad;
+      const R* src = a.tck + ((sys * (a.nckt + 1) + c) * RR) * a.npad;
       LQG_UNROLL for (int k = 0; k < TPL; ++k) {
         LQG_UNROLL for (int i = 0; i < O; ++i) {
-          dO[k][i] = src[i * a.npad + nn[k]];
           xprev[k][i] = xat(k, t0 > 0 ? t0 - 1 : 0, i);
           xq[k][i] = xat(k, t0, i);
         }
-        LQG_UNROLL for (int i = 0; i < RR; ++i) muR[k][i] = src[(O + i) * a.npad + nn[k]];
+      }
+      if (c > 0) {
+        // the mean state entering row t0 from the kept c_{t0-1}, x_{t0-1} and the operator of step t0 - 1 (k_trial_sp's update)
+        const R* __restrict__ opp = lo - Ops::N;
+        R Fp[M * M];
+        LQG_UNROLL for (int i = 0; i < M * M; ++i) if (FMD.b[i]) Fp[i] = opp[Ops::F_OFF + i];
+        LQG_UNROLL for (int k = 0; k < TPL; ++k) {
+          R cvp[M];
+          LQG_UNROLL for (int i = 0; i < O; ++i) cvp[i] = xprev[k][i];
+          LQG_UNROLL for (int i = 0; i < RR; ++i) cvp[O + i] = src[i * a.npad + nn[k]];
+          LQG_UNROLL for (int i = 0; i < M; ++i) {
+            R v = R(0);
+            LQG_UNROLL for (int q = 0; q < M; ++q) if (FMD.b[i * M + q]) v += Fp[i * M + q] * cvp[q];
+            if (i < O) { dO[k][i < O ? i : 0] = v; }
+            else muR[k][i >= O ? i - O : 0] = cvp[i] + v;
+          }
+        }
+      } else {
+        LQG_UNROLL for (int k = 0; k < TPL; ++k) {
+          LQG_UNROLL for (int i = 0; i < O; ++i) dO[k][i] = R(0);
+          LQG_UNROLL for (int i = 0; i < RR; ++i) muR[k][i] = R(0);
+        }
       }
       LQG_UNROLL for (int j = 0; j < CKT; ++j) {
         const int t = t0 + j;

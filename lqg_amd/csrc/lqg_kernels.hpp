@@ -275,8 +275,9 @@ struct ForwardArgs {
   long n_sys;
   int T, nva, nwa, nvd, nwd;
   // MIXED mode of the structure-specialised libraries (k_forward_sp<double, ..., OT = float>), both may be null: the rounding
-  // residual of the operator's Fj - I block, fl32(F - fl32(F)), as [n_sys][T+1][hilo_reals], and per system whether
-  // max_t |Fj - I| reached LQG_HILO_MIN — the per-trial sweep then applies hi + lo (k_trial_sp<..., HL>)
+  // residual of the operator's Fj - I block, fl32(F - fl32(F)), as [n_sys][T+1][hilo_reals] — written from the first step
+  // at which |Fj - I| reaches LQG_HILO_MIN — and per system that step + 1 (0: never): the per-trial sweep applies hi + lo from
+  // there on (k_trial_sp<..., HL>)
   float* ops_lo;
   int* hl;
 };
@@ -546,12 +547,13 @@ struct TrialArgs {
   long ll_sb, ll_sn;
   long n_trials;
   int T;
-  // k_trial_sp<..., CKT > 0> (the reverse-mode sweep's forward pass, lqg_adjoint_trial_sp.hpp): the mean state (dO, muR) BEFORE
-  // every CKT-th row, and before the last row T, kept at tck[((sys * (nckt + 1) + rec) * M + e) * npad + trial]
+  // k_trial_sp<..., CKT > 0> (the reverse-mode sweep's forward pass, lqg_adjoint_trial_sp.hpp): c_{t-1} (the RR = M - ND
+  // conditioned unobserved means of the step before) for every row t that starts a chunk of CKT, and for the last row T, kept at
+  // tck[((sys * (nckt + 1) + rec) * RR + e) * npad + trial] — the mean state entering row t follows from it, x_{t-1} and the operator
   R* tck;
   long npad;
   int nckt;
-  // MIXED mode (see ForwardArgs): when hl is set, a launch of k_trial_sp<..., HL> walks only the systems whose flag equals HL
+  // MIXED mode (see ForwardArgs): when hl is set, a launch of k_trial_sp<..., HL> walks only the systems with (hl[sys] != 0) == HL
   const float* ops_lo;
   const int* hl;
 };

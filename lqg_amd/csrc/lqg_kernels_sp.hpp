@@ -217,28 +217,34 @@ constexpr Mask<NX + NB, NX + NB> trial_operator_mask() {
 // SYSTEMATIC error per step into every trial — the same rounding every step of a stationary filter.  Measured (NumPy emulation
 // of the fp32 per-trial sweep, PointMassBoundedActor over the bench's candidate ranges, T = 1067, error / max(|ll|, T d)):
 // rounded operators 1.19e-6 worst, hi + lo operators 1.2e-7, exact operators 1.07e-7; the 1-D tracking models (|F - I| <= 0.6
-// against 5 .. 74 for the point mass) sit at 1e-7 either way.  So systems whose block reaches LQG_HILO_MIN anywhere on the
-// horizon get their residual stream applied by the per-trial sweep; the others never read it.
+// against 5 .. 74 for the point mass) sit at 1e-7 either way.  So from the FIRST step at which a system's block reaches
+// LQG_HILO_MIN (looked at every 8th step) the builder also writes the residual block of every step (ForwardArgs::hl = that step
+// + 1; 0 = never: such systems cost two integer instructions per entry every 8th step, no stores), and the per-trial sweeps
+// apply hi + lo from that step on.
 #ifndef LQG_HILO_MIN
 #define LQG_HILO_MIN 2.0
 #endif
-template <int I, typename OT, typename R, int M, int N, Mask<M, N> MK>
-LQG_DEV void store_residual(const Mat<R, M, N, MK>& a, OT* __restrict__ p, R& mx) {
+// largest |entry| of an fp64 block, as the largest high dword of |v| (monotone in |v|; full-rate integer operations — the builder
+// walks T dependent steps on a nearly empty chip, where every instruction costs its whole latency: an fp64 abs-max per entry
+// and step cost 0.25 ms of config 3's 0.6 ms sweep)
+template <int I, int M, int N, Mask<M, N> MK>
+LQG_DEV void block_absmax_hi(const Mat<double, M, N, MK>& a, unsigned (&mx)[2]) {
   if constexpr (I < M * N) {
     if constexpr (MK.b[I]) {
-      const R v = a.v[I];
-      p[I] = (OT)(v - (R)(OT)v);
-      const R av = v < R(0) ? -v : v;
-      mx = av > mx ? av : mx;
+      const unsigned h = (unsigned)__double2hiint(a.v[I]) & 0x7fffffffu;
+      mx[I & 1] = h > mx[I & 1] ? h : mx[I & 1];
     }
-    store_residual<I + 1, OT>(a, p, mx);
+    block_absmax_hi<I + 1>(a, mx);
+  }
+}
+template <int I, typename OT, typename R, int M, int N, Mask<M, N> MK>
+LQG_DEV void store_residual(const Mat<R, M, N, MK>& a, OT* __restrict__ p) {
+  if constexpr (I < M * N) {
+    if constexpr (MK.b[I]) p[I] = (OT)(a.v[I] - (R)(OT)a.v[I]);
+    store_residual<I + 1, OT>(a, p);
   }
 }
 
-// NTR >= 1 (fused): the NTR trials of each system are swept in-lane (1: the headline; 2: two identical decoupled
-// components solved as ONE system with two trials, lqg_amd/plan.py); NTR == 0: the per-step trial operators are written
-// to the operator stream for k_trial (many trials per system), exactly as k_forward does.  ll_sn: trial stride of ll.
-// CK > 0: checkpointed gains (see k_riccati_sp): `rc` carries the actor's cost matrices and the checkpoint stream.
 // OT: element type of the operator stream (NTR == 0), see k_forward.
 // X4 (round 5, fp32, NTR x d = 4): the lane's data row is ONE 16-byte vector — trajectories laid [T+1][system][trial][component]
 // (plan._trial_stack(rows=True)): one global_load_dwordx4 per step instead of four dword loads from four rows.
@@ -306,7 +312,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sp_fwd_waves<R, NX + NB>()))
 
   R Li[O * O], U2[RR * O], hl = R(0), pd = R(1);
   unsigned pois = 0u;                             // largest pos_finite_key of the pivot products (lqg_small.hpp)
-  [[maybe_unused]] R fmx = R(0);                  // MIXED: max_t |Fj - I| of this system (ForwardArgs::hl)
+  [[maybe_unused]] int hl_first = -1;             // MIXED: first step whose |Fj - I| block reaches LQG_HILO_MIN (ForwardArgs::hl)
   // FUSED scoring (round 4): log N(x_t; mu, S) = -1/2 |w|^2 + log(prod of the Cholesky pivots' reciprocal roots) - (d/2) log 2 pi.
   // Per step only  part[n] += 1/2 |w|^2  (one fma per trial) and the log-determinant term run: fp32 takes ONE v_log_f32
   // (log2, 1 ulp; the ln 2 factor is applied in fp64 at the flush), fp64 multiplies the pivot products of the block together
@@ -471,7 +477,13 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sp_fwd_waves<R, NX + NB>()))
       if constexpr (!std::is_same_v<OT, R>) {
         // MIXED: what the rounding to OT dropped from the block, and the block's largest entry (round 5)
         if (a.ops_lo) {
-          store_residual<0, OT>(FjD, a.ops_lo + ((long)s * (a.T + 1) + t) * (long)hilo_len<M>(), fmx);
+          if (hl_first < 0 && (t & 7) == 0) {          // (looked at every 8th step: a crossing is seen at most 7 steps late)
+            static_assert(std::is_same_v<R, double>, "the MIXED builder runs in fp64");
+            unsigned mx[2] = {0u, 0u};
+            block_absmax_hi<0>(FjD, mx);
+            if ((mx[0] > mx[1] ? mx[0] : mx[1]) >= (unsigned)__double2hiint((double)LQG_HILO_MIN)) hl_first = t;
+          }
+          if (hl_first >= 0) store_residual<0, OT>(FjD, a.ops_lo + ((long)s * (a.T + 1) + t) * (long)hilo_len<M>());
         }
       }
       LQG_UNROLL for (int i = 0; i < RR * O; ++i) op[Ops::U_OFF + i] = (OT)U2[i];
@@ -567,7 +579,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sp_fwd_waves<R, NX + NB>()))
       LQG_UNROLL for (int j = 0; j <= i; ++j) op[Ops::L_OFF + (e++)] = (OT)Li[i * O + j];
     store_or_nan(&op[Ops::H_OFF], (OT)(hl + kLogNorm), pois >= kPosFiniteLimit<R>);
     if constexpr (!std::is_same_v<OT, R>) {
-      if (a.hl) a.hl[s] = fmx >= R(LQG_HILO_MIN) ? 1 : 0;
+      if (a.hl) a.hl[s] = hl_first + 1;
     }
   }
 }
@@ -810,11 +822,12 @@ LQG_DEV void trial_lo_rows(const float* __restrict__ lo, const R (&cv)[M], R (&m
   }
 }
 
-// CKT > 0: the mean state is also KEPT every CKT steps (TrialArgs::tck) — the forward pass of the reverse-mode sweep.
+// CKT > 0: the restart data of every CKT-th row is also KEPT (TrialArgs::tck, see keepc) — the forward pass of the reverse-mode sweep.
 // BLK: lanes per workgroup.  64 by default; 512 / 1024 put 1024+ trials of ONE candidate into one workgroup, whose waves walk
 // the candidate's operator stream together through the CU's scalar cache (one fetch per CU instead of one per 128 trials).
-// HL (MIXED mode, TrialArgs::hl set): the launch with HL walks the systems flagged by the builder (|Fj - I| large somewhere on
-// the horizon) and applies hi + lo operators; the launch without walks the others — the unflagged systems' loop is untouched.
+// HL (MIXED mode, TrialArgs::hl set): the launch with HL walks the systems flagged by the builder (hl[sys] = 1 + the first step
+// whose |Fj - I| block is large) and applies hi + lo operators from that step on; the launch without walks the others — the
+// unflagged systems' loop is untouched.
 template <typename R, int M, int ND, int TPL, Mask<M, M> FM, int CKT = 0, int BLK = LQG_BLOCK, bool HL = false>
 __global__ void __launch_bounds__(BLK) k_trial_sp(const R* __restrict__ ops_all, const TrialArgs<R> a) {
   constexpr int O = ND, RR = M - ND;
@@ -826,6 +839,7 @@ __global__ void __launch_bounds__(BLK) k_trial_sp(const R* __restrict__ ops_all,
     if ((a.hl[sys] != 0) != HL) return;
   }
   [[maybe_unused]] const float* __restrict__ lo_sys = HL ? a.ops_lo + sys * (long)(a.T + 1) * hilo_len<M>() : nullptr;
+  [[maybe_unused]] const int lo_from = HL ? a.hl[sys] - 1 : 0;    // residual blocks exist (and matter) from this step on
   const long n0 = (long)blockIdx.x * (BLK * TPL) + threadIdx.x;
   const R* __restrict__ op = ops_all + sys * (long)(a.T + 1) * Ops::N;
   const R* xr[TPL];
@@ -854,17 +868,18 @@ __global__ void __launch_bounds__(BLK) k_trial_sp(const R* __restrict__ ops_all,
   // 117 VGPRs: config 3 3.54 -> 4.59 ms (measured).  Larger ones (M >= 8: the 2-D hand model of config 4,
   // m = 10) are arithmetic-heavy and already register-bound: first / last step peeled, blocks of 8 unguarded steps, one
   // flush of the fp32 partial sums per block: config 4 (262 144 trials) per-trial sweep 1.92 -> 1.35 ms.
-  [[maybe_unused]] auto keep = [&](int t) LQG_LAMBDA_INLINE {
+  // CKT > 0: what the reverse-mode sweep restarts a chunk from.  The mean state (dO, muR) entering row t + 1 is a function of
+  // this step's (x_t, c_t) and operator — so the RR reals of c_t are kept (not the M of the state: half the checkpoint traffic
+  // for the tracking models), as record (t + 1) / CKT when t + 1 starts a chunk, and as record nckt for the last row.
+  [[maybe_unused]] auto keepc = [&](int t, int k, const R (&cv)[M]) LQG_LAMBDA_INLINE {
     if constexpr (CKT > 0) {
-      if ((t % CKT) == 0 || t == a.T) {
-        const int rec = t == a.T ? a.nckt : t / CKT;
-        R* dst = a.tck + ((sys * (a.nckt + 1) + rec) * M) * a.npad;
-        LQG_UNROLL for (int k = 0; k < TPL; ++k)
-          if (live[k]) {
-            const long n = n0 + (long)k * BLK;
-            LQG_UNROLL for (int i = 0; i < O; ++i) dst[i * a.npad + n] = dO[k][i];
-            LQG_UNROLL for (int i = 0; i < RR; ++i) dst[(O + i) * a.npad + n] = muR[k][i];
-          }
+      const int tn = t + 1;
+      if ((tn % CKT) == 0 || tn == a.T) {
+        if (live[k]) {
+          const int rec = tn == a.T ? a.nckt : tn / CKT;
+          R* dst = a.tck + ((sys * (a.nckt + 1) + rec) * RR) * a.npad + n0 + (long)k * BLK;
+          LQG_UNROLL for (int i = 0; i < RR; ++i) dst[i * a.npad] = cv[O + i];
+        }
       }
     }
   };
@@ -872,7 +887,6 @@ __global__ void __launch_bounds__(BLK) k_trial_sp(const R* __restrict__ ops_all,
   if constexpr (BLOCK8) {
     auto body8 = [&]<bool FIRST, bool LAST>(int t, const R (&cur)[NPF], const R* __restrict__ opt) LQG_LAMBDA_INLINE {
 #define LQG_OP(i_) (PF ? cur[PF ? (i_) : 0] : opt[i_])
-      keep(t);
       R Li[O * (O + 1) / 2];
       LQG_UNROLL for (int i = 0; i < O * (O + 1) / 2; ++i) Li[i] = LQG_OP(Ops::L_OFF + i);
       const R hlc = LQG_OP(Ops::H_OFF);
@@ -899,9 +913,12 @@ __global__ void __launch_bounds__(BLK) k_trial_sp(const R* __restrict__ ops_all,
             LQG_UNROLL for (int j = 0; j < O; ++j) v += LQG_OP(Ops::U_OFF + p * O + j) * w[j];
             cv[O + p] = v;
           }
+          keepc(t, k, cv);
           R mn[M];
           trial_mean_rows<R, M, ND, FM, PF, NPF, 0>(cur, opt, cv, mn);
-          if constexpr (HL) trial_lo_rows<R, M, FM, 0>(lo_sys + (long)t * hilo_len<M>(), cv, mn);
+          if constexpr (HL) {
+            if (t >= lo_from) trial_lo_rows<R, M, FM, 0>(lo_sys + (long)t * hilo_len<M>(), cv, mn);
+          }
           LQG_UNROLL for (int i = 0; i < O; ++i) { dO[k][i] = mn[i]; xprev[k][i] = cv[i]; }
           LQG_UNROLL for (int p = 0; p < RR; ++p) muR[k][p] = cv[O + p] + mn[O + p];   // (the stream holds Fj - I)
         }
@@ -956,7 +973,6 @@ __global__ void __launch_bounds__(BLK) k_trial_sp(const R* __restrict__ ops_all,
     // read through `opt`
     auto body = [&](int t, const R (&cur)[NPF], const R* __restrict__ opt) {
   #define LQG_OP(i_) (PF ? cur[PF ? (i_) : 0] : opt[i_])
-      keep(t);
       R Li[O * (O + 1) / 2];
       LQG_UNROLL for (int i = 0; i < O * (O + 1) / 2; ++i) Li[i] = LQG_OP(Ops::L_OFF + i);
       const R hlc = LQG_OP(Ops::H_OFF);
@@ -986,9 +1002,12 @@ __global__ void __launch_bounds__(BLK) k_trial_sp(const R* __restrict__ ops_all,
             LQG_UNROLL for (int j = 0; j < O; ++j) v += LQG_OP(Ops::U_OFF + p * O + j) * w[j];
             cv[O + p] = v;
           }
+          keepc(t, k, cv);
           R mn[M];
           trial_mean_rows<R, M, ND, FM, PF, NPF, 0>(cur, opt, cv, mn);
-          if constexpr (HL) trial_lo_rows<R, M, FM, 0>(lo_sys + (long)t * hilo_len<M>(), cv, mn);
+          if constexpr (HL) {
+            if (t >= lo_from) trial_lo_rows<R, M, FM, 0>(lo_sys + (long)t * hilo_len<M>(), cv, mn);
+          }
           LQG_UNROLL for (int i = 0; i < O; ++i) { dO[k][i] = mn[i]; xprev[k][i] = cv[i]; }
           LQG_UNROLL for (int p = 0; p < RR; ++p) muR[k][p] = cv[O + p] + mn[O + p];   // (the stream holds Fj - I)
         }
@@ -1030,7 +1049,7 @@ __global__ void __launch_bounds__(BLK) k_trial_sp(const R* __restrict__ ops_all,
 // 256-lane workgroup owns up to 256 x TPL trials of one candidate; the operator blocks of CKL steps are fetched ONCE per
 // workgroup by coalesced vector loads into LDS (double-buffered: the next chunk is requested while this one is walked) and
 // read back as LDS broadcasts.  Same arithmetic, same order as k_trial_sp: results agree bitwise (tests/test_gpu_parity.py).
-// CKT > 0 keeps the mean state every CKT steps (TrialArgs::tck), as k_trial_sp<..., CKT>.
+// CKT > 0 keeps the restart data of every CKT-th row (TrialArgs::tck), as k_trial_sp<..., CKT>.
 #ifndef LQG_TRIAL_LDS_BLOCK
 #define LQG_TRIAL_LDS_BLOCK 256
 #endif
@@ -1086,17 +1105,18 @@ __global__ void __launch_bounds__(LQG_TRIAL_LDS_BLOCK) k_trial_lds(const R* __re
       if (i < CKN) lops[buf][i] = nx[q];
     }
   };
-  [[maybe_unused]] auto keep = [&](int t) LQG_LAMBDA_INLINE {
+  // CKT > 0: what the reverse-mode sweep restarts a chunk from.  The mean state (dO, muR) entering row t + 1 is a function of
+  // this step's (x_t, c_t) and operator — so the RR reals of c_t are kept (not the M of the state: half the checkpoint traffic
+  // for the tracking models), as record (t + 1) / CKT when t + 1 starts a chunk, and as record nckt for the last row.
+  [[maybe_unused]] auto keepc = [&](int t, int k, const R (&cv)[M]) LQG_LAMBDA_INLINE {
     if constexpr (CKT > 0) {
-      if ((t % CKT) == 0 || t == a.T) {
-        const int rec = t == a.T ? a.nckt : t / CKT;
-        R* dst = a.tck + ((sys * (a.nckt + 1) + rec) * M) * a.npad;
-        LQG_UNROLL for (int k = 0; k < TPL; ++k)
-          if (live[k]) {
-            const long n = n0 + (long)k * BLK;
-            LQG_UNROLL for (int i = 0; i < O; ++i) dst[i * a.npad + n] = dO[k][i];
-            LQG_UNROLL for (int i = 0; i < RR; ++i) dst[(O + i) * a.npad + n] = muR[k][i];
-          }
+      const int tn = t + 1;
+      if ((tn % CKT) == 0 || tn == a.T) {
+        if (live[k]) {
+          const int rec = tn == a.T ? a.nckt : tn / CKT;
+          R* dst = a.tck + ((sys * (a.nckt + 1) + rec) * RR) * a.npad + n0 + (long)k * BLK;
+          LQG_UNROLL for (int i = 0; i < RR; ++i) dst[i * a.npad] = cv[O + i];
+        }
       }
     }
   };
@@ -1112,7 +1132,6 @@ __global__ void __launch_bounds__(LQG_TRIAL_LDS_BLOCK) k_trial_lds(const R* __re
       const int t = c * CKL + j;
       if (t <= a.T) {
         const R* __restrict__ opt = lops[obuf] + j * Ops::N;
-        keep(t);
         R Li[O * (O + 1) / 2];
         LQG_UNROLL for (int i = 0; i < O * (O + 1) / 2; ++i) Li[i] = opt[Ops::L_OFF + i];
         const R hlc = opt[Ops::H_OFF];
@@ -1142,6 +1161,7 @@ __global__ void __launch_bounds__(LQG_TRIAL_LDS_BLOCK) k_trial_lds(const R* __re
               LQG_UNROLL for (int q = 0; q < O; ++q) v += opt[Ops::U_OFF + p * O + q] * w[q];
               cv[O + p] = v;
             }
+            keepc(t, k, cv);
             R mn[M];
             trial_mean_rows<R, M, ND, FM, false, 1, 0>(none, opt, cv, mn);
             LQG_UNROLL for (int i = 0; i < O; ++i) { dO[k][i] = mn[i]; xprev[k][i] = cv[i]; }

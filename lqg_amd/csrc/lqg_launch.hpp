@@ -52,7 +52,7 @@ inline bool affine(const lqg_problem* p) {
 struct Workspace {
   size_t ls_off, ls_bytes, ops_off, ops_bytes, total;
   long ldb;
-  size_t lo_off, hl_off;      // LQG_F32_SYS64 only (0 otherwise): residual stream of the operator's F block, per-system flags
+  size_t lo_off, hl_off;      // LQG_F32_SYS64 only (0 otherwise): residual stream of the operator's F block, per-system first step + 1
 };
 // reals per step of the residual stream (the dense m x m image of the Fj - I block's rounding residual)
 inline size_t hilo_reals(const lqg_dims& d) {

@@ -39,7 +39,8 @@ struct TrialChunkArgs {
   R* phi;            // [sys][n_chunks-1][M][M]
   double* part;      // [sys][n_chunks][n_trials]
   // MIXED mode (ForwardArgs::ops_lo / hl in lqg_kernels.hpp), kernels compiled with HLC: the systems flagged in hl add the
-  // rounding residual of the operator's Fj - I block to every mean update (hi + lo), unit-vector pushes included
+  // rounding residual of the operator's Fj - I block to the mean updates from step hl[sys] - 1 on (hi + lo), unit-vector
+  // pushes included
   const float* ops_lo;
   const int* hl;
 };
@@ -128,8 +129,12 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial_zs(const R* __restrict__ op
   const int t0 = c * a.chunk_len, t1 = t0 + a.chunk_len;               // (c <= n_chunks - 2: the chunk is complete)
   const R* __restrict__ op = ops_all + (sys * (long)(a.T + 1) + t0) * Ops::N;
   [[maybe_unused]] const float* lo = nullptr;
+  [[maybe_unused]] int lo_from = 0;                      // (hl[sys] = 1 + the first step with a residual block, 0 = none)
   if constexpr (HLC) {
-    if (a.hl && a.hl[sys] != 0) lo = a.ops_lo + (sys * (long)(a.T + 1) + t0) * hilo_len<M>();
+    if (a.hl && a.hl[sys] != 0) {
+      lo = a.ops_lo + (sys * (long)(a.T + 1) + t0) * hilo_len<M>();
+      lo_from = a.hl[sys] - 1;
+    }
   }
   const R* xr[TPL];
   bool live[TPL];
@@ -151,7 +156,7 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial_zs(const R* __restrict__ op
       R xt[O];
       LQG_UNROLL for (int i = 0; i < O; ++i) xt[i] = xq[k][i];
       LQG_UNROLL for (int i = 0; i < O; ++i) xq[k][i] = hom ? R(0) : xr[k][row * a.x.st + i * a.x.sd];
-      (void)tc_step<R, M, ND, FMP, HLC>(op, xt, xprev[k], dO[k], muR[k], true, lo);
+      (void)tc_step<R, M, ND, FMP, HLC>(op, xt, xprev[k], dO[k], muR[k], true, t >= lo_from ? lo : nullptr);
     }
     op += Ops::N;
     if constexpr (HLC) {
@@ -213,8 +218,12 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial_ll(const R* __restrict__ op
   const int t1 = last ? a.T : t0 + a.chunk_len;
   const R* __restrict__ op = ops_all + (sys * (long)(a.T + 1) + t0) * Ops::N;
   [[maybe_unused]] const float* lo = nullptr;
+  [[maybe_unused]] int lo_from = 0;                      // (hl[sys] = 1 + the first step with a residual block, 0 = none)
   if constexpr (HLC) {
-    if (a.hl && a.hl[sys] != 0) lo = a.ops_lo + (sys * (long)(a.T + 1) + t0) * hilo_len<M>();
+    if (a.hl && a.hl[sys] != 0) {
+      lo = a.ops_lo + (sys * (long)(a.T + 1) + t0) * hilo_len<M>();
+      lo_from = a.hl[sys] - 1;
+    }
   }
   const R* xr[TPL];
   bool live[TPL];
@@ -250,7 +259,7 @@ __global__ void __launch_bounds__(LQG_BLOCK) k_trial_ll(const R* __restrict__ op
       R xt[O];
       LQG_UNROLL for (int i = 0; i < O; ++i) xt[i] = xq[k][i];
       LQG_UNROLL for (int i = 0; i < O; ++i) xq[k][i] = xr[k][row * a.x.st + i * a.x.sd];
-      const R zz = tc_step<R, M, ND, FMP, HLC>(op, xt, xprev[k], dO[k], muR[k], t < a.T, lo);
+      const R zz = tc_step<R, M, ND, FMP, HLC>(op, xt, xprev[k], dO[k], muR[k], t < a.T, t >= lo_from ? lo : nullptr);
       if (t > 0) part[k] += R(0.5) * zz + hlc;
       if (flush) { acc[k] -= (double)part[k]; part[k] = R(0); }
     }
