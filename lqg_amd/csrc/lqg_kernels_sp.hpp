@@ -362,12 +362,18 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sp_fwd_waves<R, NX + NB>()))
 #if LQG_SP_PREFETCH
   // software pipeline of the two per-step HBM streams: the rows of step t+1 are requested at the top of step t
   R xnx[NT][O], Lnx[NU * NB];
+  // (streamed gains are requested TWO steps ahead: the counter that orders a wave's memory operations is in-order, so a wait for
+  // a gain row requested in the same iteration as the operator stores also waits for those stores — on the MIXED builder, one
+  // wave per SIMD, that exposed ~200 ns per step once the compiler moved the row's first use next to its request)
+  [[maybe_unused]] R Lnx2[CK == 0 ? NU * NB : 1];
   if (FUSED) {
     LQG_UNROLL for (int k = 0; k < NT; ++k)
       LQG_UNROLL for (int i = 0; i < O; ++i) xnx[k][i] = xprev[k][i];
   }
   if constexpr (CK == 0) {
     LQG_UNROLL for (int e = 0; e < NU * NB; ++e) Lnx[e] = a.Ls[e * a.ldb + s];
+    const R* src1 = a.Ls + (long)(a.T > 1 ? 1 : 0) * (NU * NB) * a.ldb + s;
+    LQG_UNROLL for (int e = 0; e < NU * NB; ++e) Lnx2[e] = src1[e * a.ldb];
   }
 #endif
   // ---- checkpointed gains: the chunk's L_t are recomputed backward from the kept S into registers
@@ -508,9 +514,9 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sp_fwd_waves<R, NX + NB>()))
     {   // requests for step t+1 (row t+1 of x always exists; the last step re-reads its own gain row), issued BEFORE the
         // Sigma update below so that ~100 FMAs stand between the loads and the loop back-edge
       if constexpr (CK == 0) {
-        const int tn = (t + 1 < a.T) ? t + 1 : t;
+        const int tn = (t + 2 < a.T) ? t + 2 : a.T - 1;
         const R* src = a.Ls + (long)tn * (NU * NB) * a.ldb + s;
-        LQG_UNROLL for (int e = 0; e < NU * NB; ++e) Lnx[e] = src[e * a.ldb];
+        LQG_UNROLL for (int e = 0; e < NU * NB; ++e) { Lnx[e] = Lnx2[e]; Lnx2[e] = src[e * a.ldb]; }
       }
       if (FUSED) {
         if constexpr (X4) {
