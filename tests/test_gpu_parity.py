@@ -524,6 +524,31 @@ def test_fp32_point_mass_many_trials_hi_lo_operators(B, n):
         assert float(((ll - ref).abs() / scale).max()) < 1e-6, ov
 
 
+@pytest.mark.parametrize("B,n", [(96, 6), (96, 1500), (256, 800)])
+def test_fp32_point_mass_batch_with_and_without_large_operator_blocks(B, n):
+    """One batch in which every second candidate has a large action cost: its F_j - I block stays at 1.0, below LQG_HILO_MIN, so the
+    MIXED mode's builder flags only the others.  The two launches of the one-pass sweep (k_trial_sp and k_trial_sp<HL>; 96 x 1500 on
+    64-lane workgroups, 256 x 800 on the 256 x 2 geometry) and the per-system test of the time-chunked sweep (96 x 6: at most 2048
+    waves of trials) must between them cover every candidate exactly once."""
+    import lqg_amd
+    from lqg_amd import options, workload
+    dev = torch.device("cuda")
+    T, d = 1067, 2
+    gen = torch.Generator(device=dev); gen.manual_seed(9)
+    names = ("action_variability", "sigma_target", "sigma_cursor", "action_cost")
+    kw = {k: workload.log_uniform(B, *workload.RANGES[k], gen, dev, torch.float32) for k in names}
+    kw["action_cost"][1::2] = 1000.0
+    m32 = lqg_amd.PointMassBoundedActor(T=T, device=dev, dtype=torch.float32, **kw)
+    x = lqg_amd.PointMassBoundedActor(T=T, device=dev, dtype=torch.float32).simulate(6, n=n)[..., :d].contiguous()
+    ref = m32.to(torch.float64).log_likelihood(x.double())
+    assert bool(torch.isfinite(ref).all())
+    scale = ref.abs().clamp_min(float(T * d))
+    with options.override(F32_WIDE=0):
+        ll = m32.log_likelihood(x).double()
+    err = (ll - ref).abs() / scale
+    assert float(err[0::2].max()) < 1e-6 and float(err[1::2].max()) < 1e-6, (float(err[0::2].max()), float(err[1::2].max()))
+
+
 def test_per_trial_sweep_geometries_are_bitwise_identical():
     """lqg_tuning.trial_lds (round 5): the lane per-trial sweep on 64-lane workgroups, on the wider workgroups the default rule
     takes for many trials x many candidates, with the operator stream staged in LDS (k_trial_lds) and the A/B geometries — the
