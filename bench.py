@@ -28,6 +28,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+import bench_line           # noqa: E402  (the contract line: compaction + the side file; no torch, no GPU)
+
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector == FP32 matrix (MFMA f32) peak
 PEAK_FP64_TFLOPS = 78.6    # datasheet FP64 vector == FP64 matrix peak
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -710,6 +712,7 @@ def leg_one_system(cfg):
                          "per_trial_sweep_ms": ph["trial_ms"], "path": ph["path"],
                          "max_rel_err_vs_fp64_oracle": bc.oracle_check(m, x, ll, n_samples=4)}
         leg["speedup"] = leg["sequential"]["wall_ms"] / leg["time_parallel"]["wall_ms"]
+        leg["value"], leg["unit"] = leg["trials"] / (leg["time_parallel"]["wall_ms"] * 1e-3), "trial-evals/s"
         return leg
     return run
 
@@ -835,6 +838,7 @@ def leg_delay12(torch, args, dev):
                          "systems": 2 * len(pd) + 1 if method == "fd" else 1, "finite": bool(all(v == v for v in g_.values()))}
         except Exception as e:
             legd[key] = {"error": repr(e)[:300]}
+    legd["value"] = legd["trials_1"]["wall_ms"]        # the summary figure of the contract line (unit above: ms per evaluation)
     return legd
 
 
@@ -873,6 +877,9 @@ def leg_delay12_batch(torch, args, dev):
         out[f"candidates_{nc}"] = leg
         del m
         torch.cuda.empty_cache()
+    best = [v["wall_ms"] for v in out["candidates_4096"].values() if isinstance(v, dict) and "wall_ms" in v]
+    if best:
+        out["value"] = min(best)                       # the summary figure: ms per objective sweep of 4096 candidates x 120 trials
     return out
 
 
@@ -1077,6 +1084,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
+    extra = None
     if args.only:
         if world != 1:
             raise SystemExit("--only runs one secondary leg on one GPU")
@@ -1096,9 +1104,9 @@ def main():
                            cpu=(world == 1 and not args.no_cpu_baseline))
         if world == 1 and not args.no_extra and out is not None:
             try:
-                out["extra"] = extra_legs(torch, args, dev)
+                extra = extra_legs(torch, args, dev)
             except Exception as e:          # the secondary legs must never cost the headline line
-                out["extra"] = {"error": repr(e)}
+                extra = {"error": repr(e)}
         elif world > 1 and not args.no_extra:
             # N > 1: BASELINE config 4 literally — 262144 / N trials per rank, one all-reduce per step (strong scaling) — measured
             # collectively by the same ranks after the headline (every rank runs the same code on the same shapes: a failure is
@@ -1112,9 +1120,16 @@ def main():
                 except Exception as e:
                     c4 = {"error": repr(e)[:300]}
             if out is not None:
-                out["extra"] = {"config4_sharded": c4}
+                extra = {"config4_sharded": c4}
     if rank == 0 and out is not None:
-        print(json.dumps(out), flush=True)
+        # ONE line the driver can parse and keep whole (< 8000 characters): the headline + [value, unit, frac] per secondary
+        # leg; the legs in full go to gpurun_out/bench_extra.json (bench_line.py; round 5's 24.6 kB line came back unparsed)
+        if extra is not None:
+            bench_line.write_extra(out, extra, os.path.join(ROOT, bench_line.EXTRA_FILE))
+        if args.only:
+            print(json.dumps(bench_line._strict(out)), flush=True)      # a PMC pass of one leg: that leg in full
+        else:
+            print(json.dumps(bench_line.compact(out, extra)), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
