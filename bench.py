@@ -230,6 +230,16 @@ def collective_info(torch, dist, args, world):
             "devices_visible": int(torch.cuda.device_count()), "device": torch.cuda.get_device_name(torch.cuda.current_device())}
 
 
+def gather_partials(torch, dist, local):
+    """Every rank's partial objective (the fp64 scalar it fed the all-reduce), in rank order, on every rank."""
+    local = local.reshape(1).double()
+    if dist is None:
+        return [float(local.item())]
+    allo = [torch.zeros_like(local) for _ in range(dist.get_world_size())]
+    dist.all_gather(allo, local)
+    return [float(v.item()) for v in allo]
+
+
 def host_specs(torch, np, workload, LQGSpec, system, sel, np_dt):
     """Selected systems of both specs as NumPy arrays; a time-invariant (stride-0) time axis stays a stride-0 broadcast."""
     def host(spec):
@@ -397,12 +407,7 @@ def headline_leg(torch, dist, args, dev, rank, world, dtype_name, log2_batch, st
     fwd_ms = [sum(e[1].elapsed_ms(e[2]) for e in es) for es in ev_sets]
     ll_host = ll[:, 0].double().cpu().numpy()
     ar_us = allreduce_us(torch, dist, 1)
-    local_obj = _hip.sum_trials(ll.view(1, B)).reshape(1)      # this rank's partial objective (what it fed the all-reduce)
-    per_rank_obj = [float(local_obj.item())]
-    if dist is not None:
-        allo = [torch.zeros_like(local_obj) for _ in range(dist.get_world_size())]
-        dist.all_gather(allo, local_obj)
-        per_rank_obj = [float(v.item()) for v in allo]
+    per_rank_obj = gather_partials(torch, dist, _hip.sum_trials(ll.view(1, B)))   # each rank's partial objective (what it fed the all-reduce)
     if rank != 0:
         return None
 
@@ -534,6 +539,7 @@ def config3(torch, dist, args, dev, rank, world):
     obj, elapsed, per_rank, step_ms = timed_steps(torch, dist, step, args.steps, args.warmup)
     ph = plan.phase_ms()
     ar_us = allreduce_us(torch, dist, Bc)
+    per_rank_obj = gather_partials(torch, dist, _hip.sum_trials(plan.run()).sum())   # this rank's share, summed over candidates
     if rank != 0:
         return None
     w = 4 if args.dtype == "f32" else 8
@@ -552,7 +558,7 @@ def config3(torch, dist, args, dev, rank, world):
         "world_size": world if dist is None else dist.get_world_size(),
         "per_rank_s": per_rank, "allreduce_us": ar_us["mean"] if ar_us else None, "allreduce_us_percentiles": ar_us,
         "collective": collective_info(torch, dist, args, world), "share_gpu": bool(args.share_gpu),
-        "objective_checksum": float(obj.sum()),
+        "objective_checksum": float(obj.sum()), "per_rank_objective": per_rank_obj,
         "phase_ms": {"riccati": ph[0], "forward": ph[1], "trial": ph[2]},
         "roofline": config3_roofline(ph, Bc, Nt // world, T, w),
         "best_candidate": int(obj.argmax()), "objective_max": float(obj.max()),
@@ -563,7 +569,9 @@ def config4(torch, dist, args, dev, rank, world, n_total=262144, steps=None, war
     """BASELINE config 4, literally: the 2-D hand model (notebooks/HandModel.ipynb: x = b = 10, u = 2, y = 4, d = 4, T = 1000),
     ONE parameter vector, 262 144 trials sharded over the ranks (262144 / N per rank, contiguous blocks); every
     rank solves the one system itself (a few kB of specs), one all-reduce of the scalar fp64 objective per step.  Strong
-    scaling.  Data are simulated per rank from a rank-dependent seed (the shards of one synthetic data set)."""
+    scaling.  The synthetic data set is defined in 8 blocks of n_total / 8 trials (block k simulated from seed 1400 + k);
+    rank r of N (N | 8) owns the blocks [8 r / N, 8 (r + 1) / N): the SAME data set at every N, so the all-reduced objective of
+    an N-rank run equals the 1-rank run's to fp64 rounding (tests/test_gpu_fullsize.py)."""
     import numpy as np
     import bench_configs as bc
     from lqg_amd import _hip, workload
@@ -574,7 +582,12 @@ def config4(torch, dist, args, dev, rank, world, n_total=262144, steps=None, war
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
     T, n_loc = 1000, n_total // world
     m = bc.hand2d_system(T, dev, dtype)
-    x = workload.pack_trials(m.simulate(1400 + rank, n=n_loc)[..., :4].contiguous())
+    if 8 % world == 0 and n_total % 8 == 0:
+        per = 8 // world
+        x = torch.cat([m.simulate(1400 + rank * per + k, n=n_total // 8)[..., :4] for k in range(per)], dim=0).contiguous()
+    else:                                            # N does not divide 8: rank-seeded shards (not comparable across N)
+        x = m.simulate(1400 + rank, n=n_loc)[..., :4].contiguous()
+    x = workload.pack_trials(x)
     plan = LogLikelihoodPlan(m, x, events=True)
 
     def step():
@@ -588,6 +601,7 @@ def config4(torch, dist, args, dev, rank, world, n_total=262144, steps=None, war
     ph = plan.phase_ms()
     ar_us = allreduce_us(torch, dist, 1)
     ll = plan.run()
+    per_rank_obj = gather_partials(torch, dist, _hip.sum_trials(ll).sum())
     parity = None
     if rank == 0:
         try:
@@ -610,7 +624,8 @@ def config4(torch, dist, args, dev, rank, world, n_total=262144, steps=None, war
         "world_size": world if dist is None else dist.get_world_size(), "per_rank_s": per_rank,
         "allreduce_us": ar_us["mean"] if ar_us else None, "allreduce_us_percentiles": ar_us,
         "collective": collective_info(torch, dist, args, world), "share_gpu": bool(args.share_gpu),
-        "objective_sum": float(obj.sum()), "phase_ms": {"riccati": ph[0], "forward": ph[1], "trial": ph[2]},
+        "objective_sum": float(obj.sum()), "per_rank_objective": per_rank_obj,
+        "phase_ms": {"riccati": ph[0], "forward": ph[1], "trial": ph[2]},
         "max_rel_err_vs_fp64_oracle": parity,
         "roofline": {"bound": "hbm", "kernel": f"per-trial sweep over {n_loc} trajectories per rank (x streamed once)",
                      "kernel_ms": ph[2], "system_sweeps_ms": ph[0] + ph[1], "achieved": b4 / (ph[2] * 1e-3) / 1e9,

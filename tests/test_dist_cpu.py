@@ -6,6 +6,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -130,11 +131,15 @@ def test_shard_bounds_cover_everything():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_trial_and_candidate_sharding_world2(tmp_path, oracle_lib):
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 8])
+def test_trial_and_candidate_sharding(tmp_path, oracle_lib, world):
+    """world 2 and world 8 (the node the driver scales to).  Nothing divides evenly at 8: 9 trials -> shards of 2,1,1,...;
+    3 candidates and the 5 trials per condition -> EMPTY shards on the upper ranks (they contribute zeros to the all-reduce
+    and zero-length blocks to the all-gather); the result equals the single-process value on every rank."""
+    port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    r0, r1 = np.load(tmp_path / "r0.npy"), np.load(tmp_path / "r1.npy")
-    assert np.array_equal(r0, r1)            # identical on every rank after the all-reduce
+    rs = [np.load(tmp_path / f"r{r}.npy") for r in range(world)]
+    assert all(np.array_equal(rs[0], r) for r in rs[1:])            # identical on every rank after the all-reduce
 
 
 def test_bench_gpus_n_starts_n_ranks_itself():

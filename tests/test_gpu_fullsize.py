@@ -212,6 +212,54 @@ def test_two_ranks_share_the_gpu_config3_trial_split():
     assert abs(two["objective_max"] / one["objective_max"] - 1) < 1e-12
 
 
+def test_eight_ranks_share_the_gpu_headline():
+    """The 8-rank flow the driver's scaling run will take (VERDICT r05 task 5), on the one GPU there is: eight ranks, eight
+    different shards (seed 1234 + rank), eight distinct partial objectives whose sum is the all-reduced objective; rank 0's
+    partial equals the single-rank run's."""
+    common = ["--log2-batch", "14", "--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline"]
+    one = _run_bench(*common)
+    eight = _run_bench("--gpus", "8", "--share-gpu", *common)
+    assert eight["n_gpus"] == 8 and eight["world_size"] == 8 and eight["collective"]["world_size"] == 8 and eight["share_gpu"]
+    pr = eight["per_rank_objective"]
+    assert len(pr) == 8 and len(set(pr)) == 8 and len(eight["per_rank_solves_per_s"]) == 8
+    assert abs(pr[0] / one["objective_sum"] - 1) < 1e-12
+    assert abs(sum(pr) / eight["objective_sum"] - 1) < 1e-12
+    assert eight["scaling"] == "weak" and eight["all_finite"] and eight["parity"]["max_rel_err_vs_fp64_oracle"] < 1e-6
+    assert abs(eight["value"] * eight["ms_per_step"] * 1e-3 / (8 * 2 ** 14) - 1) < 1e-9     # whole-job aggregate over all ranks
+
+
+def test_eight_ranks_share_the_gpu_config3_128_trials_per_rank():
+    """`--config 3` over 8 ranks: every rank holds all 4096 candidates and 128 of the 1024 trials; the all-reduced [4096]
+    objective equals the single-rank one to fp64 rounding; eight distinct partial objectives."""
+    common = ["--config", "3", "--steps", "2", "--warmup", "1"]
+    one = _run_bench(*common)
+    eight = _run_bench("--gpus", "8", "--share-gpu", *common)
+    assert eight["n_gpus"] == 8 and eight["world_size"] == 8 and eight["scaling"] == "strong"
+    assert eight["config"]["trials_per_rank"] == 128 and len(eight["per_rank_s"]) == 8
+    pr = eight["per_rank_objective"]
+    assert len(pr) == 8 and len(set(pr)) == 8
+    assert abs(sum(pr) / eight["objective_checksum"] - 1) < 1e-12
+    assert eight["best_candidate"] == one["best_candidate"]
+    assert abs(eight["objective_checksum"] / one["objective_checksum"] - 1) < 1e-12
+    assert abs(eight["objective_max"] / one["objective_max"] - 1) < 1e-12
+
+
+def test_eight_ranks_share_the_gpu_config4_32768_trials_per_rank():
+    """`--config 4` literally: 262 144 trials of the 2-D hand model, 32 768 per rank over 8 ranks.  The data set is defined in
+    8 seeded blocks, so the 1-rank run (all 8 blocks) and the 8-rank run (one block each) score the SAME trials: the objective
+    agrees to fp64 rounding of the partial sums."""
+    common = ["--config", "4", "--steps", "2", "--warmup", "1"]
+    one = _run_bench(*common)
+    eight = _run_bench("--gpus", "8", "--share-gpu", *common)
+    assert one["config"]["trials_per_rank"] == 262144 and eight["config"]["trials_per_rank"] == 32768
+    assert eight["n_gpus"] == 8 and eight["world_size"] == 8 and eight["scaling"] == "strong"
+    pr = eight["per_rank_objective"]
+    assert len(pr) == 8 and len(set(pr)) == 8
+    assert abs(sum(pr) / eight["objective_sum"] - 1) < 1e-12
+    assert abs(eight["objective_sum"] / one["objective_sum"] - 1) < 1e-12
+    assert eight["max_rel_err_vs_fp64_oracle"] < 1e-6 and one["max_rel_err_vs_fp64_oracle"] < 1e-6
+
+
 def test_driver_launch_line_on_rccl_with_one_rank():
     """The launch line the driver uses for N > 1 — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
     127.0.0.1 --master-port P bench.py --gpus N ...` — at N = 1 on the one GPU there is: the process group comes up on the `nccl`

@@ -81,25 +81,39 @@ def _compile_worker(pat_dir, q):
     import ctypes as C
     from lqg_amd import specialize as sp
     importlib.reload(sp)
+    # count compiler invocations: a wrapper that logs one line per call, then runs the real hipcc as its child
+    wrapper = os.path.join(pat_dir, "hipcc_counted.sh")
+    sp._build.HIPCC = wrapper
     dims, masks, key = sp.class_pattern(lqg_amd.BoundedActor, 2, dim=1)
     so = sp.compile_pattern(key + "_race", dims, masks)
     lib = C.CDLL(so)
-    q.put((so, lib.lqg_log_likelihood_sp is not None))
+    q.put((so, lib.lqg_log_likelihood_sp is not None, os.stat(so).st_ino))
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
-def test_two_processes_compiling_the_same_pattern_both_get_a_loadable_library(tmp_path):
+@pytest.mark.parametrize("nproc", [2, 8])
+def test_processes_compiling_the_same_cold_pattern_compile_once_and_load_one_file(tmp_path, nproc):
+    """The ranks of one node (2, and the 8 the driver scales to) ask for the same COLD pattern at once: the inter-process lock
+    lets exactly ONE of them run the compiler; all of them load the same finished file (same path, same inode); no temporaries
+    remain."""
     pat_dir = str(tmp_path / "pat")
+    os.makedirs(pat_dir)
+    log = os.path.join(pat_dir, "compiles.log")
+    wrapper = os.path.join(pat_dir, "hipcc_counted.sh")
+    with open(wrapper, "w") as f:
+        f.write(f'#!/bin/bash\necho "$$" >> {log}\n/opt/rocm/bin/hipcc "$@"\n')
+    os.chmod(wrapper, 0o755)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_compile_worker, args=(pat_dir, q)) for _ in range(2)]
+    ps = [ctx.Process(target=_compile_worker, args=(pat_dir, q)) for _ in range(nproc)]
     for p in ps:
         p.start()
-    res = [q.get(timeout=300) for _ in ps]
+    res = [q.get(timeout=600) for _ in ps]
     for p in ps:
         p.join(60)
         assert p.exitcode == 0
-    assert res[0][0] == res[1][0] and all(ok for _, ok in res)
+    assert len({r[0] for r in res}) == 1 and len({r[2] for r in res}) == 1 and all(r[1] for r in res)
+    assert len(open(log).read().split()) == 1, open(log).read()      # exactly one compile
     left = [f for f in os.listdir(pat_dir) if ".tmp." in f]
     assert not left, left                                  # no half-written temporaries remain
     shutil.rmtree(pat_dir, ignore_errors=True)
