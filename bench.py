@@ -772,6 +772,67 @@ def leg_m2(torch, args, dev):
     return out
 
 
+def leg_timevarying(dn):
+    def run(torch, args, dev):
+        """`System.log_likelihood` on genuinely time-varying specs — the reference's literal data model ((T, ...)-stacked arrays,
+        lqg/spec.py:5-19) with every non-zero entry of every matrix moving in time and over the systems, [T][element][system]
+        storage — served by the pattern libraries since round 6 (k_riccati_tv_sp -> k_forward_tv_sp with nothing materialised).
+        Two workloads: `costs_stay_psd` (Q_t, R_t moved by a congruence, as a model whose PARAMETERS move in time produces them:
+        the two 1-D components decouple) is the leg's value; `per_entry_jitter` (mode M2's workload: Q_t loses positive
+        semi-definiteness, the decoupling is rightly refused, the joint n = 10 problem is solved) beside it.  Roofline: the
+        structurally non-zero spec entries + the trajectory, read once."""
+        import numpy as np
+        import bench_m2
+        import bench_configs as bc
+        from lqg_amd import workload
+        from lqg_amd.plan import LogLikelihoodPlan
+        dtype = torch.float32 if dn == "f32" else torch.float64
+        w = 4 if dn == "f32" else 8
+        B, T = 1 << 17, 500
+        out = {"dtype": dn, "systems": B, "T": T, "unit": "solves/s"}
+        for name, psd in (("costs_stay_psd", True), ("per_entry_jitter", False)):
+            system, base = bench_m2.m2_system(dev, dtype, B, T, psd=psd)
+            x = workload.pack_trials(workload.simulate_one_trial_each(base, seed=5))
+            del base
+            plan = LogLikelihoodPlan(system, x, events=True)
+            for _ in range(2):
+                ll = plan.run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ms = []
+            for _ in range(5):
+                e0.record()
+                ll = plan.run()
+                e1.record()
+                e1.synchronize()
+                ms.append(e0.elapsed_time(e1))
+            ms = float(np.median(ms))
+            ph = plan.phase_ms()
+            # bytes the sweeps must read: the non-zero entries of every time-varying field per step + the trajectory rows
+            from lqg_amd import _hip
+            nz = 0
+            for comp, cols, _ in (system.decoupled(4) or [(system, [0, 1, 2, 3], None)]):
+                mk = _hip._time_varying_pattern(None, comp, len(cols))[1]       # (cached on the component by the plan)
+                nz += sum(int(mk[k].sum()) for k in ("Aa", "Ba", "Fa", "Va", "Wa", "Ad", "Bd", "Fd", "Vd", "Wd"))
+                nz += sum(int(np.triu(mk[k]).sum()) for k in ("Q", "Rr"))        # symmetric: the upper triangle is loaded
+            alg = B * (T * nz + (T + 1) * 4 + 1) * w
+            leg = {"ms": ms, "solves_per_s": B / (ms * 1e-3), "components": len(plan.work), "path": plan.description,
+                   "specialised": [bool(wk["specialised"]) for wk in plan.work], "phase_ms": {"riccati": ph[0], "forward": ph[1]},
+                   "nonzero_spec_entries_per_step": nz, "algorithmic_bytes_per_launch_set": alg,
+                   "hbm_frac_algorithmic": alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                   "max_rel_err_vs_fp64_oracle": bc.oracle_check(system, x, ll, n_samples=6)}
+            out[name] = leg
+            del plan, system, x, ll
+            torch.cuda.empty_cache()
+        out["value"] = out["costs_stay_psd"]["solves_per_s"]
+        out["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS,
+                           "achieved": out["costs_stay_psd"]["hbm_frac_algorithmic"] * PEAK_HBM_GBS,
+                           "frac": out["costs_stay_psd"]["hbm_frac_algorithmic"], "traffic": None,
+                           "kernel": "k_riccati_tv_sp + k_forward_tv_sp over both decoupled components (spec entries streamed once per step)"}
+        return out
+    return run
+
+
 def leg_config3(torch, args, dev):
     # BASELINE config 3 at its literal shape (4096 candidates x 1024 trials, T = 1067): trial-evals/s, k_trial_sp time
     class A3:
@@ -1042,7 +1103,7 @@ LEGS = {
     "specialised_joint_n6": leg_specialised_joint,
     "dense_generic_f32": leg_dense_generic("f32"), "dense_generic_f64": leg_dense_generic("f64"),
     "config2_one_system": leg_one_system(2), "config4_one_system": leg_one_system(4),
-    "one_vector_value_and_grad": leg_one_vector, "m2_f32": leg_m2, "config3": leg_config3, "config4_sharded": leg_config4,
+    "one_vector_value_and_grad": leg_one_vector, "m2_f32": leg_m2, "timevarying_f64": leg_timevarying("f64"), "config3": leg_config3, "config4_sharded": leg_config4,
     "config5_one_system": leg_config5_one_system, "delay12": leg_delay12, "delay12_batch": leg_delay12_batch,
 }
 

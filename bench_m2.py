@@ -43,18 +43,36 @@ def soa(base, T, B, gen, jitter, sym=False, positive_diag=False):
     return out
 
 
-def m2_system(dev, dtype, B, T):
+def soa_congruent(base, T, B, gen, jitter):
+    """base[B, n, n] symmetric -> D_t base D_t with D_t = diag(1 + jitter xi_t): every non-zero entry moves in time and over the
+    systems, positive semi-definiteness and the sparsity pattern are kept (a congruence).  Layout as soa()."""
+    n = base.shape[-1]
+    dg = 1.0 + jitter * torch.randn((T, n, B), dtype=base.dtype, device=base.device, generator=gen)
+    phys = (base.permute(1, 2, 0).unsqueeze(0) * dg.unsqueeze(2) * dg.unsqueeze(1)).contiguous()
+    out = phys.permute(3, 0, 1, 2)
+    assert out.stride(0) == 1 and out.stride(1) == n * n * B, out.stride()
+    return out
+
+
+def m2_system(dev, dtype, B, T, psd=False):
     """The headline model with every non-zero entry of every spec matrix moving in time and over the systems (multiplicative
-    jitter): genuinely time-varying [T, ...] stacks in the [T][element][system] layout.  -> (system, time-invariant base)."""
+    jitter): genuinely time-varying [T, ...] stacks in the [T][element][system] layout.  -> (system, time-invariant base).
+
+    psd=False (mode M2's workload since round 3): every entry of Q and R jitters on its own — Q_t of the tracking models has a
+    zero eigenvalue, so it is no longer positive semi-definite, the eigenvalue floor of lqr.py:27-28 cannot be proven inactive
+    and the exact block decoupling is (rightly) refused: the joint n = 10 problem is solved.  psd=True: the costs move by a
+    congruence D_t Q D_t (what a model whose PARAMETERS move in time produces: the costs stay costs) — the two 1-D components
+    decouple as for the time-invariant model."""
     gen = torch.Generator(device=dev)
     gen.manual_seed(4321)
     base, _ = workload.headline_system(B, T, seed=77, device=dev, dtype=dtype)
     a0, d0 = base.actor, base.dynamics
     first = lambda t: t[:, 0] if t.dim() == 4 else t[0].expand(B, *t.shape[1:])
     jit = 1e-3
+    cost = (lambda t: soa_congruent(first(t), T, B, gen, jit)) if psd else (lambda t: soa(first(t), T, B, gen, jit, sym=True))
     act = dict(A=soa(first(a0.A), T, B, gen, jit), B=soa(first(a0.B), T, B, gen, jit), F=soa(first(a0.F), T, B, gen, jit),
                V=soa(first(a0.V), T, B, gen, jit), W=soa(first(a0.W), T, B, gen, jit),
-               Q=soa(first(a0.Q), T, B, gen, jit, sym=True), R=soa(first(a0.R), T, B, gen, jit, sym=True))
+               Q=cost(a0.Q), R=cost(a0.R))
     actor = lqg_amd.LQGSpec(Q=act["Q"], q=a0.q, Qf=a0.Qf if a0.Qf.dim() == 3 else a0.Qf, qf=a0.qf, P=a0.P, R=act["R"],
                             r=a0.r, A=act["A"], B=act["B"], V=act["V"], F=act["F"], W=act["W"])
     dyn = lqg_amd.LQGSpec(Q=d0.Q, q=d0.q, Qf=d0.Qf, qf=d0.qf, P=d0.P, R=d0.R, r=d0.r,
@@ -71,6 +89,18 @@ def m2_pattern():
     system, _ = m2_system(torch.device("cpu"), torch.float64, 4, 3)
     dims, masks = specialize.pattern_of_time_varying(system, 4)
     return dims, masks, specialize.pattern_key(dims, masks)
+
+
+def tv_component_patterns():
+    """[(dims, masks, key)] of the decoupled components of the psd=True workload (bench.py leg `timevarying_f64`,
+    tests/test_gpu_timevarying.py): what `System.log_likelihood` asks the pattern cache for on such a model."""
+    from lqg_amd import specialize
+    system, _ = m2_system(torch.device("cpu"), torch.float64, 4, 3, psd=True)
+    out = {}
+    for sub, cols, _ in (system.decoupled(4, None) or [(system, [0, 1, 2, 3], None)]):
+        dims, masks = specialize.pattern_of_time_varying(sub, len(cols))
+        out[specialize.pattern_key(dims, masks)] = (dims, masks, specialize.pattern_key(dims, masks))
+    return list(out.values())
 
 
 def run(dev, dtype_name="f32", log2_batch=17, T=500, reps=5):

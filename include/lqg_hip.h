@@ -123,7 +123,10 @@ typedef struct lqg_tuning {
                                     two trials per lane, from 768 trials per system and 256 systems: a candidate's trials walk
                                     its operator stream together through one CU's scalar cache), -1 64-lane workgroups,
                                     1 k_trial_lds (operators staged in LDS), 2 .. 5 A/B geometries (csrc/lqg_sp_entry.hpp)  */
-  int32_t reserved[1];           /* must be 0                                                                           */
+  int32_t hilo;                  /* LQG_F32_SYS64 through a pattern library: 0 rule (the residual stream of the operator's Fj - I
+                                    block is sized by lqg_workspace_bytes and hi + lo operators serve the systems whose block
+                                    reaches 2.0), -1 off: no residual stream in the workspace, operators rounded once for every
+                                    system (what the generic kernels of the main library do in any case)                   */
 } lqg_tuning;
 
 typedef struct lqg_problem {

@@ -43,8 +43,7 @@ class Tuning(C.Structure):
     """include/lqg_hip.h: lqg_tuning (all zero = the library's default rules; filled by lqg_amd.options.fill_tuning)."""
     _fields_ = [(n, C.c_int32) for n in ("coop", "trial_chunks", "trial_chunk_waves", "trial_chunk_max_waves", "trial_chunk_tpl",
                                           "coop_trial_chunks", "coop_trial_rows", "coop_sparse", "scan_lane", "scan_rt_waves",
-                                          "coop_adjoint", "scan_order", "coop_trial_tpb", "coop_trial_wide", "trial_lds")] + \
-               [("reserved", C.c_int32 * 1)]
+                                          "coop_adjoint", "scan_order", "coop_trial_tpb", "coop_trial_wide", "trial_lds", "hilo")]
 
 
 class Problem(C.Structure):

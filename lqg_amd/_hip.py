@@ -275,8 +275,11 @@ def specialised_entry(ln, system, d):
 def specialised_library(ln, system, d, check_strategy=True):
     """The structure-specialised library for this launch, or None (lqg_amd/specialize.py).
 
-    Eligible: every spec field time-invariant, no affine cost terms.  LQG_NO_SPECIALIZE=1 forces the generic dense
-    library (A/B measurements, tests)."""
+    Time-invariant specs without affine cost terms: the pattern of the spec VALUES (zoo classes: of the class).  Specs that vary
+    in time (the reference's data model is (T, ...)-stacked: lqg/spec.py:5-19, lqg/utils.py:10-35) and / or carry affine cost
+    terms, as long as they keep one sparsity pattern over systems and steps (round 6): the conservative masks of
+    specialize.pattern_of_time_varying; `lqg_log_likelihood_sp` then runs k_riccati_tv_sp -> k_forward_tv_sp (csrc/lqg_sp_entry.hpp:
+    run_sp_tv).  LQG_NO_SPECIALIZE=1 forces the generic dense library (A/B measurements, tests)."""
     import os
     if system is None or options.flag("NO_SPECIALIZE") or ln.p.n_trials < 1:
         return None
@@ -284,16 +287,33 @@ def specialised_library(ln, system, d, check_strategy=True):
         return None             # (pattern libraries hold lane kernels: one system's matrices in registers)
     if check_strategy and _abi.load().lqg_strategy(C.byref(ln.p)) == _abi.STRATEGY_COOP:
         return None             # few systems of a large joint dimension: the cooperative kernels of the main library
-    p = ln.p
-    for spec, fields in ((p.actor, ("Q", "R", "A", "B", "V", "F", "W")), (p.dynamics, ("A", "B", "V", "F", "W"))):
-        for f in fields:
-            if getattr(spec, f).st != 0 and ln.T > 1:
-                return None
-    if any(getattr(p.actor, f).ptr for f in ("q", "qf", "P", "r")):
-        return None
     from lqg_amd import specialize
-    dims, masks, key = specialize.system_pattern(system, d)
+    if _varies_or_affine(ln):
+        dims, masks, key = _time_varying_pattern(ln, system, d)
+    else:
+        dims, masks, key = specialize.system_pattern(system, d)
     return specialize.load_pattern(key, dims, masks)
+
+
+def _varies_or_affine(ln):
+    """True when the launch's specs vary in time (a non-zero time stride at T > 1) or carry affine cost terms: what the
+    time-invariant kernels of the pattern libraries do not serve."""
+    p = ln.p
+    varying = ln.T > 1 and any(getattr(spec, f).st != 0 for spec, fields in ((p.actor, ("Q", "R", "A", "B", "V", "F", "W")),
+                                                                             (p.dynamics, ("A", "B", "V", "F", "W"))) for f in fields)
+    return varying or any(getattr(p.actor, f).ptr for f in ("q", "qf", "P", "r"))
+
+
+def _time_varying_pattern(ln, system, d):
+    """(dims, masks, key) of specialize.pattern_of_time_varying, cached on the system per (d, versions of its spec tensors): the
+    masks are reductions over every system and step — a few launches, not something to repeat per evaluation."""
+    from lqg_amd import specialize
+    cache = system.__dict__.setdefault("_lqg_materialised_pattern", {})
+    key = (int(d), specialize.spec_versions(system), "tv")
+    if key not in cache:
+        dims, masks = specialize.pattern_of_time_varying(system, d)
+        cache[key] = (dims, masks, specialize.pattern_key(dims, masks))
+    return cache[key]
 
 
 def materialised_entry(ln, system, d):
@@ -311,11 +331,7 @@ def materialised_entry(ln, system, d):
     if key not in cache:
         varying = any(getattr(spec, f).st != 0 for spec, fields in ((ln.p.actor, ("Q", "R", "A", "B", "V", "F", "W")),
                                                                     (ln.p.dynamics, ("A", "B", "V", "F", "W"))) for f in fields)
-        if varying and ln.T > 1:
-            dims, masks = specialize.pattern_of_time_varying(system, d)
-            cache[key] = (dims, masks, specialize.pattern_key(dims, masks))
-        else:
-            cache[key] = specialize.system_pattern(system, d)
+        cache[key] = _time_varying_pattern(ln, system, d) if (varying and ln.T > 1) else specialize.system_pattern(system, d)
     dims, masks, pkey = cache[key]
     lib = specialize.load_pattern(pkey, dims, masks)
     return getattr(lib, "lqg_solve_materialised_sp", None) if lib is not None else None

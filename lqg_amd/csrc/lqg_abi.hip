@@ -209,7 +209,7 @@ int check_problem(const lqg_problem* p, const char* who, bool mixed = false) {
       tn.trial_lds < -1 || tn.trial_lds > 5 || tn.coop_adjoint < 0 || tn.coop_adjoint > 1 || tn.scan_order < -1 || tn.scan_order > 2 ||
       (tn.scan_rt_waves != 0 && tn.scan_rt_waves != 8 && tn.scan_rt_waves != 16) || tn.trial_chunks < -1 ||
       tn.coop_trial_chunks < -1 || tn.trial_chunk_waves < 0 || tn.trial_chunk_max_waves < 0 || tn.trial_chunk_tpl < 0 ||
-      tn.trial_chunk_tpl > 2 || tpb < 0 || tpb > 128 || (tpb & (tpb - 1)) != 0 || tn.reserved[0] != 0)
+      tn.trial_chunk_tpl > 2 || tpb < 0 || tpb > 128 || (tpb & (tpb - 1)) != 0 || tn.hilo < -1 || tn.hilo > 0)
     return fail(LQG_ERR_ARG, "%s: lqg_tuning holds a value outside its documented range (include/lqg_hip.h)", who);
   return 0;
 }

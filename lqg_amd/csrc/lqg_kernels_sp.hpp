@@ -81,13 +81,14 @@ constexpr int sp_chunk() {
 // one backward step: S <- Q + A'SA + L'HL + L'G + G'L with L = -Ht^-1 G (lqr.py:22-34), L returned
 template <typename R, int NB, int NU, typename MA, typename MB, typename MQ, typename MR>
 LQG_DEV void riccati_step_sp(R (&S)[NB * NB], const MA& A, const MB& Bm, const MQ& Q, const MR& Rm, const R eps,
-                             R (&L)[NU * NB], R* Ht_out = nullptr) {
+                             R (&L)[NU * NB], R* Ht_out = nullptr, const R* Pc = nullptr) {
   const auto Sm = from_dense<R, NB, NB>(S);
   const auto SA = mul(Sm, A);
   const auto SB = mul(Sm, Bm);
   R H[NU * NU], G[NU * NB];
   to_dense(mul_tn_sym_add(Bm, SB, Rm), H);                       // H = R + B^T S B     lqr.py:22
   to_dense(mul_tn(Bm, SA), G);                                   // G = B^T S A         lqr.py:23
+  if (Pc) { LQG_UNROLL for (int i = 0; i < NU * NB; ++i) G[i] += Pc[i]; }   // G = P + B^T S A (cross cost; dense, time-varying sweeps only)
   R ev0 = min_eig_sym<R, NU>(H);
   R shift = eps - ev0;
   shift = (shift > R(0)) ? shift : R(0);
@@ -607,8 +608,13 @@ __global__ void __launch_bounds__(LQG_BLOCK, 2) k_riccati_tv_sp(const RiccatiArg
     const auto Bm = load_masked<R, NB, NU, PAT::Ba>(a.B.p + s * a.B.sb + t * a.B.st, a.B.sr, a.B.sc);
     const auto Q = load_sym_masked<R, NB, PAT::Q>(a.Q.p + s * a.Q.sb + t * a.Q.st, a.Q.sr, a.Q.sc);
     const auto Rm = load_sym_masked<R, NU, PAT::Rr>(a.Rm.p + s * a.Rm.sb + t * a.Rm.st, a.Rm.sr, a.Rm.sc);
-    R L[NU * NB], Ht[NU * NU];
-    riccati_step_sp<R, NB, NU>(S, A, Bm, Q, Rm, a.eps, L, Ht);
+    R L[NU * NB], Ht[NU * NU], Pc[NU * NB];
+    if (a.P.p) {                                   // cross cost u' P x (lqr.py:23).  q, qf, r only move the affine gain l and the
+      const R* pp = a.P.p + s * a.P.sb + t * a.P.st;   // cost-to-go offset s (lqr.py:24, 31, 34): neither enters L, S or the likelihood
+      LQG_UNROLL for (int i = 0; i < NU; ++i)
+        LQG_UNROLL for (int j = 0; j < NB; ++j) Pc[i * NB + j] = pp[i * a.P.sr + j * a.P.sc];
+    }
+    riccati_step_sp<R, NB, NU>(S, A, Bm, Q, Rm, a.eps, L, Ht, a.P.p ? Pc : nullptr);
     if (a.Ls) {                                    // (null when the caller's L output doubles as the forward sweep's gain stream)
       R* dst = a.Ls + (long)t * (NU * NB) * a.ldb + s;
       LQG_UNROLL for (int e = 0; e < NU * NB; ++e) dst[e * a.ldb] = L[e];
@@ -622,9 +628,12 @@ __global__ void __launch_bounds__(LQG_BLOCK, 2) k_riccati_tv_sp(const RiccatiArg
   }
 }
 
-template <typename R, int NX, int NB, int NU, int NY, int ND, typename PAT, bool DENSE_P>
+// FUSED = false (round 6: lqg_log_likelihood_sp for time-varying specs with several trials per system, or in the mixed mode): no
+// trial is swept in-lane; the step's trial operator goes to the operator stream (element type OT, as k_forward_sp) for k_trial_sp.
+template <typename R, int NX, int NB, int NU, int NY, int ND, typename PAT, bool DENSE_P, bool FUSED = true, typename OT = R>
 __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? 2 : 1) k_forward_tv_sp(const ForwardArgs<R> a, const DView<R> Lv) {
   constexpr int M = NX + NB, O = ND, RR = M - ND;
+  using Ops = TrialOps<M, ND>;
   const long s = blockIdx.x * (long)LQG_BLOCK + threadIdx.x;
   if (s >= a.n_sys) return;
   constexpr auto PMASK = kalman_state_mask<PAT, NB, NY, DENSE_P>();
@@ -638,8 +647,8 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? 2 : 1) k_forward_t
   }
   R Sg[M * M], xprev[O], dO[O], muR[RR];
   double acc = 0.0;
-  const R* xp = a.x.p + s * a.x.sb;
-  LQG_UNROLL for (int i = 0; i < O; ++i) { xprev[i] = xp[i * a.x.sd]; dO[i] = R(0); }
+  const R* xp = FUSED ? a.x.p + s * a.x.sb : nullptr;
+  LQG_UNROLL for (int i = 0; i < O; ++i) { xprev[i] = FUSED ? xp[i * a.x.sd] : R(0); dO[i] = R(0); }
   LQG_UNROLL for (int i = 0; i < RR; ++i) muR[i] = R(0);
   const R kLogNorm = R(0.5 * ND * 1.8378770664093453);
   R Li[O * O], U2[RR * O], hl;
@@ -737,20 +746,34 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? 2 : 1) k_forward_t
     if constexpr (FIRST) to_dense(GG, Sg);                               // Sigma0 := G[0] G[0]^T  system.py:212
     // ---- condition on x_t, score it, propagate the mean                system.py:219-221, 244-248
     condition();
-    innovate(t, !FIRST);
-    R cvec[M], mn[M];
-    LQG_UNROLL for (int j = 0; j < O; ++j) cvec[j] = xt[j];
-    LQG_UNROLL for (int p = 0; p < RR; ++p) {
-      R v = muR[p];
-      LQG_UNROLL for (int j = 0; j < O; ++j) v += U2[p * O + j] * w[j];
-      cvec[O + p] = v;
-    }
-    dev_matvec_row<O, 0>(Fj, cvec, mn);                                  // rows < O as deviation from x_t
-    LQG_UNROLL for (int i = 0; i < O; ++i) { dO[i] = mn[i]; xprev[i] = xt[i]; }
-    LQG_UNROLL for (int p = 0; p < RR; ++p) muR[p] = mn[O + p];
-    if (a.mu.p) {
-      R* dst = const_cast<R*>(a.mu.p) + s * a.mu.sb + (long)t * a.mu.st;
-      LQG_UNROLL for (int i = 0; i < M; ++i) dst[i * a.mu.sd] = (i < O) ? xt[i] + mn[i] : mn[i];
+    if constexpr (FUSED) {
+      innovate(t, !FIRST);
+      R cvec[M], mn[M];
+      LQG_UNROLL for (int j = 0; j < O; ++j) cvec[j] = xt[j];
+      LQG_UNROLL for (int p = 0; p < RR; ++p) {
+        R v = muR[p];
+        LQG_UNROLL for (int j = 0; j < O; ++j) v += U2[p * O + j] * w[j];
+        cvec[O + p] = v;
+      }
+      dev_matvec_row<O, 0>(Fj, cvec, mn);                                  // rows < O as deviation from x_t
+      LQG_UNROLL for (int i = 0; i < O; ++i) { dO[i] = mn[i]; xprev[i] = xt[i]; }
+      LQG_UNROLL for (int p = 0; p < RR; ++p) muR[p] = mn[O + p];
+      if (a.mu.p) {
+        R* dst = const_cast<R*>(a.mu.p) + s * a.mu.sb + (long)t * a.mu.st;
+        LQG_UNROLL for (int i = 0; i < M; ++i) dst[i * a.mu.sd] = (i < O) ? xt[i] + mn[i] : mn[i];
+      }
+    } else {                                                               // the step's trial operator (as k_forward_sp)
+      OT* op = reinterpret_cast<OT*>(a.ops) + ((long)s * (a.T + 1) + t) * Ops::N;
+      const auto FjD = block2x2(restrict_to<PAT::AdmI>(minus_identity(Ad)), mul(Bd, L), mul(K, FAd),
+                                add(sub(minus_identity(Aa), mul(K, FAa)), mul(BK, L)));
+      static_assert(mask_eq(decltype(FjD)::mask, trial_operator_mask<PAT, NX, NB, NU, NY, ND, DENSE_P>()),
+                    "trial_operator_mask() must mirror the mask algebra of the operator built here");
+      store_dense<0>(FjD, op + Ops::F_OFF);
+      LQG_UNROLL for (int i = 0; i < RR * O; ++i) op[Ops::U_OFF + i] = (OT)U2[i];
+      int e = 0;
+      LQG_UNROLL for (int i = 0; i < O; ++i)
+        LQG_UNROLL for (int j = 0; j <= i; ++j) op[Ops::L_OFF + (e++)] = (OT)Li[i * O + j];
+      store_or_nan(&op[Ops::H_OFF], (OT)(hl + kLogNorm), pois >= kPosFiniteLimit<R>);
     }
     // ---- Sigma' = F2 C F2^T + GG,  C = Srr - U2 U2^T                    system.py:223-230
     Mat<R, RR, RR> C;
@@ -768,8 +791,16 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? 2 : 1) k_forward_t
   step.template operator()<true>(0);
   for (int t = 1; t < a.T; ++t) step.template operator()<false>(t);
   condition();
-  innovate(a.T, true);
-  if (a.ll) store_or_nan(&a.ll[s * a.ll_sb], (R)acc, pois >= kPosFiniteLimit<R>);
+  if constexpr (FUSED) {
+    innovate(a.T, true);
+    if (a.ll) store_or_nan(&a.ll[s * a.ll_sb], (R)acc, pois >= kPosFiniteLimit<R>);
+  } else {
+    OT* op = reinterpret_cast<OT*>(a.ops) + ((long)s * (a.T + 1) + a.T) * Ops::N;
+    int e = 0;
+    LQG_UNROLL for (int i = 0; i < O; ++i)
+      LQG_UNROLL for (int j = 0; j <= i; ++j) op[Ops::L_OFF + (e++)] = (OT)Li[i * O + j];
+    store_or_nan(&op[Ops::H_OFF], (OT)(hl + kLogNorm), pois >= kPosFiniteLimit<R>);
+  }
 }
 
 // ---------------------------------------------------------------- per-trial sweep with the operator's structure

@@ -81,7 +81,9 @@ inline Workspace carve(const lqg_problem* p, bool need_ops) {
   w.ops_bytes = need_ops ? (size_t)p->n_sys * (size_t)(p->T + 1) * ops_reals(p->dims) * esz : 0;
   // (+ the scratch of the time-chunked per-trial sweep, lqg_trial_chunk.hpp: by convention it FOLLOWS the operator stream)
   w.total = w.ops_off + (w.ops_bytes + 255) / 256 * 256 + (need_ops ? trial_chunk_scratch(p).total : 0);
-  if (need_ops && p->dtype == LQG_F32_SYS64) {
+  if (need_ops && p->dtype == LQG_F32_SYS64 && p->tuning.hilo >= 0) {
+    // (tuning.hilo = -1: no residual stream — the caller runs the generic kernels, which never read it, or the stream with the
+    // residual would not fit its workspace limit and rounded operators are the better fall-back than leaving the mixed mode)
     // operators rounded ONCE to fp32 carry a systematic error of eps32 |F - I| |state| per step into every trial; where the
     // block is large (point-mass models: whitening gains of 10 .. 70) the per-trial sweep adds the residual back (hi + lo)
     w.lo_off = (w.total + 255) / 256 * 256;

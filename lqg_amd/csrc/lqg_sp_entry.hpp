@@ -238,8 +238,8 @@ int run_sp_mixed(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll
   R* Ls = reinterpret_cast<R*>(base + w.ls_off);
   R* ops = reinterpret_cast<R*>(base + w.ops_off);  // (written as float by the kernel: OT)
   // hi + lo operators for the systems whose Fj - I block is large (lqg_kernels_sp.hpp: LQG_HILO_MIN)
-  float* ops_lo = reinterpret_cast<float*>(base + w.lo_off);
-  int* hl = reinterpret_cast<int*>(base + w.hl_off);
+  float* ops_lo = w.lo_off ? reinterpret_cast<float*>(base + w.lo_off) : nullptr;      // (tuning.hilo = -1: no residual stream)
+  int* hl = w.lo_off ? reinterpret_cast<int*>(base + w.hl_off) : nullptr;
   auto mark = [&](int i) {
     if (p->phase_events[i]) (void)hipEventRecord(static_cast<hipEvent_t>(p->phase_events[i]), st);
   };
@@ -273,6 +273,68 @@ int run_sp_mixed(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll
   return e == hipSuccess ? 0 : (int)e;
 }
 
+// Specs that vary in TIME under the pattern the library is compiled for (round 6; the reference's data model IS (T, ...)-stacked,
+// lqg/spec.py:5-19, lqg/utils.py:10-35): k_riccati_tv_sp -> k_forward_tv_sp load the structurally non-zero entries of every step.
+// One trial per system is swept in-lane; several trials (and the mixed mode LQG_F32_SYS64: fp64 system sweeps over the double
+// spec arrays, operators rounded once to float, no residual stream) go through the operator stream and the pattern's per-trial
+// sweep.  The cross cost P enters G = P + B'SA (lqr.py:23); q, qf, r only move the affine gain l and the offset s of the
+// cost-to-go (lqr.py:24, 31, 34), neither of which the moments or the likelihood read (system.py:169-181 use gains.L) — ignored.
+template <typename PAT, int NX, int NB, int NU, int NY, int ND>
+int run_sp_tv(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll_sn, void* workspace, size_t workspace_bytes,
+              hipStream_t st) {
+  const bool mixed = p->dtype == LQG_F32_SYS64;
+  const bool fused = p->n_trials == 1 && !mixed;
+  const Workspace w = carve(p, !fused);
+  if (!workspace || workspace_bytes < w.total) return LQG_ERR_WORKSPACE;
+  auto mark = [&](int i) {
+    if (p->phase_events[i]) (void)hipEventRecord(static_cast<hipEvent_t>(p->phase_events[i]), st);
+  };
+  const lqg_spec& a = p->actor;
+  const lqg_spec& d = p->dynamics;
+  const lqg_view none{nullptr, 0, 0, 0, 0};
+  const lqg_traj no_traj{nullptr, 0, 0, 0, 0};
+  const dim3 grid(blocks_for(p->n_sys)), block(LQG_BLOCK);
+  char* base = static_cast<char*>(workspace);
+  auto go = [&](auto tag, auto otag) -> hipError_t {
+    using R = decltype(tag);
+    using OT = decltype(otag);
+    R* Ls = reinterpret_cast<R*>(base + w.ls_off);
+    R* ops = fused ? nullptr : reinterpret_cast<R*>(base + w.ops_off);       // (written as OT by the kernel)
+    mark(0);
+    lqg::RiccatiArgs<R> rk{dv<R>(a.Q), dv<R>(none), dv<R>(a.Qf), dv<R>(none), dv<R>(a.P), dv<R>(a.R), dv<R>(none),
+                           dv<R>(a.A), dv<R>(a.B), dv<R>(none), dv<R>(none), dv<R>(none), Ls, w.ldb, (long)p->n_sys,
+                           p->T, (R)p->eps};
+    hipLaunchKernelGGL((lqg::k_riccati_tv_sp<R, NB, NU, PAT>), grid, block, 0, st, rk);
+    mark(1);
+    const lqg::DView<R> Lv{Ls, 1, (long)(NU * NB) * w.ldb, (long)NB * w.ldb, w.ldb};
+    lqg::ForwardArgs<R> fk{dv<R>(a.A), dv<R>(a.B), dv<R>(a.F), dv<R>(a.V), dv<R>(a.W),
+                           dv<R>(d.A), dv<R>(d.B), dv<R>(d.F), dv<R>(d.V), dv<R>(d.W),
+                           dv<R>(p->Sigma0), Ls, w.ldb, dt<R>(fused ? x : no_traj), fused ? static_cast<R*>(ll) : nullptr, ll_sb, ops,
+                           dv<R>(none), dt<R>(no_traj), dv<R>(none), (long)p->n_sys, p->T, p->dims.nva, p->dims.nwa,
+                           p->dims.nvd, p->dims.nwd, nullptr, nullptr};
+    if (fused) {
+      if constexpr (std::is_same_v<R, OT>) {
+        if (p->Sigma0.ptr) hipLaunchKernelGGL((lqg::k_forward_tv_sp<R, NX, NB, NU, NY, ND, PAT, true>), grid, block, 0, st, fk, Lv);
+        else hipLaunchKernelGGL((lqg::k_forward_tv_sp<R, NX, NB, NU, NY, ND, PAT, false>), grid, block, 0, st, fk, Lv);
+      }
+      mark(2);
+      mark(3);
+      return hipGetLastError();
+    }
+    if (p->Sigma0.ptr) hipLaunchKernelGGL((lqg::k_forward_tv_sp<R, NX, NB, NU, NY, ND, PAT, true, false, OT>), grid, block, 0, st, fk, Lv);
+    else hipLaunchKernelGGL((lqg::k_forward_tv_sp<R, NX, NB, NU, NY, ND, PAT, false, false, OT>), grid, block, 0, st, fk, Lv);
+    mark(2);
+    const hipError_t te = trial_sweep_sp<OT, PAT, NX, NB, NU, NY, ND>(p, x, ll, ll_sb, ll_sn, ops, st);
+    mark(3);
+    return te != hipSuccess ? te : hipGetLastError();
+  };
+  hipError_t e;
+  if (mixed) e = go(double{}, float{});
+  else if (p->dtype == LQG_F64) e = go(double{}, double{});
+  else e = go(float{}, float{});
+  return e == hipSuccess ? 0 : (int)e;
+}
+
 template <typename PAT, int NX, int NB, int NU, int NY, int ND>
 int log_likelihood_sp(const lqg_problem* p, lqg_traj x, void* ll, int64_t ll_sb, int64_t ll_sn, void* workspace,
                       size_t workspace_bytes, void* stream) {
@@ -280,8 +342,10 @@ int log_likelihood_sp(const lqg_problem* p, lqg_traj x, void* ll, int64_t ll_sb,
   const lqg_dims& dm = p->dims;
   if (dm.x != NX || dm.b != NB || dm.u != NU || dm.y != NY || dm.d != ND) return LQG_ERR_DIMS;
   if (p->n_trials < 1 || p->T < 1) return LQG_ERR_ARG;
-  if (!forward_ti(p) || !actor_ti_riccati(p) || affine(p)) return LQG_ERR_ARG;
+  if (p->dtype != LQG_F64 && p->dtype != LQG_F32 && p->dtype != LQG_F32_SYS64) return LQG_ERR_ARG;
   if (p->n_sys == 0) return 0;
+  if (!forward_ti(p) || !actor_ti_riccati(p) || affine(p))       // specs that vary in time and / or affine cost terms
+    return run_sp_tv<PAT, NX, NB, NU, NY, ND>(p, x, ll, (long)ll_sb, (long)ll_sn, workspace, workspace_bytes, (hipStream_t)stream);
   if (p->dtype == LQG_F64)
     return run_sp<double, PAT, NX, NB, NU, NY, ND>(p, x, ll, (long)ll_sb, (long)ll_sn, workspace, workspace_bytes,
                                                    (hipStream_t)stream);

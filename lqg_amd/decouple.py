@@ -88,8 +88,16 @@ def _take(t, rows, cols=None, time_axis=True):
         out._lqg_base = base
         return out
     if cols is None:
-        return torch.index_select(t, -1, _index(rows, t.device))
-    return torch.index_select(torch.index_select(t, -2, _index(rows, t.device)), -1, _index(cols, t.device))
+        out = torch.index_select(t, -1, _index(rows, t.device))
+    else:
+        out = torch.index_select(torch.index_select(t, -2, _index(rows, t.device)), -1, _index(cols, t.device))
+    if t.dim() == nd + 2 and t.shape[0] > 1 and t.stride(0) == 1 and out.stride(0) != 1:
+        # a batched time-varying field stored [T][element][system] (workload.pack_systems: a wave's 64 lanes read 64 consecutive
+        # elements per (step, entry)) keeps that storage — index_select returns [system][T][element], 64 cache lines per wave-load
+        perm = tuple(range(1, out.dim())) + (0,)
+        inv = (out.dim() - 1,) + tuple(range(out.dim() - 1))
+        out = out.permute(perm).contiguous().permute(inv)
+    return out
 
 
 _index_cache = {}

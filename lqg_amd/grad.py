@@ -107,7 +107,8 @@ class Sweep:
                 self.slabs = 1
                 self.nbytes = int(self.sp.lqg_grad_workspace_bytes_sp(C.byref(ln.p)))
                 if self.nbytes > 0:
-                    self.ws = torch.empty(max(self.nbytes, 256), dtype=torch.uint8, device=ln.device)
+                    self.ws, self.transient = None, False
+                    self._workspace()
                     self.fresh = False
                     return
                 self.sp = None
@@ -142,8 +143,20 @@ class Sweep:
         assert self.total == self.lib.lqg_grad_elements(C.byref(ln.p.dims))
         self.slabs = int(self.lib.lqg_grad_slabs(C.byref(ln.p)))          # 1 (time-invariant) or T (bars per step)
         self.nbytes = int(self.lib.lqg_grad_workspace_bytes(C.byref(ln.p), self.ld))
-        self.ws = torch.empty(max(self.nbytes, 256), dtype=torch.uint8, device=ln.device)
+        self.ws, self.transient = None, False
+        self._workspace()
         self.fresh = False              # True while the workspace holds an unconsumed forward state
+
+    def _workspace(self):
+        if self.ws is None:
+            self.ws = torch.empty(max(self.nbytes, 256), dtype=torch.uint8, device=self.ln.device)
+        return self.ws
+
+    def release(self):
+        """Give the workspace back (and with it the forward state: `reverse` then re-runs the forward sweep).  A `transient` sweep
+        does so after every forward and every reverse: of the pieces of a candidate-chunked evaluation (`_one`) only the one being
+        swept holds a workspace, under autograd too — where all pieces run forward before any runs backward."""
+        self.ws, self.fresh = None, False
 
     def _call(self, phases, g, ll, out):
         ln, N = self.ln, self.N
@@ -152,7 +165,7 @@ class Sweep:
         with torch.cuda.device(ln.device):
             _abi.check(entry(
                 C.byref(ln.p), ln.traj(self.x, self.xb), ptr(g), N if ln.batched else 0, 1, ptr(ll),
-                N if ln.batched else 0, 1, ptr(out), self.ld, ptr(self.ws), self.nbytes, phases, ln.stream()),
+                N if ln.batched else 0, 1, ptr(out), self.ld, ptr(self._workspace()), self.nbytes, phases, ln.stream()),
                 "lqg_log_likelihood_grad")
 
     def forward(self):
@@ -160,6 +173,13 @@ class Sweep:
         self._call(1, None, ll, None)
         self.fresh = True
         return ll if self.out_dtype is None else ll.to(self.out_dtype)
+
+    def forward_value_only(self):
+        """`forward()` of a transient sweep: the value is kept, the workspace is not."""
+        ll = self.forward()
+        if self.transient:
+            self.release()
+        return ll
 
     def reverse(self, g=None):
         """-> {name: [B, N, r, c]} per-(system, trial) bars (lqg_hip.h: order of the gradient elements); with
@@ -173,6 +193,8 @@ class Sweep:
             self.forward()
         self._call(2, g, None, out)
         self.fresh = False
+        if self.transient:
+            self.release()
         bars = {}
         for k, (o, r, c) in self.lay.items():
             v = out[:, o:o + r * c, :self.lanes].reshape(self.slabs, r, c, ln.B, self.per_sys).permute(3, 4, 0, 1, 2)
@@ -303,7 +325,8 @@ class _LogLikelihood(torch.autograd.Function):
         ctx.has_s0 = Sigma0 is not None
         with torch.no_grad():
             ctx.sweep = Sweep(system.actor, system.dynamics, x, Sigma0=Sigma0, system=system)
-            return ctx.sweep.forward()
+            ctx.sweep.transient = bool(getattr(system, "_lqg_transient_workspace", False))
+            return ctx.sweep.forward_value_only()
 
     @staticmethod
     def backward(ctx, g):
@@ -362,9 +385,15 @@ def _one(system, x, Sigma0):
     if chunks is not None and len(chunks) > 1:
         from lqg_amd import workload
         outs = []
+        B = system.n_systems
         for lo, hi in chunks:                      # (slices are views: the bars flow back to the caller's leaves through autograd)
             S0 = Sigma0 if (Sigma0 is None or Sigma0.dim() == 2) else Sigma0[lo:hi]
-            outs.append(_one_piece(workload.slice_system(system, lo, hi), x if x.dim() == 3 else x[lo:hi], S0))
+            piece = workload.slice_system(system, lo, hi)
+            # each piece gives its workspace back after its forward and re-runs the forward sweep inside its backward: under
+            # autograd every piece runs forward before any runs backward, and the workspaces must not coexist
+            piece._lqg_transient_workspace = True
+            xs = x[lo:hi] if (x.dim() == 4 and x.shape[0] == B) else x          # (a [1, n, T+1, d] x is shared, not indexed)
+            outs.append(_one_piece(piece, xs, S0))
         return torch.cat(outs, dim=0)
     return _one_piece(system, x, Sigma0)
 

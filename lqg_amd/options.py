@@ -32,6 +32,7 @@ TRIAL_LDS         ""        lane per-trial sweep with the operator stream staged
 FUSE_TRIALS_MAX   2048      (system, trial) pairs up to which a small multi-trial evaluation runs as fused pairs (0: never)
 MIXED             1         fp32 problems on the operator stream run their system sweeps in fp64 (LQG_F32_SYS64)
 MIXED_MIN_TRIALS  3         trials per system from which they do
+HILO              1         the mixed mode keeps the rounding residual of the operator's Fj - I block (hi + lo operators for systems whose block reaches 2.0); 0: operators rounded once, no residual stream in the workspace -> tuning.hilo
 F32_WIDE          1         ill-conditioned fp32 problems run over an fp64 image of specs and data (plan.F32_MAX_COND)
 F32_MAX_COND      1e7       cond((V V')[:d, :d]) above which they do
 X4_LAYOUT         0         1: merged fp32 components whose lane reads four floats per row are laid [T+1][B][trial][component] (one 16-byte load per step, k_forward_sp<X4>); measured, see DESIGN.md §7
@@ -52,7 +53,7 @@ import os
 DEFAULTS = {
     "SCAN": "", "SCAN_MAX_SYSTEMS": 0, "SCAN_MIN_STEPS": 0, "SCAN_MAX_COND": 1e7, "SCAN_LANE": 1, "SCAN_RT_WAVES": 0, "SCAN_ORDER": "",
     "COOP": "", "COOP_SPARSE": 1, "COOP_TRIAL_ROWS": 1, "COOP_TRIAL_TPB": 0, "COOP_TRIAL_WIDE": "", "COOP_TRIAL_CHUNKS": "", "COOP_ADJOINT": 0, "ADJOINT_SP": 1, "TRIAL_CHUNKS": "", "TRIAL_LDS": "", "TRIAL_CHUNK_WAVES": 0,
-    "TRIAL_CHUNK_MAX_WAVES": 0, "TRIAL_CHUNK_TPL": 0, "FUSE_TRIALS_MAX": 2048, "MIXED": 1, "MIXED_MIN_TRIALS": 3,
+    "TRIAL_CHUNK_MAX_WAVES": 0, "TRIAL_CHUNK_TPL": 0, "FUSE_TRIALS_MAX": 2048, "MIXED": 1, "MIXED_MIN_TRIALS": 3, "HILO": 1,
     "F32_WIDE": 1, "F32_MAX_COND": 1e7, "X4_LAYOUT": 0, "NO_SPECIALIZE": 0, "NO_DECOUPLE": 0, "NO_MERGE": 0, "GRAPH": 1, "GRAPH_AFFINE": 1,
     "SETUP_KERNEL": 1, "JIT": 1,
 }
@@ -142,4 +143,5 @@ def fill_tuning(t):
     t.coop_trial_wide = _tri("COOP_TRIAL_WIDE")
     v = get("TRIAL_LDS")
     t.trial_lds = 0 if v == "" else (-1 if int(v) == 0 else int(v))
+    t.hilo = 0 if flag("HILO") else -1
     return t

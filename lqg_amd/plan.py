@@ -247,12 +247,20 @@ class LogLikelihoodPlan:
                 ln_m = _hip.Launch(sub_m.actor, sub_m.dynamics, d=len(cols), n_trials=n, Sigma0=S0, eps=eps,
                                    traj_dtype=torch.float32)
                 nbytes_m = lib.lqg_workspace_bytes(C.byref(ln_m.p), _abi.OP_LOG_LIKELIHOOD)
+                if nbytes_m > ops_workspace_limit(ln.device) and ln_m.p.tuning.hilo == 0:
+                    # the operator stream fits but stream + residual stream (hi + lo operators, about as large again) does not:
+                    # rounded operators on fp64-built gains are the better fall-back than all-fp32 sweeps
+                    ln_m.p.tuning.hilo = -1
+                    nbytes_m = lib.lqg_workspace_bytes(C.byref(ln_m.p), _abi.OP_LOG_LIKELIHOOD)
                 if nbytes_m <= ops_workspace_limit(ln.device):
                     sub, ln, nbytes = sub_m, ln_m, nbytes_m
                 else:
                     mixed = False
             xb, is_b = _hip._prep_x(ln, xs)
             sp = None if use_scan else _hip.specialised_entry(ln, sub0, len(cols))
+            if mixed and sp is None and not use_scan and ln.p.tuning.hilo == 0:
+                ln.p.tuning.hilo = -1            # the generic kernels never read a residual stream: do not size one
+                nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
             if use_scan:
                 use_scan = lib is _abi.load()            # (an auxiliary lane-kernel library has no scan entry)
             scan_entry = None
@@ -264,7 +272,7 @@ class LogLikelihoodPlan:
                 fn = C.cast(spl.lqg_trial_sweep_sp, C.c_void_p) if spl is not None else C.c_void_p(None)
                 scan_entry = (lambda *a, _f=lib.lqg_log_likelihood_scan_with, _t=fn: _f(*a, _t))
                 scan_sp = spl is not None
-            if sp is not None and n == 2 and not mixed:   # the specialised library sweeps two trials in-lane: no operator stream
+            if sp is not None and n == 2 and not mixed and not _hip._varies_or_affine(ln):   # the specialised library sweeps two trials in-lane: no operator stream (time-invariant kernels only)
                 ln.p.n_trials = 1
                 nbytes = lib.lqg_workspace_bytes(C.byref(ln.p), _abi.OP_LOG_LIKELIHOOD)
                 ln.p.n_trials = 2

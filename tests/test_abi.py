@@ -54,7 +54,7 @@ int main(void) {
   printf("%zu %zu %zu %zu ", sizeof(lqg_tuning), offsetof(lqg_problem, tuning), offsetof(lqg_tuning, coop_trial_chunks),
          offsetof(lqg_tuning, scan_rt_waves));
   printf("%zu %zu %zu %zu %zu %zu\n", offsetof(lqg_tuning, coop_adjoint), offsetof(lqg_tuning, scan_order), offsetof(lqg_tuning, coop_trial_tpb),
-         offsetof(lqg_tuning, coop_trial_wide), offsetof(lqg_tuning, trial_lds), offsetof(lqg_tuning, reserved));
+         offsetof(lqg_tuning, coop_trial_wide), offsetof(lqg_tuning, trial_lds), offsetof(lqg_tuning, hilo));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as td:
@@ -69,7 +69,7 @@ int main(void) {
             P.phase_events.offset, C.sizeof(_abi.Tuning), P.tuning.offset, _abi.Tuning.coop_trial_chunks.offset,
             _abi.Tuning.scan_rt_waves.offset, _abi.Tuning.coop_adjoint.offset, _abi.Tuning.scan_order.offset,
             _abi.Tuning.coop_trial_tpb.offset, _abi.Tuning.coop_trial_wide.offset, _abi.Tuning.trial_lds.offset,
-            _abi.Tuning.reserved.offset]
+            _abi.Tuning.hilo.offset]
     assert got == want
 
 
@@ -123,8 +123,9 @@ def test_argument_errors_do_not_launch(lib):
     q = _abi.Problem()
     q.dtype, q.T, q.n_sys, q.n_trials = _abi.F32, 10, 1, 1
     q.dims = _abi.Dims(2, 2, 1, 2, 2, 2, 2, 2, 2)
-    q.tuning.reserved[0] = 1
-    assert lib.lqg_kalman_forward(C.byref(q), nv, None) == -3
+    for bad in (1, -2):                                   # hilo: 0 rule, -1 off
+        q.tuning.hilo = bad
+        assert lib.lqg_kalman_forward(C.byref(q), nv, None) == -3
 
 
 def test_setup_entry_checks_its_arguments_before_launching(lib):
@@ -221,6 +222,11 @@ def test_mixed_dtype_is_served_by_the_log_likelihood_entry_only(lib, monkeypatch
     # round 5: + the residual stream of the operator's Fj - I block ([n_sys][T+1][m m] floats, m = 10) and one flag per system
     resid = al(100 * 501 * 100 * 4) + al(100 * 4)
     assert wmx - w32 == gains32 + resid             # the gain scratch doubles (fp64), the operator stream stays fp32
+    # round 6: tuning.hilo = -1 takes the residual stream out of the sizing — what plan.py asks for when the generic
+    # kernels run (they never read it) or when only stream + residual would pass the workspace limit
+    mix.p.tuning.hilo = -1
+    assert lib.lqg_workspace_bytes(C.byref(mix.p), _abi.OP_LOG_LIKELIHOOD) - w32 == gains32
+    mix.p.tuning.hilo = 0
     nv, nt = _abi.NULL_VIEW, _abi.NULL_TRAJ
     assert lib.lqg_kalman_forward(C.byref(mix.p), nv, None) == -3 and b"LQG_F32_SYS64" in lib.lqg_last_error()
     assert lib.lqg_riccati_backward(C.byref(mix.p), nv, nv, nv, None) == -3

@@ -508,6 +508,62 @@ def test_reverse_mode_serves_the_delay_models_end_to_end():
 
 
 @gpu
+@pytest.mark.parametrize("shared_x", [False, True])
+def test_candidate_chunked_cooperative_adjoint_bounds_the_live_workspace(monkeypatch, shared_x):
+    """the candidate chunking of the cooperative reverse sweep (grad._candidate_chunks / _one: 4096 DelayedSubjectiveActor
+    candidates would ask for 172 GB in one piece) must bound the PEAK, under autograd too — every piece runs forward before any
+    runs backward, so a piece gives its workspace back after its forward and re-runs the forward sweep inside its backward.
+    Workspace limit pinned to two systems' worth -> 3 pieces of 6 candidates: same gradients as the unchunked run, peak memory
+    below three systems' worth (unchunked: six).  shared_x: a [1, n, T+1, d] x is shared by the pieces, not sliced to nothing."""
+    from lqg_amd import grad as G, plan as _plan
+    from lqg_amd.tracking.delay import DelayedSubjectiveActor
+    dev, dt, B = "cuda", torch.float64, 6
+    with torch.no_grad():
+        x = DelayedSubjectiveActor(T=120, device=dev, dtype=dt).simulate(4, n=12)[..., :2].contiguous()
+    xin = x[None] if shared_x else x
+
+    def run():
+        sig = torch.linspace(5.0, 9.0, B, device=dev, dtype=dt).requires_grad_(True)
+        m = DelayedSubjectiveActor(T=120, sigma_target=sig, device=dev, dtype=dt)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        ll = m.log_likelihood(xin)
+        ll.sum().backward()
+        torch.cuda.synchronize()
+        return ll.detach().clone(), sig.grad.clone(), torch.cuda.max_memory_allocated() - base
+
+    ll0, g0, peak0 = run()                                           # one piece
+    sig = torch.linspace(5.0, 9.0, B, device=dev, dtype=dt)
+    m = DelayedSubjectiveActor(T=120, sigma_target=sig, device=dev, dtype=dt)
+    assert G._candidate_chunks(m, x, None) is None                   # fits the device's limit in one piece
+    from lqg_amd import _hip, workload
+    one = workload.slice_system(m, 0, 1)
+    ln = _hip.Launch(one.actor, one.dynamics, d=2, n_trials=12)
+    per = int(ln.require_gpu(_abi_mod().FAM_ADJOINT).lqg_grad_workspace_bytes(C_mod().byref(ln.p), 64))
+    assert per > (4 << 20)                                           # the workspace dominates the other allocations of this test
+    monkeypatch.setattr(_plan, "OPS_WORKSPACE_LIMIT", 2 * per + 1024)
+    assert G._candidate_chunks(m, x, None) == [(0, 2), (2, 4), (4, 6)]
+    ll1, g1, peak1 = run()
+    assert torch.allclose(ll1, ll0, rtol=1e-13, atol=0) and torch.allclose(g1, g0, rtol=1e-12, atol=0)
+    assert peak0 > 5.5 * per                                         # the unchunked run holds all six systems' state
+    assert peak1 < 3.0 * per, (peak1 / per, peak0 / per)             # chunked: one piece of two at a time
+
+
+def _abi_mod():
+    from lqg_amd import _abi
+    return _abi
+
+
+def _C_mod_cache():
+    import ctypes
+    return ctypes
+
+
+C_mod = _C_mod_cache
+
+
+@gpu
 def test_value_and_grad_adjoint_agrees_with_finite_difference_method():
     import lqg_amd
     from lqg_amd.infer import gradient

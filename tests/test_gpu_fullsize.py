@@ -246,18 +246,21 @@ def test_eight_ranks_share_the_gpu_config3_128_trials_per_rank():
 
 def test_eight_ranks_share_the_gpu_config4_32768_trials_per_rank():
     """`--config 4` literally: 262 144 trials of the 2-D hand model, 32 768 per rank over 8 ranks.  The data set is defined in
-    8 seeded blocks, so the 1-rank run (all 8 blocks) and the 8-rank run (one block each) score the SAME trials: the objective
-    agrees to fp64 rounding of the partial sums."""
-    common = ["--config", "4", "--steps", "2", "--warmup", "1"]
-    one = _run_bench(*common)
-    eight = _run_bench("--gpus", "8", "--share-gpu", *common)
-    assert one["config"]["trials_per_rank"] == 262144 and eight["config"]["trials_per_rank"] == 32768
-    assert eight["n_gpus"] == 8 and eight["world_size"] == 8 and eight["scaling"] == "strong"
-    pr = eight["per_rank_objective"]
-    assert len(pr) == 8 and len(set(pr)) == 8
-    assert abs(sum(pr) / eight["objective_sum"] - 1) < 1e-12
-    assert abs(eight["objective_sum"] / one["objective_sum"] - 1) < 1e-12
-    assert eight["max_rel_err_vs_fp64_oracle"] < 1e-6 and one["max_rel_err_vs_fp64_oracle"] < 1e-6
+    8 seeded blocks, so the 1-rank run (all 8 blocks) and the 8-rank run (one block each) score the SAME trials.  In fp64 the
+    objective agrees to 1e-12.  In fp32 a shard of 32 768 trials takes the time-chunked per-trial sweep (more waves in flight)
+    where 262 144 trials run one pass: the same trials in a different fp32 evaluation order, 1e-7 per log-likelihood (both
+    within 1e-6 of the oracle) and 7e-11 on the sum of 262 144 of them — asserted at 1e-9."""
+    for dtype, tol in (("f32", 1e-9), ("f64", 1e-12)):
+        common = ["--config", "4", "--steps", "2", "--warmup", "1", "--dtype", dtype]
+        one = _run_bench(*common)
+        eight = _run_bench("--gpus", "8", "--share-gpu", *common)
+        assert one["config"]["trials_per_rank"] == 262144 and eight["config"]["trials_per_rank"] == 32768
+        assert eight["n_gpus"] == 8 and eight["world_size"] == 8 and eight["scaling"] == "strong"
+        pr = eight["per_rank_objective"]
+        assert len(pr) == 8 and len(set(pr)) == 8
+        assert abs(sum(pr) / eight["objective_sum"] - 1) < 1e-12
+        assert abs(eight["objective_sum"] / one["objective_sum"] - 1) < tol, dtype
+        assert eight["max_rel_err_vs_fp64_oracle"] < 1e-6 and one["max_rel_err_vs_fp64_oracle"] < 1e-6
 
 
 def test_driver_launch_line_on_rccl_with_one_rank():

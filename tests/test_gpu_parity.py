@@ -466,8 +466,28 @@ def test_time_varying_structured_specs_materialise_through_the_pattern_library(o
         assert abs(float(o_sp["ll"][j, 0]) / float(llr[0]) - 1) < max(tol * 0.1, 1e-10)
 
 
+def _oracle_pairs_err(oracle_lib, m32, x, ll, T, d, n_pairs=8, seed=0):
+    """The fp32 result against the ORACLE itself (not only the repo's fp64 HIP path): >= n_pairs sampled (candidate, trial) pairs, the fp64 C
+    oracle (oracle/lqg_oracle.c, the restatement pinned to the reference) on the fp64 image of the same fp32 inputs.  Returns the worst
+    error in the measure these tests state: |ll - ref| / max(|ref|, T d)."""
+    from lqg_amd import workload
+    rng = np.random.default_rng(seed)
+    B, n = m32.n_systems, x.shape[-3]
+    pairs = {(int(rng.integers(0, B)), int(rng.integers(0, n))) for _ in range(4 * n_pairs)}
+    pairs = sorted(pairs)[:: max(1, len(pairs) // n_pairs)][:n_pairs]
+    assert len(pairs) >= min(n_pairs, B * n)
+    one_of = lambda spec, j: {f: (getattr(spec, f)[j] if getattr(spec, f).dim() == workload._batched_ndim(f)
+                                  else getattr(spec, f)).double().cpu().numpy() for f in spec._fields}
+    worst = 0.0
+    for c, t in pairs:
+        xs = (x[c, t] if x.dim() == 4 else x[t]).double().cpu().numpy()[None]
+        ref = float(oracle_lib.log_likelihood(one_of(m32.actor, c), one_of(m32.dynamics, c), xs, None)[0])
+        worst = max(worst, abs(float(ll[c, t]) - ref) / max(abs(ref), T * d))
+    return worst
+
+
 @pytest.mark.parametrize("T,tol_default,tol_fp32", [(500, 1e-6, 3e-6), (1067, 1e-6, 1.5e-5), (2000, 1e-6, 1.5e-5)])
-def test_fp32_candidate_ranges_point_mass(T, tol_default, tol_fp32):
+def test_fp32_candidate_ranges_point_mass(T, tol_default, tol_fp32, oracle_lib):
     """PointMassBoundedActor over the bench's candidate ranges, fp32 default routes against the fp64 path on the fp64 image of the SAME
     fp32 inputs.  A log-likelihood is a sum of T d per-step terms of either sign; for candidates with a small action variability they nearly
     cancel on these data (|ll| down to 0.1 against ~1e3 for the rest), and an error relative to |ll| then measures the zero crossing, not
@@ -495,6 +515,7 @@ def test_fp32_candidate_ranges_point_mass(T, tol_default, tol_fp32):
             ll = m32.log_likelihood(x).double()
         err = (ll - ref).abs()
         assert float((err / scale).max()) < tol, ov
+        assert _oracle_pairs_err(oracle_lib, m32, x, ll, T, d, n_pairs=8, seed=T) < tol, ov     # the same statement against the C oracle
         big = ref.abs() >= T * d
         assert bool(big.any()) and float((err[big] / ref[big].abs()).max()) < tol, ov         # plain relative where the sum does not cancel
         small = ref.abs() < 0.1 * T * d
@@ -503,7 +524,7 @@ def test_fp32_candidate_ranges_point_mass(T, tol_default, tol_fp32):
 
 
 @pytest.mark.parametrize("B,n", [(300, 500), (256, 800)])
-def test_fp32_point_mass_many_trials_hi_lo_operators(B, n):
+def test_fp32_point_mass_many_trials_hi_lo_operators(B, n, oracle_lib):
     """The one-pass per-trial sweeps of the MIXED mode (64-lane workgroups: 300 x 500; the 256 x 2 geometry: 256 x 800) on the
     point mass at T = 1067: the systems whose Fj - I block is large are walked by k_trial_sp<..., HL> with hi + lo operators
     (the test above runs 8 trials per candidate: the time-chunked sweep).  Same statement: 1e-6 of max(|ll|, T d)."""
@@ -522,10 +543,11 @@ def test_fp32_point_mass_many_trials_hi_lo_operators(B, n):
         with options.override(**ov):
             ll = m32.log_likelihood(x).double()
         assert float(((ll - ref).abs() / scale).max()) < 1e-6, ov
+        assert _oracle_pairs_err(oracle_lib, m32, x, ll, T, d, n_pairs=8, seed=B) < 1e-6, ov
 
 
 @pytest.mark.parametrize("B,n", [(96, 6), (96, 1500), (256, 800)])
-def test_fp32_point_mass_batch_with_and_without_large_operator_blocks(B, n):
+def test_fp32_point_mass_batch_with_and_without_large_operator_blocks(B, n, oracle_lib):
     """One batch in which every second candidate has a large action cost: its F_j - I block stays at 1.0, below LQG_HILO_MIN, so the
     MIXED mode's builder flags only the others.  The two launches of the one-pass sweep (k_trial_sp and k_trial_sp<HL>; 96 x 1500 on
     64-lane workgroups, 256 x 800 on the 256 x 2 geometry) and the per-system test of the time-chunked sweep (96 x 6: at most 2048
@@ -547,6 +569,7 @@ def test_fp32_point_mass_batch_with_and_without_large_operator_blocks(B, n):
         ll = m32.log_likelihood(x).double()
     err = (ll - ref).abs() / scale
     assert float(err[0::2].max()) < 1e-6 and float(err[1::2].max()) < 1e-6, (float(err[0::2].max()), float(err[1::2].max()))
+    assert _oracle_pairs_err(oracle_lib, m32, x, ll, T, d, n_pairs=12, seed=n) < 1e-6       # flagged and unflagged candidates, C oracle
 
 
 def test_per_trial_sweep_geometries_are_bitwise_identical():
