@@ -224,23 +224,47 @@ def floor_provably_inactive(system, eps=1e-8):
         return cache[key]
     a = system.actor
     first = specialize._first
+    # "zero" to the rounding of the dtype the specs are STORED in: a matrix that is positive semi-definite in exact arithmetic with
+    # a zero eigenvalue (every tracking model's Q) carries eigenvalues of -eps |Q| once its entries are rounded — fp32 specs that
+    # move in time (round 6) would otherwise never pass.  The reference's own eigh of H in that dtype resolves no finer.
+    tol = -1e-12 if a.Q.dtype == torch.float64 else -2e-6
 
-    def lower_bound(M):                                  # Gershgorin: every eigenvalue >= min_i (M_ii - sum_{j != i} |M_ij|)
+    def lower_bound(M):
+        """(symmetric part in fp64, lower bound of its smallest eigenvalue RELATIVE to max(1, |M|max)).  Gershgorin on M itself —
+        every eigenvalue >= min_i (M_ii - sum_{j != i} |M_ij|) — and, where that is inconclusive, on the unit-diagonal scaling
+        E M E (E = diag M^-1/2, a congruence: same signature): a cost D Q D whose Q is diagonally dominant passes the second
+        form whatever the D (time-varying costs, round 6).  Elementwise, no factorisation."""
         M = 0.5 * (M + M.transpose(-1, -2)).detach().double()
         diag = torch.diagonal(M, dim1=-2, dim2=-1)
-        off = M.abs().sum(-1) - diag.abs()
-        return M, (diag - off).min()
+        rows = M.abs().sum(-1)
+        scale = M.abs().max().clamp_min(1.0)
+        lb1 = (diag - (rows - diag.abs())).min() / scale
+        pos = diag > 0
+        inv = torch.where(pos, diag.clamp_min(1e-300).rsqrt(), torch.zeros_like(diag))
+        offs = (M.abs() * inv.unsqueeze(-1) * inv.unsqueeze(-2)).sum(-1) - pos.double()
+        # a row with a zero diagonal entry must vanish altogether; a negative diagonal entry fails both forms
+        bad = ((~pos) & (rows > 0)).any()
+        lb2 = torch.where(bad, torch.full_like(lb1, -1.0), torch.where(pos, 1.0 - offs, torch.zeros_like(offs)).min())
+        # (lambda_min(M) >= lambda_min(E M E) min_i M_ii when the scaled matrix is positive semi-definite)
+        abs2 = torch.where(lb2 >= 0, lb2 * torch.where(pos, diag, torch.full_like(diag, float("inf"))).min(), torch.full_like(lb2, -1.0))
+        return M, lb1, lb2, lb1 * scale, abs2
 
-    Rs, r_lb = lower_bound(first(a.R))
-    Qs, q_lb = lower_bound(first(a.Q))
-    Qfs, qf_lb = lower_bound(a.Qf)
-    tol = -1e-12
-    checks = torch.stack([r_lb - eps, q_lb - tol, qf_lb - tol])
-    ok = bool((checks >= 0).all())                       # the one synchronisation
+    def eig_min(M, chunk=1 << 18):
+        """Smallest eigenvalue over a (possibly huge) stack of small matrices, in slabs (one syevd over 65 M matrices asks rocSOLVER
+        for more workspace than it can get)."""
+        flat = M.reshape(-1, *M.shape[-2:])
+        return min(float(torch.linalg.eigvalsh(flat[i:i + chunk]).min()) for i in range(0, flat.shape[0], chunk))
+
+    Rs, _, _, r_abs1, r_abs2 = lower_bound(first(a.R))
+    Qs, q_lb1, q_lb2, _, _ = lower_bound(first(a.Q))
+    Qfs, qf_lb1, qf_lb2, _, _ = lower_bound(a.Qf)
+    checks = torch.stack([torch.maximum(r_abs1, r_abs2) - eps, torch.maximum(q_lb1, q_lb2) - tol, torch.maximum(qf_lb1, qf_lb2) - tol])
+    flags = (checks >= 0).tolist()                       # the one synchronisation
+    ok = all(flags)
     if not ok:
-        r_ok = bool(r_lb >= eps) or bool(torch.linalg.eigvalsh(Rs).min() >= eps)
-        q_ok = r_ok and (bool(q_lb >= tol) or bool(torch.linalg.eigvalsh(Qs).min() >= tol * max(1.0, float(Qs.abs().max()))))
-        ok = q_ok and (bool(qf_lb >= tol) or bool(torch.linalg.eigvalsh(Qfs).min() >= tol * max(1.0, float(Qfs.abs().max()))))
+        r_ok = flags[0] or eig_min(Rs) >= eps
+        q_ok = r_ok and (flags[1] or eig_min(Qs) >= tol * max(1.0, float(Qs.abs().max())))
+        ok = q_ok and (flags[2] or eig_min(Qfs) >= tol * max(1.0, float(Qfs.abs().max())))
     cache[key] = ok
     return ok
 

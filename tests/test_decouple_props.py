@@ -3,6 +3,8 @@ independent blocks under random permutations of the state / belief / control / o
 graph's components are exactly the blocks, observed dims lead each component's state list, and blocks without observed
 dims are dropped (they do not enter the likelihood)."""
 import numpy as np
+import pytest
+import torch
 from hypothesis import given, settings, strategies as st
 
 from lqg_amd.decouple import components_from_masks
@@ -122,3 +124,24 @@ def test_replacing_a_spec_voids_the_class_level_structure():
     assert decouple.identical_groups(m, 4, m.decoupled(4)) == [[0], [1]]
     m64 = lqg_amd.BoundedActor(dim=2, T=5, device="cpu").to(torch.float64)          # a cast keeps the structure
     assert hasattr(m64, "_zoo_structure") and m64.actor.A.dtype == torch.float64
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_time_varying_costs_that_stay_costs_decouple_and_broken_ones_do_not(dtype):
+    """Round 6: specs that move in time.  Costs moved by a congruence D_t Q D_t stay positive semi-definite (certified by Gershgorin
+    on the unit-diagonal scaling, to the rounding of the storage dtype): the floor of lqr.py:27-28 is provably inactive and the two
+    1-D components decouple.  Per-entry jitter breaks Q's zero eigenvalue into a negative one: refused, the joint problem is solved."""
+    import bench_m2
+    from lqg_amd import decouple
+    dev = torch.device("cpu")
+    good, _ = bench_m2.m2_system(dev, dtype, 16, 12, psd=True)
+    assert decouple.floor_provably_inactive(good) and len(good.decoupled(4)) == 2
+    for sub, cols, _ in good.decoupled(4):                       # the split keeps [T][element][system] storage
+        assert sub.actor.A.stride(0) == 1 and sub.dynamics.F.stride(0) == 1 and sub.actor.A.shape[1] == 12
+    bad, _ = bench_m2.m2_system(dev, dtype, 16, 12, psd=False)
+    assert not decouple.floor_provably_inactive(bad) and bad.decoupled(4) is None
+    # one step of one system with an indefinite cost is enough to refuse
+    worse, _ = bench_m2.m2_system(dev, dtype, 16, 12, psd=True)
+    worse.actor.Q[3, 7, 0, 1] -= 1e-2
+    worse.actor.Q[3, 7, 1, 0] -= 1e-2
+    assert not decouple.floor_provably_inactive(worse)
