@@ -133,6 +133,7 @@ struct AspArgs {
   const R* gsum;             // [parts][n_sys] sums of the upstream weights     (stream path)
   int parts;
   R* Lbar;                   // [T][NU * NB][ldb]
+  R* Kbar;                   // [T][NB * NY][ldb]: K-bar_t without its P-bar term, the set entries of K's mask first (k_asp_sys_rev -> k_asp_kal_rev)
   R* out;                    // gradient [Layout::TOTAL][ld]
   long ld;
 };
@@ -183,16 +184,33 @@ struct SysConst {
 // From (P_t, Sigma_t, L_t): Kalman step kf.py:10-14, joint system system.py:167-207, conditioning on the observed block
 // system.py:219-230 in Cholesky / Schur form (lqg_kernels.hpp).  Everything a consumer needs is handed to `use` (a generic
 // lambda): the forward kernels advance the state and emit operators, the reverse kernel differentiates.
-template <int ND, typename R, int NX, int NB, int NU, int NY, typename PAT, Mask<NB, NB> PM, typename Use>
-LQG_DEV void sys_step(const SysConst<R, NX, NB, NU, NY, PAT>& c, const Mat<R, NB, NB, PM>& Pm, R (&Sg)[(NX + NB) * (NX + NB)],
-                      const Mat<R, NU, NB>& L, const bool first, Use&& use) {
-  constexpr int M = NX + NB, O = ND, RR = M - ND;
+// Kalman step kf.py:10-14 from P_t: everything the joint system and the Kalman adjoint read
+template <typename R, int NX, int NB, int NU, int NY, typename PAT, Mask<NB, NB> PM>
+LQG_DEV auto kalman_part(const SysConst<R, NX, NB, NU, NY, PAT>& c, const Mat<R, NB, NB, PM>& Pm) {
   const auto AP = mul(c.Aa, Pm);
   const auto Pp = mul_nt_sym_add(AP, c.Aa, c.VVa);                      // kf.py:10
   const auto FP = mul(c.Fa, Pp);
   const auto Gi = spd_inverse_masked(mul_nt_sym_add(FP, c.Fa, c.WWa)); // kf.py:11
   const auto K = mul_tn(FP, Gi);                                       // kf.py:12
   const auto Pn = sym_sub_mul(Pp, K, FP);                              // kf.py:14
+  struct Out {
+    std::remove_cvref_t<decltype(AP)> AP; std::remove_cvref_t<decltype(Pp)> Pp; std::remove_cvref_t<decltype(FP)> FP;
+    std::remove_cvref_t<decltype(Gi)> Gi; std::remove_cvref_t<decltype(K)> K; std::remove_cvref_t<decltype(Pn)> Pn;
+  };
+  return Out{AP, Pp, FP, Gi, K, Pn};
+}
+// the Kalman gain's type (its structural mask follows from the pattern and the mask of P)
+template <typename T>
+__device__ T&& dev_declval() noexcept;                   // (std::declval is a host function; never defined, unevaluated use only)
+template <typename R, int NX, int NB, int NU, int NY, typename PAT, Mask<NB, NB> PM>
+using KalmanGain = decltype(kalman_part(dev_declval<const SysConst<R, NX, NB, NU, NY, PAT>&>(), dev_declval<const Mat<R, NB, NB, PM>&>()).K);
+
+// joint system system.py:167-207 and conditioning on the observed block system.py:219-230 (Cholesky / Schur form,
+// lqg_kernels.hpp) from (K_t, Sigma_t, L_t); `use(BK, Fj, KN2, KN3, GG, Li, dinv, U2, C, F2, F2C)`
+template <int ND, typename R, int NX, int NB, int NU, int NY, typename PAT, typename KT, typename Use>
+LQG_DEV void joint_part(const SysConst<R, NX, NB, NU, NY, PAT>& c, const KT& K, R (&Sg)[(NX + NB) * (NX + NB)],
+                        const Mat<R, NU, NB>& L, const bool first, Use&& use) {
+  constexpr int M = NX + NB, O = ND, RR = M - ND;
   const auto BK = add(c.Ba, mul(K, c.DB));
   const auto Fj = block2x2(c.Ad, mul(c.Bd, L), mul(K, c.FAd), add(sub(c.Aa, mul(K, c.FAa)), mul(BK, L)));
   const auto KN2 = mul(K, c.N2);
@@ -223,7 +241,20 @@ LQG_DEV void sys_step(const SysConst<R, NX, NB, NU, NY, PAT>& c, const Mat<R, NB
     }
   const auto F2 = cols<O, RR>(Fj);
   const auto F2C = mul(F2, C);
-  use(AP, Pp, FP, Gi, K, Pn, BK, Fj, KN2, KN3, GG, Li, dinv, U2, C, F2, F2C);
+  use(BK, Fj, KN2, KN3, GG, Li, dinv, U2, C, F2, F2C);
+}
+
+// one forward step of the system part from (P_t, Sigma_t, L_t): both halves; everything a consumer needs is handed to `use` (a
+// generic lambda): the forward kernel advances the state and emits operators.
+template <int ND, typename R, int NX, int NB, int NU, int NY, typename PAT, Mask<NB, NB> PM, typename Use>
+LQG_DEV void sys_step(const SysConst<R, NX, NB, NU, NY, PAT>& c, const Mat<R, NB, NB, PM>& Pm, R (&Sg)[(NX + NB) * (NX + NB)],
+                      const Mat<R, NU, NB>& L, const bool first, Use&& use) {
+  const auto kp = kalman_part(c, Pm);
+  joint_part<ND>(c, kp.K, Sg, L, first, [&](const auto& BK, const auto& Fj, const auto& KN2, const auto& KN3, const auto& GG,
+                                            const auto& Li, const auto& dinv, const auto& U2, const auto& C, const auto& F2,
+                                            const auto& F2C) LQG_LAMBDA_INLINE {
+    use(kp.AP, kp.Pp, kp.FP, kp.Gi, kp.K, kp.Pn, BK, Fj, KN2, KN3, GG, Li, dinv, U2, C, F2, F2C);
+  });
 }
 
 // control gains of the steps t0 .. t0 + CK - 1 recomputed backward from the checkpoint S_{t0 + CK} (k_riccati_sp<CK>)
@@ -421,22 +452,59 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES
   }
 }
 
-// ================================================================= phase 2: reverse system sweep
-// Per chunk (last to first): the states P_t, Sigma_t (and the in-lane trials' means) of its steps are recomputed from the
-// chunk's checkpoint into registers, then the steps are differentiated backward.  NTR == 0: the trial sums come from
-// k_asp_trial_rev (A.sums, A.parts partial records per step); NTR >= 1: formed in-lane.
+// ================================================================= phase 2: reverse system sweep, cut in two (round 6)
+// Round 5 ran ALL system adjoints in one kernel: 438 VGPRs at the headline shape (two in-lane trials), one wave per SIMD, 0.35 of
+// the VALU issue rate.  The adjoint of the Kalman-covariance recursion reads nothing of the moment recursion but K-bar_t — as the
+// Riccati adjoint reads nothing but L-bar_t — so it is its own backward kernel now:
+//   k_asp_sys_rev   Sigma-bar / mu-bar sweep: joint system, moment recursion, conditioning and the in-lane trials' adjoints; emits
+//                   K-bar_t (the part that does not involve P-bar) and L-bar_t per step.  The chunk's recomputed states live in
+//                   LDS ([slot][element][lane]: conflict-free, static offsets) instead of a register stack; the chunk's Kalman
+//                   gains K_t (3 of 6 entries for the tracking models) stay in registers — P itself is no longer stacked.
+//   k_asp_kal_rev   P-bar sweep: consumes K-bar_t, recomputes the chunk's P_t from the same checkpoints; bars of Fa, VVa, WWa,
+//                   (the Kalman part of) Aa, and Sigma0.
+// Per chunk (last to first): the states of its steps are recomputed from the chunk's checkpoint, then the steps are
+// differentiated backward.  NTR == 0: the trial sums come from k_asp_trial_rev (A.sums, A.parts partial records per step);
+// NTR >= 1: formed in-lane.
+
+// what of the chunk's recomputed states goes to LDS: the budget is 80 reals per lane = 20 kB per 64-lane workgroup in fp32 (eight
+// workgroups = two waves per SIMD fit a CU's 160 kB), 40 kB in fp64 (four workgroups: one wave per SIMD)
+template <int M, int NTM, int CKS>
+struct RevStack {
+  static constexpr int NSM = M * (M + 1) / 2;
+  static constexpr int BUDGET = 80;
+  static constexpr bool SIG = CKS * NSM <= BUDGET;                       // Sigma_t (lower triangle)
+  static constexpr bool TRL = SIG && NTM > 0 && CKS * (NSM + NTM) <= BUDGET;   // the in-lane trials' mean states
+  static constexpr int PER_SLOT = (SIG ? NSM : 0) + (TRL ? NTM : 0);
+  static constexpr int REALS = CKS * PER_SLOT;
+  static constexpr int S_OFF = 0, T_OFF = SIG ? NSM : 0;
+};
+#ifndef LQG_ASP_REV_WAVES_F32
+#define LQG_ASP_REV_WAVES_F32 2   // waves per SIMD the fp32 Sigma-bar sweep is allocated for when its stack fits LDS
+#endif
+template <typename R, int M, int NTM, int CK>
+constexpr int rev_waves() {
+  return (sizeof(R) == 4 && RevStack<M, NTM, (CK - 1 > 0 ? CK - 1 : 1)>::SIG) ? LQG_ASP_REV_WAVES_F32 : 1;
+}
+
 template <typename R, int NX, int NB, int NU, int NY, int ND, typename PAT, int NTR, bool DENSE_P, int CK>
-__global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES_F32 : 1)) k_asp_sys_rev(const AspArgs<R> A) {
+__global__ void __launch_bounds__(LQG_BLOCK, (rev_waves<R, NX + NB, NTR * (NX + NB), CK>())) k_asp_sys_rev(const AspArgs<R> A) {
   constexpr int M = NX + NB, O = ND, RR = M - ND;
   constexpr int NT = NTR > 0 ? NTR : 1;
   using Rec = CkRec<NB, M, NTR>;
   using MK = Masks<PAT, NX, NB, NU, NY, DENSE_P>;
   using SM = Sums<M, ND, MK::FJ>;
   using Lay = adj::Layout<NX, NB, NU, NY>;
-  constexpr int NSB = NB * (NB + 1) / 2, NSM = M * (M + 1) / 2;
+  using KT = KalmanGain<R, NX, NB, NU, NY, PAT, MK::PM>;
+  constexpr int NSM = M * (M + 1) / 2;
+  static_assert(LQG_ASP_STACK0 == 0, "the state before a chunk's first step is re-read from its checkpoint");
+  constexpr int S0 = 1;                                  // first stacked slot
+  constexpr int CKS = CK - S0 > 0 ? CK - S0 : 1;
+  using ST = RevStack<M, NTR * M, CKS>;
+  __shared__ R lds_stack[ST::REALS > 0 ? ST::REALS * LQG_BLOCK : 1];
   const ForwardArgs<R>& a = A.f;
   const long s = blockIdx.x * (long)LQG_BLOCK + threadIdx.x;
   if (s >= a.n_sys) return;
+  R* const lds = lds_stack + threadIdx.x;               // element e of slot q: lds[(q * PER_SLOT + e) * LQG_BLOCK]
   SysConst<R, NX, NB, NU, NY, PAT> c;
   c.load(a, s);
   const auto rQ = load_sym_masked<R, NB, PAT::Q>(A.rc.Q.p + s * A.rc.Q.sb, A.rc.Q.sr, A.rc.Q.sc);
@@ -447,15 +515,13 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES
 
   // accumulated bars (time-invariant specs: one per matrix), on the masks of their primals
   Mat<R, NX, NX, PAT::Ad> bAd;  Mat<R, NX, NU, PAT::Bd> bBd;  Mat<R, NB, NB, PAT::Aa> bAa;  Mat<R, NB, NU, PAT::Ba> bBa;
-  Mat<R, NY, NB, PAT::Fa> bFa;  Mat<R, NB, NB, PAT::VVa> bVVa;  Mat<R, NY, NY, PAT::WWa> bWWa;  Mat<R, NX, NX, PAT::N1> bN1;
+  Mat<R, NY, NB, PAT::Fa> bFa;  Mat<R, NX, NX, PAT::N1> bN1;
   decltype(c.FAa) bFAa;  decltype(c.FAd) bFAd;  decltype(c.DB) bDB;  decltype(c.N2) bN2;  decltype(c.N3) bN3;
-  set_zero(bAd); set_zero(bBd); set_zero(bAa); set_zero(bBa); set_zero(bFa); set_zero(bVVa); set_zero(bWWa); set_zero(bN1);
+  set_zero(bAd); set_zero(bBd); set_zero(bAa); set_zero(bBa); set_zero(bFa); set_zero(bN1);
   set_zero(bFAa); set_zero(bFAd); set_zero(bDB); set_zero(bN2); set_zero(bN3);
 
   R Sigb[M * M];
   LQG_UNROLL for (int i = 0; i < M * M; ++i) Sigb[i] = R(0);
-  Mat<R, NB, NB, MK::PM> Pb;
-  set_zero(Pb);
   R pre[NT][M];
   LQG_UNROLL for (int n = 0; n < NT; ++n)
     LQG_UNROLL for (int i = 0; i < M; ++i) pre[n][i] = R(0);
@@ -481,30 +547,76 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES
     for (int part = 0; part < A.parts; ++part) gs_stream += A.gsum[(long)part * a.n_sys + s];
   }
   R Lbuf[CK][NU * NB];
-  // register stack of the chunk's states (static indices only).  LQG_ASP_STACK0 = 0: the state before the chunk's FIRST step, its
-  // checkpoint, is not stacked but read again when the walk back reaches it
-  constexpr int S0 = LQG_ASP_STACK0 ? 0 : 1;             // first stacked slot
-  constexpr int CKS = CK - S0 > 0 ? CK - S0 : 1;
-  R Pst[CKS][NSB], Sst[CKS][NSM];
-  TrialState<R, M, ND> Tst[CKS][NT];
+  KT Kst[CK];                                            // the chunk's Kalman gains (static indices only)
+  // what of the stack does not fit LDS stays in registers (static indices only)
+  R Sst[ST::SIG ? 1 : CKS][ST::SIG ? 1 : NSM];
+  TrialState<R, M, ND> Tst[ST::TRL ? 1 : CKS][NT];
+  auto push = [&](const int q, const R (&Sg)[M * M], const TrialState<R, M, ND> (&st)[NT]) LQG_LAMBDA_INLINE {
+    int e = 0;
+    LQG_UNROLL for (int i = 0; i < M; ++i)
+      LQG_UNROLL for (int k = 0; k <= i; ++k) {
+        if constexpr (ST::SIG) lds[(q * ST::PER_SLOT + ST::S_OFF + e) * LQG_BLOCK] = Sg[i * M + k];
+        else Sst[ST::SIG ? 0 : q][ST::SIG ? 0 : e] = Sg[i * M + k];
+        ++e;
+      }
+    if constexpr (NTR > 0) {
+      LQG_UNROLL for (int n = 0; n < NT; ++n) {
+        if constexpr (ST::TRL) {
+          LQG_UNROLL for (int i = 0; i < O; ++i) lds[(q * ST::PER_SLOT + ST::T_OFF + n * M + i) * LQG_BLOCK] = st[n].dO[i];
+          LQG_UNROLL for (int i = 0; i < RR; ++i) lds[(q * ST::PER_SLOT + ST::T_OFF + n * M + O + i) * LQG_BLOCK] = st[n].muR[i];
+        } else {
+          Tst[ST::TRL ? 0 : q][n] = st[n];
+        }
+      }
+    }
+  };
+  auto pop = [&](const int q, R (&Sg)[M * M], TrialState<R, M, ND> (&st)[NT]) LQG_LAMBDA_INLINE {
+    int e = 0;
+    LQG_UNROLL for (int i = 0; i < M; ++i)
+      LQG_UNROLL for (int k = 0; k <= i; ++k) {
+        R v;
+        if constexpr (ST::SIG) v = lds[(q * ST::PER_SLOT + ST::S_OFF + e) * LQG_BLOCK];
+        else v = Sst[ST::SIG ? 0 : q][ST::SIG ? 0 : e];
+        ++e;
+        Sg[i * M + k] = v;
+        Sg[k * M + i] = v;
+      }
+    LQG_UNROLL for (int n = 0; n < NT; ++n) {
+      if constexpr (NTR > 0 && ST::TRL) {
+        LQG_UNROLL for (int i = 0; i < O; ++i) st[n].dO[i] = lds[(q * ST::PER_SLOT + ST::T_OFF + n * M + i) * LQG_BLOCK];
+        LQG_UNROLL for (int i = 0; i < RR; ++i) st[n].muR[i] = lds[(q * ST::PER_SLOT + ST::T_OFF + n * M + O + i) * LQG_BLOCK];
+      } else if constexpr (NTR > 0) {
+        st[n] = Tst[ST::TRL ? 0 : q][n];
+      } else {
+        LQG_UNROLL for (int i = 0; i < O; ++i) st[n].dO[i] = R(0);
+        LQG_UNROLL for (int i = 0; i < RR; ++i) st[n].muR[i] = R(0);
+      }
+    }
+  };
+  auto load_ck = [&](const int rec, R (&Sg)[M * M], TrialState<R, M, ND> (&st)[NT]) LQG_LAMBDA_INLINE {
+    const R* src = A.ck + (long)rec * Rec::W * a.ldb + s;
+    load_tri_arr<R, M>(src + Rec::S_OFF * a.ldb, a.ldb, Sg);
+    LQG_UNROLL for (int n = 0; n < NT; ++n) {
+      LQG_UNROLL for (int i = 0; i < O; ++i) st[n].dO[i] = NTR > 0 ? src[(Rec::T_OFF + n * M + i) * a.ldb] : R(0);
+      LQG_UNROLL for (int i = 0; i < RR; ++i) st[n].muR[i] = NTR > 0 ? src[(Rec::T_OFF + n * M + O + i) * a.ldb] : R(0);
+    }
+  };
   auto chunk = [&]<bool WHOLE>(const int t0) LQG_LAMBDA_INLINE {      // WHOLE: CK full steps, none of them step 0
     refill_gains<R, NB, NU, CK, WHOLE>(A.rc, s, t0, c.Aa, c.Ba, rQ, rR, Lbuf);
-    // ---- recompute: states before the steps t0 .. t0 + CK - 1
+    // ---- recompute: the gains K_t of the chunk's steps and the states before the steps t0 + 1 .. t0 + CK - 1
     {
       Mat<R, NB, NB, MK::PM> Pm;
       R Sg[M * M];
       TrialState<R, M, ND> st[NT];
       R xprev[NT][O];
-      const R* src = A.ck + (long)(t0 / CK) * Rec::W * a.ldb + s;
       {
+        const R* src = A.ck + (long)(t0 / CK) * Rec::W * a.ldb + s;
         R Pd[NB * NB];
         load_tri_arr<R, NB>(src + Rec::P_OFF * a.ldb, a.ldb, Pd);
         LQG_UNROLL for (int i = 0; i < NB * NB; ++i) if (MK::PM.b[i]) Pm.v[i] = Pd[i];
-        load_tri_arr<R, M>(src + Rec::S_OFF * a.ldb, a.ldb, Sg);
-        LQG_UNROLL for (int n = 0; n < NT; ++n) {
-          LQG_UNROLL for (int i = 0; i < O; ++i) st[n].dO[i] = NTR > 0 ? src[(Rec::T_OFF + n * M + i) * a.ldb] : R(0);
-          LQG_UNROLL for (int i = 0; i < RR; ++i) st[n].muR[i] = NTR > 0 ? src[(Rec::T_OFF + n * M + O + i) * a.ldb] : R(0);
-          if constexpr (NTR > 0) {
+        load_ck(t0 / CK, Sg, st);
+        if constexpr (NTR > 0) {
+          LQG_UNROLL for (int n = 0; n < NT; ++n) {
             const R* xr = xp + n * a.x.sn + (long)(t0 > 0 ? t0 - 1 : 0) * a.x.st;
             LQG_UNROLL for (int i = 0; i < O; ++i) xprev[n][i] = xr[i * a.x.sd];
           }
@@ -513,24 +625,15 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES
       LQG_UNROLL for (int j = 0; j < CK; ++j) {
         const int t = t0 + j;
         if (WHOLE || t < a.T) {
-          if (j >= S0) {
-            R Pd[NB * NB];
-            to_dense(Pm, Pd);
-            int e = 0;
-            LQG_UNROLL for (int i = 0; i < NB; ++i)
-              LQG_UNROLL for (int k = 0; k <= i; ++k) Pst[j >= S0 ? j - S0 : 0][e++] = Pd[i * NB + k];
-            e = 0;
-            LQG_UNROLL for (int i = 0; i < M; ++i)
-              LQG_UNROLL for (int k = 0; k <= i; ++k) Sst[j >= S0 ? j - S0 : 0][e++] = Sg[i * M + k];
-            LQG_UNROLL for (int n = 0; n < NT; ++n) Tst[j >= S0 ? j - S0 : 0][n] = st[n];
-          }
+          if (j >= S0) push(j >= S0 ? j - S0 : 0, Sg, st);
+          const auto kp = kalman_part(c, Pm);
+          Kst[j] = kp.K;
           if (j + 1 < CK && (WHOLE || t + 1 < a.T)) {   // (the state after the chunk's last step is carried from the later chunk)
             Mat<R, NU, NB> L;
             LQG_UNROLL for (int e = 0; e < NU * NB; ++e) L.v[e] = Lbuf[j][e];
-            sys_step<ND>(c, Pm, Sg, L, !WHOLE && t == 0, [&](const auto&, const auto&, const auto&, const auto&, const auto&, const auto& Pn,
-                                                    const auto&, const auto& Fj, const auto&, const auto&, const auto& GG,
-                                                    const R (&Li)[O * O], const R (&)[O], const R (&U2)[RR * O], const auto&,
-                                                    const auto& F2, const auto& F2C) LQG_LAMBDA_INLINE {
+            joint_part<ND>(c, kp.K, Sg, L, !WHOLE && t == 0, [&](const auto&, const auto& Fj, const auto&, const auto&, const auto& GG,
+                                                             const R (&Li)[O * O], const R (&)[O], const R (&U2)[RR * O], const auto&,
+                                                             const auto& F2, const auto& F2C) LQG_LAMBDA_INLINE {
               if constexpr (NTR > 0) {
                 LQG_UNROLL for (int n = 0; n < NT; ++n) {
                   R xt[O], w[O], cv[M];
@@ -541,8 +644,8 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES
                 }
               }
               to_dense(mul_nt_sym_add(F2C, F2, GG), Sg);
-              assign_state(Pm, Pn);
             });
+            assign_state(Pm, kp.Pn);
           }
         }
       }
@@ -551,39 +654,17 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES
     LQG_UNROLL for (int j = CK - 1; j >= 0; --j) {
       const int t = t0 + j;
       if (WHOLE || t < a.T) {
-        Mat<R, NB, NB, MK::PM> Pm;
         R Sg[M * M];
         TrialState<R, M, ND> st0[NT];
-        if (j >= S0) {
-          int e = 0;
-          LQG_UNROLL for (int i = 0; i < NB; ++i)
-            LQG_UNROLL for (int k = 0; k <= i; ++k) {
-              const R v = Pst[j >= S0 ? j - S0 : 0][e++];
-              if (MK::PM.b[i * NB + k]) Pm.v[i * NB + k] = v;
-              if (MK::PM.b[k * NB + i]) Pm.v[k * NB + i] = v;
-            }
-          e = 0;
-          LQG_UNROLL for (int i = 0; i < M; ++i)
-            LQG_UNROLL for (int k = 0; k <= i; ++k) { const R v = Sst[j >= S0 ? j - S0 : 0][e++]; Sg[i * M + k] = v; Sg[k * M + i] = v; }
-          LQG_UNROLL for (int n = 0; n < NT; ++n) st0[n] = Tst[j >= S0 ? j - S0 : 0][n];
-        } else {                                                       // the chunk's checkpoint
-          const R* src = A.ck + (long)(t0 / CK) * Rec::W * a.ldb + s;
-          R Pd[NB * NB];
-          load_tri_arr<R, NB>(src + Rec::P_OFF * a.ldb, a.ldb, Pd);
-          LQG_UNROLL for (int i = 0; i < NB * NB; ++i) if (MK::PM.b[i]) Pm.v[i] = Pd[i];
-          load_tri_arr<R, M>(src + Rec::S_OFF * a.ldb, a.ldb, Sg);
-          LQG_UNROLL for (int n = 0; n < NT; ++n) {
-            LQG_UNROLL for (int i = 0; i < O; ++i) st0[n].dO[i] = NTR > 0 ? src[(Rec::T_OFF + n * M + i) * a.ldb] : R(0);
-            LQG_UNROLL for (int i = 0; i < RR; ++i) st0[n].muR[i] = NTR > 0 ? src[(Rec::T_OFF + n * M + O + i) * a.ldb] : R(0);
-          }
-        }
+        if (j >= S0) pop(j >= S0 ? j - S0 : 0, Sg, st0);
+        else load_ck(t0 / CK, Sg, st0);                                  // the chunk's checkpoint
+        const KT K = Kst[j];
         Mat<R, NU, NB> L;
         LQG_UNROLL for (int e = 0; e < NU * NB; ++e) L.v[e] = Lbuf[j][e];
-        sys_step<ND>(c, Pm, Sg, L, !WHOLE && t == 0, [&](const auto& AP, const auto& Pp, const auto& FP, const auto& Gi, const auto& K,
-                                                const auto& Pn, const auto& BK, const auto& Fj, const auto& KN2, const auto& KN3,
-                                                const auto& GG, const R (&Li)[O * O], const R (&dinv)[O], const R (&U2)[RR * O],
-                                                const auto& C, const auto& F2, const auto& F2C) LQG_LAMBDA_INLINE {
-          (void)AP; (void)Pn; (void)KN2; (void)GG; (void)dinv; (void)C;
+        joint_part<ND>(c, K, Sg, L, !WHOLE && t == 0, [&](const auto& BK, const auto& Fj, const auto& KN2, const auto& KN3,
+                                                      const auto& GG, const R (&Li)[O * O], const R (&dinv)[O], const R (&U2)[RR * O],
+                                                      const auto& C, const auto& F2, const auto& F2C) LQG_LAMBDA_INLINE {
+          (void)KN2; (void)GG; (void)dinv; (void)C;
           // Li1 = chol(Sigma_{t+1}[:o, :o])^-1, Ni1 = Li1' Li1
           R Li1[O * O];
           {
@@ -720,10 +801,10 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES
               LQG_UNROLL for (int q = 0; q < RR; ++q) Sigb[(O + p) * M + O + q] = Chd[p * RR + q];
           }
           if (!WHOLE && t == 0) {                                                          // Sigma_0 = G_0 G_0'
-            const auto S0 = from_dense<R, M, M>(Sigb);
-            accum(G11, blk<0, 0, NX, NX>(S0));
-            accum(G21, blk<NX, 0, NB, NX>(S0));
-            accum(G22, blk<NX, NX, NB, NB>(S0));
+            const auto S0m = from_dense<R, M, M>(Sigb);
+            accum(G11, blk<0, 0, NX, NX>(S0m));
+            accum(G21, blk<NX, 0, NB, NX>(S0m));
+            accum(G22, blk<NX, NX, NB, NB>(S0m));
           }
           // ---- joint system -> Kbar, Lbar and the accumulated bars                      system.py:167-207
           const auto F11 = blk<0, 0, NX, NX>(Fb);
@@ -731,13 +812,20 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES
           const auto F21 = blk<NX, 0, NB, NX>(Fb);
           const auto F22 = blk<NX, NX, NB, NB>(Fb);
           const auto BKb = mul_nt(F22, L);                                                 // [NB, NU]
-          Mat<R, NB, NY, std::remove_cvref_t<decltype(K)>::mask> Kb;
-          set_zero(Kb);
-          accum(Kb, mul_nt(F21, c.FAd));
-          accum(Kb, mul_nt(F22, c.FAa), R(-1));
-          accum(Kb, mul_nt(BKb, c.DB));
-          accum(Kb, mul_nt(G21, c.N2), R(2));
-          accum(Kb, mul(G22, KN3), R(2));
+          {
+            Mat<R, NB, NY, KT::mask> Kb;
+            set_zero(Kb);
+            accum(Kb, mul_nt(F21, c.FAd));
+            accum(Kb, mul_nt(F22, c.FAa), R(-1));
+            accum(Kb, mul_nt(BKb, c.DB));
+            accum(Kb, mul_nt(G21, c.N2), R(2));
+            accum(Kb, mul(G22, KN3), R(2));
+            // K-bar_t without its P-bar term (- P-bar FP'), which k_asp_kal_rev adds: the set entries of K's mask, in row-major order
+            R* dst = A.Kbar + (long)t * (NB * NY) * a.ldb + s;
+            int e = 0;
+            LQG_UNROLL for (int i = 0; i < NB * NY; ++i)
+              if (KT::mask.b[i]) dst[(e++) * a.ldb] = Kb.v[i];
+          }
           {
             const auto Lb = add(mul_tn(c.Bd, F12), mul_tn(BK, F22));                       // [NU, NB]
             R* dst = A.Lbar + (long)t * (NU * NB) * a.ldb + s;
@@ -753,23 +841,6 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES
           accum(bN1, G11);
           accum(bN2, mul_tn(K, G21), R(2));
           accum(bN3, mul_tn(K, mul(G22, K)));
-          // ---- Kalman step                                                              kf.py:10-14
-          accum(Kb, mul_nt(Pb, FP), R(-1));
-          const auto KbGi = mul(Kb, Gi);                                                   // [NB, NY]
-          const auto Gmb = scaled(mul(Gi, mul(FP, KbGi)), R(-1));                          // [NY, NY]
-          const auto FPb = add(sub(transpose(KbGi), mul_tn(K, Pb)), mul(Gmb, c.Fa));       // [NY, NB]
-          accum(bFa, mul(FPb, Pp));
-          accum(bFa, mul_tn(Gmb, FP));
-          accum(bWWa, Gmb);
-          const auto Ppb = sym_part(add(Pb, mul_tn(c.Fa, FPb)));
-          accum(bVVa, Ppb);
-          const auto PA = mul(Ppb, c.Aa);
-          accum(bAa, mul(PA, Pm), R(2));
-          {
-            const auto Pb1 = sym_part(mul_tn(c.Aa, PA));
-            LQG_UNROLL for (int i = 0; i < NB * NB; ++i)
-              if (MK::PM.b[i]) Pb.v[i] = decltype(Pb1)::mask.b[i] ? Pb1.v[i] : R(0);
-          }
           // the state after step t - 1 is the state before step t
           LQG_UNROLL for (int i = 0; i < O; ++i)
             LQG_UNROLL for (int k = 0; k < O; ++k) SooN[i * O + k] = Sg[i * M + k];
@@ -785,6 +856,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES
   }
   // ---- chain the hoisted products' bars to the stored matrices, write the gradient
   // FAa = Fa Aa, FAd = Fd Ad, DB = Fd Bd - Fa Ba, N2 = Fd N1, N3 = Fd N1 Fd' + WWd
+  // (the bars of VVa, WWa, Sigma0 and the Kalman parts of Aa, Fa: k_asp_kal_rev, which runs next and ADDS to AA and AF)
   {
     R* o = A.out + s;
     const long ld = A.ld;
@@ -802,7 +874,6 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES
     accum(bFd, mul(sym_part(bN3), mul(c.Fd, c.N1)), R(2));
     accum(bN1, mul_tn(c.Fd, bN2));
     accum(bN1, mul_tn(c.Fd, mul(bN3, c.Fd)));
-    if (!(DENSE_P && a.Sigma0.p)) accum(bVVa, Pb);                                         // default Sigma0 = V_0 V_0'  system.py:160
     // bars of fields that no parameter moves (PAT::live_*: lqg_amd/specialize.py) are written as zeros — everything that only
     // feeds them (their accumulators, the hoisted products' bars, the F11 block of MC, ...) is dead code and compiled out
     auto put = [&]<bool LIVE>(int off, const auto& m) LQG_LAMBDA_INLINE {
@@ -825,10 +896,125 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES
     put.template operator()<PAT::live_Aa>(Lay::AA, bAa);
     put.template operator()<PAT::live_Ba>(Lay::AB, bBa);
     put.template operator()<PAT::live_Fa>(Lay::AF, bFa);
-    put.template operator()<PAT::live_Va>(Lay::AVV, bVVa);
-    put.template operator()<PAT::live_Wa>(Lay::AWW, bWWa);
-    store_col(o + Lay::AS0 * ld, ld, Pb);
   }
+}
+
+// ================================================================= phase 2b: adjoint of the Kalman-covariance recursion
+// Backward in time over K-bar_t (left by k_asp_sys_rev, which must have run): the chunk's P_t are recomputed from the same
+// checkpoints into registers (P alone: NB (NB + 1) / 2 reals per step).  Writes the bars of VVa, WWa and Sigma0, ADDS its parts
+// of Aa and Fa to what k_asp_sys_rev wrote.                                                                     kf.py:10-14
+template <typename R, int NX, int NB, int NU, int NY, int ND, typename PAT, int NTR, bool DENSE_P, int CK>
+__global__ void __launch_bounds__(LQG_BLOCK, (NB <= 3 ? 2 : 1)) k_asp_kal_rev(const AspArgs<R> A) {   // (b = 4 dense: 86 spills at two waves)
+  constexpr int M = NX + NB;
+  using Rec = CkRec<NB, M, NTR>;
+  using MK = Masks<PAT, NX, NB, NU, NY, DENSE_P>;
+  using Lay = adj::Layout<NX, NB, NU, NY>;
+  using KT = KalmanGain<R, NX, NB, NU, NY, PAT, MK::PM>;
+  constexpr int NSB = NB * (NB + 1) / 2;
+  const ForwardArgs<R>& a = A.f;
+  const long s = blockIdx.x * (long)LQG_BLOCK + threadIdx.x;
+  if (s >= a.n_sys) return;
+  SysConst<R, NX, NB, NU, NY, PAT> c;
+  c.load(a, s);
+  Mat<R, NB, NB, PAT::Aa> bAa;  Mat<R, NY, NB, PAT::Fa> bFa;  Mat<R, NB, NB, PAT::VVa> bVVa;  Mat<R, NY, NY, PAT::WWa> bWWa;
+  set_zero(bAa); set_zero(bFa); set_zero(bVVa); set_zero(bWWa);
+  Mat<R, NB, NB, MK::PM> Pb;
+  set_zero(Pb);
+  constexpr int S0 = 1;
+  constexpr int CKS = CK - S0 > 0 ? CK - S0 : 1;
+  R Pst[CKS][NSB];
+  auto load_p = [&](const int rec, Mat<R, NB, NB, MK::PM>& Pm) LQG_LAMBDA_INLINE {
+    const R* src = A.ck + (long)rec * Rec::W * a.ldb + s;
+    R Pd[NB * NB];
+    load_tri_arr<R, NB>(src + Rec::P_OFF * a.ldb, a.ldb, Pd);
+    LQG_UNROLL for (int i = 0; i < NB * NB; ++i) if (MK::PM.b[i]) Pm.v[i] = Pd[i];
+  };
+  auto chunk = [&]<bool WHOLE>(const int t0) LQG_LAMBDA_INLINE {
+    {
+      Mat<R, NB, NB, MK::PM> Pm;
+      load_p(t0 / CK, Pm);
+      LQG_UNROLL for (int j = 0; j + 1 < CK; ++j) {
+        if (WHOLE || t0 + j + 1 < a.T) {
+          const auto kp = kalman_part(c, Pm);
+          assign_state(Pm, kp.Pn);
+          R Pd[NB * NB];
+          to_dense(Pm, Pd);
+          int e = 0;
+          LQG_UNROLL for (int i = 0; i < NB; ++i)
+            LQG_UNROLL for (int k = 0; k <= i; ++k) Pst[j][e++] = Pd[i * NB + k];
+        }
+      }
+    }
+    LQG_UNROLL for (int j = CK - 1; j >= 0; --j) {
+      const int t = t0 + j;
+      if (WHOLE || t < a.T) {
+        Mat<R, NB, NB, MK::PM> Pm;
+        if (j >= S0) {
+          int e = 0;
+          LQG_UNROLL for (int i = 0; i < NB; ++i)
+            LQG_UNROLL for (int k = 0; k <= i; ++k) {
+              const R v = Pst[j >= S0 ? j - S0 : 0][e++];
+              if (MK::PM.b[i * NB + k]) Pm.v[i * NB + k] = v;
+              if (MK::PM.b[k * NB + i]) Pm.v[k * NB + i] = v;
+            }
+        } else {
+          load_p(t0 / CK, Pm);
+        }
+        const auto kp = kalman_part(c, Pm);
+        Mat<R, NB, NY, KT::mask> Kb;
+        {
+          const R* src = A.Kbar + (long)t * (NB * NY) * a.ldb + s;
+          int e = 0;
+          LQG_UNROLL for (int i = 0; i < NB * NY; ++i)
+            if (KT::mask.b[i]) Kb.v[i] = src[(e++) * a.ldb];
+        }
+        accum(Kb, mul_nt(Pb, kp.FP), R(-1));
+        const auto KbGi = mul(Kb, kp.Gi);                                                // [NB, NY]
+        const auto Gmb = scaled(mul(kp.Gi, mul(kp.FP, KbGi)), R(-1));                    // [NY, NY]
+        const auto FPb = add(sub(transpose(KbGi), mul_tn(kp.K, Pb)), mul(Gmb, c.Fa));    // [NY, NB]
+        accum(bFa, mul(FPb, kp.Pp));
+        accum(bFa, mul_tn(Gmb, kp.FP));
+        accum(bWWa, Gmb);
+        const auto Ppb = sym_part(add(Pb, mul_tn(c.Fa, FPb)));
+        accum(bVVa, Ppb);
+        const auto PA = mul(Ppb, c.Aa);
+        accum(bAa, mul(PA, Pm), R(2));
+        {
+          const auto Pb1 = sym_part(mul_tn(c.Aa, PA));
+          LQG_UNROLL for (int i = 0; i < NB * NB; ++i)
+            if (MK::PM.b[i]) Pb.v[i] = decltype(Pb1)::mask.b[i] ? Pb1.v[i] : R(0);
+        }
+      }
+    }
+  };
+  {
+    const int nck = (a.T + CK - 1) / CK;
+    int t0 = (nck - 1) * CK;
+    if (t0 + CK > a.T && t0 > 0) { chunk.template operator()<false>(t0); t0 -= CK; }
+    for (; t0 > 0; t0 -= CK) chunk.template operator()<true>(t0);
+    chunk.template operator()<false>(0);
+  }
+  R* o = A.out + s;
+  const long ld = A.ld;
+  if (!(DENSE_P && a.Sigma0.p)) accum(bVVa, Pb);                                           // default Sigma0 = V_0 V_0'  system.py:160
+  auto put = [&]<bool LIVE>(int off, const auto& m) LQG_LAMBDA_INLINE {
+    if constexpr (LIVE) store_col(o + off * ld, ld, m);
+    else {
+      using MT = std::remove_cvref_t<decltype(m)>;
+      LQG_UNROLL for (int i = 0; i < MT::rows * MT::cols; ++i) o[(off + i) * ld] = R(0);
+    }
+  };
+  auto add_to = [&]<bool LIVE>(int off, const auto& m) LQG_LAMBDA_INLINE {
+    using MT = std::remove_cvref_t<decltype(m)>;
+    if constexpr (LIVE) {
+      LQG_UNROLL for (int i = 0; i < MT::rows * MT::cols; ++i) if (MT::mask.b[i]) o[(off + i) * ld] += m.v[i];
+    }
+  };
+  put.template operator()<PAT::live_Va>(Lay::AVV, bVVa);
+  put.template operator()<PAT::live_Wa>(Lay::AWW, bWWa);
+  add_to.template operator()<PAT::live_Aa>(Lay::AA, bAa);
+  add_to.template operator()<PAT::live_Fa>(Lay::AF, bFa);
+  store_col(o + Lay::AS0 * ld, ld, Pb);
 }
 
 // ================================================================= phase 2: adjoint of the Riccati recursion (forward in time)

@@ -23,7 +23,7 @@ namespace host {
 #endif
 
 struct AspWorkspace {
-  size_t sck_off, ck_off, ops_off, tck_off, sums_off, gsum_off, lbar_off, total;
+  size_t sck_off, ck_off, ops_off, tck_off, sums_off, gsum_off, lbar_off, kbar_off, total;
   long ldb, npad;
   int nck, nckt, parts;
 };
@@ -57,6 +57,8 @@ inline AspWorkspace asp_carve(const lqg_problem* p) {
   off += fused ? 0 : al((size_t)w.parts * p->n_sys * esz);
   w.lbar_off = off;
   off += al((size_t)p->T * NU * NB * w.ldb * esz);
+  w.kbar_off = off;
+  off += al((size_t)p->T * NB * NY * w.ldb * esz);
   w.total = off;
   return w;
 }
@@ -116,6 +118,7 @@ int run_asp(const lqg_problem* p, lqg_traj x, const void* g, long g_sb, long g_s
   A.parts = w.parts;
   A.gsum = fused ? nullptr : reinterpret_cast<R*>(base + w.gsum_off);
   A.Lbar = reinterpret_cast<R*>(base + w.lbar_off);
+  A.Kbar = reinterpret_cast<R*>(base + w.kbar_off);
   A.out = static_cast<R*>(grad);
   A.ld = ld;
   lqg::asp::TrialRevArgs<R> tr{};
@@ -174,9 +177,9 @@ int run_asp(const lqg_problem* p, lqg_traj x, const void* g, long g_sb, long g_s
     if (!fused)
       hipLaunchKernelGGL((lqg::asp::k_asp_trial_rev<R, M, ND, LQG_ASP_TPL, LQG_ASP_CKT, MK::FJ>), tgrid, tblock, 0, st, ops, tr);
     if (rev_only) mark(1);
-    if (p->n_trials == 1) LQG_ASP_SYS(k_asp_sys_rev, 1);
-    else if (p->n_trials == 2) LQG_ASP_SYS(k_asp_sys_rev, 2);
-    else LQG_ASP_SYS(k_asp_sys_rev, 0);
+    if (p->n_trials == 1) { LQG_ASP_SYS(k_asp_sys_rev, 1); LQG_ASP_SYS(k_asp_kal_rev, 1); }
+    else if (p->n_trials == 2) { LQG_ASP_SYS(k_asp_sys_rev, 2); LQG_ASP_SYS(k_asp_kal_rev, 2); }
+    else { LQG_ASP_SYS(k_asp_sys_rev, 0); LQG_ASP_SYS(k_asp_kal_rev, 0); }
     if (rev_only) mark(2);
     hipLaunchKernelGGL((lqg::asp::k_asp_ric_rev<R, NB, NU, NX, NY, PAT, CK>), grid, block, 0, st, A);
     if (rev_only) mark(3);
