@@ -35,7 +35,7 @@ PEAK_FP64_TFLOPS = 78.6    # datasheet FP64 vector == FP64 matrix peak
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 COPY_HBM_GBS = 6290.0      # MI355X_MICROARCH.md: measured device copy rate
 VALU_WAVE_INSTS_PER_S = 1024 * 2.4e9 / 2    # 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc.json")      # scripts/pmc_legs.sh + scripts/pmc_records.py
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc.json")      # scripts/pmc_legs.sh + scripts/pmc_records.py
 
 
 def algorithmic_flops_per_step(x, b, u, y, d):
@@ -133,7 +133,7 @@ def launch_ranks(args):
 
 def pmc_record(leg, kernel):
     """The PMC-derived HBM bytes / VALU instructions per launch of `kernel` (a family name: "forward", "riccati", "trial")
-    inside bench leg `leg`, but only if the committed profile (profiles/r05_pmc.json, collected by scripts/pmc_legs.sh as
+    inside bench leg `leg`, but only if the committed profile (profiles/r06_pmc.json, collected by scripts/pmc_legs.sh as
     separate --pmc passes of `bench.py --only <leg>`) was taken on exactly this build: same library source hash, same
     pattern-library header hash.  None otherwise — a leg then reports `traffic: null` rather than a stale figure."""
     try:
@@ -827,9 +827,13 @@ def leg_timevarying(dn):
             del plan, system, x, ll
             torch.cuda.empty_cache()
         out["value"] = out["costs_stay_psd"]["solves_per_s"]
+        # (the PMC pass sees both workloads' launches of the same kernels: the family figure is their per-launch average)
+        rf, rr = pmc_record(f"timevarying_{dn}", "forward"), pmc_record(f"timevarying_{dn}", "riccati")
         out["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS,
                            "achieved": out["costs_stay_psd"]["hbm_frac_algorithmic"] * PEAK_HBM_GBS,
-                           "frac": out["costs_stay_psd"]["hbm_frac_algorithmic"], "traffic": None,
+                           "frac": out["costs_stay_psd"]["hbm_frac_algorithmic"],
+                           "traffic": (rf["hbm_bytes_per_launch"] + rr["hbm_bytes_per_launch"]) if (rf and rr) else None,
+                           "traffic_note": "per launch of ONE component (k_riccati_tv_sp + k_forward_tv_sp); the leg launches two",
                            "kernel": "k_riccati_tv_sp + k_forward_tv_sp over both decoupled components (spec entries streamed once per step)"}
         return out
     return run
@@ -1110,11 +1114,15 @@ LEGS = {
 }
 
 
+# legs that run only when asked for by name (`--only <leg>`): not part of the default line
+ONLY_LEGS = {"timevarying_f32": leg_timevarying("f32")}
+
+
 def extra_legs(torch, args, dev, only=None):
     """Secondary legs, outside the headline's timed region (same workload generators, same timing protocol).  Each is
     self-sufficient: its own roofline object (bound, achieved, peak, frac, traffic from the stamped PMC record)."""
     extra = {}
-    for name, fn in LEGS.items():
+    for name, fn in (LEGS if only is None else dict(LEGS, **ONLY_LEGS)).items():
         if only is not None and name != only:
             continue
         key = name
@@ -1170,7 +1178,7 @@ def main():
         if key is None:                                    # the headline itself in the named dtype (PMC passes)
             out = headline_leg(torch, None, args, dev, 0, 1, args.only[-3:], args.log2_batch, args.steps, args.warmup)
         else:
-            if key not in LEGS:
+            if key not in LEGS and key not in ONLY_LEGS:
                 raise SystemExit(f"--only {key}: unknown leg; known: headline_f32, headline_f64, {', '.join(LEGS)}")
             out = extra_legs(torch, args, dev, only=key)
     elif args.config == 3:

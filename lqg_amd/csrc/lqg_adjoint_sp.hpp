@@ -28,9 +28,9 @@
 #ifndef LQG_ASP_STACK0
 #define LQG_ASP_STACK0 0          // 1: the state before a chunk's first step stays in registers too; 0: re-read from its checkpoint (measured: 4.14 vs 4.32 ms)
 #endif
-#ifndef LQG_ASP_SYS_WAVES_F32
-#define LQG_ASP_SYS_WAVES_F32 1   // waves per SIMD the fp32 system sweeps are allocated for (2: the reverse sweep spills 180 registers, 4.1 -> 10.6 ms measured)
-#endif
+#ifndef LQG_ASP_FWD_WAVES_F32
+#define LQG_ASP_FWD_WAVES_F32 4   // waves per SIMD the fp32 forward system sweep of a small joint dimension (x + b <= 5) is held to: it sits at
+#endif                            // 128 +- 3 VGPRs, and 131 cost a whole wave of occupancy (1.49 -> 2.11 ms per 2^18 systems, same-box A/B, round 6)
 
 namespace lqg {
 namespace asp {
@@ -319,7 +319,7 @@ struct Masks {
 // NTR >= 1: the NTR trials of each system are swept in-lane (value written here); NTR == 0: the per-step trial operators go
 // to the operator stream (lqg_kernels.hpp TrialOps) for k_asp_trial_fwd / k_asp_trial_rev.
 template <typename R, int NX, int NB, int NU, int NY, int ND, typename PAT, int NTR, bool DENSE_P, int CK>
-__global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES_F32 : 1)) k_asp_sys_fwd(const AspArgs<R> A) {
+__global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 && NX + NB <= 5 ? LQG_ASP_FWD_WAVES_F32 : 1)) k_asp_sys_fwd(const AspArgs<R> A) {
   constexpr int M = NX + NB, O = ND, RR = M - ND;
   constexpr int NT = NTR > 0 ? NTR : 1;
   using Ops = TrialOps<M, ND>;
@@ -452,6 +452,477 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES
   }
 }
 
+// Which reverse system sweep run_asp launches.  0 (default): ONE kernel, k_asp_sys_rev_fused — round 5's, 438 VGPRs at the headline
+// shape, one wave per SIMD.  1: the round-6 cut, k_asp_sys_rev + k_asp_kal_rev — 256 VGPRs, the chunk's states in LDS, two waves
+// per SIMD.  Measured on one box, alternating, 2^18 headline systems x 2 in-lane trials (profiles/r06_rev_split.txt): fused 3.72 ms;
+// cut 3.94 + 0.47 ms (two waves per SIMD reached, but every wave then waits 59 % of its cycles on the chunk-start loads that one
+// 438-register wave overlaps with its own arithmetic); cut with a register stack at one wave 3.57 + 0.47.  The cut does not pay.
+#ifndef LQG_ASP_SPLIT_KAL
+#define LQG_ASP_SPLIT_KAL 0
+#endif
+#ifndef LQG_ASP_REV_PREFETCH
+#define LQG_ASP_REV_PREFETCH 0    // 1: the fused sweep requests a chunk's checkpoint one chunk ahead — measured 3.73 -> 4.03 ms (416 registers,
+                                  // the requests hold 37 of them through the walk back; profiles/r06_rev_split.txt): not kept
+#endif
+
+// ================================================================= phase 2: reverse system sweep, ONE kernel (round 5; the default)
+// Per chunk (last to first): the states P_t, Sigma_t (and the in-lane trials' means) of its steps are recomputed from the
+// chunk's checkpoint into registers, then the steps are differentiated backward.  NTR == 0: the trial sums come from
+// k_asp_trial_rev (A.sums, A.parts partial records per step); NTR >= 1: formed in-lane.
+template <typename R, int NX, int NB, int NU, int NY, int ND, typename PAT, int NTR, bool DENSE_P, int CK>
+__global__ void __launch_bounds__(LQG_BLOCK, 1) k_asp_sys_rev_fused(const AspArgs<R> A) {
+  constexpr int M = NX + NB, O = ND, RR = M - ND;
+  constexpr int NT = NTR > 0 ? NTR : 1;
+  using Rec = CkRec<NB, M, NTR>;
+  using MK = Masks<PAT, NX, NB, NU, NY, DENSE_P>;
+  using SM = Sums<M, ND, MK::FJ>;
+  using Lay = adj::Layout<NX, NB, NU, NY>;
+  constexpr int NSB = NB * (NB + 1) / 2, NSM = M * (M + 1) / 2;
+  const ForwardArgs<R>& a = A.f;
+  const long s = blockIdx.x * (long)LQG_BLOCK + threadIdx.x;
+  if (s >= a.n_sys) return;
+  SysConst<R, NX, NB, NU, NY, PAT> c;
+  c.load(a, s);
+  const auto rQ = load_sym_masked<R, NB, PAT::Q>(A.rc.Q.p + s * A.rc.Q.sb, A.rc.Q.sr, A.rc.Q.sc);
+  const auto rR = load_sym_masked<R, NU, PAT::Rr>(A.rc.Rm.p + s * A.rc.Rm.sb, A.rc.Rm.sr, A.rc.Rm.sc);
+  const R* xp = NTR > 0 ? a.x.p + s * a.x.sb : nullptr;
+  R gw[NT];
+  LQG_UNROLL for (int n = 0; n < NT; ++n) gw[n] = (NTR > 0 && A.g) ? A.g[s * A.g_sb + n * A.g_sn] : R(1);
+
+  // accumulated bars (time-invariant specs: one per matrix), on the masks of their primals
+  Mat<R, NX, NX, PAT::Ad> bAd;  Mat<R, NX, NU, PAT::Bd> bBd;  Mat<R, NB, NB, PAT::Aa> bAa;  Mat<R, NB, NU, PAT::Ba> bBa;
+  Mat<R, NY, NB, PAT::Fa> bFa;  Mat<R, NB, NB, PAT::VVa> bVVa;  Mat<R, NY, NY, PAT::WWa> bWWa;  Mat<R, NX, NX, PAT::N1> bN1;
+  decltype(c.FAa) bFAa;  decltype(c.FAd) bFAd;  decltype(c.DB) bDB;  decltype(c.N2) bN2;  decltype(c.N3) bN3;
+  set_zero(bAd); set_zero(bBd); set_zero(bAa); set_zero(bBa); set_zero(bFa); set_zero(bVVa); set_zero(bWWa); set_zero(bN1);
+  set_zero(bFAa); set_zero(bFAd); set_zero(bDB); set_zero(bN2); set_zero(bN3);
+
+  R Sigb[M * M];
+  LQG_UNROLL for (int i = 0; i < M * M; ++i) Sigb[i] = R(0);
+  Mat<R, NB, NB, MK::PM> Pb;
+  set_zero(Pb);
+  R pre[NT][M];
+  LQG_UNROLL for (int n = 0; n < NT; ++n)
+    LQG_UNROLL for (int i = 0; i < M; ++i) pre[n][i] = R(0);
+
+  // state AFTER the step being differentiated: the observed block of Sigma_{t+1} and the trials' means at t + 1
+  R SooN[O * O];
+  TrialState<R, M, ND> stN[NT];
+  const int nck = (a.T + CK - 1) / CK;
+  {
+    const R* src = A.ck + (long)nck * Rec::W * a.ldb + s;
+    R Sf[M * M];
+    load_tri_arr<R, M>(src + Rec::S_OFF * a.ldb, a.ldb, Sf);
+    LQG_UNROLL for (int i = 0; i < O; ++i)
+      LQG_UNROLL for (int j = 0; j < O; ++j) SooN[i * O + j] = Sf[i * M + j];
+    LQG_UNROLL for (int n = 0; n < NT; ++n) {
+      LQG_UNROLL for (int i = 0; i < O; ++i) stN[n].dO[i] = NTR > 0 ? src[(Rec::T_OFF + n * M + i) * a.ldb] : R(0);
+      LQG_UNROLL for (int i = 0; i < RR; ++i) stN[n].muR[i] = NTR > 0 ? src[(Rec::T_OFF + n * M + O + i) * a.ldb] : R(0);
+    }
+  }
+
+  R gs_stream = R(0);
+  if constexpr (NTR == 0) {
+    for (int part = 0; part < A.parts; ++part) gs_stream += A.gsum[(long)part * a.n_sys + s];
+  }
+  R Lbuf[CK][NU * NB];
+  // register stack of the chunk's states (static indices only).  LQG_ASP_STACK0 = 0: the state before the chunk's FIRST step, its
+  // checkpoint, is not stacked but read again when the walk back reaches it
+  constexpr int S0 = 1;                                  // first stacked slot
+  constexpr int CKS = CK - S0 > 0 ? CK - S0 : 1;
+  R Pst[CKS][NSB], Sst[CKS][NSM];
+  TrialState<R, M, ND> Tst[CKS][NT];
+#if LQG_ASP_REV_PREFETCH
+  // The chunk's checkpoint — the Riccati cost-to-go S and the record (P, Sigma, trial means): NS + Rec::W reals — is REQUESTED while
+  // the chunk after it (in time) is still being differentiated and consumed when this chunk starts: one 438-register wave per SIMD
+  // has nobody to hide the chunk-start loads behind but itself (round 6: the sweep waited 26 % of its cycles).
+  constexpr int NSR = NB * (NB + 1) / 2;
+  R pfS[NSR], pfR[Rec::W];
+  auto prefetch = [&](const int t0n) LQG_LAMBDA_INLINE {
+    const R* ssrc = A.rc.Ls + (long)(t0n / CK) * NSR * A.rc.ldb + s;
+    LQG_UNROLL for (int e = 0; e < NSR; ++e) pfS[e] = ssrc[e * A.rc.ldb];
+    const R* rsrc = A.ck + (long)(t0n / CK) * Rec::W * a.ldb + s;
+    LQG_UNROLL for (int e = 0; e < Rec::W; ++e) pfR[e] = rsrc[e * a.ldb];
+  };
+  prefetch((nck - 1) * CK);
+#endif
+  auto chunk = [&]<bool WHOLE>(const int t0) LQG_LAMBDA_INLINE {      // WHOLE: CK full steps, none of them step 0
+#if LQG_ASP_REV_PREFETCH
+    {   // refill_gains from the prefetched S_{t0 + CK} (packed upper triangle by rows, k_riccati_sp<CK>)
+      R Sr[NB * NB];
+      int e = 0;
+      LQG_UNROLL for (int i = 0; i < NB; ++i)
+        LQG_UNROLL for (int j = i; j < NB; ++j) { const R v = pfS[e++]; Sr[i * NB + j] = v; Sr[j * NB + i] = v; }
+      LQG_UNROLL for (int j = CK - 1; j >= 0; --j)
+        if (WHOLE || t0 + j < A.rc.T) riccati_step_sp<R, NB, NU>(Sr, c.Aa, c.Ba, rQ, rR, A.rc.eps, Lbuf[j]);
+    }
+#else
+    refill_gains<R, NB, NU, CK, WHOLE>(A.rc, s, t0, c.Aa, c.Ba, rQ, rR, Lbuf);
+#endif
+    // ---- recompute: states before the steps t0 .. t0 + CK - 1
+    {
+      Mat<R, NB, NB, MK::PM> Pm;
+      R Sg[M * M];
+      TrialState<R, M, ND> st[NT];
+      R xprev[NT][O];
+      const R* src = A.ck + (long)(t0 / CK) * Rec::W * a.ldb + s;
+      {
+#if LQG_ASP_REV_PREFETCH
+        {
+          int e = 0;
+          LQG_UNROLL for (int i = 0; i < NB; ++i)
+            LQG_UNROLL for (int k = 0; k <= i; ++k) {
+              const R v = pfR[Rec::P_OFF + (e++)];
+              if (MK::PM.b[i * NB + k]) Pm.v[i * NB + k] = v;
+              if (MK::PM.b[k * NB + i]) Pm.v[k * NB + i] = v;
+            }
+          e = 0;
+          LQG_UNROLL for (int i = 0; i < M; ++i)
+            LQG_UNROLL for (int k = 0; k <= i; ++k) { const R v = pfR[Rec::S_OFF + (e++)]; Sg[i * M + k] = v; Sg[k * M + i] = v; }
+        }
+#else
+        R Pd[NB * NB];
+        load_tri_arr<R, NB>(src + Rec::P_OFF * a.ldb, a.ldb, Pd);
+        LQG_UNROLL for (int i = 0; i < NB * NB; ++i) if (MK::PM.b[i]) Pm.v[i] = Pd[i];
+        load_tri_arr<R, M>(src + Rec::S_OFF * a.ldb, a.ldb, Sg);
+#endif
+        LQG_UNROLL for (int n = 0; n < NT; ++n) {
+#if LQG_ASP_REV_PREFETCH
+          LQG_UNROLL for (int i = 0; i < O; ++i) st[n].dO[i] = NTR > 0 ? pfR[NTR > 0 ? Rec::T_OFF + n * M + i : 0] : R(0);
+          LQG_UNROLL for (int i = 0; i < RR; ++i) st[n].muR[i] = NTR > 0 ? pfR[NTR > 0 ? Rec::T_OFF + n * M + O + i : 0] : R(0);
+#else
+          LQG_UNROLL for (int i = 0; i < O; ++i) st[n].dO[i] = NTR > 0 ? src[(Rec::T_OFF + n * M + i) * a.ldb] : R(0);
+          LQG_UNROLL for (int i = 0; i < RR; ++i) st[n].muR[i] = NTR > 0 ? src[(Rec::T_OFF + n * M + O + i) * a.ldb] : R(0);
+#endif
+          if constexpr (NTR > 0) {
+            const R* xr = xp + n * a.x.sn + (long)(t0 > 0 ? t0 - 1 : 0) * a.x.st;
+            LQG_UNROLL for (int i = 0; i < O; ++i) xprev[n][i] = xr[i * a.x.sd];
+          }
+        }
+      }
+      LQG_UNROLL for (int j = 0; j < CK; ++j) {
+        const int t = t0 + j;
+        if (WHOLE || t < a.T) {
+          if (j >= S0) {
+            R Pd[NB * NB];
+            to_dense(Pm, Pd);
+            int e = 0;
+            LQG_UNROLL for (int i = 0; i < NB; ++i)
+              LQG_UNROLL for (int k = 0; k <= i; ++k) Pst[j >= S0 ? j - S0 : 0][e++] = Pd[i * NB + k];
+            e = 0;
+            LQG_UNROLL for (int i = 0; i < M; ++i)
+              LQG_UNROLL for (int k = 0; k <= i; ++k) Sst[j >= S0 ? j - S0 : 0][e++] = Sg[i * M + k];
+            LQG_UNROLL for (int n = 0; n < NT; ++n) Tst[j >= S0 ? j - S0 : 0][n] = st[n];
+          }
+          if (j + 1 < CK && (WHOLE || t + 1 < a.T)) {   // (the state after the chunk's last step is carried from the later chunk)
+            Mat<R, NU, NB> L;
+            LQG_UNROLL for (int e = 0; e < NU * NB; ++e) L.v[e] = Lbuf[j][e];
+            sys_step<ND>(c, Pm, Sg, L, !WHOLE && t == 0, [&](const auto&, const auto&, const auto&, const auto&, const auto&, const auto& Pn,
+                                                    const auto&, const auto& Fj, const auto&, const auto&, const auto& GG,
+                                                    const R (&Li)[O * O], const R (&)[O], const R (&U2)[RR * O], const auto&,
+                                                    const auto& F2, const auto& F2C) LQG_LAMBDA_INLINE {
+              if constexpr (NTR > 0) {
+                LQG_UNROLL for (int n = 0; n < NT; ++n) {
+                  R xt[O], w[O], cv[M];
+                  const R* xr = xp + n * a.x.sn + (long)t * a.x.st;
+                  LQG_UNROLL for (int i = 0; i < O; ++i) xt[i] = xr[i * a.x.sd];
+                  trial_forward<R, M, ND>(Fj, Li, U2, xt, xprev[n], st[n], w, cv, true);
+                  LQG_UNROLL for (int i = 0; i < O; ++i) xprev[n][i] = xt[i];
+                }
+              }
+              to_dense(mul_nt_sym_add(F2C, F2, GG), Sg);
+              assign_state(Pm, Pn);
+            });
+          }
+        }
+      }
+    }
+#if LQG_ASP_REV_PREFETCH
+    if (t0 > 0) prefetch(t0 - CK);                        // consumed by the next call; in flight while this chunk is walked back
+#endif
+    // ---- reverse over the chunk
+    LQG_UNROLL for (int j = CK - 1; j >= 0; --j) {
+      const int t = t0 + j;
+      if (WHOLE || t < a.T) {
+        Mat<R, NB, NB, MK::PM> Pm;
+        R Sg[M * M];
+        TrialState<R, M, ND> st0[NT];
+        if (j >= S0) {
+          int e = 0;
+          LQG_UNROLL for (int i = 0; i < NB; ++i)
+            LQG_UNROLL for (int k = 0; k <= i; ++k) {
+              const R v = Pst[j >= S0 ? j - S0 : 0][e++];
+              if (MK::PM.b[i * NB + k]) Pm.v[i * NB + k] = v;
+              if (MK::PM.b[k * NB + i]) Pm.v[k * NB + i] = v;
+            }
+          e = 0;
+          LQG_UNROLL for (int i = 0; i < M; ++i)
+            LQG_UNROLL for (int k = 0; k <= i; ++k) { const R v = Sst[j >= S0 ? j - S0 : 0][e++]; Sg[i * M + k] = v; Sg[k * M + i] = v; }
+          LQG_UNROLL for (int n = 0; n < NT; ++n) st0[n] = Tst[j >= S0 ? j - S0 : 0][n];
+        } else {                                                       // the chunk's checkpoint
+          const R* src = A.ck + (long)(t0 / CK) * Rec::W * a.ldb + s;
+          R Pd[NB * NB];
+          load_tri_arr<R, NB>(src + Rec::P_OFF * a.ldb, a.ldb, Pd);
+          LQG_UNROLL for (int i = 0; i < NB * NB; ++i) if (MK::PM.b[i]) Pm.v[i] = Pd[i];
+          load_tri_arr<R, M>(src + Rec::S_OFF * a.ldb, a.ldb, Sg);
+          LQG_UNROLL for (int n = 0; n < NT; ++n) {
+            LQG_UNROLL for (int i = 0; i < O; ++i) st0[n].dO[i] = NTR > 0 ? src[(Rec::T_OFF + n * M + i) * a.ldb] : R(0);
+            LQG_UNROLL for (int i = 0; i < RR; ++i) st0[n].muR[i] = NTR > 0 ? src[(Rec::T_OFF + n * M + O + i) * a.ldb] : R(0);
+          }
+        }
+        Mat<R, NU, NB> L;
+        LQG_UNROLL for (int e = 0; e < NU * NB; ++e) L.v[e] = Lbuf[j][e];
+        sys_step<ND>(c, Pm, Sg, L, !WHOLE && t == 0, [&](const auto& AP, const auto& Pp, const auto& FP, const auto& Gi, const auto& K,
+                                                const auto& Pn, const auto& BK, const auto& Fj, const auto& KN2, const auto& KN3,
+                                                const auto& GG, const R (&Li)[O * O], const R (&dinv)[O], const R (&U2)[RR * O],
+                                                const auto& C, const auto& F2, const auto& F2C) LQG_LAMBDA_INLINE {
+          (void)AP; (void)Pn; (void)KN2; (void)GG; (void)dinv; (void)C;
+          // Li1 = chol(Sigma_{t+1}[:o, :o])^-1, Ni1 = Li1' Li1
+          R Li1[O * O];
+          {
+            R Lc[O * O], d1[O];
+            chol_lower<R, O>(SooN, Lc, d1);
+            tri_inverse_lower<R, O>(Lc, d1, Li1);
+          }
+          R Wm[RR * O];                                   // Wm = U2 Li = S_ro S_oo^-1
+          LQG_UNROLL for (int p = 0; p < RR; ++p)
+            LQG_UNROLL for (int jj = 0; jj < O; ++jj) {
+              R v = R(0);
+              LQG_UNROLL for (int k = jj; k < O; ++k) v += U2[p * O + k] * Li[k * O + jj];
+              Wm[p * O + jj] = v;
+            }
+          // ---- the trial sums of this step
+          R gs = R(0), W2[O * O], CA[RR * O];
+          Mat<R, M, M, MK::FJ> MC;
+          if constexpr (NTR > 0) {
+            LQG_UNROLL for (int i = 0; i < O * O; ++i) W2[i] = R(0);
+            LQG_UNROLL for (int i = 0; i < RR * O; ++i) CA[i] = R(0);
+            set_zero(MC);
+            LQG_UNROLL for (int n = 0; n < NT; ++n) {
+              R xm1[O], xt[O], x1[O], w0[O], w1[O], cv[M], a0[O], a1[O];
+              const R* xr = xp + n * a.x.sn;
+              LQG_UNROLL for (int i = 0; i < O; ++i) {
+                xt[i] = xr[(long)t * a.x.st + i * a.x.sd];
+                x1[i] = xr[(long)(t + 1) * a.x.st + i * a.x.sd];
+                xm1[i] = xr[(long)(t > 0 ? t - 1 : 0) * a.x.st + i * a.x.sd];
+              }
+              TrialState<R, M, ND> s0 = st0[n];
+              trial_forward<R, M, ND>(Fj, Li, U2, xt, xm1, s0, w0, cv, false);
+              LQG_UNROLL for (int i = 0; i < O; ++i) {
+                R v = R(0);
+                LQG_UNROLL for (int k = 0; k <= i; ++k) v += Li1[i * O + k] * ((x1[k] - xt[k]) - stN[n].dO[k]);
+                w1[i] = v;
+              }
+              LQG_UNROLL for (int i = 0; i < O; ++i) {
+                R v0 = R(0), v1 = R(0);
+                LQG_UNROLL for (int k = i; k < O; ++k) { v0 += Li[k * O + i] * w0[k]; v1 += Li1[k * O + i] * w1[k]; }
+                a0[i] = v0;
+                a1[i] = v1;
+              }
+              const R g = gw[n];
+              gs += g;
+              R post[M];
+              LQG_UNROLL for (int i = 0; i < M; ++i) post[i] = pre[n][i] + (i < O ? g * a1[i < O ? i : 0] : R(0));
+              LQG_UNROLL for (int i = 0; i < O; ++i)
+                LQG_UNROLL for (int k = 0; k < O; ++k) W2[i * O + k] += g * a1[i] * a1[k];
+              LQG_UNROLL for (int i = 0; i < M; ++i)
+                LQG_UNROLL for (int k = 0; k < M; ++k) if (MK::FJ.b[i * M + k]) MC.v[i * M + k] += post[i] * cv[k];
+              R ch[RR];
+              LQG_UNROLL for (int p = 0; p < RR; ++p) {
+                R v = R(0);
+                LQG_UNROLL for (int i = 0; i < M; ++i) if (std::remove_cvref_t<decltype(F2)>::mask.b[i * RR + p]) v += F2.v[i * RR + p] * post[i];
+                ch[p] = v;
+              }
+              LQG_UNROLL for (int p = 0; p < RR; ++p)
+                LQG_UNROLL for (int k = 0; k < O; ++k) CA[p * O + k] += ch[p] * a0[k];
+              LQG_UNROLL for (int k = 0; k < O; ++k) {
+                R v = R(0);
+                LQG_UNROLL for (int p = 0; p < RR; ++p) v += Wm[p * O + k] * ch[p];
+                pre[n][k] = -v;
+              }
+              LQG_UNROLL for (int p = 0; p < RR; ++p) pre[n][O + p] = ch[p];
+              stN[n] = st0[n];
+            }
+          } else {
+            LQG_UNROLL for (int i = 0; i < O * O; ++i) W2[i] = R(0);
+            LQG_UNROLL for (int i = 0; i < RR * O; ++i) CA[i] = R(0);
+            set_zero(MC);
+            gs = gs_stream;
+            for (int part = 0; part < A.parts; ++part) {
+              const R* sm = A.sums + (((long)part * a.n_sys + s) * a.T + t) * SM::N;
+              int e = 0;
+              LQG_UNROLL for (int i = 0; i < O; ++i)
+                LQG_UNROLL for (int k = 0; k <= i; ++k) {
+                  const R v = sm[SM::W_OFF + (e++)];
+                  W2[i * O + k] += v;
+                  if (k != i) W2[k * O + i] += v;
+                }
+              LQG_UNROLL for (int i = 0; i < RR * O; ++i) CA[i] += sm[SM::C_OFF + i];
+              LQG_UNROLL for (int i = 0; i < M; ++i)
+                LQG_UNROLL for (int k = 0; k < M; ++k) if (MK::FJ.b[i * M + k]) MC.v[i * M + k] += sm[SM::mc(i, k)];
+            }
+          }
+          // ---- log-density of x_{t+1}, all trials                                        system.py:244-248
+          LQG_UNROLL for (int i = 0; i < O; ++i)
+            LQG_UNROLL for (int k = 0; k < O; ++k) {
+              R ni = R(0);
+              LQG_UNROLL for (int q = (i > k ? i : k); q < O; ++q) ni += Li1[q * O + i] * Li1[q * O + k];
+              Sigb[i * M + k] += R(0.5) * (W2[i * O + k] - gs * ni);
+            }
+          // ---- Sigma_{t+1} = F2 C F2' + GG,  mu_{t+1} = Fj c
+          const auto SbM = from_dense<R, M, M>(Sigb);
+          const auto FbR = mul(SbM, F2C);                                                 // [M, RR]
+          Mat<R, M, M, MK::FJ> Fb;
+          LQG_UNROLL for (int i = 0; i < M; ++i)
+            LQG_UNROLL for (int k = 0; k < M; ++k)
+              if (MK::FJ.b[i * M + k]) {
+                R v = MC.v[i * M + k];
+                if (k >= O) { if (decltype(FbR)::mask.b[i * RR + (k >= O ? k - O : 0)]) v += R(2) * FbR.v[i * RR + (k >= O ? k - O : 0)]; }
+                Fb.v[i * M + k] = v;
+              }
+          auto G11 = blk<0, 0, NX, NX>(SbM);
+          auto G21 = blk<NX, 0, NB, NX>(SbM);
+          auto G22 = blk<NX, NX, NB, NB>(SbM);
+          // ---- conditioning on x_t, in terms of Wm and a (no product of two inverses: oracle/lqg_adjoint_np.py)
+          {
+            const auto SF = mul(SbM, F2);
+            const auto Ch = sym_part(mul_tn(F2, SF));                                      // [RR, RR]
+            R Chd[RR * RR], ChW[RR * O];
+            to_dense(Ch, Chd);
+            LQG_UNROLL for (int p = 0; p < RR; ++p)
+              LQG_UNROLL for (int k = 0; k < O; ++k) {
+                R v = R(0);
+                LQG_UNROLL for (int q = 0; q < RR; ++q) v += Chd[p * RR + q] * Wm[q * O + k];
+                ChW[p * O + k] = v;
+              }
+            LQG_UNROLL for (int i = 0; i < O; ++i)
+              LQG_UNROLL for (int k = i; k < O; ++k) {
+                R v = R(0);
+                LQG_UNROLL for (int p = 0; p < RR; ++p)
+                  v += Wm[p * O + i] * (ChW[p * O + k] - CA[p * O + k]) + Wm[p * O + k] * (ChW[p * O + i] - CA[p * O + i]);
+                Sigb[i * M + k] = R(0.5) * v;
+                Sigb[k * M + i] = R(0.5) * v;
+              }
+            LQG_UNROLL for (int p = 0; p < RR; ++p)
+              LQG_UNROLL for (int k = 0; k < O; ++k) {
+                const R v = R(0.5) * (CA[p * O + k] - R(2) * ChW[p * O + k]);
+                Sigb[(O + p) * M + k] = v;
+                Sigb[k * M + O + p] = v;
+              }
+            LQG_UNROLL for (int p = 0; p < RR; ++p)
+              LQG_UNROLL for (int q = 0; q < RR; ++q) Sigb[(O + p) * M + O + q] = Chd[p * RR + q];
+          }
+          if (!WHOLE && t == 0) {                                                          // Sigma_0 = G_0 G_0'
+            const auto S0 = from_dense<R, M, M>(Sigb);
+            accum(G11, blk<0, 0, NX, NX>(S0));
+            accum(G21, blk<NX, 0, NB, NX>(S0));
+            accum(G22, blk<NX, NX, NB, NB>(S0));
+          }
+          // ---- joint system -> Kbar, Lbar and the accumulated bars                      system.py:167-207
+          const auto F11 = blk<0, 0, NX, NX>(Fb);
+          const auto F12 = blk<0, NX, NX, NB>(Fb);
+          const auto F21 = blk<NX, 0, NB, NX>(Fb);
+          const auto F22 = blk<NX, NX, NB, NB>(Fb);
+          const auto BKb = mul_nt(F22, L);                                                 // [NB, NU]
+          Mat<R, NB, NY, std::remove_cvref_t<decltype(K)>::mask> Kb;
+          set_zero(Kb);
+          accum(Kb, mul_nt(F21, c.FAd));
+          accum(Kb, mul_nt(F22, c.FAa), R(-1));
+          accum(Kb, mul_nt(BKb, c.DB));
+          accum(Kb, mul_nt(G21, c.N2), R(2));
+          accum(Kb, mul(G22, KN3), R(2));
+          {
+            const auto Lb = add(mul_tn(c.Bd, F12), mul_tn(BK, F22));                       // [NU, NB]
+            R* dst = A.Lbar + (long)t * (NU * NB) * a.ldb + s;
+            store_col(dst, a.ldb, Lb);
+          }
+          accum(bAd, F11);
+          accum(bBd, mul_nt(F12, L));
+          accum(bFAd, mul_tn(K, F21));
+          accum(bAa, F22);
+          accum(bFAa, mul_tn(K, F22), R(-1));
+          accum(bBa, BKb);
+          accum(bDB, mul_tn(K, BKb));
+          accum(bN1, G11);
+          accum(bN2, mul_tn(K, G21), R(2));
+          accum(bN3, mul_tn(K, mul(G22, K)));
+          // ---- Kalman step                                                              kf.py:10-14
+          accum(Kb, mul_nt(Pb, FP), R(-1));
+          const auto KbGi = mul(Kb, Gi);                                                   // [NB, NY]
+          const auto Gmb = scaled(mul(Gi, mul(FP, KbGi)), R(-1));                          // [NY, NY]
+          const auto FPb = add(sub(transpose(KbGi), mul_tn(K, Pb)), mul(Gmb, c.Fa));       // [NY, NB]
+          accum(bFa, mul(FPb, Pp));
+          accum(bFa, mul_tn(Gmb, FP));
+          accum(bWWa, Gmb);
+          const auto Ppb = sym_part(add(Pb, mul_tn(c.Fa, FPb)));
+          accum(bVVa, Ppb);
+          const auto PA = mul(Ppb, c.Aa);
+          accum(bAa, mul(PA, Pm), R(2));
+          {
+            const auto Pb1 = sym_part(mul_tn(c.Aa, PA));
+            LQG_UNROLL for (int i = 0; i < NB * NB; ++i)
+              if (MK::PM.b[i]) Pb.v[i] = decltype(Pb1)::mask.b[i] ? Pb1.v[i] : R(0);
+          }
+          // the state after step t - 1 is the state before step t
+          LQG_UNROLL for (int i = 0; i < O; ++i)
+            LQG_UNROLL for (int k = 0; k < O; ++k) SooN[i * O + k] = Sg[i * M + k];
+        });
+      }
+    }
+  };
+  {
+    int t0 = (nck - 1) * CK;
+    if (t0 + CK > a.T && t0 > 0) { chunk.template operator()<false>(t0); t0 -= CK; }     // the last, partial chunk
+    for (; t0 > 0; t0 -= CK) chunk.template operator()<true>(t0);
+    chunk.template operator()<false>(0);                                // (step 0: Sigma_0 = G_0 G_0')
+  }
+  // ---- chain the hoisted products' bars to the stored matrices, write the gradient
+  // FAa = Fa Aa, FAd = Fd Ad, DB = Fd Bd - Fa Ba, N2 = Fd N1, N3 = Fd N1 Fd' + WWd
+  {
+    R* o = A.out + s;
+    const long ld = A.ld;
+    accum(bAd, mul_tn(c.Fd, bFAd));
+    accum(bBd, mul_tn(c.Fd, bDB));
+    accum(bAa, mul_tn(c.Fa, bFAa));
+    accum(bBa, mul_tn(c.Fa, bDB), R(-1));
+    accum(bFa, mul_nt(bFAa, c.Aa));
+    accum(bFa, mul_nt(bDB, c.Ba), R(-1));
+    Mat<R, NY, NX, PAT::Fd> bFd;
+    set_zero(bFd);
+    accum(bFd, mul_nt(bFAd, c.Ad));
+    accum(bFd, mul_nt(bDB, c.Bd));
+    accum(bFd, mul(bN2, c.N1));
+    accum(bFd, mul(sym_part(bN3), mul(c.Fd, c.N1)), R(2));
+    accum(bN1, mul_tn(c.Fd, bN2));
+    accum(bN1, mul_tn(c.Fd, mul(bN3, c.Fd)));
+    if (!(DENSE_P && a.Sigma0.p)) accum(bVVa, Pb);                                         // default Sigma0 = V_0 V_0'  system.py:160
+    // bars of fields that no parameter moves (PAT::live_*: lqg_amd/specialize.py) are written as zeros — everything that only
+    // feeds them (their accumulators, the hoisted products' bars, the F11 block of MC, ...) is dead code and compiled out
+    auto put = [&]<bool LIVE>(int off, const auto& m) LQG_LAMBDA_INLINE {
+      if constexpr (LIVE) store_col(o + off * ld, ld, m);
+      else {
+        using MT = std::remove_cvref_t<decltype(m)>;
+        LQG_UNROLL for (int i = 0; i < MT::rows * MT::cols; ++i) o[(off + i) * ld] = R(0);
+      }
+    };
+    put.template operator()<PAT::live_Ad>(Lay::DA, bAd);
+    put.template operator()<PAT::live_Bd>(Lay::DB, bBd);
+    put.template operator()<PAT::live_Fd>(Lay::DF, bFd);
+    put.template operator()<PAT::live_Vd>(Lay::DVV, bN1);
+    {
+      Mat<R, NY, NY, PAT::WWd> bWWd;
+      set_zero(bWWd);
+      accum(bWWd, bN3);
+      put.template operator()<PAT::live_Wd>(Lay::DWW, bWWd);
+    }
+    put.template operator()<PAT::live_Aa>(Lay::AA, bAa);
+    put.template operator()<PAT::live_Ba>(Lay::AB, bBa);
+    put.template operator()<PAT::live_Fa>(Lay::AF, bFa);
+    put.template operator()<PAT::live_Va>(Lay::AVV, bVVa);
+    put.template operator()<PAT::live_Wa>(Lay::AWW, bWWa);
+    store_col(o + Lay::AS0 * ld, ld, Pb);
+  }
+}
+
 // ================================================================= phase 2: reverse system sweep, cut in two (round 6)
 // Round 5 ran ALL system adjoints in one kernel: 438 VGPRs at the headline shape (two in-lane trials), one wave per SIMD, 0.35 of
 // the VALU issue rate.  The adjoint of the Kalman-covariance recursion reads nothing of the moment recursion but K-bar_t — as the
@@ -468,10 +939,13 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 ? LQG_ASP_SYS_WAVES
 
 // what of the chunk's recomputed states goes to LDS: the budget is 80 reals per lane = 20 kB per 64-lane workgroup in fp32 (eight
 // workgroups = two waves per SIMD fit a CU's 160 kB), 40 kB in fp64 (four workgroups: one wave per SIMD)
+#ifndef LQG_ASP_REV_LDS_BUDGET
+#define LQG_ASP_REV_LDS_BUDGET 80
+#endif
 template <int M, int NTM, int CKS>
 struct RevStack {
   static constexpr int NSM = M * (M + 1) / 2;
-  static constexpr int BUDGET = 80;
+  static constexpr int BUDGET = LQG_ASP_REV_LDS_BUDGET;
   static constexpr bool SIG = CKS * NSM <= BUDGET;                       // Sigma_t (lower triangle)
   static constexpr bool TRL = SIG && NTM > 0 && CKS * (NSM + NTM) <= BUDGET;   // the in-lane trials' mean states
   static constexpr int PER_SLOT = (SIG ? NSM : 0) + (TRL ? NTM : 0);

@@ -177,9 +177,15 @@ int run_asp(const lqg_problem* p, lqg_traj x, const void* g, long g_sb, long g_s
     if (!fused)
       hipLaunchKernelGGL((lqg::asp::k_asp_trial_rev<R, M, ND, LQG_ASP_TPL, LQG_ASP_CKT, MK::FJ>), tgrid, tblock, 0, st, ops, tr);
     if (rev_only) mark(1);
+#if LQG_ASP_SPLIT_KAL
     if (p->n_trials == 1) { LQG_ASP_SYS(k_asp_sys_rev, 1); LQG_ASP_SYS(k_asp_kal_rev, 1); }
     else if (p->n_trials == 2) { LQG_ASP_SYS(k_asp_sys_rev, 2); LQG_ASP_SYS(k_asp_kal_rev, 2); }
     else { LQG_ASP_SYS(k_asp_sys_rev, 0); LQG_ASP_SYS(k_asp_kal_rev, 0); }
+#else
+    if (p->n_trials == 1) LQG_ASP_SYS(k_asp_sys_rev_fused, 1);
+    else if (p->n_trials == 2) LQG_ASP_SYS(k_asp_sys_rev_fused, 2);
+    else LQG_ASP_SYS(k_asp_sys_rev_fused, 0);
+#endif
     if (rev_only) mark(2);
     hipLaunchKernelGGL((lqg::asp::k_asp_ric_rev<R, NB, NU, NX, NY, PAT, CK>), grid, block, 0, st, A);
     if (rev_only) mark(3);

@@ -597,17 +597,41 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sp_fwd_waves<R, NX + NB>()))
 // the union over systems and steps, lqg_amd/specialize.py), the same two sweeps run on the pattern's masks: only the
 // structurally non-zero entries are loaded per step, the step is the ~250 instructions of the headline path, and L, H, K,
 // mu, Sigma are stored dense (structural zeros as zeros).  One trial per system, swept in-lane.
-template <typename R, int NB, int NU, typename PAT>
-__global__ void __launch_bounds__(LQG_BLOCK, 2) k_riccati_tv_sp(const RiccatiArgs<R> a) {
+#ifndef LQG_TV_UNIFORM_BASE
+#define LQG_TV_UNIFORM_BASE 1     // spec loads of the time-varying sweeps: wave-uniform entry pointer + lane offset (0: one per-lane pointer expression)
+#endif
+// CANON (round 6): every time-varying field is stored [T][row][col][system] with one leading dimension `ldc` (elements): the loads
+// are scalar-base + lane-offset (lqg_sparse.hpp: load_masked_c) and none of the per-field strides but st is read.
+template <typename R, int NB, int NU, typename PAT, bool CANON = false>
+__global__ void __launch_bounds__(LQG_BLOCK, 2) k_riccati_tv_sp(const RiccatiArgs<R> a, const long ldc = 0) {
   const long s = blockIdx.x * (long)LQG_BLOCK + threadIdx.x;
   if (s >= a.n_sys) return;
+  [[maybe_unused]] const unsigned ldb = (unsigned)(ldc * (long)sizeof(R)), lob = (unsigned)(s * (long)sizeof(R));
   R S[NB * NB];
   load_sym<R, NB>(a.Qf.p + s * a.Qf.sb, a.Qf.sr, a.Qf.sc, S);
   for (int t = a.T - 1; t >= 0; --t) {
+#if LQG_TV_UNIFORM_BASE
+    if constexpr (CANON) {
+      const auto A = load_masked_c<R, NB, NB, PAT::Aa>(a.A.p + (long)t * a.A.st, ldb, lob);
+      const auto Bm = load_masked_c<R, NB, NU, PAT::Ba>(a.B.p + (long)t * a.B.st, ldb, lob);
+      const auto Q = load_sym_masked_c<R, NB, PAT::Q>(a.Q.p + (long)t * a.Q.st, ldb, lob);
+      const auto Rm = load_sym_masked_c<R, NU, PAT::Rr>(a.Rm.p + (long)t * a.Rm.st, ldb, lob);
+      R L[NU * NB];
+      riccati_step_sp<R, NB, NU>(S, A, Bm, Q, Rm, a.eps, L);
+      R* dst = a.Ls + (long)t * (NU * NB) * a.ldb + s;
+      LQG_UNROLL for (int e = 0; e < NU * NB; ++e) dst[e * a.ldb] = L[e];
+      continue;                                    // (the canonical instantiation serves the log-likelihood only: no P, no L / l / H outputs)
+    }
+    const auto A = load_masked_u<R, NB, NB, PAT::Aa>(a.A.p + (long)t * a.A.st, a.A.sr, a.A.sc, s * a.A.sb);
+    const auto Bm = load_masked_u<R, NB, NU, PAT::Ba>(a.B.p + (long)t * a.B.st, a.B.sr, a.B.sc, s * a.B.sb);
+    const auto Q = load_sym_masked_u<R, NB, PAT::Q>(a.Q.p + (long)t * a.Q.st, a.Q.sr, a.Q.sc, s * a.Q.sb);
+    const auto Rm = load_sym_masked_u<R, NU, PAT::Rr>(a.Rm.p + (long)t * a.Rm.st, a.Rm.sr, a.Rm.sc, s * a.Rm.sb);
+#else
     const auto A = load_masked<R, NB, NB, PAT::Aa>(a.A.p + s * a.A.sb + t * a.A.st, a.A.sr, a.A.sc);
     const auto Bm = load_masked<R, NB, NU, PAT::Ba>(a.B.p + s * a.B.sb + t * a.B.st, a.B.sr, a.B.sc);
     const auto Q = load_sym_masked<R, NB, PAT::Q>(a.Q.p + s * a.Q.sb + t * a.Q.st, a.Q.sr, a.Q.sc);
     const auto Rm = load_sym_masked<R, NU, PAT::Rr>(a.Rm.p + s * a.Rm.sb + t * a.Rm.st, a.Rm.sr, a.Rm.sc);
+#endif
     R L[NU * NB], Ht[NU * NU], Pc[NU * NB];
     if (a.P.p) {                                   // cross cost u' P x (lqr.py:23).  q, qf, r only move the affine gain l and the
       const R* pp = a.P.p + s * a.P.sb + t * a.P.st;   // cost-to-go offset s (lqr.py:24, 31, 34): neither enters L, S or the likelihood
@@ -630,12 +654,20 @@ __global__ void __launch_bounds__(LQG_BLOCK, 2) k_riccati_tv_sp(const RiccatiArg
 
 // FUSED = false (round 6: lqg_log_likelihood_sp for time-varying specs with several trials per system, or in the mixed mode): no
 // trial is swept in-lane; the step's trial operator goes to the operator stream (element type OT, as k_forward_sp) for k_trial_sp.
-template <typename R, int NX, int NB, int NU, int NY, int ND, typename PAT, bool DENSE_P, bool FUSED = true, typename OT = R>
-__global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? 2 : 1) k_forward_tv_sp(const ForwardArgs<R> a, const DView<R> Lv) {
+#ifndef LQG_TV_PREFETCH
+#define LQG_TV_PREFETCH 0
+#endif
+#ifndef LQG_TV_WAVES_F64
+#define LQG_TV_WAVES_F64 1
+#endif
+template <typename R, int NX, int NB, int NU, int NY, int ND, typename PAT, bool DENSE_P, bool FUSED = true, typename OT = R, bool CANON = false>
+__global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? 2 : LQG_TV_WAVES_F64) k_forward_tv_sp(const ForwardArgs<R> a, const DView<R> Lv,
+                                                                                               const long ldc = 0) {
   constexpr int M = NX + NB, O = ND, RR = M - ND;
   using Ops = TrialOps<M, ND>;
   const long s = blockIdx.x * (long)LQG_BLOCK + threadIdx.x;
   if (s >= a.n_sys) return;
+  [[maybe_unused]] const unsigned ldb = (unsigned)(ldc * (long)sizeof(R)), lob = (unsigned)(s * (long)sizeof(R));
   constexpr auto PMASK = kalman_state_mask<PAT, NB, NY, DENSE_P>();
   Mat<R, NB, NB, PMASK> Pm;
   {
@@ -687,6 +719,31 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? 2 : 1) k_forward_t
     if (score) acc -= (double)(R(0.5) * zz + hl + kLogNorm);
   };
   // this step's specs: structurally non-zero entries only
+#if LQG_TV_UNIFORM_BASE
+  // wave-uniform entry pointers (scalar) + the lane's own element offset per field (lqg_sparse.hpp: load_masked_u)
+  const long oAa = s * a.aA.sb, oBa = s * a.aB.sb, oFa = s * a.aF.sb, oVa = s * a.aV.sb, oWa = s * a.aW.sb;
+  const long oAd = s * a.dA.sb, oBd = s * a.dB.sb, oFd = s * a.dF.sb, oVd = s * a.dV.sb, oWd = s * a.dW.sb;
+  auto ldAa = [&](int t) { if constexpr (CANON) return load_masked_c<R, NB, NB, PAT::Aa>(a.aA.p + (long)t * a.aA.st, ldb, lob);
+                           else return load_masked_u<R, NB, NB, PAT::Aa>(a.aA.p + (long)t * a.aA.st, a.aA.sr, a.aA.sc, oAa); };
+  auto ldBa = [&](int t) { if constexpr (CANON) return load_masked_c<R, NB, NU, PAT::Ba>(a.aB.p + (long)t * a.aB.st, ldb, lob);
+                           else return load_masked_u<R, NB, NU, PAT::Ba>(a.aB.p + (long)t * a.aB.st, a.aB.sr, a.aB.sc, oBa); };
+  auto ldFa = [&](int t) { if constexpr (CANON) return load_masked_c<R, NY, NB, PAT::Fa>(a.aF.p + (long)t * a.aF.st, ldb, lob);
+                           else return load_masked_u<R, NY, NB, PAT::Fa>(a.aF.p + (long)t * a.aF.st, a.aF.sr, a.aF.sc, oFa); };
+  auto ldVVa = [&](int t) { if constexpr (CANON) return load_gram_masked_raw_c<R, NB, PAT::VVa, PAT::Va>(a.aV.p + (long)t * a.aV.st, a.nva, ldb, lob);
+                            else return load_gram_masked_raw<R, NB, PAT::VVa, PAT::Va>(a.aV.p + (long)t * a.aV.st, a.aV.sr, a.aV.sc, a.nva, oVa); };
+  auto ldWWa = [&](int t) { if constexpr (CANON) return load_gram_masked_raw_c<R, NY, PAT::WWa, PAT::Wa>(a.aW.p + (long)t * a.aW.st, a.nwa, ldb, lob);
+                            else return load_gram_masked_raw<R, NY, PAT::WWa, PAT::Wa>(a.aW.p + (long)t * a.aW.st, a.aW.sr, a.aW.sc, a.nwa, oWa); };
+  auto ldAd = [&](int t) { if constexpr (CANON) return load_masked_c<R, NX, NX, PAT::Ad>(a.dA.p + (long)t * a.dA.st, ldb, lob);
+                           else return load_masked_u<R, NX, NX, PAT::Ad>(a.dA.p + (long)t * a.dA.st, a.dA.sr, a.dA.sc, oAd); };
+  auto ldBd = [&](int t) { if constexpr (CANON) return load_masked_c<R, NX, NU, PAT::Bd>(a.dB.p + (long)t * a.dB.st, ldb, lob);
+                           else return load_masked_u<R, NX, NU, PAT::Bd>(a.dB.p + (long)t * a.dB.st, a.dB.sr, a.dB.sc, oBd); };
+  auto ldN1 = [&](int t) { if constexpr (CANON) return load_gram_masked_raw_c<R, NX, PAT::N1, PAT::Vd>(a.dV.p + (long)t * a.dV.st, a.nvd, ldb, lob);
+                           else return load_gram_masked_raw<R, NX, PAT::N1, PAT::Vd>(a.dV.p + (long)t * a.dV.st, a.dV.sr, a.dV.sc, a.nvd, oVd); };
+  auto ldFd = [&](int t) { if constexpr (CANON) return load_masked_c<R, NY, NX, PAT::Fd>(a.dF.p + (long)t * a.dF.st, ldb, lob);
+                           else return load_masked_u<R, NY, NX, PAT::Fd>(a.dF.p + (long)t * a.dF.st, a.dF.sr, a.dF.sc, oFd); };
+  auto ldWWd = [&](int t) { if constexpr (CANON) return load_gram_masked_raw_c<R, NY, PAT::WWd, PAT::Wd>(a.dW.p + (long)t * a.dW.st, a.nwd, ldb, lob);
+                            else return load_gram_masked_raw<R, NY, PAT::WWd, PAT::Wd>(a.dW.p + (long)t * a.dW.st, a.dW.sr, a.dW.sc, a.nwd, oWd); };
+#else
   auto ldAa = [&](int t) { return load_masked<R, NB, NB, PAT::Aa>(a.aA.p + s * a.aA.sb + t * a.aA.st, a.aA.sr, a.aA.sc); };
   auto ldBa = [&](int t) { return load_masked<R, NB, NU, PAT::Ba>(a.aB.p + s * a.aB.sb + t * a.aB.st, a.aB.sr, a.aB.sc); };
   auto ldFa = [&](int t) { return load_masked<R, NY, NB, PAT::Fa>(a.aF.p + s * a.aF.sb + t * a.aF.st, a.aF.sr, a.aF.sc); };
@@ -697,8 +754,14 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? 2 : 1) k_forward_t
   auto ldN1 = [&](int t) { return load_gram_masked_raw<R, NX, PAT::N1, PAT::Vd>(a.dV.p + s * a.dV.sb + t * a.dV.st, a.dV.sr, a.dV.sc, a.nvd); };
   auto ldFd = [&](int t) { return load_masked<R, NY, NX, PAT::Fd>(a.dF.p + s * a.dF.sb + t * a.dF.st, a.dF.sr, a.dF.sc); };
   auto ldWWd = [&](int t) { return load_gram_masked_raw<R, NY, PAT::WWd, PAT::Wd>(a.dW.p + s * a.dW.sb + t * a.dW.st, a.dW.sr, a.dW.sc, a.nwd); };
+#endif
   auto ldL = [&](int t) {
     Mat<R, NU, NB> L;                             // gains of step t: the caller's L array or the gain scratch, as a strided view
+    if constexpr (CANON) {                        // (the gain scratch [T][NU NB][ldb] is canonical with its own leading dimension Lv.sc)
+      LQG_UNROLL for (int e = 0; e < NU * NB; ++e)
+        L.v[e] = canon_at<R>(Lv.p + (long)t * Lv.st, (unsigned)e, (unsigned)(Lv.sc * (long)sizeof(R)), lob);
+      return L;
+    }
     const R* src = Lv.p + s * Lv.sb + (long)t * Lv.st;
     LQG_UNROLL for (int i = 0; i < NU; ++i)
       LQG_UNROLL for (int j = 0; j < NB; ++j) L.v[i * NB + j] = src[i * Lv.sr + j * Lv.sc];
@@ -707,7 +770,25 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? 2 : 1) k_forward_t
   // (measured on 2^17 systems — two waves per SIMD — and not kept: requesting the next step's rows one or four steps ahead
   // (17.6 -> 19.0 ms forward, 5.4 -> 6.0 ms Riccati) and running the Kalman step of t + 1 inside iteration t as a second
   // dependency chain (17.8 -> 18.9 ms))
+#if LQG_TV_PREFETCH
+  // the specs of step t + 1 are requested at the START of step t (one wave or two per SIMD have nothing else to hide a step's
+  // ~25 dependent loads behind: the log-likelihood route of round 6 ran 5.7 us per step in fp64 without this)
+  auto nAa = ldAa(0); auto nBa = ldBa(0); auto nFa = ldFa(0); auto nVVa = ldVVa(0); auto nWWa = ldWWa(0);
+  auto nAd = ldAd(0); auto nBd = ldBd(0); auto nN1 = ldN1(0); auto nFd = ldFd(0); auto nWWd = ldWWd(0);
+  Mat<R, NU, NB> nL = ldL(0);
+#endif
   auto step = [&]<bool FIRST>(int t) {
+#if LQG_TV_PREFETCH
+    const auto Aa = nAa;  const auto Ba = nBa;  const auto Fa = nFa;  const auto VVa = nVVa;  const auto WWa = nWWa;
+    const auto Ad = nAd;  const auto Bd = nBd;  const auto N1 = nN1;  const auto Fd = nFd;  const auto WWd = nWWd;
+    const Mat<R, NU, NB> L = nL;
+    {
+      const int tn = t + 1 < a.T ? t + 1 : t;
+      nAa = ldAa(tn); nBa = ldBa(tn); nFa = ldFa(tn); nVVa = ldVVa(tn); nWWa = ldWWa(tn);
+      nAd = ldAd(tn); nBd = ldBd(tn); nN1 = ldN1(tn); nFd = ldFd(tn); nWWd = ldWWd(tn);
+      nL = ldL(tn);
+    }
+#else
     const auto Aa = ldAa(t);
     const auto Ba = ldBa(t);
     const auto Fa = ldFa(t);
@@ -719,6 +800,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? 2 : 1) k_forward_t
     const auto Fd = ldFd(t);
     const auto WWd = ldWWd(t);
     const Mat<R, NU, NB> L = ldL(t);
+#endif
     const auto FAa = restrict_to<PAT::FAa>(mul(Fa, Aa));
     const auto FAd = restrict_to<PAT::FAd>(mul(Fd, Ad));
     const auto DB = restrict_to<PAT::DB>(sub(mul(Fd, Bd), mul(Fa, Ba)));
@@ -731,7 +813,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? 2 : 1) k_forward_t
     const auto Gi = spd_inverse_masked(mul_nt_sym_add(FP, Fa, WWa));
     const auto K = mul_tn(FP, Gi);
     assign_state(Pm, sym_sub_mul(Pp, K, FP));
-    if (a.Kout.p) {
+    if (!CANON && a.Kout.p) {                    // (the canonical instantiation serves the log-likelihood: nothing materialised)
       R Kd[NB * NY];
       to_dense(K, Kd);
       store_mat<R, NB, NY>(const_cast<R*>(a.Kout.p) + s * a.Kout.sb + t * a.Kout.st, a.Kout.sr, a.Kout.sc, Kd);
@@ -758,7 +840,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? 2 : 1) k_forward_t
       dev_matvec_row<O, 0>(Fj, cvec, mn);                                  // rows < O as deviation from x_t
       LQG_UNROLL for (int i = 0; i < O; ++i) { dO[i] = mn[i]; xprev[i] = xt[i]; }
       LQG_UNROLL for (int p = 0; p < RR; ++p) muR[p] = mn[O + p];
-      if (a.mu.p) {
+      if (!CANON && a.mu.p) {
         R* dst = const_cast<R*>(a.mu.p) + s * a.mu.sb + (long)t * a.mu.st;
         LQG_UNROLL for (int i = 0; i < M; ++i) dst[i * a.mu.sd] = (i < O) ? xt[i] + mn[i] : mn[i];
       }
@@ -786,7 +868,7 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? 2 : 1) k_forward_t
       }
     const auto F2 = cols<O, RR>(Fj);
     to_dense(mul_nt_sym_add(mul(F2, C), F2, GG), Sg);
-    if (a.Sig.p) store_mat<R, M, M>(const_cast<R*>(a.Sig.p) + s * a.Sig.sb + t * a.Sig.st, a.Sig.sr, a.Sig.sc, Sg);
+    if (!CANON && a.Sig.p) store_mat<R, M, M>(const_cast<R*>(a.Sig.p) + s * a.Sig.sb + t * a.Sig.st, a.Sig.sr, a.Sig.sc, Sg);
   };
   step.template operator()<true>(0);
   for (int t = 1; t < a.T; ++t) step.template operator()<false>(t);

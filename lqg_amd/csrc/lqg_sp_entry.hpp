@@ -279,10 +279,37 @@ int run_sp_mixed(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll
 // spec arrays, operators rounded once to float, no residual stream) go through the operator stream and the pattern's per-trial
 // sweep.  The cross cost P enters G = P + B'SA (lqr.py:23); q, qf, r only move the affine gain l and the offset s of the
 // cost-to-go (lqr.py:24, 31, 34), neither of which the moments or the likelihood read (system.py:169-181 use gains.L) — ignored.
+// Leading dimension of the CANONICAL storage [T][row][col][system] (workload.pack_systems) when every spec field the two sweeps read
+// has it — sb = 1, sc = ld, sr = cols ld, st = rows cols ld (or 0: time-invariant) with one ld — and the 32-bit offsets of the
+// canonical loaders (lqg_sparse.hpp) cannot overflow; 0 otherwise (then the strided loaders serve the call).  No cross cost P.
+inline long canon_layout(const lqg_problem* p) {
+  const lqg_spec& a = p->actor;
+  const lqg_spec& d = p->dynamics;
+  const lqg_dims& m = p->dims;
+  if (a.P.ptr) return 0;
+  long ld = 0;
+  auto ok = [&](const lqg_view& v, long rows, long cols) {
+    if (!v.ptr || v.sb != 1 || v.sc <= 0) return false;
+    if (ld == 0) ld = v.sc;
+    return v.sc == ld && v.sr == cols * ld && (v.st == rows * cols * ld || v.st == 0);
+  };
+  const bool all = ok(a.A, m.b, m.b) && ok(a.B, m.b, m.u) && ok(a.F, m.y, m.b) && ok(a.V, m.b, m.nva) && ok(a.W, m.y, m.nwa) &&
+                   ok(a.Q, m.b, m.b) && ok(a.R, m.u, m.u) && ok(d.A, m.x, m.x) && ok(d.B, m.x, m.u) && ok(d.F, m.y, m.x) &&
+                   ok(d.V, m.x, m.nvd) && ok(d.W, m.y, m.nwd);
+  if (!all) return 0;
+  const long esz = p->dtype == LQG_F32 ? 4 : 8;
+  long widest = 1;
+  for (long e : {(long)m.b * m.b, (long)m.b * m.nva, (long)m.y * m.nwa, (long)m.x * m.x, (long)m.x * m.nvd, (long)m.y * m.nwd, (long)m.y * m.b})
+    widest = e > widest ? e : widest;
+  if (widest * ld * esz >= (1L << 31) || (long)p->n_sys * esz >= (1L << 32) || round_up(p->n_sys, 64) * esz * m.u * m.b >= (1L << 31)) return 0;
+  return ld;
+}
+
 template <typename PAT, int NX, int NB, int NU, int NY, int ND>
 int run_sp_tv(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll_sn, void* workspace, size_t workspace_bytes,
               hipStream_t st) {
   const bool mixed = p->dtype == LQG_F32_SYS64;
+  const long ldc = canon_layout(p);
   const bool fused = p->n_trials == 1 && !mixed;
   const Workspace w = carve(p, !fused);
   if (!workspace || workspace_bytes < w.total) return LQG_ERR_WORKSPACE;
@@ -304,7 +331,8 @@ int run_sp_tv(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll_sn
     lqg::RiccatiArgs<R> rk{dv<R>(a.Q), dv<R>(none), dv<R>(a.Qf), dv<R>(none), dv<R>(a.P), dv<R>(a.R), dv<R>(none),
                            dv<R>(a.A), dv<R>(a.B), dv<R>(none), dv<R>(none), dv<R>(none), Ls, w.ldb, (long)p->n_sys,
                            p->T, (R)p->eps};
-    hipLaunchKernelGGL((lqg::k_riccati_tv_sp<R, NB, NU, PAT>), grid, block, 0, st, rk);
+    if (ldc) hipLaunchKernelGGL((lqg::k_riccati_tv_sp<R, NB, NU, PAT, true>), grid, block, 0, st, rk, ldc);
+    else hipLaunchKernelGGL((lqg::k_riccati_tv_sp<R, NB, NU, PAT, false>), grid, block, 0, st, rk, 0L);
     mark(1);
     const lqg::DView<R> Lv{Ls, 1, (long)(NU * NB) * w.ldb, (long)NB * w.ldb, w.ldb};
     lqg::ForwardArgs<R> fk{dv<R>(a.A), dv<R>(a.B), dv<R>(a.F), dv<R>(a.V), dv<R>(a.W),
@@ -312,17 +340,23 @@ int run_sp_tv(const lqg_problem* p, lqg_traj x, void* ll, long ll_sb, long ll_sn
                            dv<R>(p->Sigma0), Ls, w.ldb, dt<R>(fused ? x : no_traj), fused ? static_cast<R*>(ll) : nullptr, ll_sb, ops,
                            dv<R>(none), dt<R>(no_traj), dv<R>(none), (long)p->n_sys, p->T, p->dims.nva, p->dims.nwa,
                            p->dims.nvd, p->dims.nwd, nullptr, nullptr};
+    // (the canonical-layout instantiations: the default-Sigma0 ones only — with an explicit Sigma0 the strided loaders serve the call)
+#define LQG_TV_FWD(DP_, FU_, OT_, CN_) \
+  hipLaunchKernelGGL((lqg::k_forward_tv_sp<R, NX, NB, NU, NY, ND, PAT, DP_, FU_, OT_, CN_>), grid, block, 0, st, fk, Lv, (CN_) ? ldc : 0L)
     if (fused) {
       if constexpr (std::is_same_v<R, OT>) {
-        if (p->Sigma0.ptr) hipLaunchKernelGGL((lqg::k_forward_tv_sp<R, NX, NB, NU, NY, ND, PAT, true>), grid, block, 0, st, fk, Lv);
-        else hipLaunchKernelGGL((lqg::k_forward_tv_sp<R, NX, NB, NU, NY, ND, PAT, false>), grid, block, 0, st, fk, Lv);
+        if (p->Sigma0.ptr) LQG_TV_FWD(true, true, R, false);
+        else if (ldc) LQG_TV_FWD(false, true, R, true);
+        else LQG_TV_FWD(false, true, R, false);
       }
       mark(2);
       mark(3);
       return hipGetLastError();
     }
-    if (p->Sigma0.ptr) hipLaunchKernelGGL((lqg::k_forward_tv_sp<R, NX, NB, NU, NY, ND, PAT, true, false, OT>), grid, block, 0, st, fk, Lv);
-    else hipLaunchKernelGGL((lqg::k_forward_tv_sp<R, NX, NB, NU, NY, ND, PAT, false, false, OT>), grid, block, 0, st, fk, Lv);
+    if (p->Sigma0.ptr) LQG_TV_FWD(true, false, OT, false);
+    else if (ldc) LQG_TV_FWD(false, false, OT, true);
+    else LQG_TV_FWD(false, false, OT, false);
+#undef LQG_TV_FWD
     mark(2);
     const hipError_t te = trial_sweep_sp<OT, PAT, NX, NB, NU, NY, ND>(p, x, ll, ll_sb, ll_sn, ops, st);
     mark(3);
@@ -389,14 +423,14 @@ int solve_materialised_sp(const lqg_problem* p, lqg_traj x, lqg_view L, lqg_view
                            p->T, (R)p->eps};
     const lqg::DView<R> Lv = own_l ? dv<R>(L)
                                    : lqg::DView<R>{Ls, 1, (long)(NU * NB) * w.ldb, (long)NB * w.ldb, w.ldb};
-    hipLaunchKernelGGL((lqg::k_riccati_tv_sp<R, NB, NU, PAT>), grid, block, 0, st, rk);
+    hipLaunchKernelGGL((lqg::k_riccati_tv_sp<R, NB, NU, PAT>), grid, block, 0, st, rk, 0L);
     mark(1);
     lqg::ForwardArgs<R> fk{dv<R>(a.A), dv<R>(a.B), dv<R>(a.F), dv<R>(a.V), dv<R>(a.W),
                            dv<R>(d.A), dv<R>(d.B), dv<R>(d.F), dv<R>(d.V), dv<R>(d.W),
                            dv<R>(p->Sigma0), Ls, w.ldb, dt<R>(x), static_cast<R*>(ll), (long)ll_sb, nullptr, dv<R>(Sigma),
                            dt<R>(mu), dv<R>(K), (long)p->n_sys, p->T, p->dims.nva, p->dims.nwa, p->dims.nvd, p->dims.nwd};
-    if (p->Sigma0.ptr) hipLaunchKernelGGL((lqg::k_forward_tv_sp<R, NX, NB, NU, NY, ND, PAT, true>), grid, block, 0, st, fk, Lv);
-    else hipLaunchKernelGGL((lqg::k_forward_tv_sp<R, NX, NB, NU, NY, ND, PAT, false>), grid, block, 0, st, fk, Lv);
+    if (p->Sigma0.ptr) hipLaunchKernelGGL((lqg::k_forward_tv_sp<R, NX, NB, NU, NY, ND, PAT, true>), grid, block, 0, st, fk, Lv, 0L);
+    else hipLaunchKernelGGL((lqg::k_forward_tv_sp<R, NX, NB, NU, NY, ND, PAT, false>), grid, block, 0, st, fk, Lv, 0L);
     mark(2);
     mark(3);
   };

@@ -126,6 +126,88 @@ LQG_DEV Mat<R, M, N, MK> load_masked(const R* __restrict__ p, long sr, long sc) 
       if (MK(i, j)) r.v[i * N + j] = p[i * sr + j * sc];
   return r;
 }
+// The same loads with the address split into a WAVE-UNIFORM entry pointer (p + i sr + j sc: scalar registers, scalar arithmetic)
+// and the lane's own element offset `lo` (one 64-bit add per load).  The time-varying sweeps (lqg_kernels_sp.hpp) re-form every
+// address every step: as one per-lane pointer expression that was 289 integer VALU instructions + 201 v_readlane (the strides no
+// longer fit the scalar registers) against 269 floating-point ones per step of k_forward_tv_sp<double> (round 6).
+template <typename R, int M, int N, Mask<M, N> MK>
+LQG_DEV Mat<R, M, N, MK> load_masked_u(const R* __restrict__ p, long sr, long sc, long lo) {
+  Mat<R, M, N, MK> r;
+  LQG_UNROLL for (int i = 0; i < M; ++i)
+    LQG_UNROLL for (int j = 0; j < N; ++j)
+      if (MK(i, j)) { const R* __restrict__ q = p + (i * sr + j * sc); r.v[i * N + j] = q[lo]; }
+  return r;
+}
+// CANONICAL storage [T][row][col][system] (workload.pack_systems: sb = 1, sc = ld, sr = cols ld, st = rows cols ld with ONE ld for every
+// field): an entry is the field's step pointer (scalar registers) + a 32-bit scalar offset (entry index x ld bytes) + the lane's 32-bit
+// byte offset — the form the hardware addresses in one instruction (global_load v, v_lane, s[base:base+1]): no per-load vector
+// arithmetic, and of the strides only `ldb` stays live.  `pt`: the field at this step (wave-uniform); ldb = ld sizeof(R); lob = lane
+// sizeof(R).  The caller guarantees rows cols ldb < 2^31 and n_sys sizeof(R) < 2^32 (host check: lqg_sp_entry.hpp canon_layout).
+template <typename R>
+LQG_DEV R canon_at(const R* __restrict__ pt, unsigned entry, unsigned ldb, unsigned lob) {
+  const char* q = reinterpret_cast<const char*>(pt) + entry * ldb;      // wave-uniform
+  return *reinterpret_cast<const R*>(q + lob);
+}
+template <typename R, int M, int N, Mask<M, N> MK>
+LQG_DEV Mat<R, M, N, MK> load_masked_c(const R* __restrict__ pt, unsigned ldb, unsigned lob) {
+  Mat<R, M, N, MK> r;
+  LQG_UNROLL for (int i = 0; i < M; ++i)
+    LQG_UNROLL for (int j = 0; j < N; ++j)
+      if (MK(i, j)) r.v[i * N + j] = canon_at<R>(pt, (unsigned)(i * N + j), ldb, lob);
+  return r;
+}
+template <typename R, int N, Mask<N, N> MK>
+LQG_DEV Mat<R, N, N, MK> load_sym_masked_c(const R* __restrict__ pt, unsigned ldb, unsigned lob) {
+  Mat<R, N, N, MK> r;
+  LQG_UNROLL for (int i = 0; i < N; ++i)
+    LQG_UNROLL for (int j = i; j < N; ++j)
+      if (MK(i, j)) {
+        R v = (i == j) ? canon_at<R>(pt, (unsigned)(i * N + i), ldb, lob)
+                       : R(0.5) * (canon_at<R>(pt, (unsigned)(i * N + j), ldb, lob) + canon_at<R>(pt, (unsigned)(j * N + i), ldb, lob));
+        r.v[i * N + j] = v;
+        r.v[j * N + i] = v;
+      }
+  return r;
+}
+// V V' of a stored V[N, nv] (nv columns in storage: run time), the entries of MV only (cf. load_gram_masked_raw)
+template <typename R, int N, Mask<N, N> MK, Mask<N, N> MV>
+LQG_DEV Mat<R, N, N, MK> load_gram_masked_raw_c(const R* __restrict__ pt, int nv, unsigned ldb, unsigned lob) {
+  Mat<R, N, N, MK> r;
+  LQG_UNROLL for (int i = 0; i < N * N; ++i) r.v[i] = R(0);
+  LQG_UNROLL for (int k = 0; k < N; ++k) {
+    if (k < nv) {
+      R col[N];
+      LQG_UNROLL for (int i = 0; i < N; ++i) col[i] = MV(i, k) ? canon_at<R>(pt, (unsigned)(i * nv + k), ldb, lob) : R(0);
+      LQG_UNROLL for (int i = 0; i < N; ++i)
+        LQG_UNROLL for (int j = i; j < N; ++j)
+          if (MK(i, j) && MV(i, k) && MV(j, k)) r.v[i * N + j] += col[i] * col[j];
+    }
+  }
+  for (int k = N; k < nv; ++k) {
+    R col[N];
+    LQG_UNROLL for (int i = 0; i < N; ++i) col[i] = canon_at<R>(pt, (unsigned)(i * nv + k), ldb, lob);
+    LQG_UNROLL for (int i = 0; i < N; ++i)
+      LQG_UNROLL for (int j = i; j < N; ++j)
+        if (MK(i, j)) r.v[i * N + j] += col[i] * col[j];
+  }
+  LQG_UNROLL for (int i = 0; i < N; ++i)
+    LQG_UNROLL for (int j = 0; j < i; ++j) r.v[i * N + j] = r.v[j * N + i];
+  return r;
+}
+template <typename R, int N, Mask<N, N> MK>
+LQG_DEV Mat<R, N, N, MK> load_sym_masked_u(const R* __restrict__ p, long sr, long sc, long lo) {
+  Mat<R, N, N, MK> r;
+  LQG_UNROLL for (int i = 0; i < N; ++i)
+    LQG_UNROLL for (int j = i; j < N; ++j)
+      if (MK(i, j)) {
+        const R* __restrict__ q0 = p + (i * sr + j * sc);
+        const R* __restrict__ q1 = p + (j * sr + i * sc);
+        R v = (i == j) ? q0[lo] : R(0.5) * (q0[lo] + q1[lo]);
+        r.v[i * N + j] = v;
+        r.v[j * N + i] = v;
+      }
+  return r;
+}
 // symmetric part of a stored square matrix; MK must be symmetric
 template <typename R, int N, Mask<N, N> MK>
 LQG_DEV Mat<R, N, N, MK> load_sym_masked(const R* __restrict__ p, long sr, long sc) {
@@ -159,13 +241,16 @@ LQG_DEV Mat<R, N, N, MK> load_gram_masked(const R* __restrict__ p, long sr, long
 // nv > N, are loaded in full).  The time-varying sweeps load the factor every step, and a zoo model's noise factors are
 // (block-)diagonal: 84 of the 192 memory instructions of a step of k_forward_tv_sp were zeros of V and W.
 template <typename R, int N, Mask<N, N> MK, Mask<N, N> MV>
-LQG_DEV Mat<R, N, N, MK> load_gram_masked_raw(const R* __restrict__ p, long sr, long sc, int nv) {
+LQG_DEV Mat<R, N, N, MK> load_gram_masked_raw(const R* __restrict__ p, long sr, long sc, int nv, long lo = 0) {
   Mat<R, N, N, MK> r;
   LQG_UNROLL for (int i = 0; i < N * N; ++i) r.v[i] = R(0);
   LQG_UNROLL for (int k = 0; k < N; ++k) {
     if (k < nv) {
       R col[N];
-      LQG_UNROLL for (int i = 0; i < N; ++i) col[i] = MV(i, k) ? p[i * sr + k * sc] : R(0);
+      LQG_UNROLL for (int i = 0; i < N; ++i) {
+        const R* __restrict__ q = p + (i * sr + k * sc);          // (wave-uniform entry pointer + the lane's offset: see load_masked_u)
+        col[i] = MV(i, k) ? q[lo] : R(0);
+      }
       LQG_UNROLL for (int i = 0; i < N; ++i)
         LQG_UNROLL for (int j = i; j < N; ++j)
           if (MK(i, j) && MV(i, k) && MV(j, k)) r.v[i * N + j] += col[i] * col[j];
@@ -173,7 +258,7 @@ LQG_DEV Mat<R, N, N, MK> load_gram_masked_raw(const R* __restrict__ p, long sr, 
   }
   for (int k = N; k < nv; ++k) {
     R col[N];
-    LQG_UNROLL for (int i = 0; i < N; ++i) col[i] = p[i * sr + k * sc];
+    LQG_UNROLL for (int i = 0; i < N; ++i) col[i] = p[i * sr + k * sc + lo];
     LQG_UNROLL for (int i = 0; i < N; ++i)
       LQG_UNROLL for (int j = i; j < N; ++j)
         if (MK(i, j)) r.v[i * N + j] += col[i] * col[j];

@@ -91,6 +91,16 @@ class _Specs:
         self.actor, self.dynamics = actor, dynamics
 
 
+_deferred = []          # graphs whose owner was finalised during another capture (GraphedLogLik.__del__)
+
+
+def _drain_deferred():
+    """Release parked graphs: outside any capture, after the device has finished with them."""
+    if _deferred and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.synchronize()
+        _deferred.clear()
+
+
 class GraphedLogLik:
     """obj[c] = sum_n log p(x_n | theta[c]) for a FIXED number of parameter vectors, fixed data, fixed model class."""
 
@@ -306,9 +316,22 @@ class GraphedLogLik:
                         self._forward()
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self.out = self._forward()
+                # No finalizer may run inside the capture: a garbage GraphedLogLik (or anything else whose __del__ synchronises the
+                # device) collected by the cyclic GC in the middle of it is an illegal call on a capturing stream, and the HIP
+                # runtime aborts the process (seen in round 6: `Fatal Python error: Aborted ... Garbage-collecting`, in whichever
+                # test happened to capture when the collector fired).  Collect now, keep the collector off until the capture ends.
+                import gc
+                _drain_deferred()
+                gc.collect()
+                was_enabled = gc.isenabled()
+                gc.disable()
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self.out = self._forward()
+                finally:
+                    if was_enabled:
+                        gc.enable()
                 self.graph = g
                 from lqg_amd.tracking import _build
                 self._pins = _build.cached_tensors()      # constants the captured constructor reads by address
@@ -322,6 +345,12 @@ class GraphedLogLik:
 
     def __del__(self):
         try:
+            if self.graph is not None and torch.cuda.is_current_stream_capturing():
+                # collected while ANOTHER graph is being captured (reference counting can do that too): synchronising now would
+                # break that capture — park what the graph owns until the next capture / release drains it
+                _deferred.append((self.graph, self.out, self._keep, self._pins))
+                self.graph, self.out, self._keep, self._pins = None, None, None, None
+                return
             self.release()
         except Exception:
             pass

@@ -123,13 +123,16 @@ def loglik_grad(actor, dyn, x, g=None, Sigma0=None, eps=1e-8):
             Wm = U2 @ Li
             pre = np.concatenate([-Wm.T @ ch, ch])
 
-    # ---- per system, reverse: Sigma-bar / P-bar recursions and the bars, fed by the trial sums
+    # ---- per system, reverse, in TWO backward sweeps as the round-6 kernels run them (the Kalman-covariance adjoint reads nothing
+    # of the moment recursion but K-bar_t): (i) Sigma-bar recursion, joint system and the bars they own, fed by the trial sums,
+    # leaving K-bar_t (without its P-bar term) and L-bar_t per step [k_asp_sys_rev]; (ii) the P-bar recursion over K-bar_t
+    # [k_asp_kal_rev]; then (iii), forward in time, the Riccati adjoint over L-bar_t [k_asp_ric_rev]
     names = ("dA", "dB", "dF", "dVV", "dWW", "aA", "aB", "aF", "aVV", "aWW", "aQ", "aR")
     shapes = dict(dA=(xd, xd), dB=(xd, u), dF=(ny, xd), dVV=(xd, xd), dWW=(ny, ny), aA=(b, b), aB=(b, u), aF=(ny, b),
                   aVV=(b, b), aWW=(ny, ny), aQ=(b, b), aR=(u, u))
     bar = {k: np.zeros((T,) + shapes[k]) for k in names}
-    Lbar = [None] * T
-    Sigb, Pb = np.zeros((m, m)), np.zeros((b, b))
+    Lbar, Kbar = [None] * T, [None] * T
+    Sigb = np.zeros((m, m))
     for t in range(T - 1, -1, -1):
         Ad, Bd, Fd, VVd, WWd, Aa, Ba, Fa, VVa, WWa = sp(t)
         L = Ls[t]
@@ -163,8 +166,15 @@ def loglik_grad(actor, dyn, x, g=None, Sigma0=None, eps=1e-8):
         aB = F22 @ L.T - Fa.T @ Db
         aF = -KtF22 @ Aa.T - Db @ Ba.T
         Lbar[t] = Bd.T @ F12 + Ba.T @ F22 + D.T @ KtF22
-        Pp, Gi, FPp = f["Pp"], f["Gi"], f["FPp"]
-        Kb = Kb - Pb @ FPp.T
+        Kbar[t] = Kb
+        bar["aA"][t], bar["aB"][t], bar["aF"][t] = aA, aB, aF
+    Pb = np.zeros((b, b))
+    for t in range(T - 1, -1, -1):
+        Ad, Bd, Fd, VVd, WWd, Aa, Ba, Fa, VVa, WWa = sp(t)
+        f = system_step(Sigs[t], Ps[t], Ls[t], sp(t), o)
+        K, Pp, Gi, FPp = f["K"], f["Pp"], f["Gi"], f["FPp"]
+        aA, aF = bar["aA"][t], bar["aF"][t]
+        Kb = Kbar[t] - Pb @ FPp.T
         KbGi = Kb @ Gi
         Ppb = Pb - (K @ Fa).T @ Pb + KbGi @ Fa
         aF += (KbGi - Pb @ K).T @ Pp
@@ -174,7 +184,7 @@ def loglik_grad(actor, dyn, x, g=None, Sigma0=None, eps=1e-8):
         bar["aWW"][t] = Gmb
         bar["aVV"][t] = Ppb
         aA += 2.0 * Ppb @ Aa @ Ps[t]
-        bar["aA"][t], bar["aB"][t], bar["aF"][t] = aA, aB, aF
+        bar["aA"][t], bar["aF"][t] = aA, aF
         Pb = sym(Aa.T @ Ppb @ Aa)
     S0b = Pb
     Sb = np.zeros((b, b))

@@ -2,10 +2,10 @@
 # Per-leg PMC passes of the bench (run on the GPU box):  bash scripts/pmc_legs.sh <tag> [leg ...]
 # For every leg: `python3 bench.py --only <leg>` under rocprofv3 with ONE counter per pass (FETCH_SIZE and WRITE_SIZE do not fit
 # one pass; --pmc is only ever combined with --kernel-trace), plus one --kernel-trace --stats pass of the default headline.
-# scripts/pmc_records.py <tag> turns the tables into gpurun_out/<tag>_pmc.json (install as profiles/r05_pmc.json).
+# scripts/pmc_records.py <tag> turns the tables into gpurun_out/<tag>_pmc.json (install as profiles/r06_pmc.json).
 cd "$(dirname "$0")/.."
 TAG=$1; shift
-LEGS=${@:-"headline_f32 headline_f64 m2_f32 config3 config5_one_system config4_sharded dense_generic_f32 dense_generic_f64 specialised_joint_n6 value_and_grad_headline value_and_grad_config3"}
+LEGS=${@:-"headline_f32 headline_f64 m2_f32 timevarying_f64 config3 config5_one_system config4_sharded dense_generic_f32 dense_generic_f64 specialised_joint_n6 value_and_grad_headline value_and_grad_config3"}
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 mkdir -p gpurun_out
 for leg in $LEGS; do

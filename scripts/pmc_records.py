@@ -1,6 +1,6 @@
 """gpurun_out/pmc_<tag>_<leg>_{FETCH_SIZE,WRITE_SIZE,SQ_INSTS_VALU,GRBM_GUI_ACTIVE}/ -> gpurun_out/<tag>_pmc.json: one record per
 (bench leg, kernel family) — what bench.py's `roofline.traffic` / VALU fractions / sustained clock read once the file is installed
-as profiles/r05_pmc.json.
+as profiles/r06_pmc.json.
 
 HBM bytes per launch = 2 x FETCH_SIZE (gfx950: the counter tallies 128-B requests at 64 B — /opt/skills/guides/
 MI355X_MICROARCH.md "HBM"; calibrated in round 1 on k_riccati's exactly-known byte count) + WRITE_SIZE, both in KiB in the
@@ -27,15 +27,16 @@ KERNELS = {
     "headline_f32": {"forward": r"k_forward_sp<float", "riccati": r"k_riccati_sp<float"},
     "headline_f64": {"forward": r"k_forward_sp<double", "riccati": r"k_riccati_sp<double"},
     "m2_f32": {"forward": r"k_forward_tv_sp<", "riccati": r"k_riccati_tv_sp<"},
+    "timevarying_f64": {"forward": r"k_forward_tv_sp<double", "riccati": r"k_riccati_tv_sp<double"},
     "config3": {"trial": r"k_trial_sp", "forward": r"k_forward_sp<", "riccati": r"k_riccati_sp<"},
     "config5_one_system": {"trial": r"k_trial"},
     "config4_sharded": {"trial": r"k_trial", "system": r"k_scan|k_forward|k_riccati"},
     "dense_generic_f32": {"forward": r"k_forward<float", "riccati": r"k_riccati<float"},
     "dense_generic_f64": {"forward": r"k_forward<double", "riccati": r"k_riccati<double"},
     "specialised_joint_n6": {"forward": r"k_forward_sp<float", "riccati": r"k_riccati_sp<float"},
-    "value_and_grad_headline": {"sys_fwd": r"k_asp_sys_fwd<float", "sys_rev": r"k_asp_sys_rev<float", "ric_rev": r"k_asp_ric_rev<float",
+    "value_and_grad_headline": {"sys_fwd": r"k_asp_sys_fwd<float", "sys_rev": r"k_asp_sys_rev(_fused)?<float", "ric_rev": r"k_asp_ric_rev<float",
                                 "riccati": r"k_riccati_sp<float"},
-    "value_and_grad_config3": {"sys_fwd": r"k_asp_sys_fwd<float", "sys_rev": r"k_asp_sys_rev<float", "ric_rev": r"k_asp_ric_rev<float",
+    "value_and_grad_config3": {"sys_fwd": r"k_asp_sys_fwd<float", "sys_rev": r"k_asp_sys_rev(_fused)?<float", "ric_rev": r"k_asp_ric_rev<float",
                                "riccati": r"k_riccati_sp<float", "trial_fwd": r"k_trial_spIf", "trial_rev": r"k_asp_trial_revIf"},
 }
 COUNTERS = ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE")
@@ -99,7 +100,7 @@ def main():
                        hbm_bytes_per_launch=((2.0 * f + (w or 0.0)) * 1024.0 if f is not None else None),
                        launches_averaged={"FETCH_SIZE": nf, "WRITE_SIZE": nw, "SQ_INSTS_VALU": nv, "GRBM_GUI_ACTIVE": ng},
                        valu_wave_insts_per_launch=v,
-                       profile=f"profiles/r05_pmc.json <- rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py --only {leg} "
+                       profile=f"profiles/r06_pmc.json <- rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py --only {leg} "
                                f"--steps 3 --warmup 1 (scripts/pmc_legs.sh {tag}; one counter per pass)")
             if g:                            # sustained clock of the family's full-size dispatches in the GRBM pass
                 ns = sum(sum(dur[name].get(i, 0.0) for i in il) / max(1, len(il)) for name, il in ids.items())

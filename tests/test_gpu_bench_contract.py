@@ -34,7 +34,8 @@ def test_driver_command_prints_one_parseable_line():
     assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and roof["unit"] == "GB/s"
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
     assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * roof["achieved"]
-    assert roof["frac"] > 0.3 and 0 < roof["whole_step_frac"] < roof["frac"] and "bound" in roof["limits"]
+    # (limits.bound / traffic come from the committed PMC record and are present only when it was taken on exactly this build)
+    assert roof["frac"] > 0.3 and 0 < roof["whole_step_frac"] < roof["frac"] and "limits" in roof and "traffic" in roof
     cpu = d["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["single_thread"]["value"] > 0 and cpu["cpu_model"]
     assert d["parity"]["max_rel_err_vs_fp64_oracle"] < 1e-6 and d["all_finite"]
