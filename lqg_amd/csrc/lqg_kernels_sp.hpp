@@ -706,9 +706,20 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? 2 : LQG_TV_WAVES_F
       }
   };
   R w[O], xt[O];
+#if LQG_TV_PREFETCH
+  // the data row of step t + 1 is requested at the start of step t as well (it is consumed in the middle of the step, by
+  // `innovate`: requested there, its whole latency was exposed once per step)
+  R xrow[O], xnx[O];                             // row of the step being run / row requested for the next one
+  LQG_UNROLL for (int i = 0; i < O; ++i) { xnx[i] = FUSED ? xp[i * a.x.sd] : R(0); xrow[i] = xnx[i]; }
+#endif
   auto innovate = [&](int row, bool score) {
+#if LQG_TV_PREFETCH
+    LQG_UNROLL for (int i = 0; i < O; ++i) xt[i] = xrow[i];
+    (void)row;
+#else
     const R* xr = xp + (long)row * a.x.st;
     LQG_UNROLL for (int i = 0; i < O; ++i) xt[i] = xr[i * a.x.sd];
+#endif
     R zz = R(0);
     LQG_UNROLL for (int i = 0; i < O; ++i) {
       R v = R(0);
@@ -782,6 +793,11 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? 2 : LQG_TV_WAVES_F
     const auto Aa = nAa;  const auto Ba = nBa;  const auto Fa = nFa;  const auto VVa = nVVa;  const auto WWa = nWWa;
     const auto Ad = nAd;  const auto Bd = nBd;  const auto N1 = nN1;  const auto Fd = nFd;  const auto WWd = nWWd;
     const Mat<R, NU, NB> L = nL;
+    if constexpr (FUSED) {                       // row t was requested a step ago: hand it to this step; request row t + 1 (rows run to T)
+      LQG_UNROLL for (int i = 0; i < O; ++i) xrow[i] = xnx[i];
+      const R* xr = xp + (long)(t + 1) * a.x.st;
+      LQG_UNROLL for (int i = 0; i < O; ++i) xnx[i] = xr[i * a.x.sd];
+    }
     {
       const int tn = t + 1 < a.T ? t + 1 : t;
       nAa = ldAa(tn); nBa = ldBa(tn); nFa = ldFa(tn); nVVa = ldVVa(tn); nWWa = ldWWa(tn);
@@ -874,6 +890,9 @@ __global__ void __launch_bounds__(LQG_BLOCK, sizeof(R) == 4 ? 2 : LQG_TV_WAVES_F
   for (int t = 1; t < a.T; ++t) step.template operator()<false>(t);
   condition();
   if constexpr (FUSED) {
+#if LQG_TV_PREFETCH
+    LQG_UNROLL for (int i = 0; i < O; ++i) xrow[i] = xnx[i];           // row T, requested during the last step
+#endif
     innovate(a.T, true);
     if (a.ll) store_or_nan(&a.ll[s * a.ll_sb], (R)acc, pois >= kPosFiniteLimit<R>);
   } else {
