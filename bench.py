@@ -1078,25 +1078,34 @@ def leg_value_and_grad_config3(torch, args, dev):
     x = workload.pack_trials(truth.simulate(13, n=Nt).contiguous())
 
     def check(ll):
-        # the same sweep on 2 candidates x 24 trials, T = 120 against the round-1 lane kernels in fp64 (tests/test_adjoint.py
-        # holds the full comparisons with the restatement)
-        from lqg_amd import grad as G, options
-        sub, _ = workload.bounded_system(2, 120, seed=5, device=dev, dtype=torch.float64)
-        xs = truth.to(torch.float64).simulate(13, n=24)[:, :121].contiguous() if hasattr(truth, "to") else None
-        out = {}
-        for sp in (1, 0):
+        # the same sweep on 3 candidates x 24 trials, T = 120 in fp64, chained to the gradient of the FOUR model parameters through the
+        # constructor (every bar of every field enters: a bar the split sweep wrongly left at zero, or an error in any of aA / aB / aF /
+        # aQ / dA / dB / dF / aQf, shows here — ADVICE r05), against (i) the round-1 lane kernels, one (system, trial) pair per lane, and
+        # (ii) central differences of the forward path (tests/test_adjoint.py holds the entry-by-entry comparisons with the restatement)
+        from lqg_amd import options
+        names = ("sigma_target", "sigma_cursor", "action_cost", "action_variability")
+        base = dict(sigma_target=[12.0, 20.0, 31.0], sigma_cursor=[2.0, 3.0, 4.5], action_cost=[0.2, 0.3, 0.6], action_variability=[0.4, 0.5, 0.7])
+        xs = truth.to(torch.float64).simulate(13, n=24)[:, :121].contiguous()
+
+        def value_grad(sp):
+            par = {k: torch.tensor(base[k], dtype=torch.float64, device=dev, requires_grad=True) for k in names}
             with options.override(ADJOINT_SP=sp):
-                sw = G.Sweep(sub.actor, sub.dynamics, xs, system=sub)
-                l_ = sw.forward()
-                b_ = sw.reverse(None)
-                out[sp] = (l_.double(), {k: v.sum(1).double() for k, v in b_.items()})
-        # (the split sweep forms the bars on the pattern's masks only: compared where it has entries)
-        err = 0.0
-        for k in ("aVV", "aWW", "dVV", "dWW", "aR"):
-            nz = out[1][1][k] != 0
-            err = max(err, float(((out[1][1][k] - out[0][1][k]).abs()[nz].max() / out[0][1][k].abs()[nz].max().clamp_min(1e-9))))
-        return {"candidates": 2, "trials": 24, "T": 120, "bars_max_rel_diff_split_vs_round1_kernels_f64": err,
-                "value_max_rel_diff": float((out[1][0] / out[0][0] - 1).abs().max())}
+                val = lqg_amd.BoundedActor(T=120, device=dev, dtype=torch.float64, **par).log_likelihood(xs).sum(-1)
+                val.sum().backward()
+            return val.detach(), torch.stack([par[k].grad for k in names], -1)
+        v1, g1 = value_grad(1)
+        v0, g0 = value_grad(0)
+        h, fd = 1e-5, torch.zeros_like(g1)
+        with torch.no_grad():
+            for j, k in enumerate(names):
+                f = lambda s_: lqg_amd.BoundedActor(T=120, device=dev, dtype=torch.float64, **{
+                    q: torch.tensor(base[q], dtype=torch.float64, device=dev) * ((1 + s_ * h) if q == k else 1.0) for q in names}).log_likelihood(xs).sum(-1)
+                fd[:, j] = (f(1) - f(-1)) / (2 * h * torch.tensor(base[k], dtype=torch.float64, device=dev))
+        rel = lambda a_, b_: float(((a_ - b_).abs() / b_.abs().clamp_min(1e-12)).max())
+        return {"candidates": 3, "trials": 24, "T": 120, "parameters": list(names),
+                "parameter_gradient_max_rel_diff_split_vs_round1_kernels_f64": rel(g1, g0),
+                "parameter_gradient_max_rel_diff_split_vs_central_differences_f64": rel(g1, fd),
+                "value_max_rel_diff": float((v1 / v0 - 1).abs().max())}
 
     out = _grad_leg(torch, dev, system, x, Bc, Nt, T, (2, 2, 1, 2, 2), "value_and_grad_config3", fd_check=check)
     out["trial_steps_per_s"] = float(Bc) * Nt * T / (out["ms_per_value_and_grad"] * 1e-3)

@@ -233,7 +233,13 @@ class GradPlan:
     """Value + gradient of one (system, data) pair, decided ONCE (decoupling into components, identical components merged as
     trials, adjoint libraries, workspaces, argument structs) so that repeated evaluations are pure launches — the analogue of
     plan.LogLikelihoodPlan for the reverse mode; bench.py keeps one per timed leg.  `run(g)` -> (ll[(B,) n], [bars per
-    component]): the bars are those of the components' spec matrices ({name: [B, 1, r, c]}, summed over the trials)."""
+    component]): the bars are those of the components' spec matrices ({name: [B, 1, r, c]}, summed over the trials).
+
+    For the ZOO classes (and their decoupled components) the adjoint masks are a property of the constructor: hoisted products
+    that cancel for every parameter value (`F_d B_d - F_a B_a = 0` for a shared spec) are pruned, and bars of fields no parameter
+    moves are zeros.  Such bars are exact only CONTRACTED through the constructor to its parameters (what `lqg_amd.grad` /
+    `lqg_amd.infer` do); they are not the partial derivatives with respect to each spec matrix taken on its own.  A System built
+    from leaf matrices gets structurally full masks for every field that requires grad (specialize.pattern_of(grad_full=True))."""
 
     def __init__(self, system, x, events=False):
         from lqg_amd import _hipev, decouple
@@ -308,7 +314,8 @@ class GradPlan:
 def raw_grad(actor, dynamics, x, g=None, Sigma0=None, eps=1e-8, want_value=True, system=None):
     """Both phases at once.  x[n,T+1,d] or [B,n,T+1,d]; g like the log-likelihood ([n] / [B,n]) or None.
     Returns (ll, {name: [B, N, r, c] per-(system, trial) bars — [B, 1, r, c], summed over the trials, from the specialised
-    adjoint libraries and the cooperative sweep}, launch)."""
+    adjoint libraries and the cooperative sweep}, launch).  With `system` a zoo class (or one of its decoupled components) the bars
+    are valid contracted through the constructor only (GradPlan's docstring); pass system=None for the partials of each matrix."""
     sw = Sweep(actor, dynamics, x, Sigma0=Sigma0, eps=eps, system=system)
     ll = sw.forward()
     return ll, sw.reverse(g), sw.ln

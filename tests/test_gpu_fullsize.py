@@ -291,3 +291,24 @@ def test_driver_launch_line_on_rccl_with_one_rank():
     assert out["parity"]["max_rel_err_vs_fp64_oracle"] < 1e-6
     one = _run_bench("--log2-batch", "14", "--steps", "3", "--warmup", "1", "--no-extra", "--no-cpu-baseline")
     assert abs(out["objective_sum"] / one["objective_sum"] - 1) < 1e-12
+
+
+def test_more_than_65535_systems_with_several_trials_each():
+    """the per-trial sweeps put the system index in grid.y.  More than 65 535 systems with three or more trials each
+    (forward: operator stream + k_trial_sp; reverse: k_asp_trial_rev) must launch and agree with a small batch of the same candidates —
+    verified on gfx950 / ROCm 7.2 at 70 000 and 140 000 systems (round 6: scripts/r06_gridy_probe.py)."""
+    dev = torch.device("cuda")
+    for B, n, dt, tol in ((70000, 3, torch.float32, 1e-5), (140000, 5, torch.float64, 1e-12)):
+        sig = torch.linspace(3.0, 40.0, B, device=dev, dtype=dt)
+        x = lqg_amd.BoundedActor(T=40, device=dev, dtype=dt).simulate(5, n=n).contiguous()
+        ll = lqg_amd.BoundedActor(T=40, sigma_target=sig, device=dev, dtype=dt).log_likelihood(x)
+        idx = torch.tensor([0, 65535, 65536, B - 1], device=dev)
+        ref = lqg_amd.BoundedActor(T=40, sigma_target=sig[idx], device=dev, dtype=dt).log_likelihood(x)
+        assert ll.shape == (B, n) and bool(torch.isfinite(ll).all())
+        assert float(((ll[idx] - ref) / ref).abs().max()) < tol
+        s2 = sig.clone().requires_grad_(True)
+        lqg_amd.BoundedActor(T=40, sigma_target=s2, device=dev, dtype=dt).log_likelihood(x).sum().backward()
+        s3 = sig[idx].clone().requires_grad_(True)
+        lqg_amd.BoundedActor(T=40, sigma_target=s3, device=dev, dtype=dt).log_likelihood(x).sum().backward()
+        assert bool(torch.isfinite(s2.grad).all())
+        assert float(((s2.grad[idx] - s3.grad) / s3.grad).abs().max()) < (1e-3 if dt == torch.float32 else 1e-9)
