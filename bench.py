@@ -796,7 +796,8 @@ def leg_timevarying(dn):
             system, base = bench_m2.m2_system(dev, dtype, B, T, psd=psd)
             x = workload.pack_trials(workload.simulate_one_trial_each(base, seed=5))
             del base
-            plan = LogLikelihoodPlan(system, x, events=True)
+            conc = os.environ.get("LQG_BENCH_TV_CONCURRENT")
+            plan = LogLikelihoodPlan(system, x, events=True, concurrent=(None if conc is None else bool(int(conc))))
             for _ in range(2):
                 ll = plan.run()
             torch.cuda.synchronize()

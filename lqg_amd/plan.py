@@ -313,11 +313,12 @@ class LogLikelihoodPlan:
                                   dtype=self.ll.dtype, device=self.ll.device)
         # concurrent=True runs the independent components on side streams.  With few systems (one parameter vector, a
         # handful of candidates) each per-system sweep is a single latency-bound wave and the components simply overlap:
-        # the default (None) turns it on below 2^14 systems (config 4: 8.2 -> ~5 ms wall).  At B = 2^18 two launches in
-        # flight give +4 % (the bench stacks the components into one launch instead).
+        # the default (None) turns it on up to 2^16 systems — one wave per SIMD or less per launch (config 4: 8.2 -> ~5 ms wall; round 6,
+        # two time-varying fp64 components of 2^16 systems each: 6.40 -> 4.25 ms, profiles/r06_timevarying.txt).  At B = 2^18 two
+        # launches in flight give +4 % (the bench stacks the components into one launch instead).
         if concurrent is None:
             n_sys = self.work[0]["ln"].B
-            concurrent = len(self.work) > 1 and n_sys < (1 << 14)
+            concurrent = len(self.work) > 1 and n_sys <= (1 << 16)
         self.side = [torch.cuda.Stream(device=self.device) for _ in self.work[1:]] if concurrent else []
         self._fork = torch.cuda.Event() if self.side else None
         self._join = [torch.cuda.Event() for _ in self.side]
