@@ -460,6 +460,9 @@ __global__ void __launch_bounds__(LQG_BLOCK, (sizeof(R) == 4 && NX + NB <= 5 ? L
 #ifndef LQG_ASP_SPLIT_KAL
 #define LQG_ASP_SPLIT_KAL 0
 #endif
+#ifndef LQG_ASP_REV_XWINDOW
+#define LQG_ASP_REV_XWINDOW 1     // the reverse system sweeps carry the in-lane trials' data rows in a rolling window (profiles/r06_rev_split.txt)
+#endif
 #ifndef LQG_ASP_REV_PREFETCH
 #define LQG_ASP_REV_PREFETCH 0    // 1: the fused sweep requests a chunk's checkpoint one chunk ahead — measured 3.73 -> 4.03 ms (416 registers,
                                   // the requests hold 37 of them through the walk back; profiles/r06_rev_split.txt): not kept
@@ -524,6 +527,18 @@ __global__ void __launch_bounds__(LQG_BLOCK, 1) k_asp_sys_rev_fused(const AspArg
   if constexpr (NTR == 0) {
     for (int part = 0; part < A.parts; ++part) gs_stream += A.gsum[(long)part * a.n_sys + s];
   }
+#if LQG_ASP_REV_XWINDOW
+  // the in-lane trials' data rows t - 1, t, t + 1 of the step being differentiated, carried backward through the whole sweep
+  // (each step needs ONE row it has not seen: requested a step ahead instead of three rows at the point of use)
+  [[maybe_unused]] R xwin[NT][3][O];
+  if constexpr (NTR > 0) {
+    LQG_UNROLL for (int n = 0; n < NT; ++n)
+      LQG_UNROLL for (int q = 0; q < 3; ++q) {
+        const int row = a.T - 2 + q > 0 ? a.T - 2 + q : 0;
+        LQG_UNROLL for (int i = 0; i < O; ++i) xwin[n][q][i] = xp[n * a.x.sn + (long)row * a.x.st + i * a.x.sd];
+      }
+  }
+#endif
   R Lbuf[CK][NU * NB];
   // register stack of the chunk's states (static indices only).  LQG_ASP_STACK0 = 0: the state before the chunk's FIRST step, its
   // checkpoint, is not stacked but read again when the walk back reaches it
@@ -699,12 +714,24 @@ __global__ void __launch_bounds__(LQG_BLOCK, 1) k_asp_sys_rev_fused(const AspArg
             set_zero(MC);
             LQG_UNROLL for (int n = 0; n < NT; ++n) {
               R xm1[O], xt[O], x1[O], w0[O], w1[O], cv[M], a0[O], a1[O];
+#if LQG_ASP_REV_XWINDOW
+              // rows t - 1, t, t + 1 from the rolling window; the ONE new row the step before this one needs (t - 2) is requested
+              // now and shifted in at the end of the step: its latency hides behind this step's arithmetic
+              R xnew[O];
+              {
+                const R* xr = xp + n * a.x.sn + (long)(t > 1 ? t - 2 : 0) * a.x.st;
+                LQG_UNROLL for (int i = 0; i < O; ++i) xnew[i] = xr[i * a.x.sd];
+              }
+              LQG_UNROLL for (int i = 0; i < O; ++i) { xm1[i] = xwin[n][0][i]; xt[i] = xwin[n][1][i]; x1[i] = xwin[n][2][i]; }
+              LQG_UNROLL for (int i = 0; i < O; ++i) { xwin[n][2][i] = xt[i]; xwin[n][1][i] = xm1[i]; xwin[n][0][i] = xnew[i]; }
+#else
               const R* xr = xp + n * a.x.sn;
               LQG_UNROLL for (int i = 0; i < O; ++i) {
                 xt[i] = xr[(long)t * a.x.st + i * a.x.sd];
                 x1[i] = xr[(long)(t + 1) * a.x.st + i * a.x.sd];
                 xm1[i] = xr[(long)(t > 0 ? t - 1 : 0) * a.x.st + i * a.x.sd];
               }
+#endif
               TrialState<R, M, ND> s0 = st0[n];
               trial_forward<R, M, ND>(Fj, Li, U2, xt, xm1, s0, w0, cv, false);
               LQG_UNROLL for (int i = 0; i < O; ++i) {
@@ -1020,6 +1047,18 @@ __global__ void __launch_bounds__(LQG_BLOCK, (rev_waves<R, NX + NB, NTR * (NX + 
   if constexpr (NTR == 0) {
     for (int part = 0; part < A.parts; ++part) gs_stream += A.gsum[(long)part * a.n_sys + s];
   }
+#if LQG_ASP_REV_XWINDOW
+  // the in-lane trials' data rows t - 1, t, t + 1 of the step being differentiated, carried backward through the whole sweep
+  // (each step needs ONE row it has not seen: requested a step ahead instead of three rows at the point of use)
+  [[maybe_unused]] R xwin[NT][3][O];
+  if constexpr (NTR > 0) {
+    LQG_UNROLL for (int n = 0; n < NT; ++n)
+      LQG_UNROLL for (int q = 0; q < 3; ++q) {
+        const int row = a.T - 2 + q > 0 ? a.T - 2 + q : 0;
+        LQG_UNROLL for (int i = 0; i < O; ++i) xwin[n][q][i] = xp[n * a.x.sn + (long)row * a.x.st + i * a.x.sd];
+      }
+  }
+#endif
   R Lbuf[CK][NU * NB];
   KT Kst[CK];                                            // the chunk's Kalman gains (static indices only)
   // what of the stack does not fit LDS stays in registers (static indices only)
@@ -1162,12 +1201,24 @@ __global__ void __launch_bounds__(LQG_BLOCK, (rev_waves<R, NX + NB, NTR * (NX + 
             set_zero(MC);
             LQG_UNROLL for (int n = 0; n < NT; ++n) {
               R xm1[O], xt[O], x1[O], w0[O], w1[O], cv[M], a0[O], a1[O];
+#if LQG_ASP_REV_XWINDOW
+              // rows t - 1, t, t + 1 from the rolling window; the ONE new row the step before this one needs (t - 2) is requested
+              // now and shifted in at the end of the step: its latency hides behind this step's arithmetic
+              R xnew[O];
+              {
+                const R* xr = xp + n * a.x.sn + (long)(t > 1 ? t - 2 : 0) * a.x.st;
+                LQG_UNROLL for (int i = 0; i < O; ++i) xnew[i] = xr[i * a.x.sd];
+              }
+              LQG_UNROLL for (int i = 0; i < O; ++i) { xm1[i] = xwin[n][0][i]; xt[i] = xwin[n][1][i]; x1[i] = xwin[n][2][i]; }
+              LQG_UNROLL for (int i = 0; i < O; ++i) { xwin[n][2][i] = xt[i]; xwin[n][1][i] = xm1[i]; xwin[n][0][i] = xnew[i]; }
+#else
               const R* xr = xp + n * a.x.sn;
               LQG_UNROLL for (int i = 0; i < O; ++i) {
                 xt[i] = xr[(long)t * a.x.st + i * a.x.sd];
                 x1[i] = xr[(long)(t + 1) * a.x.st + i * a.x.sd];
                 xm1[i] = xr[(long)(t > 0 ? t - 1 : 0) * a.x.st + i * a.x.sd];
               }
+#endif
               TrialState<R, M, ND> s0 = st0[n];
               trial_forward<R, M, ND>(Fj, Li, U2, xt, xm1, s0, w0, cv, false);
               LQG_UNROLL for (int i = 0; i < O; ++i) {
