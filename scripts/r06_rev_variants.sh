@@ -9,11 +9,11 @@ for spec in "$@"; do
   mkdir -p $LQG_PAT_DIR
   cp -n lqg_amd/csrc/pat/pat_*.so lqg_amd/csrc/pat/pat_*.stamp $LQG_PAT_DIR/ 2>/dev/null
   export LQG_ADJ_FLAGS="$flags"
-  python bench.py --only value_and_grad_headline > gpurun_out/revvar/$tag.json 2> gpurun_out/revvar/$tag.err
+  python bench.py --only ${LEG:-value_and_grad_headline} > gpurun_out/revvar/$tag.json 2> gpurun_out/revvar/$tag.err
   python - <<PY
 import json
 try:
-    v=json.load(open("gpurun_out/revvar/$tag.json"))["value_and_grad_headline"]
+    v=json.load(open("gpurun_out/revvar/$tag.json"))[list(json.load(open("gpurun_out/revvar/$tag.json")))[0]]
     print("$tag [$flags]  %.3f ms " % v["ms_per_value_and_grad"], {k: round(x,3) for k,x in v["kernel_ms"].items()})
 except Exception as e:
     print("$tag failed", e, open("gpurun_out/revvar/$tag.err").read()[-800:])
