@@ -229,42 +229,67 @@ def floor_provably_inactive(system, eps=1e-8):
     # move in time (round 6) would otherwise never pass.  The reference's own eigh of H in that dtype resolves no finer.
     tol = -1e-12 if a.Q.dtype == torch.float64 else -2e-6
 
-    def lower_bound(M):
-        """(symmetric part in fp64, lower bound of its smallest eigenvalue RELATIVE to max(1, |M|max)).  Gershgorin on M itself —
-        every eigenvalue >= min_i (M_ii - sum_{j != i} |M_ij|) — and, where that is inconclusive, on the unit-diagonal scaling
-        E M E (E = diag M^-1/2, a congruence: same signature): a cost D Q D whose Q is diagonally dominant passes the second
-        form whatever the D (time-varying costs, round 6).  Elementwise, no factorisation."""
-        M = 0.5 * (M + M.transpose(-1, -2)).detach().double()
-        diag = torch.diagonal(M, dim1=-2, dim2=-1)
-        rows = M.abs().sum(-1)
-        scale = M.abs().max().clamp_min(1.0)
-        lb1 = (diag - (rows - diag.abs())).min() / scale
-        pos = diag > 0
-        inv = torch.where(pos, diag.clamp_min(1e-300).rsqrt(), torch.zeros_like(diag))
-        offs = (M.abs() * inv.unsqueeze(-1) * inv.unsqueeze(-2)).sum(-1) - pos.double()
-        # a row with a zero diagonal entry must vanish altogether; a negative diagonal entry fails both forms
-        bad = ((~pos) & (rows > 0)).any()
-        lb2 = torch.where(bad, torch.full_like(lb1, -1.0), torch.where(pos, 1.0 - offs, torch.zeros_like(offs)).min())
-        # (lambda_min(M) >= lambda_min(E M E) min_i M_ii when the scaled matrix is positive semi-definite)
-        abs2 = torch.where(lb2 >= 0, lb2 * torch.where(pos, diag, torch.full_like(diag, float("inf"))).min(), torch.full_like(lb2, -1.0))
-        return M, lb1, lb2, lb1 * scale, abs2
+    def slabs(M, max_elems=1 << 24):
+        """Views of a (possibly huge) stack of small matrices, cut along its longest leading axis so that the fp64 temporaries of one
+        slab stay small (2^17 systems x 500 steps of 6 x 6 fp32 costs are 9.4 GB; their fp64 images and intermediates were 60+ GB)."""
+        if M.numel() <= max_elems or M.dim() < 3:
+            yield M
+            return
+        ax = max(range(M.dim() - 2), key=lambda i: M.shape[i])
+        step = max(1, int(max_elems // max(1, M.numel() // M.shape[ax])))
+        for lo in range(0, M.shape[ax], step):
+            yield M.narrow(ax, lo, min(step, M.shape[ax] - lo))
 
-    def eig_min(M, chunk=1 << 18):
+    def lower_bound(Mfull):
+        """Lower bounds of the smallest eigenvalue over the whole stack: (relative to max(1, |M|max): Gershgorin on M, on its
+        unit-diagonal scaling; absolute: the same two).  Gershgorin on M itself — every eigenvalue >= min_i (M_ii - sum_{j != i}
+        |M_ij|) — and, where that is inconclusive, on the unit-diagonal scaling E M E (E = diag M^-1/2, a congruence: same
+        signature): a cost D Q D whose Q is diagonally dominant passes the second form whatever the D (time-varying costs, round 6).
+        Elementwise, no factorisation, slab by slab."""
+        dev = Mfull.device
+        inf = torch.tensor(float("inf"), dtype=torch.float64, device=dev)
+        g1, g2, dmin, scale = inf.clone(), inf.clone(), inf.clone(), torch.ones((), dtype=torch.float64, device=dev)
+        bad = torch.zeros((), dtype=torch.bool, device=dev)
+        for Ms in slabs(Mfull):
+            M = 0.5 * (Ms + Ms.transpose(-1, -2)).detach().double()
+            diag = torch.diagonal(M, dim1=-2, dim2=-1)
+            rows = M.abs().sum(-1)
+            scale = torch.maximum(scale, M.abs().max())
+            g1 = torch.minimum(g1, (diag - (rows - diag.abs())).min())
+            pos = diag > 0
+            inv = torch.where(pos, diag.clamp_min(1e-300).rsqrt(), torch.zeros_like(diag))
+            offs = (M.abs() * inv.unsqueeze(-1) * inv.unsqueeze(-2)).sum(-1) - pos.double()
+            # a row with a zero diagonal entry must vanish altogether; a negative diagonal entry fails both forms
+            bad = bad | ((~pos) & (rows > 0)).any()
+            g2 = torch.minimum(g2, torch.where(pos, 1.0 - offs, torch.zeros_like(offs)).min())
+            dmin = torch.minimum(dmin, torch.where(pos, diag, torch.full_like(diag, float("inf"))).min())
+        lb1 = g1 / scale
+        lb2 = torch.where(bad, torch.full_like(g2, -1.0), g2)
+        # (lambda_min(M) >= lambda_min(E M E) min_i M_ii when the scaled matrix is positive semi-definite)
+        abs2 = torch.where(lb2 >= 0, lb2 * dmin, torch.full_like(lb2, -1.0))
+        return scale, lb1, lb2, g1, abs2
+
+    def eig_min(Mfull, chunk=1 << 18):
         """Smallest eigenvalue over a (possibly huge) stack of small matrices, in slabs (one syevd over 65 M matrices asks rocSOLVER
         for more workspace than it can get)."""
-        flat = M.reshape(-1, *M.shape[-2:])
-        return min(float(torch.linalg.eigvalsh(flat[i:i + chunk]).min()) for i in range(0, flat.shape[0], chunk))
+        best = float("inf")
+        for Ms in slabs(Mfull):
+            flat = (0.5 * (Ms + Ms.transpose(-1, -2))).detach().double().reshape(-1, *Ms.shape[-2:])
+            for i in range(0, flat.shape[0], chunk):
+                best = min(best, float(torch.linalg.eigvalsh(flat[i:i + chunk]).min()))
+        return best
 
-    Rs, _, _, r_abs1, r_abs2 = lower_bound(first(a.R))
-    Qs, q_lb1, q_lb2, _, _ = lower_bound(first(a.Q))
-    Qfs, qf_lb1, qf_lb2, _, _ = lower_bound(a.Qf)
+    R_, Q_, Qf_ = first(a.R), first(a.Q), a.Qf
+    r_scale, _, _, r_abs1, r_abs2 = lower_bound(R_)
+    q_scale, q_lb1, q_lb2, _, _ = lower_bound(Q_)
+    qf_scale, qf_lb1, qf_lb2, _, _ = lower_bound(Qf_)
     checks = torch.stack([torch.maximum(r_abs1, r_abs2) - eps, torch.maximum(q_lb1, q_lb2) - tol, torch.maximum(qf_lb1, qf_lb2) - tol])
     flags = (checks >= 0).tolist()                       # the one synchronisation
     ok = all(flags)
     if not ok:
-        r_ok = flags[0] or eig_min(Rs) >= eps
-        q_ok = r_ok and (flags[1] or eig_min(Qs) >= tol * max(1.0, float(Qs.abs().max())))
-        ok = q_ok and (flags[2] or eig_min(Qfs) >= tol * max(1.0, float(Qfs.abs().max())))
+        r_ok = flags[0] or eig_min(R_) >= eps
+        q_ok = r_ok and (flags[1] or eig_min(Q_) >= tol * max(1.0, float(q_scale)))
+        ok = q_ok and (flags[2] or eig_min(Qf_) >= tol * max(1.0, float(qf_scale)))
     cache[key] = ok
     return ok
 

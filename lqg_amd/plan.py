@@ -313,12 +313,14 @@ class LogLikelihoodPlan:
                                   dtype=self.ll.dtype, device=self.ll.device)
         # concurrent=True runs the independent components on side streams.  With few systems (one parameter vector, a
         # handful of candidates) each per-system sweep is a single latency-bound wave and the components simply overlap:
-        # the default (None) turns it on up to 2^16 systems — one wave per SIMD or less per launch (config 4: 8.2 -> ~5 ms wall; round 6,
-        # two time-varying fp64 components of 2^16 systems each: 6.40 -> 4.25 ms, profiles/r06_timevarying.txt).  At B = 2^18 two
-        # launches in flight give +4 % (the bench stacks the components into one launch instead).
+        # the default (None) turns it on up to 2^17 systems — at most two waves per SIMD per launch (config 4: 8.2 -> ~5 ms wall) — and
+        # for the time-varying sweeps at any size: they wait on their per-step spec loads, and two launches in flight hide each
+        # other's (round 6, two components: fp64 2^16 systems 6.40 -> 4.25 ms, fp32 2^17 systems 6.2 -> 4.25 ms,
+        # profiles/r06_timevarying.txt).  The time-invariant VALU-bound sweeps gain 4 % at B = 2^18 (the bench stacks their
+        # components into one launch instead).
         if concurrent is None:
             n_sys = self.work[0]["ln"].B
-            concurrent = len(self.work) > 1 and n_sys <= (1 << 16)
+            concurrent = len(self.work) > 1 and (n_sys <= (1 << 17) or any(_hip._varies_or_affine(wk["ln"]) for wk in self.work))
         self.side = [torch.cuda.Stream(device=self.device) for _ in self.work[1:]] if concurrent else []
         self._fork = torch.cuda.Event() if self.side else None
         self._join = [torch.cuda.Event() for _ in self.side]

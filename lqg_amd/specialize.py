@@ -135,6 +135,16 @@ def pattern_of_time_varying(system, d):
     return dims, masks
 
 
+def _varies_in_time(system):
+    """True when a spec stack of the system has more than one time slice that is not a stride-0 view."""
+    for spec in (system.actor, system.dynamics):
+        for f in ("A", "B", "F", "V", "W", "Q", "R"):
+            t = getattr(spec, f)
+            if t.dim() >= 3 and t.shape[-3] > 1 and t.stride(-3) != 0:
+                return True
+    return False
+
+
 def pattern_key(dims, masks):
     h = hashlib.sha1(repr(sorted(dims.items())).encode())
     for k in _FIELDS:
@@ -469,6 +479,11 @@ def system_pattern(system, d, grad_full=False):
         zoo_dim = getattr(system, "_zoo_structure", None) if cls in zoo else None   # exact classes only
         if zoo_dim is not None:
             cache[d] = class_pattern(cls, d_in, **zoo_dim)
+        elif not grad_full and _varies_in_time(system):
+            # stacks that move in time: union masks by reduction (pattern_of would take fp64 images of every stack and multiply
+            # them out — 2^17 systems x 500 steps: 250 GB of temporaries, round 6)
+            dims, masks = pattern_of_time_varying(system, d_in)
+            cache[d] = (dims, masks, pattern_key(dims, masks))
         else:
             dims, masks = pattern_of(system, d_in, grad_full=grad_full)
             cache[d] = (dims, masks, pattern_key(dims, masks))
