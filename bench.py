@@ -791,6 +791,8 @@ def leg_timevarying(dn):
         # (fp64 at 2^17 systems: 124 GB of [T][element][system] spec stacks + as much again for the decoupled components' own
         # stacks + the fp64 temporaries of the positive-semi-definiteness certificate pass 288 GB; 2^16 = one wave per SIMD)
         B, T = (1 << 17) if dn == "f32" else (1 << 16), 500
+        if os.environ.get("LQG_BENCH_TV_LOG2B"):
+            B = 1 << int(os.environ["LQG_BENCH_TV_LOG2B"])
         out = {"dtype": dn, "systems": B, "T": T, "unit": "solves/s"}
         for name, psd in (("costs_stay_psd", True), ("per_entry_jitter", False)):
             system, base = bench_m2.m2_system(dev, dtype, B, T, psd=psd)
