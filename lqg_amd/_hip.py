@@ -290,6 +290,11 @@ def specialised_library(ln, system, d, check_strategy=True):
     from lqg_amd import specialize
     if _varies_or_affine(ln):
         dims, masks, key = _time_varying_pattern(ln, system, d)
+        # a pattern nobody has compiled yet costs ~40 s of hipcc: only for work that repays it (TV_JIT_MIN_WORK system-steps, the
+        # scale of _abi.JIT_MIN_SYSTEMS); a few systems over a short horizon run on the dense generic kernels in milliseconds.
+        # (Time-invariant patterns keep round 5's rule — compile on first use: the zoo's are prebuilt, a user's model is one pattern.)
+        if ln.B * ln.T < options.get("TV_JIT_MIN_WORK") and not specialize.pattern_on_disk(key):
+            return None
     else:
         dims, masks, key = specialize.system_pattern(system, d)
     return specialize.load_pattern(key, dims, masks)

@@ -36,6 +36,7 @@ HILO              1         the mixed mode keeps the rounding residual of the op
 F32_WIDE          1         ill-conditioned fp32 problems run over an fp64 image of specs and data (plan.F32_MAX_COND)
 F32_MAX_COND      1e7       cond((V V')[:d, :d]) above which they do
 X4_LAYOUT         0         1: merged fp32 components whose lane reads four floats per row are laid [T+1][B][trial][component] (one 16-byte load per step, k_forward_sp<X4>); measured, see DESIGN.md §7
+TV_JIT_MIN_WORK   1048576   systems x steps from which a time-varying / affine model whose pattern library does not exist yet gets one compiled (~40 s of hipcc, once; cached on disk); below, the dense generic kernels serve it
 NO_SPECIALIZE     0         1: generic dense kernels instead of the pattern libraries
 NO_DECOUPLE       0         1: solve the joint problem even when it splits into independent components
 NO_MERGE          0         1: do not solve identical components once
@@ -54,7 +55,7 @@ DEFAULTS = {
     "SCAN": "", "SCAN_MAX_SYSTEMS": 0, "SCAN_MIN_STEPS": 0, "SCAN_MAX_COND": 1e7, "SCAN_LANE": 1, "SCAN_RT_WAVES": 0, "SCAN_ORDER": "",
     "COOP": "", "COOP_SPARSE": 1, "COOP_TRIAL_ROWS": 1, "COOP_TRIAL_TPB": 0, "COOP_TRIAL_WIDE": "", "COOP_TRIAL_CHUNKS": "", "COOP_ADJOINT": 0, "ADJOINT_SP": 1, "TRIAL_CHUNKS": "", "TRIAL_LDS": "", "TRIAL_CHUNK_WAVES": 0,
     "TRIAL_CHUNK_MAX_WAVES": 0, "TRIAL_CHUNK_TPL": 0, "FUSE_TRIALS_MAX": 2048, "MIXED": 1, "MIXED_MIN_TRIALS": 3, "HILO": 1,
-    "F32_WIDE": 1, "F32_MAX_COND": 1e7, "X4_LAYOUT": 0, "NO_SPECIALIZE": 0, "NO_DECOUPLE": 0, "NO_MERGE": 0, "GRAPH": 1, "GRAPH_AFFINE": 1,
+    "F32_WIDE": 1, "F32_MAX_COND": 1e7, "X4_LAYOUT": 0, "TV_JIT_MIN_WORK": 1 << 20, "NO_SPECIALIZE": 0, "NO_DECOUPLE": 0, "NO_MERGE": 0, "GRAPH": 1, "GRAPH_AFFINE": 1,
     "SETUP_KERNEL": 1, "JIT": 1,
 }
 _overrides = {}

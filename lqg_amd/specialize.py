@@ -236,6 +236,14 @@ def compile_pattern(key, dims, masks, verbose=False):
     return so
 
 
+def pattern_on_disk(key):
+    """True when the stamped library of this pattern exists already (no compile would be needed)."""
+    if key in _libs:
+        return _libs[key] is not None
+    so = os.path.join(_build.cache_dir(PAT_DIR, "pat"), f"pat_{key}.so")
+    return _build.stamped(so, _headers_hash())
+
+
 def load_pattern(key, dims, masks, verbose=False):
     """ctypes handle of the specialised library for this pattern (compiled on first use), or None.
 
